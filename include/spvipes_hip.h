@@ -1,0 +1,131 @@
+/* spvipes_hip.h -- C ABI of the MI355X (gfx950) hot-path library  libspvipes_hip.so
+ *
+ * Drop-in boundary for the per-minibatch VAE step of nrclaudio/spVIPES.  The reference has no
+ * native code and no FFI of its own: its hot path is a sequence of stock torch ops inside
+ * src/spVIPES/module/spVIPESmodule.py and src/spVIPES/nn/networks.py.  Each entry point below
+ * names the reference lines whose arithmetic it replaces; spvipes_amd/_abi.py is the ctypes
+ * binding, INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless marked host; no allocation happens inside
+ *     (workspaces are passed in); every call only enqueues work on `stream`
+ *     (a hipStream_t passed as void*; NULL = the default stream) and returns immediately;
+ *   - return value: SPV_OK (0) or a negative SPV_ERR_*; spv_last_error() gives the text;
+ *   - thread-compatible, not thread-safe; no exceptions cross the ABI;
+ *   - "bf16" = raw 16-bit words (uint16_t).  Packed operand images are zero padded by
+ *     spv_pack_bf16 so that whole tiles are always in bounds;
+ *   - precision mode `nsplit`: 1 = bf16 operands, fp32 accumulate;
+ *                              3 = split-bf16 (hi/lo) operands, ~fp32 products ("fp32" mode).
+ */
+#ifndef SPVIPES_HIP_H
+#define SPVIPES_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPV_OK 0
+#define SPV_ERR_ARG (-1)
+#define SPV_ERR_LAUNCH (-2)
+#define SPV_ERR_UNSUPPORTED (-3)
+
+#define SPV_COUNT_F32 0
+#define SPV_COUNT_U16 1
+
+#define SPV_NB_CMAX 64      /* rows of the (count, gene) lgamma/digamma table         */
+#define SPV_DEC_KP 16       /* K slots of the private factor regressor (n_p + 1 <= 16) */
+#define SPV_DEC_KS 32       /* K slots of the shared factor regressor  (n_s + 1 <= 32) */
+#define SPV_DEC_CELLS_PER_WG 128
+
+int spv_version(void);
+const char* spv_last_error(void);
+
+/* Count matrix of one group: X[cell][gene], row-major, resident in HBM.
+ * rows == NULL means "cells 0..B-1"; otherwise cell b of the minibatch is row rows[b]
+ * (the AnnDataLoader row gather, dataloaders/_ann_dataloader.py, fused into the kernels).
+ * col_off selects the group's own genes inside an outer-joined matrix
+ * (x[:, groups_var_indices[g]], module/spVIPESmodule.py:428-430). */
+typedef struct spv_counts {
+  const void* X;
+  int64_t ld;       /* elements per row                    */
+  const int32_t* rows;
+  int32_t col_off;
+  int32_t dtype;    /* SPV_COUNT_F32 | SPV_COUNT_U16       */
+} spv_counts;
+
+/* fp32 [R][C] (+ one optional extra column: a per-row vector, or the constant 1) -> bf16 hi (and
+ * lo = bf16(x - hi) when dst_lo != NULL) image dst[Rp][ld_dst], written at column dst_col_off
+ * over `cslot` columns and `Rp` rows, zero filled outside the source. */
+int spv_pack_bf16(const float* src, int64_t ld_src, int32_t R, int32_t C,
+                  const float* extra_col, int32_t extra_one,
+                  uint16_t* dst_hi, uint16_t* dst_lo, int64_t ld_dst, int32_t dst_col_off,
+                  int32_t Rp, int32_t cslot, void* stream);
+
+/* A1 + first layer of both encoders of a group (module/spVIPESmodule.py:428-435,
+ * nn/networks.py:119):  h1 = relu(log1p(X[rows]) @ W1^T + b1) for the concatenated
+ * [private ; shared] fc1 (N1 = 2 * n_hidden output columns), library = log(sum_g log1p(x)).
+ *   W1_hi/lo : bf16 [N1p][ldw] (rows = output units, K = genes contiguous, ldw % 32 == 0)
+ *   slabs    : fp32 workspace [splits][B][N1];  rowsum_ws: fp32 [splits][B]
+ *   h1       : fp32 [B][N1];  library: fp32 [B] */
+int spv_enc_fc1_fwd(const spv_counts* x, int32_t B, int32_t G,
+                    const uint16_t* W1_hi, const uint16_t* W1_lo, int64_t ldw, int32_t N1,
+                    const float* bias, int32_t nsplit, int32_t splits,
+                    float* slabs, float* rowsum_ws, float* h1, float* library, void* stream);
+
+/* fc1 weight gradient (autograd of nn/networks.py:119):  dW1[N1][G] = dh^T @ log1p(X[rows]).
+ *   dh_hi/lo : bf16 [Bp32][ld_dh] (ld_dh >= round_up(N1,128), zero padded)  */
+int spv_enc_fc1_wgrad(const spv_counts* x, int32_t B, int32_t G,
+                      const uint16_t* dh_hi, const uint16_t* dh_lo, int64_t ld_dh, int32_t N1,
+                      int32_t nsplit, float* dW, int64_t ldc, void* stream);
+
+/* Plain bf16 MFMA GEMM, fp32 out:  C[M][N] (+)= sum_k A(m,k) B(k,n).
+ *   a_kmajor == 0: A is mem[m][k] (k contiguous); a_kmajor == 1: A is mem[k][m].
+ *   B is always k-major: mem[k][n].   Operands zero padded to tile multiples (64 x 320 / 128 x 32).
+ *   splits > 1: C is a stack of `splits` fp32 slabs (slab_stride elements apart), one per K range. */
+int spv_gemm_bf16(int32_t a_kmajor, const uint16_t* A_hi, const uint16_t* A_lo, int64_t lda,
+                  const uint16_t* B_hi, const uint16_t* B_lo, int64_t ldb,
+                  float* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
+                  int32_t nsplit, int32_t splits, int64_t slab_stride, void* stream);
+
+/* Decoder + NB-mixture likelihood (nn/networks.py:314-325, module/spVIPESmodule.py:758-759,
+ * :817-824).  Field meanings are documented in spvipes_amd/csrc/spv_decoder.h (DecParams has
+ * exactly this layout). */
+typedef struct spv_dec_params {
+  const void* X; int64_t ldx; const int32_t* rows; int32_t col_off; int32_t count_is_u16;
+  int32_t B, G, Bp, Gp;
+  const uint16_t* Wm_hi; const uint16_t* Wm_lo; int32_t KMp; int32_t ksteps_m;
+  const uint16_t* Am_hi; const uint16_t* Am_lo;
+  const uint16_t* Wps_hi; const uint16_t* Wps_lo;
+  const uint16_t* Aps_hi; const uint16_t* Aps_lo;
+  const void* gene_tab;      /* float4 [Gp]              */
+  const void* cnt_tab;       /* float2 [SPV_NB_CMAX][Gp] */
+  const float* a_p; const float* a_s; const float* lse_p; const float* lse_s;
+  const float* w_row;
+  int32_t gene_splits; int32_t genes_per_split;
+  float* part_max_p; float* part_sum_p; float* part_max_s; float* part_sum_s;
+  float* rec_part; float* tp_part; float* ts_part;
+  float* dtheta_part;
+  void* dL; void* tP; void* tS; int64_t ldg; int32_t grads_f32;
+} spv_dec_params;
+
+/* theta = exp(px_r) and the per-(count, gene) lgamma / digamma table (module/spVIPESmodule.py:758
+ * and the lgamma terms of scvi-tools' log_mixture_nb). */
+int spv_dec_tables(const float* px_r, int32_t G, int32_t Gp, void* gene_tab, void* cnt_tab, void* stream);
+
+/* softmax denominators of both rate heads; writes lse_p/lse_s and a_k = library - lse_k
+ * (the cast away of const on those four pointers is deliberate: they are this call's outputs). */
+int spv_dec_lse(const spv_dec_params* p, const float* library, void* stream);
+
+/* rec_part/tp_part/ts_part [gene_splits][Bp], dtheta_part [Bp/128][Gp]; when train != 0 also the
+ * per-element gradients dL, tP, tS [Bp][ldg] (bf16, or fp32 when grads_f32). nsplit: 1 | 3. */
+int spv_dec_nb_fwd(const spv_dec_params* p, int32_t nsplit, int32_t train, void* stream);
+
+/* in place: tP <- tP - softmax_p * Tp[b],  tS <- tS - softmax_s * Ts[b]  */
+int spv_dec_softmax_bwd(const spv_dec_params* p, const float* Tp, const float* Ts, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPVIPES_HIP_H */

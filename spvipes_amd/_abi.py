@@ -1,0 +1,104 @@
+"""ctypes binding of libspvipes_hip.so (C ABI: include/spvipes_hip.h).
+
+There is NO fallback: if the library is missing or a call fails, this raises.  Tensors are passed
+as raw device pointers; every call is enqueued on torch's current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libspvipes_hip.so")
+
+SPV_COUNT_F32, SPV_COUNT_U16 = 0, 1
+NB_CMAX, DEC_KP, DEC_KS, DEC_CELLS_PER_WG = 64, 16, 32, 128
+DEC_KPS = DEC_KP + DEC_KS
+
+
+class SpvCounts(C.Structure):
+    _fields_ = [("X", C.c_void_p), ("ld", C.c_int64), ("rows", C.c_void_p), ("col_off", C.c_int32), ("dtype", C.c_int32)]
+
+
+class SpvDecParams(C.Structure):
+    _fields_ = [
+        ("X", C.c_void_p), ("ldx", C.c_int64), ("rows", C.c_void_p), ("col_off", C.c_int32), ("count_is_u16", C.c_int32),
+        ("B", C.c_int32), ("G", C.c_int32), ("Bp", C.c_int32), ("Gp", C.c_int32),
+        ("Wm_hi", C.c_void_p), ("Wm_lo", C.c_void_p), ("KMp", C.c_int32), ("ksteps_m", C.c_int32),
+        ("Am_hi", C.c_void_p), ("Am_lo", C.c_void_p),
+        ("Wps_hi", C.c_void_p), ("Wps_lo", C.c_void_p), ("Aps_hi", C.c_void_p), ("Aps_lo", C.c_void_p),
+        ("gene_tab", C.c_void_p), ("cnt_tab", C.c_void_p),
+        ("a_p", C.c_void_p), ("a_s", C.c_void_p), ("lse_p", C.c_void_p), ("lse_s", C.c_void_p), ("w_row", C.c_void_p),
+        ("gene_splits", C.c_int32), ("genes_per_split", C.c_int32),
+        ("part_max_p", C.c_void_p), ("part_sum_p", C.c_void_p), ("part_max_s", C.c_void_p), ("part_sum_s", C.c_void_p),
+        ("rec_part", C.c_void_p), ("tp_part", C.c_void_p), ("ts_part", C.c_void_p), ("dtheta_part", C.c_void_p),
+        ("dL", C.c_void_p), ("tP", C.c_void_p), ("tS", C.c_void_p), ("ldg", C.c_int64), ("grads_f32", C.c_int32),
+    ]
+
+
+_SIGNATURES = {
+    "spv_version": (C.c_int, []),
+    "spv_last_error": (C.c_char_p, []),
+    "spv_pack_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "spv_enc_fc1_fwd": (C.c_int, [C.POINTER(SpvCounts), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                  C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "spv_enc_fc1_wgrad": (C.c_int, [C.POINTER(SpvCounts), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                    C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "spv_gemm_bf16": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
+    "spv_dec_tables": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "spv_dec_lse": (C.c_int, [C.POINTER(SpvDecParams), C.c_void_p, C.c_void_p]),
+    "spv_dec_nb_fwd": (C.c_int, [C.POINTER(SpvDecParams), C.c_int32, C.c_int32, C.c_void_p]),
+    "spv_dec_softmax_bwd": (C.c_int, [C.POINTER(SpvDecParams), C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+_lib = None
+
+
+class SpvError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the HIP library.  Raises if it has not been built -- there is no CPU path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SpvError(
+            f"{LIB_PATH} is missing: build it with `python -m spvipes_amd.build` (hipcc, gfx950). "
+            "spvipes_amd has no CPU or eager-PyTorch fallback for the hot path."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export the symbol
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().spv_last_error()
+        raise SpvError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise SpvError("spvipes_amd kernels need tensors resident in HBM (got a CPU tensor)")
+    return t.data_ptr()
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m

@@ -1,0 +1,288 @@
+// Tiled bf16 MFMA GEMM core shared by the encoder / decoder contractions.
+//
+//   C[m][n] (+)= sum_k A(m,k) * B(k,n)        fp32 accumulate, fp32 output
+//
+// Operand sources
+//   SRC_PLAIN : a bf16 image in HBM (optionally a hi/lo pair, NSPLIT == 3), zero padded by the
+//               producer so that every tile the grid touches is in bounds.
+//               natural  : mem[row][k]   (k contiguous)   -> 16-byte fragment reads from LDS
+//               k-major  : mem[k][col]   (col contiguous) -> ds_read_b64_tr_b16 fragment reads
+//   SRC_COUNTS: the resident count matrix X[cell][gene] (f32 or u16), rows gathered through an
+//               index vector, log1p applied in registers on the way to LDS (A1 of SURVEY.md 8a:
+//               module/spVIPESmodule.py:428-435).  As a natural A operand (m = cell, k = gene)
+//               it also produces the per-cell sum of log1p(x) (the library, :435).
+//               As a k-major B operand (k = cell, n = gene) it feeds the fc1 weight gradient.
+//
+// 256 threads = 4 waves arranged WM x WN; each wave owns (BM/WM) x (BN/WN) of the tile as TM x TN
+// MFMA 32x32 tiles.  BK = 32.  Global->register prefetch of tile t+1 overlaps the MFMAs of tile t
+// (register staging: the count operand has to pass through VALU for log1p anyway).
+#pragma once
+#include "spv_common.h"
+
+namespace spv {
+
+enum { SRC_PLAIN = 0, SRC_COUNTS = 1 };
+enum { EPI_STORE = 0, EPI_ATOMIC = 1 };
+
+struct GemmParams {
+  const void* A; const void* A_lo; long lda;
+  const void* B; const void* B_lo; long ldb;
+  const int* rows;   // gather index of the count operand's cells (nullable = identity)
+  int col_off;       // first gene column of this group inside the count matrix
+  int n_cells;       // logical number of cells (M for natural-A counts, K for k-major-B counts)
+  int n_genes;       // logical number of genes (K for natural-A counts, N for k-major-B counts)
+  float* rowsum;     // [splits][M] partial sums of log1p(x) (natural-A counts), nullable
+  float* C; long ldc; long slab_stride;
+  int M, N, K;
+  int k_per_split;   // multiple of 32
+  int epi;
+};
+
+__host__ __device__ constexpr int kmajor_pitch(int cols) {
+  // pitch (bf16 elements) whose dword count is 16 or 48 mod 64: the four k-rows a transposed
+  // read touches then fall on disjoint bank ranges (MI355X LDS: 64 banks for ds_read_b64_tr_b16)
+  int p = cols / 2;
+  while ((p % 64) != 16 && (p % 64) != 48) p += 4;
+  return p * 2;
+}
+constexpr int NAT_PITCH = 40;  // 32 k + 8 pad (80 B rows, 16-B aligned)
+
+template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ_, bool B_KMAJ_, int A_SRC_, int B_SRC_, typename CT_, int NSPLIT_>
+struct GemmCfg {
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BK = 32;
+  static constexpr bool A_KMAJ = A_KMAJ_, B_KMAJ = B_KMAJ_;
+  static constexpr int A_SRC = A_SRC_, B_SRC = B_SRC_, NSPLIT = NSPLIT_;
+  typedef CT_ CT;
+  static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  static constexpr int A_PITCH = A_KMAJ ? kmajor_pitch(BM) : NAT_PITCH;
+  static constexpr int B_PITCH = B_KMAJ ? kmajor_pitch(BN) : NAT_PITCH;
+  static constexpr int A_ELEMS = A_KMAJ ? BK * A_PITCH : BM * NAT_PITCH;
+  static constexpr int B_ELEMS = B_KMAJ ? BK * B_PITCH : BN * NAT_PITCH;
+  static constexpr int NIMG = (NSPLIT == 3) ? 2 : 1;
+  static constexpr int LDS_BYTES = (A_ELEMS + B_ELEMS) * NIMG * 2;
+  // 16-byte chunks each thread moves per tile
+  static constexpr int A_CHUNKS = (BM * BK / 8 + 255) / 256;
+  static constexpr int B_CHUNKS = (BN * BK / 8 + 255) / 256;
+  static_assert(WM * WN == 4, "4 waves");
+  static_assert(BM % (32 * WM) == 0 && BN % (32 * WN) == 0, "tile shape");
+};
+
+// ---- staging: one 16-byte chunk (8 bf16) of an operand tile ------------------
+// chunk c of a tile with `rows` x `cols8` chunks (cols8 = fast-dimension chunks per slow row)
+template <typename Cfg, bool KMAJ, int SRC, int EXT /*BM or BN*/>
+struct Stager {
+  static constexpr int FAST8 = KMAJ ? EXT / 8 : Cfg::BK / 8;   // chunks along the contiguous dim
+  static constexpr int SLOW = KMAJ ? Cfg::BK : EXT;            // rows of the LDS image
+  static constexpr int NCH = (SLOW * FAST8 + 255) / 256;
+  static constexpr int PITCH = KMAJ ? kmajor_pitch(EXT) : NAT_PITCH;
+  // per-chunk register payload
+  u4v hi[NCH], lo[NCH];
+  float csum[NCH];
+
+  // slow/fast coordinates of chunk i for this thread
+  __device__ __forceinline__ static void coord(int i, int tid, int& s, int& f, bool& ok) {
+    const int c = tid + 256 * i;
+    ok = c < SLOW * FAST8;
+    s = c / FAST8;
+    f = c % FAST8;
+  }
+
+  // tile origin: `ext0` along the M/N dimension, `k0` along K
+  __device__ __forceinline__ void load(const GemmParams& p, const void* ptr, const void* ptr_lo, long ld, int ext0, int k0, int tid) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      int s, f; bool ok;
+      coord(i, tid, s, f, ok);
+      hi[i] = u4v{0u, 0u, 0u, 0u};
+      lo[i] = u4v{0u, 0u, 0u, 0u};
+      csum[i] = 0.f;
+      if (!ok) continue;
+      if constexpr (SRC == SRC_PLAIN) {
+        // natural: mem[ext0 + s][k0 + 8f]; k-major: mem[k0 + s][ext0 + 8f]; producer-padded
+        const long off = KMAJ ? (long)(k0 + s) * ld + ext0 + 8 * f : (long)(ext0 + s) * ld + k0 + 8 * f;
+        hi[i] = *reinterpret_cast<const u4v*>(reinterpret_cast<const bf16_t*>(ptr) + off);
+        if constexpr (Cfg::NSPLIT == 3) lo[i] = *reinterpret_cast<const u4v*>(reinterpret_cast<const bf16_t*>(ptr_lo) + off);
+      } else {
+        // counts: slow index = cell, fast index = gene
+        const int cell = KMAJ ? k0 + s : ext0 + s;
+        const int gene = KMAJ ? ext0 + 8 * f : k0 + 8 * f;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        if (cell < p.n_cells && gene < p.n_genes) {
+          const long row = p.rows ? (long)p.rows[cell] : (long)cell;
+          const typename Cfg::CT* src = reinterpret_cast<const typename Cfg::CT*>(ptr) + row * ld + p.col_off + gene;
+          const bool full = gene + 8 <= p.n_genes;
+          const bool aligned = ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+          if (full && aligned) {
+            if constexpr (sizeof(typename Cfg::CT) == 2) {
+              u4v raw = *reinterpret_cast<const u4v*>(src);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                v[2 * j] = (float)(raw[j] & 0xFFFFu);
+                v[2 * j + 1] = (float)(raw[j] >> 16);
+              }
+            } else {
+              f4v r0 = *reinterpret_cast<const f4v*>(src);
+              f4v r1 = *reinterpret_cast<const f4v*>(src + 4);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { v[j] = r0[j]; v[4 + j] = r1[j]; }
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (gene + j < p.n_genes) v[j] = count_to_float<typename Cfg::CT>(src[j]);
+          }
+        }
+        float sum = 0.f;
+        unsigned hw[4], lw[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float x0 = log1p_count(v[2 * j]), x1 = log1p_count(v[2 * j + 1]);
+          sum += x0 + x1;
+          bf16_t h0, l0, h1, l1;
+          split_bf16(x0, h0, l0);
+          split_bf16(x1, h1, l1);
+          hw[j] = (unsigned)h0 | ((unsigned)h1 << 16);
+          lw[j] = (unsigned)l0 | ((unsigned)l1 << 16);
+        }
+        hi[i] = u4v{hw[0], hw[1], hw[2], hw[3]};
+        if constexpr (Cfg::NSPLIT == 3) lo[i] = u4v{lw[0], lw[1], lw[2], lw[3]};
+        csum[i] = sum;
+      }
+    }
+  }
+
+  __device__ __forceinline__ void store(bf16_t* img_hi, bf16_t* img_lo, int tid) const {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      int s, f; bool ok;
+      coord(i, tid, s, f, ok);
+      if (!ok) continue;
+      *reinterpret_cast<u4v*>(img_hi + s * PITCH + 8 * f) = hi[i];
+      if constexpr (Cfg::NSPLIT == 3) *reinterpret_cast<u4v*>(img_lo + s * PITCH + 8 * f) = lo[i];
+    }
+  }
+};
+
+template <typename Cfg>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* sA = reinterpret_cast<bf16_t*>(smem_raw);
+  bf16_t* sA_lo = sA + Cfg::A_ELEMS * (Cfg::NIMG - 1);
+  bf16_t* sB = sA + Cfg::A_ELEMS * Cfg::NIMG;
+  bf16_t* sB_lo = sB + Cfg::B_ELEMS * (Cfg::NIMG - 1);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  const int m0 = blockIdx.x * Cfg::BM, n0 = blockIdx.y * Cfg::BN;
+  const int split = blockIdx.z;
+  const int kbeg = split * p.k_per_split;
+  int kend = kbeg + p.k_per_split;
+  const int Kpad = (p.K + 31) & ~31;
+  if (kend > Kpad) kend = Kpad;
+
+  f16v acc[Cfg::TM][Cfg::TN];
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  Stager<Cfg, Cfg::A_KMAJ, Cfg::A_SRC, Cfg::BM> stA;
+  Stager<Cfg, Cfg::B_KMAJ, Cfg::B_SRC, Cfg::BN> stB;
+  float rowsum_acc[Stager<Cfg, Cfg::A_KMAJ, Cfg::A_SRC, Cfg::BM>::NCH];
+#pragma unroll
+  for (int i = 0; i < stA.NCH; ++i) rowsum_acc[i] = 0.f;
+
+  if (kbeg < kend) {
+    stA.load(p, p.A, p.A_lo, p.lda, m0, kbeg, tid);
+    stB.load(p, p.B, p.B_lo, p.ldb, n0, kbeg, tid);
+  }
+  for (int k0 = kbeg; k0 < kend; k0 += Cfg::BK) {
+    __syncthreads();  // previous tile's fragment reads are done
+    stA.store(sA, sA_lo, tid);
+    stB.store(sB, sB_lo, tid);
+    if constexpr (Cfg::A_SRC == SRC_COUNTS && !Cfg::A_KMAJ) {
+#pragma unroll
+      for (int i = 0; i < stA.NCH; ++i) rowsum_acc[i] += stA.csum[i];
+    }
+    __syncthreads();
+    if (k0 + Cfg::BK < kend) {  // prefetch the next tile into registers; lands under the MFMAs
+      stA.load(p, p.A, p.A_lo, p.lda, m0, k0 + Cfg::BK, tid);
+      stB.load(p, p.B, p.B_lo, p.ldb, n0, k0 + Cfg::BK, tid);
+    }
+#pragma unroll
+    for (int ks = 0; ks < Cfg::BK; ks += 16) {
+      s8v a_hi[Cfg::TM], a_lo[Cfg::TM];
+#pragma unroll
+      for (int i = 0; i < Cfg::TM; ++i) {
+        const int r0 = wm * (Cfg::BM / Cfg::WM) + 32 * i;
+        if constexpr (Cfg::A_KMAJ) {
+          a_hi[i] = frag_kmajor(sA, Cfg::A_PITCH, r0, ks, lane);
+          if constexpr (Cfg::NSPLIT == 3) a_lo[i] = frag_kmajor(sA_lo, Cfg::A_PITCH, r0, ks, lane);
+        } else {
+          a_hi[i] = frag_natural(sA, Cfg::A_PITCH, r0, ks, lane);
+          if constexpr (Cfg::NSPLIT == 3) a_lo[i] = frag_natural(sA_lo, Cfg::A_PITCH, r0, ks, lane);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j) {
+        const int c0 = wn * (Cfg::BN / Cfg::WN) + 32 * j;
+        s8v b_hi, b_lo;
+        if constexpr (Cfg::B_KMAJ) {
+          b_hi = frag_kmajor(sB, Cfg::B_PITCH, c0, ks, lane);
+          if constexpr (Cfg::NSPLIT == 3) b_lo = frag_kmajor(sB_lo, Cfg::B_PITCH, c0, ks, lane);
+        } else {
+          b_hi = frag_natural(sB, Cfg::B_PITCH, c0, ks, lane);
+          if constexpr (Cfg::NSPLIT == 3) b_lo = frag_natural(sB_lo, Cfg::B_PITCH, c0, ks, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < Cfg::TM; ++i) acc[i][j] = mfma32_split<Cfg::NSPLIT>(a_hi[i], a_lo[i], b_hi, b_lo, acc[i][j]);
+      }
+    }
+  }
+
+  // ---- epilogue ---------------------------------------------------------------
+  float* C = p.C + (long)split * p.slab_stride;
+  const int h = lane >> 5, r = lane & 31;
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) {
+      const int col = n0 + wn * (Cfg::BN / Cfg::WN) + 32 * j + r;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = m0 + wm * (Cfg::BM / Cfg::WM) + 32 * i + crow(q, h);
+        if (row < p.M && col < p.N) {
+          float* dst = C + (long)row * p.ldc + col;
+          if (p.epi == EPI_ATOMIC) atomicAdd(dst, acc[i][j][q]);
+          else *dst = acc[i][j][q];
+        }
+      }
+    }
+  if constexpr (Cfg::A_SRC == SRC_COUNTS && !Cfg::A_KMAJ) {
+    // per-cell sum of log1p(x): the 4 threads of a row hold disjoint 8-gene chunks
+    if (p.rowsum != nullptr && blockIdx.y == 0) {
+#pragma unroll
+      for (int i = 0; i < stA.NCH; ++i) {
+        float v = rowsum_acc[i];
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        int s, f; bool ok;
+        stA.coord(i, tid, s, f, ok);
+        if (ok && f == 0 && m0 + s < p.M) p.rowsum[(long)split * p.M + m0 + s] = v;
+      }
+    }
+  }
+}
+
+template <typename Cfg>
+inline int launch_gemm(const GemmParams& p, int splits, hipStream_t stream) {
+  dim3 grid((p.M + Cfg::BM - 1) / Cfg::BM, (p.N + Cfg::BN - 1) / Cfg::BN, splits);
+  hipLaunchKernelGGL(gemm_kernel<Cfg>, grid, dim3(256), Cfg::LDS_BYTES, stream, p);
+  return hipGetLastError() == hipSuccess ? SPV_OK : SPV_ERR_LAUNCH;
+}
+
+}  // namespace spv

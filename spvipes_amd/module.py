@@ -1,0 +1,388 @@
+"""HIP-backed ``spVIPESmodule``: the reference's module protocol for the per-minibatch VAE step.
+
+Mirrors /root/reference/src/spVIPES/module/spVIPESmodule.py (scvi ``BaseModuleClass`` protocol):
+``_get_inference_input`` (:381) -> ``inference`` (:425) -> ``_get_generative_input`` (:407) ->
+``generative`` (:720) -> ``loss`` (:809), same argument meaning, dict key order and error
+behaviour, same parameter names (``encoder_{g}_{shared,private}.*``, ``decoder_{g}.*``,
+``px_r.{g}``: :118-120,:172-175) so a reference ``state_dict`` loads unchanged.
+
+The heavy arithmetic runs in hand-written HIP kernels (spvipes_amd/ops.py -> libspvipes_hip.so):
+count slicing + log1p + library + both encoders' first layer, and the whole decoder + NB-mixture
+likelihood with its backward.  PyTorch carries the [B, <=256] glue between them and autograd.
+Deliberately NOT reproduced: the reference's per-cell Python loops and host round trips
+(:685-701, :476-480, :817) -- the same results are computed on device in closed form.
+
+Inputs.  ``tensors_by_group`` is a sequence (one entry per group) of dicts.  Either the
+reference's layout -- ``"X"`` float32 [B, sum G] in HBM, of which only the group's own columns
+``groups_var_indices[g]`` are read -- or the resident layout this build adds for its own train
+loop: ``"counts"`` (``ops.GroupCounts``) + ``"rows"`` (int32 [B] cell indices), which fuses the
+data loader's row gather into the kernels.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _abi
+from .ops import N_HIDDEN_MIX, DecoderNBLoss, EncoderFC1, GroupCounts, Workspace
+
+X_KEY, BATCH_KEY = "X", "batch"  # scvi.REGISTRY_KEYS.X_KEY / BATCH_KEY
+
+
+@dataclass
+class LossOutput:
+    """Same fields as scvi.module.base.LossOutput as used at spVIPESmodule.py:895-897."""
+
+    loss: torch.Tensor
+    reconstruction_loss: Optional[dict] = None
+    kl_local: Optional[dict] = None
+    kl_global: Optional[torch.Tensor] = None
+    extra_metrics: dict = field(default_factory=dict)
+
+
+# ---- parameter containers with the reference's state_dict layout ---------------------------------
+class Encoder(nn.Module):
+    """Parameters of nn/networks.py:47-83 (forward lives in spVIPESmodule.inference)."""
+
+    def __init__(self, n_input: int, n_topics: int, hidden: int, dropout: float):
+        super().__init__()
+        self.n_topics, self.dropout = n_topics, dropout
+        self.fc1 = nn.Linear(n_input, hidden)
+        self.fc2 = nn.Linear(hidden, hidden)
+        self.mu_encoder = nn.Sequential(nn.Linear(hidden, n_topics, bias=True), nn.BatchNorm1d(n_topics))
+        self.lvar_encoder = nn.Sequential(nn.Linear(hidden, n_topics, bias=True), nn.BatchNorm1d(n_topics))
+
+
+class _FC1(nn.Module):
+    """scvi FCLayers with n_layers=1: fc_layers = Sequential{"Layer 0": Sequential(Linear[, BatchNorm1d(eps=1e-3, momentum=0.01)])}."""
+
+    def __init__(self, n_in: int, n_out: int, bias: bool, batch_norm: bool):
+        super().__init__()
+        mods: List[nn.Module] = [nn.Linear(n_in, n_out, bias=bias)]
+        if batch_norm:
+            mods.append(nn.BatchNorm1d(n_out, momentum=0.01, eps=0.001))
+        self.fc_layers = nn.Sequential(OrderedDict([("Layer 0", nn.Sequential(*mods))]))
+
+    @property
+    def linear(self) -> nn.Linear:
+        return self.fc_layers[0][0]
+
+    @property
+    def bn(self) -> nn.BatchNorm1d:
+        return self.fc_layers[0][1]
+
+
+class LinearDecoderSPVIPE(nn.Module):
+    """Parameters of nn/networks.py:185-262."""
+
+    def __init__(self, n_input_private: int, n_input_shared: int, n_output: int, n_hidden: int = N_HIDDEN_MIX):
+        super().__init__()
+        self.factor_regressor_private = _FC1(n_input_private, n_output, bias=False, batch_norm=True)
+        self.factor_regressor_shared = _FC1(n_input_shared, n_output, bias=False, batch_norm=True)
+        self.sigmoid_decoder = _FC1(n_input_shared + n_input_private, n_hidden, bias=True, batch_norm=True)
+        self.mixture = _FC1(n_hidden + n_input_shared + n_input_private, n_output, bias=True, batch_norm=False)
+
+
+class LazyNBMixture:
+    """What ``generative`` hands to ``loss`` in place of scvi's NegativeBinomialMixture: the decoder
+    inputs; the likelihood itself is evaluated by the fused HIP kernel inside ``loss``."""
+
+    def __init__(self, group: int, z_private, z_shared, library):
+        self.group, self.z_private, self.z_shared, self.library = group, z_private, z_shared, library
+
+
+def _fold_bn_linear(z: torch.Tensor, lin: nn.Linear, bn: nn.BatchNorm1d, training: bool):
+    """BatchNorm1d(z @ W^T) == z @ W'^T + c.  In training mode the batch mean / (biased) variance of
+    column g of z W^T are W_g . mean(z) and W_g^T cov(z) W_g, so no [B, G] tensor is formed; the
+    running statistics get torch's update (unbiased variance, bn.momentum)."""
+    W = lin.weight
+    if training:
+        B = z.shape[0]
+        zbar = z.mean(0)
+        zc = z - zbar
+        cov = zc.t() @ zc / B
+        mean = W @ zbar
+        var = ((W @ cov) * W).sum(1)
+        with torch.no_grad():
+            mom = bn.momentum
+            bn.running_mean.mul_(1 - mom).add_(mom * mean)
+            bn.running_var.mul_(1 - mom).add_(mom * var * (B / max(B - 1, 1)))
+            bn.num_batches_tracked += 1
+    else:
+        mean, var = bn.running_mean, bn.running_var
+    inv = bn.weight * torch.rsqrt(var + bn.eps)
+    return W * inv[:, None], bn.bias - mean * inv
+
+
+class spVIPESmodule(nn.Module):
+    """See the module docstring.  Constructor arguments as spVIPESmodule.py:74-95; ``precision`` is
+    this build's knob: "bf16" (bf16 MFMA operands, fp32 accumulate) or "fp32" (split-bf16 operands)."""
+
+    def __init__(
+        self,
+        groups_lengths,
+        groups_obs_names=None,
+        groups_var_names=None,
+        groups_obs_indices=None,
+        groups_var_indices=None,
+        transport_plan: Optional[torch.Tensor] = None,
+        pair_data: bool = False,
+        use_labels: bool = False,
+        n_labels: Optional[int] = None,
+        n_batch: int = 0,
+        n_hidden: int = 128,
+        n_dimensions_shared: int = 25,
+        n_dimensions_private: int = 10,
+        dropout_rate: float = 0.1,
+        use_batch_norm: bool = True,
+        use_layer_norm: bool = False,
+        log_variational_inference: bool = True,
+        log_variational_generative: bool = True,
+        dispersion: str = "gene",
+        precision: str = "bf16",
+    ):
+        super().__init__()
+        if n_batch > 1:
+            raise NotImplementedError("batch covariates (n_batch > 1) are outside the accelerated path")
+        if not (log_variational_inference and log_variational_generative):
+            raise NotImplementedError("the fused kernels implement the reference defaults log_variational_*=True")
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        lengths = list(groups_lengths.values()) if isinstance(groups_lengths, dict) else list(groups_lengths)
+        if len(lengths) != 2:
+            raise ValueError(f"Number of groups is {len(lengths)}, the only supported value is 2")
+        self.n_dimensions_shared, self.n_dimensions_private = n_dimensions_shared, n_dimensions_private
+        self.n_batch, self.n_hidden, self.dropout_rate = n_batch, n_hidden, dropout_rate
+        self.input_dims = {i: g for i, g in enumerate(lengths)}
+        self.groups_barcodes, self.groups_genes = groups_obs_names, groups_var_names
+        self.groups_obs_indices = groups_obs_indices
+        if groups_var_indices is None:
+            offs = np.concatenate([[0], np.cumsum(lengths)])
+            groups_var_indices = [np.arange(offs[i], offs[i + 1]) for i in range(2)]
+        self.groups_var_indices = [np.asarray(v) for v in groups_var_indices]
+        self.dispersion, self.precision = dispersion, precision
+        self.use_batch_norm, self.use_layer_norm = use_batch_norm, use_layer_norm
+        self.px_r = nn.ParameterList([nn.Parameter(torch.randn(g)) for g in lengths])
+        self.encoders, self.decoders = {}, {}
+        for g, G in self.input_dims.items():
+            enc = {
+                "shared": Encoder(G, n_dimensions_shared, n_hidden, dropout_rate),
+                "private": Encoder(G, n_dimensions_private, n_hidden, dropout_rate),
+            }
+            dec = LinearDecoderSPVIPE(n_dimensions_private, n_dimensions_shared, G)
+            self.encoders[g], self.decoders[g] = enc, dec
+            self.add_module(f"encoder_{g}_shared", enc["shared"])
+            self.add_module(f"encoder_{g}_private", enc["private"])
+            self.add_module(f"decoder_{g}", dec)
+        self.use_transport_plan = transport_plan is not None
+        self.transport_plan = transport_plan
+        self.use_labels, self.n_labels, self.pair_data = use_labels, n_labels, pair_data
+        self._ws: Dict[int, Workspace] = {}
+
+    # ---- helpers -----------------------------------------------------------------------------
+    @property
+    def nsplit(self) -> int:
+        return 3 if self.precision == "fp32" else 1
+
+    def _workspace(self, g: int, device) -> Workspace:
+        ws = self._ws.get(g)
+        if ws is None or ws.device != device:
+            ws = self._ws[g] = Workspace(device)
+        return ws
+
+    def _counts_of(self, g: int, group: dict):
+        """(GroupCounts, rows, B) for one group's minibatch in either input layout."""
+        if "counts" in group:
+            rows = group["rows"]
+            return group["counts"], rows, int(rows.numel())
+        X = group[X_KEY]
+        if not X.is_cuda:
+            raise _abi.SpvError("spvipes_amd runs on the GPU only: move the minibatch to HBM (no CPU fallback)")
+        idx = self.groups_var_indices[g]
+        if len(idx) != self.input_dims[g]:
+            raise ValueError("groups_var_indices does not match groups_lengths")
+        X = X.float().contiguous()
+        if len(idx) and np.array_equal(idx, np.arange(idx[0], idx[0] + len(idx))):
+            return GroupCounts(X, len(idx), int(idx[0])), None, X.shape[0]
+        sel = X.index_select(1, torch.as_tensor(idx, device=X.device)).contiguous()
+        return GroupCounts(sel, len(idx), 0), None, X.shape[0]
+
+    # ---- protocol ----------------------------------------------------------------------------
+    def _get_inference_input(self, tensors_by_group):
+        x = {i: group for i, group in enumerate(tensors_by_group)}
+        batch_index = [group.get(BATCH_KEY) for group in tensors_by_group]
+        groups = [group.get("groups") for group in tensors_by_group]
+        global_indices = [group.get("indices") for group in tensors_by_group]
+        input_dict = {"x": x, "batch_index": batch_index, "groups": groups, "global_indices": global_indices}
+        if self.use_transport_plan and not self.pair_data:
+            required_key = "processed_transport_labels"
+            if required_key not in tensors_by_group[0]:
+                raise ValueError(f"{required_key} are required when using transport plan.")
+            input_dict["processed_labels"] = [group[required_key] for group in tensors_by_group]
+        if self.use_labels:
+            if "labels" not in tensors_by_group[0]:
+                raise ValueError("Labels are required when using label-based POE.")
+            input_dict["labels"] = [group["labels"].flatten() for group in tensors_by_group]
+        return input_dict
+
+    def _get_generative_input(self, tensors_by_group, inference_outputs):
+        return {
+            "private_stats": inference_outputs["private_stats"],
+            "shared_stats": inference_outputs["shared_stats"],
+            "poe_stats": inference_outputs["poe_stats"],
+            "library": inference_outputs["library"],
+            "groups": [group.get("groups") for group in tensors_by_group],
+            "batch_index": [group.get(BATCH_KEY) for group in tensors_by_group],
+        }
+
+    def _encoder_tail(self, enc: Encoder, h1: torch.Tensor, eps: torch.Tensor, drop_mask):
+        """nn/networks.py:120-129 after fc1: fc2+relu, dropout, BN'd heads, reparameterised draw."""
+        h = F.relu(enc.fc2(h1))
+        if self.training and enc.dropout > 0:
+            if drop_mask is None:
+                h = F.dropout(h, enc.dropout, True)
+            else:
+                h = h * drop_mask / (1.0 - enc.dropout)
+        loc = enc.mu_encoder(h)
+        logvar = enc.lvar_encoder(h)
+        scale = (0.5 * logvar).exp()
+        log_z = loc + scale * eps
+        return OrderedDict([
+            ("logtheta_loc", loc), ("logtheta_logvar", logvar), ("logtheta_scale", scale),
+            ("log_z", log_z), ("theta", F.softmax(log_z, -1)), ("qz", torch.distributions.Normal(loc, scale)),
+        ])
+
+    def inference(self, x, batch_index, groups, global_indices, noise: Optional[dict] = None,
+                  dropout_masks: Optional[dict] = None, **kwargs):
+        """Runs the encoders and the PoE (spVIPESmodule.py:425-472).  ``noise`` optionally injects the
+        standard-normal draws ("enc_{g}_private", "enc_{g}_shared", "poe_{g}") for parity tests."""
+        from . import poe as P
+
+        noise = noise or {}
+        private_stats, shared_stats, library = {}, {}, {}
+        self._step_inputs = {}
+        for g, group in x.items():
+            counts, rows, B = self._counts_of(g, group)
+            self._step_inputs[g] = (counts, rows, B)
+            ep, es = self.encoders[g]["private"], self.encoders[g]["shared"]
+            ws = self._workspace(g, counts.X.device)
+            h1, lib = EncoderFC1.apply(counts, rows, B, ep.fc1.weight, ep.fc1.bias, es.fc1.weight, es.fc1.bias, self.nsplit, ws)
+            H = self.n_hidden
+            dev = h1.device
+            e_p = noise.get(f"enc_{g}_private")
+            e_s = noise.get(f"enc_{g}_shared")
+            e_p = torch.randn(B, self.n_dimensions_private, device=dev) if e_p is None else e_p
+            e_s = torch.randn(B, self.n_dimensions_shared, device=dev) if e_s is None else e_s
+            dm = dropout_masks or {}
+            private_stats[g] = self._encoder_tail(ep, h1[:, :H], e_p, dm.get(f"enc_{g}_private"))
+            shared_stats[g] = self._encoder_tail(es, h1[:, H:], e_s, dm.get(f"enc_{g}_shared"))
+            library[g] = lib.unsqueeze(1)
+
+        labels = processed_labels = None
+        if self.use_labels and "labels" in kwargs:
+            labels = dict(enumerate(kwargs["labels"]))
+        if self.use_transport_plan and not self.pair_data:
+            processed_labels = kwargs.get("processed_labels")
+        poe_stats = self._supervised_poe(shared_stats, global_indices, processed_labels, labels, noise, P)
+        return {"private_stats": private_stats, "shared_stats": shared_stats, "poe_stats": poe_stats, "library": library}
+
+    def _supervised_poe(self, shared_stats, global_indices, processed_labels, labels, noise, P):
+        """Dispatch of spVIPESmodule.py:484-509 (same priorities and errors)."""
+        if self.use_labels and labels is not None:
+            return P.label_based_poe(shared_stats, labels, noise)
+        elif self.use_transport_plan:
+            plan_block = P.batch_transport_plan(self.transport_plan, global_indices)
+            if self.pair_data:
+                return P.paired_poe(shared_stats, plan_block, noise)
+            if processed_labels is None:
+                raise ValueError("Processed labels are required when using transport plan.")
+            return P.cluster_based_poe(shared_stats, plan_block, processed_labels, noise)
+        raise ValueError("Either transport plan or labels must be provided for supervised POE.")
+
+    def generative(self, private_stats, shared_stats, poe_stats, library, groups, batch_index):
+        """spVIPESmodule.py:720-771: latent concatenation + slicing quirk; the decoder itself is
+        evaluated (fused with the likelihood) in ``loss``."""
+        if (len(private_stats.items()) > 2) or (len(shared_stats.items()) > 2):
+            raise ValueError(
+                f"Number of groups passed to `generative` is shared:{len(shared_stats.keys())}, private:{len(private_stats.keys())}, the only supported value is 2"
+            )
+        n_s, n_p = self.n_dimensions_shared, self.n_dimensions_private
+        out = {}
+        for g in (0, 1):
+            log_z = torch.cat((private_stats[g]["log_z"], poe_stats[g]["logtheta_log_z"]), dim=-1)  # :733,:737
+            z_private, z_shared = log_z[:, n_s: n_p + n_s], log_z[:, :n_s]  # :753-754
+            out[str(g)] = {
+                "px": LazyNBMixture(g, z_private, z_shared, library[g]),
+                "pz": torch.distributions.Normal(torch.zeros_like(log_z), torch.ones_like(log_z)),
+            }
+        return {"private_shared": {}, "private_poe": out}
+
+    def _reconstruction(self, g: int, px: LazyNBMixture, w_row: torch.Tensor):
+        """-sum_g log NBMixture for group g through the fused HIP decoder/likelihood kernels."""
+        dec = self.decoders[g]
+        counts, rows, B = self._step_inputs[g]
+        zp, zs = px.z_private, px.z_shared
+        Wp, cp = _fold_bn_linear(zp, dec.factor_regressor_private.linear, dec.factor_regressor_private.bn, self.training)
+        Ws, cs = _fold_bn_linear(zs, dec.factor_regressor_shared.linear, dec.factor_regressor_shared.bn, self.training)
+        zcat = torch.cat([zp, zs], dim=1)  # nn/networks.py:322
+        m = F.relu(dec.sigmoid_decoder.bn(dec.sigmoid_decoder.linear(zcat)))
+        mix = dec.mixture.linear
+        train = torch.is_grad_enabled()
+        return DecoderNBLoss.apply(counts, rows, B, zp, zs, m, Wp, cp, Ws, cs, mix.weight, mix.bias, self.px_r[g],
+                                   px.library.flatten(), w_row, self.nsplit, train, self._workspace(g, zp.device))
+
+    def loss(self, tensors_by_group, inference_outputs, generative_outputs, kl_weight: float = 1.0):
+        """spVIPESmodule.py:809-899."""
+        from .poe import kl_normal_std
+
+        B0, B1 = self._step_inputs[0][2], self._step_inputs[1][2]
+        if B0 != B1:
+            raise RuntimeError(f"The size of tensor a ({B0}) must match the size of tensor b ({B1}) at non-singleton dimension 0")
+        dev = inference_outputs["library"][0].device
+        w = torch.full((B0,), 1.0 / B0, device=dev)
+        rec_sum, rec = [], []
+        for g in (0, 1):
+            s, r = self._reconstruction(g, generative_outputs["private_poe"][str(g)]["px"], w)
+            rec_sum.append(s)
+            rec.append(r)
+        pr, po = inference_outputs["private_stats"], inference_outputs["poe_stats"]
+        kl_p = [kl_normal_std(pr[g]["logtheta_loc"], pr[g]["logtheta_scale"]) for g in (0, 1)]
+        kl_q = [kl_normal_std(po[g]["logtheta_loc"], po[g]["logtheta_qz"].scale) for g in (0, 1)]
+        loss = rec_sum[0] + rec_sum[1] + torch.mean(kl_weight * kl_p[0] + kl_weight * kl_q[0] + kl_weight * kl_p[1] + kl_weight * kl_q[1])
+        return LossOutput(
+            loss=loss,
+            reconstruction_loss={"reconst_loss_groups_1_poe": rec[0], "reconst_loss_groups_2_poe": rec[1]},
+            kl_local={
+                "kl_divergence_groups_1_private": kl_p[0], "kl_divergence_groups_1_poe": kl_q[0],
+                "kl_divergence_groups_2_private": kl_p[1], "kl_divergence_groups_2_poe": kl_q[1],
+            },
+            extra_metrics={
+                "kl_divergence_private_groups_1": kl_p[0].mean(), "kl_divergence_poe_groups_1": kl_q[0].mean(),
+                "kl_divergence_private_groups_2": kl_p[1].mean(), "kl_divergence_poe_groups_2": kl_q[1].mean(),
+            },
+        )
+
+    def forward(self, tensors, inference_kwargs=None, generative_kwargs=None, loss_kwargs=None, compute_loss=True):
+        """scvi BaseModuleClass.forward: inference -> generative -> loss."""
+        inference_inputs = self._get_inference_input(tensors)
+        inference_outputs = self.inference(**inference_inputs, **(inference_kwargs or {}))
+        generative_inputs = self._get_generative_input(tensors, inference_outputs)
+        generative_outputs = self.generative(**generative_inputs, **(generative_kwargs or {}))
+        if compute_loss:
+            return inference_outputs, generative_outputs, self.loss(tensors, inference_outputs, generative_outputs, **(loss_kwargs or {}))
+        return inference_outputs, generative_outputs
+
+    @torch.inference_mode()
+    def get_loadings(self, dataset: int, type_latent: str) -> np.ndarray:
+        """spVIPESmodule.py:773-807: diag(gamma / sqrt(running_var + eps)) @ W of a factor regressor."""
+        if type_latent not in ["shared", "private"]:
+            raise ValueError(f"Invalid value for type_latent: {type_latent}. It can only be 'shared' or 'private'")
+        reg = getattr(self.decoders[dataset], f"factor_regressor_{type_latent}")
+        b = reg.bn.weight / torch.sqrt(reg.bn.running_var + reg.bn.eps)
+        return (b[:, None] * reg.linear.weight).detach().cpu().numpy()

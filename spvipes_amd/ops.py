@@ -1,0 +1,290 @@
+"""Host side of the HIP hot path: operand packing, workspaces and autograd wrappers.
+
+Every function here calls into libspvipes_hip.so through the C ABI (spvipes_amd/_abi.py).  There
+is no CPU / eager-PyTorch implementation of these ops in this package: if the library is missing
+or a tensor is not resident on the GPU the call raises.
+
+Reference arithmetic replaced (file:line into /root/reference/src/spVIPES):
+    EncoderFC1      module/spVIPESmodule.py:428-435 (slice, log1p, library) + nn/networks.py:119 (fc1+relu)
+    DecoderNBLoss   nn/networks.py:314-325 (rates, mixing logits) + module/spVIPESmodule.py:758-759,817-824
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _abi
+from ._abi import DEC_CELLS_PER_WG, DEC_KP, DEC_KPS, DEC_KS, NB_CMAX, SpvCounts, SpvDecParams, check, ptr, round_up, stream_ptr
+
+N_HIDDEN_MIX = 256  # LinearDecoderSPVIPE's own n_hidden default (nn/networks.py:194)
+
+
+@dataclass
+class GroupCounts:
+    """Count matrix of one group resident in HBM: X[cell][ld] (float32 or uint16 bit patterns),
+    the group's own genes are columns [col_off, col_off + G)."""
+
+    X: torch.Tensor
+    G: int
+    col_off: int = 0
+
+    def __post_init__(self):
+        if not self.X.is_cuda or self.X.dim() != 2 or not self.X.is_contiguous():
+            raise _abi.SpvError("GroupCounts needs a contiguous 2-D tensor resident in HBM")
+        if self.X.dtype == torch.float32:
+            self.dtype = _abi.SPV_COUNT_F32
+        elif self.X.dtype in (torch.int16, torch.uint16):
+            self.dtype = _abi.SPV_COUNT_U16
+        else:
+            raise _abi.SpvError(f"unsupported count dtype {self.X.dtype} (float32 or uint16)")
+        if self.col_off < 0 or self.col_off + self.G > self.X.shape[1]:
+            raise _abi.SpvError("gene column range outside the count matrix")
+
+    @property
+    def n_cells(self) -> int:
+        return self.X.shape[0]
+
+    def c_struct(self, rows: Optional[torch.Tensor]) -> SpvCounts:
+        if rows is not None and (rows.dtype != torch.int32 or not rows.is_cuda or not rows.is_contiguous()):
+            raise _abi.SpvError("row index must be a contiguous int32 tensor in HBM")
+        return SpvCounts(ptr(self.X), self.X.shape[1], ptr(rows), self.col_off, self.dtype)
+
+
+class Workspace:
+    """Named device buffers reused across steps (no allocation on the hot path after warm-up).
+    Buffers that kernels rely on being zero outside the written region are created zero-filled."""
+
+    def __init__(self, device):
+        self.device = device
+        self._buf: Dict[Tuple, torch.Tensor] = {}
+
+    def get(self, name: str, shape, dtype, zero: bool = False) -> torch.Tensor:
+        key = (name, tuple(shape), dtype)
+        t = self._buf.get(key)
+        if t is None:
+            t = (torch.zeros if zero else torch.empty)(tuple(shape), dtype=dtype, device=self.device)
+            self._buf[key] = t
+        return t
+
+
+def _pack(src: torch.Tensor, dst_hi: torch.Tensor, dst_lo: Optional[torch.Tensor], *, extra_col: Optional[torch.Tensor] = None,
+          extra_one: bool = False, dst_row_off: int = 0, dst_col_off: int = 0, rows_cover: Optional[int] = None,
+          cslot: Optional[int] = None) -> None:
+    """fp32 [R][C] -> bf16 hi/lo block of a padded image (see spv_pack_bf16)."""
+    lib = _abi.load()
+    if src.dtype != torch.float32 or src.dim() != 2 or src.stride(1) != 1:
+        raise _abi.SpvError("pack source must be fp32 [R][C] with unit column stride")
+    R, Cc = src.shape
+    ld_dst = dst_hi.shape[1]
+    Rp = rows_cover if rows_cover is not None else dst_hi.shape[0] - dst_row_off
+    cs = cslot if cslot is not None else ld_dst - dst_col_off
+    off = dst_row_off * ld_dst * 2
+    check(lib.spv_pack_bf16(ptr(src), src.stride(0), R, Cc, ptr(extra_col), int(extra_one), ptr(dst_hi) + off,
+                            (ptr(dst_lo) + off) if dst_lo is not None else None, ld_dst, dst_col_off, Rp, cs, stream_ptr()),
+          "spv_pack_bf16")
+
+
+def _bf16_image(ws: Workspace, name: str, rows: int, cols: int, lo: bool):
+    hi = ws.get(name + "_hi", (rows, cols), torch.int16)
+    return hi, (ws.get(name + "_lo", (rows, cols), torch.int16) if lo else None)
+
+
+# ------------------------------------------------------------------------------------------------
+# encoder fc1
+# ------------------------------------------------------------------------------------------------
+def _fc1_splits(B: int, G: int, N1: int) -> int:
+    bm = 128 if N1 <= 32 else 64
+    tiles = -(-B // bm) * -(-N1 // (32 if N1 <= 32 else (128 if N1 <= 128 else 256)))
+    ktiles = -(-G // 32)
+    want = max(1, 512 // max(tiles, 1))
+    return max(1, min(want, ktiles // 8 if ktiles >= 8 else 1, 16))
+
+
+class EncoderFC1(torch.autograd.Function):
+    """h1 = relu(log1p(X[rows, genes]) @ [W_private; W_shared]^T + b), library = log(sum log1p(x))."""
+
+    @staticmethod
+    def forward(ctx, counts: GroupCounts, rows, B: int, w_priv, b_priv, w_sh, b_sh, nsplit: int, ws: Workspace):
+        lib = _abi.load()
+        H, G = w_priv.shape
+        N1 = 2 * H
+        bn = 32 if N1 <= 32 else (128 if N1 <= 128 else 256)
+        N1p, Gp = round_up(N1, bn), round_up(G, 32)
+        W_hi, W_lo = _bf16_image(ws, "fc1_W", N1p, Gp, nsplit == 3)
+        _pack(w_priv, W_hi, W_lo, dst_row_off=0, rows_cover=H)
+        _pack(w_sh, W_hi, W_lo, dst_row_off=H, rows_cover=N1p - H)
+        bias = torch.cat([b_priv, b_sh]).contiguous()
+        splits = _fc1_splits(B, G, N1)
+        slabs = ws.get("fc1_slabs", (splits, B, N1), torch.float32)
+        rowsum = ws.get("fc1_rowsum", (splits, B), torch.float32)
+        h1 = torch.empty((B, N1), dtype=torch.float32, device=w_priv.device)
+        library = torch.empty((B,), dtype=torch.float32, device=w_priv.device)
+        cs = counts.c_struct(rows)
+        check(lib.spv_enc_fc1_fwd(C.byref(cs), B, G, ptr(W_hi), ptr(W_lo), Gp, N1, ptr(bias), nsplit, splits, ptr(slabs),
+                                  ptr(rowsum), ptr(h1), ptr(library), stream_ptr()), "spv_enc_fc1_fwd")
+        ctx.counts, ctx.rows, ctx.B, ctx.nsplit, ctx.ws, ctx.H, ctx.G = counts, rows, B, nsplit, ws, H, G
+        ctx.save_for_backward(h1)
+        ctx.mark_non_differentiable(library)
+        return h1, library
+
+    @staticmethod
+    def backward(ctx, dh1, _dlib):
+        lib = _abi.load()
+        (h1,) = ctx.saved_tensors
+        B, H, G, ws, nsplit = ctx.B, ctx.H, ctx.G, ctx.ws, ctx.nsplit
+        N1 = 2 * H
+        dpre = (dh1 * (h1 > 0)).contiguous()
+        Bp, N1p = round_up(B, 32), round_up(N1, 128)
+        dh_hi, dh_lo = _bf16_image(ws, "fc1_dh", Bp, N1p, nsplit == 3)
+        _pack(dpre, dh_hi, dh_lo)
+        dW = torch.empty((N1, G), dtype=torch.float32, device=dh1.device)
+        cs = ctx.counts.c_struct(ctx.rows)
+        check(lib.spv_enc_fc1_wgrad(C.byref(cs), B, G, ptr(dh_hi), ptr(dh_lo), N1p, N1, nsplit, ptr(dW), G, stream_ptr()),
+              "spv_enc_fc1_wgrad")
+        db = dpre.sum(0)
+        return None, None, None, dW[:H], db[:H], dW[H:], db[H:], None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# decoder + NB-mixture likelihood
+# ------------------------------------------------------------------------------------------------
+def _gene_splits(Bp: int, Gp: int) -> Tuple[int, int]:
+    cell_blocks = Bp // DEC_CELLS_PER_WG
+    want = max(1, -(-1024 // cell_blocks))  # ~4 workgroups per CU
+    tiles = Gp // 32
+    splits = max(1, min(want, tiles))
+    per = round_up(-(-tiles // splits), 1) * 32
+    splits = -(-Gp // per)
+    return splits, per
+
+
+def _gemm(a_kmajor: bool, A_hi, A_lo, lda, B_hi, B_lo, ldb, M, N, K, nsplit, splits, ws: Workspace, name: str,
+          b_col_off: int = 0) -> torch.Tensor:
+    lib = _abi.load()
+    out = ws.get(name, (splits, M, N), torch.float32)
+    b_off = b_col_off * 2
+    check(lib.spv_gemm_bf16(int(a_kmajor), ptr(A_hi), ptr(A_lo), lda, ptr(B_hi) + b_off, (ptr(B_lo) + b_off) if B_lo is not None else None,
+                            ldb, ptr(out), N, M, N, K, nsplit, splits, M * N, stream_ptr()), "spv_gemm_bf16")
+    return out[0] if splits == 1 else out.sum(0)
+
+
+class DecoderNBLoss(torch.autograd.Function):
+    """sum_b w_b * rec_b with rec_b = -sum_g log NBMixture(log1p(x_bg); mu1, mu2, theta_g, logits_bg),
+    where mu_k = exp(library_b) * softmax_g(z_k[b] . W'_k[g] + c_k[g]) and
+    logits = [m | z_p | z_s][b] . Wm[g] + bm[g].  Returns (weighted sum, rec[B] detached)."""
+
+    @staticmethod
+    def forward(ctx, counts: GroupCounts, rows, B: int, zp, zs, m, Wp, cp, Ws, cs_, Wm, bm, px_r, library, w_row,
+                nsplit: int, train: bool, ws: Workspace):
+        lib = _abi.load()
+        dev = zp.device
+        G = counts.G
+        n_p, n_s = zp.shape[1], zs.shape[1]
+        if n_p + 1 > DEC_KP or n_s + 1 > DEC_KS:
+            raise _abi.SpvError(f"decoder kernels support n_private <= {DEC_KP - 1} and n_shared <= {DEC_KS - 1}")
+        KM = m.shape[1] + n_p + n_s + 1
+        KMp = 320  # one 320-wide N tile of the backward GEMMs; K steps beyond `ksteps` are never issued
+        if KM > KMp:
+            raise _abi.SpvError("mixture input wider than 320 columns is not supported")
+        ksteps = -(-KM // 16)
+        Bp, Gp = round_up(B, DEC_CELLS_PER_WG), round_up(G, 128)
+        lo = True  # the small regressor operands always travel as hi/lo pairs
+        mlo = nsplit == 3
+        f32 = lambda t: t.contiguous().float()
+        # ---- packed operand images -------------------------------------------------------------
+        Wm_hi, Wm_lo = _bf16_image(ws, "dec_Wm", Gp, KMp, mlo)
+        _pack(f32(Wm), Wm_hi, Wm_lo, extra_col=f32(bm))
+        Am_hi, Am_lo = _bf16_image(ws, "dec_Am", Bp, KMp, mlo)
+        _pack(torch.cat([m, zp, zs], dim=1).contiguous(), Am_hi, Am_lo, extra_one=True)
+        Wps_hi, Wps_lo = _bf16_image(ws, "dec_Wps", Gp, DEC_KPS, lo)
+        _pack(f32(Wp), Wps_hi, Wps_lo, extra_col=f32(cp), dst_col_off=0, cslot=DEC_KP)
+        _pack(f32(Ws), Wps_hi, Wps_lo, extra_col=f32(cs_), dst_col_off=DEC_KP, cslot=DEC_KS)
+        Aps_hi, Aps_lo = _bf16_image(ws, "dec_Aps", Bp, DEC_KPS, lo)
+        _pack(f32(zp), Aps_hi, Aps_lo, extra_one=True, dst_col_off=0, cslot=DEC_KP)
+        _pack(f32(zs), Aps_hi, Aps_lo, extra_one=True, dst_col_off=DEC_KP, cslot=DEC_KS)
+        # ---- tables / per-cell vectors -----------------------------------------------------------
+        gene_tab = ws.get("dec_gene_tab", (Gp, 4), torch.float32)
+        cnt_tab = ws.get("dec_cnt_tab", (NB_CMAX, Gp, 2), torch.float32)
+        check(lib.spv_dec_tables(ptr(f32(px_r)), G, Gp, ptr(gene_tab), ptr(cnt_tab), stream_ptr()), "spv_dec_tables")
+        splits, per = _gene_splits(Bp, Gp)
+        vec = lambda n: ws.get(n, (Bp,), torch.float32)
+        part = lambda n: ws.get(n, (splits, Bp), torch.float32)
+        w_pad = ws.get("dec_w_row", (Bp,), torch.float32, zero=True)
+        w_pad[:B].copy_(w_row)
+        grads_f32 = bool(train and nsplit == 3)
+        gdt = torch.float32 if grads_f32 else torch.int16
+        gname = "f32" if grads_f32 else "bf16"
+        if train:
+            dL = ws.get("dec_dL_" + gname, (Bp, Gp), gdt, zero=True)
+            tP = ws.get("dec_tP_" + gname, (Bp, Gp), gdt, zero=True)
+            tS = ws.get("dec_tS_" + gname, (Bp, Gp), gdt, zero=True)
+            dth = ws.get("dec_dtheta", (Bp // DEC_CELLS_PER_WG, Gp), torch.float32, zero=True)
+        else:
+            dL = tP = tS = dth = None
+        lse_p, lse_s, a_p, a_s = vec("dec_lse_p"), vec("dec_lse_s"), vec("dec_a_p"), vec("dec_a_s")
+        cst = counts.c_struct(rows)
+        P = SpvDecParams(
+            X=cst.X, ldx=cst.ld, rows=cst.rows, col_off=cst.col_off, count_is_u16=int(cst.dtype == _abi.SPV_COUNT_U16),
+            B=B, G=G, Bp=Bp, Gp=Gp, Wm_hi=ptr(Wm_hi), Wm_lo=ptr(Wm_lo), KMp=KMp, ksteps_m=ksteps,
+            Am_hi=ptr(Am_hi), Am_lo=ptr(Am_lo), Wps_hi=ptr(Wps_hi), Wps_lo=ptr(Wps_lo), Aps_hi=ptr(Aps_hi), Aps_lo=ptr(Aps_lo),
+            gene_tab=ptr(gene_tab), cnt_tab=ptr(cnt_tab), a_p=ptr(a_p), a_s=ptr(a_s), lse_p=ptr(lse_p), lse_s=ptr(lse_s),
+            w_row=ptr(w_pad), gene_splits=splits, genes_per_split=per,
+            part_max_p=ptr(part("dec_pmp")), part_sum_p=ptr(part("dec_psp")), part_max_s=ptr(part("dec_pms")), part_sum_s=ptr(part("dec_pss")),
+            rec_part=ptr(part("dec_rec")), tp_part=ptr(part("dec_tp")), ts_part=ptr(part("dec_ts")),
+            dtheta_part=ptr(dth), dL=ptr(dL), tP=ptr(tP), tS=ptr(tS), ldg=Gp, grads_f32=int(grads_f32),
+        )
+        check(lib.spv_dec_lse(C.byref(P), ptr(f32(library)), stream_ptr()), "spv_dec_lse")
+        check(lib.spv_dec_nb_fwd(C.byref(P), nsplit, int(train), stream_ptr()), "spv_dec_nb_fwd")
+        rec = part("dec_rec").sum(0)[:B]
+        loss = (rec * w_row).sum()
+        if train:
+            ctx.P, ctx.ws, ctx.nsplit, ctx.dims = P, ws, nsplit, (B, G, Bp, Gp, n_p, n_s, KM, KMp, m.shape[1])
+            ctx.keep = (Wm_hi, Wm_lo, Am_hi, Am_lo, Wps_hi, Wps_lo, Aps_hi, Aps_lo, dL, tP, tS, dth, lse_p, lse_s, gene_tab)
+            ctx.Tp, ctx.Ts = part("dec_tp").sum(0), part("dec_ts").sum(0)
+            ctx.grads_f32, ctx.done = grads_f32, False
+            ctx.save_for_backward(px_r)
+        ctx.mark_non_differentiable(rec)
+        return loss, rec
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_rec):
+        lib = _abi.load()
+        if ctx.done:
+            raise _abi.SpvError("DecoderNBLoss.backward may run once per forward (gradient buffers are consumed in place)")
+        ctx.done = True
+        (px_r,) = ctx.saved_tensors
+        B, G, Bp, Gp, n_p, n_s, KM, KMp, n_m = ctx.dims
+        ws, nsplit, P = ctx.ws, ctx.nsplit, ctx.P
+        Wm_hi, Wm_lo, Am_hi, Am_lo, Wps_hi, Wps_lo, Aps_hi, Aps_lo, dL, tP, tS, dth, lse_p, lse_s, gene_tab = ctx.keep
+        check(lib.spv_dec_softmax_bwd(C.byref(P), ptr(ctx.Tp), ptr(ctx.Ts), stream_ptr()), "spv_dec_softmax_bwd")
+        if ctx.grads_f32:  # fp32 mode: split the stored fp32 gradients into hi/lo images for the MFMA GEMMs
+            def split(t, name):
+                hi, lo = _bf16_image(ws, name, Bp, Gp, True)
+                _pack(t, hi, lo)
+                return hi, lo
+            dL_hi, dL_lo = split(dL, "dec_dL_split")
+            tP_hi, tP_lo = split(tP, "dec_tP_split")
+            tS_hi, tS_lo = split(tS, "dec_tS_split")
+        else:
+            dL_hi, tP_hi, tS_hi, dL_lo, tP_lo, tS_lo = dL, tP, tS, None, None, None
+        ksp = max(1, min(8, (Gp // 32) // 16))  # K splits of the contractions over genes
+        # contraction over cells:  d W[g][k] = sum_b dY[b][g] * A[b][k]
+        dWm = _gemm(True, dL_hi, dL_lo, Gp, Am_hi, Am_lo, KMp, G, KMp, Bp, nsplit, 1, ws, "dec_dWm")
+        dWp = _gemm(True, tP_hi, tP_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KP, Bp, nsplit, 1, ws, "dec_dWp")
+        dWs = _gemm(True, tS_hi, tS_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KS, Bp, nsplit, 1, ws, "dec_dWs", b_col_off=DEC_KP)
+        # contraction over genes:  d A[b][k] = sum_g dY[b][g] * W[g][k]
+        dAm = _gemm(False, dL_hi, dL_lo, Gp, Wm_hi, Wm_lo, KMp, B, KMp, G, nsplit, ksp, ws, "dec_dAm")
+        dAp = _gemm(False, tP_hi, tP_lo, Gp, Wps_hi, Wps_lo, DEC_KPS, B, DEC_KP, G, nsplit, ksp, ws, "dec_dAp")
+        dAs = _gemm(False, tS_hi, tS_lo, Gp, Wps_hi, Wps_lo, DEC_KPS, B, DEC_KS, G, nsplit, ksp, ws, "dec_dAs", b_col_off=DEC_KP)
+        g = g_loss
+        d_m = dAm[:, :n_m] * g
+        d_zp = (dAm[:, n_m:n_m + n_p] + dAp[:, :n_p]) * g
+        d_zs = (dAm[:, n_m + n_p:n_m + n_p + n_s] + dAs[:, :n_s]) * g
+        d_Wm, d_bm = dWm[:, :KM - 1] * g, dWm[:, KM - 1] * g
+        d_Wp, d_cp = dWp[:, :n_p] * g, dWp[:, n_p] * g
+        d_Ws, d_cs = dWs[:, :n_s] * g, dWs[:, n_s] * g
+        d_pxr = torch.exp(px_r) * dth.sum(0)[:G] * g  # theta = exp(px_r): d/d px_r = theta * d/d theta
+        return (None, None, None, d_zp, d_zs, d_m, d_Wp, d_cp, d_Ws, d_cs, d_Wm, d_bm, d_pxr, None, None, None, None, None)
