@@ -80,14 +80,27 @@ int spv_enc_fc1_wgrad(const spv_counts* x, int32_t B, int32_t G,
                       const uint16_t* dh_hi, const uint16_t* dh_lo, int64_t ld_dh, int32_t N1,
                       int32_t nsplit, float* dW, int64_t ldc, void* stream);
 
+/* "Accumulator-tile" order of the [cells][genes] arrays exchanged between the decoder kernels
+ * (mixing logits, dL, tP, tS):  T[cell/32][gene/32][lane][q], lane = cell%32 + 32 h,
+ * gene%32 = (q&3) + 8 (q>>2) + 4 h, q = 0..15 -- each 32x32 tile is stored as the 64 lanes x 16
+ * registers of the MFMA accumulator that produced it, 2 KiB contiguous.  n_gene_tiles = Gp / 32. */
+
 /* Plain bf16 MFMA GEMM, fp32 out:  C[M][N] (+)= sum_k A(m,k) B(k,n).
- *   a_kmajor == 0: A is mem[m][k] (k contiguous); a_kmajor == 1: A is mem[k][m].
+ *   a_kmajor == 0: A is mem[m][k] (k contiguous); a_kmajor == 1: A is mem[k][m];
+ *   a_tiles > 0: A is a tiled [cells][genes] array (above) with a_tiles gene tiles per cell tile;
+ *                a_kmajor then says whether K runs over cells (1) or over genes (0); lda is unused.
  *   B is always k-major: mem[k][n].   Operands zero padded to tile multiples (64 x 320 / 128 x 32).
  *   splits > 1: C is a stack of `splits` fp32 slabs (slab_stride elements apart), one per K range. */
 int spv_gemm_bf16(int32_t a_kmajor, const uint16_t* A_hi, const uint16_t* A_lo, int64_t lda,
                   const uint16_t* B_hi, const uint16_t* B_lo, int64_t ldb,
                   float* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
-                  int32_t nsplit, int32_t splits, int64_t slab_stride, void* stream);
+                  int32_t nsplit, int32_t splits, int64_t slab_stride, int32_t a_tiles, void* stream);
+
+/* Mixing logits of the decoder (nn/networks.py:322-325 with the bias folded into a ones column):
+ *   out(b, g) = sum_k Am[b][k] * Wm[g][k],  Am bf16 [Bp][K], Wm bf16 [Gp][K], K % 32 == 0,
+ *   Bp, Gp multiples of 128; out is f16 (out_f32 == 0) or f32 in accumulator-tile order. */
+int spv_dec_logits(const uint16_t* Am_hi, const uint16_t* Am_lo, const uint16_t* Wm_hi, const uint16_t* Wm_lo,
+                   int32_t K, int32_t Bp, int32_t Gp, int32_t nsplit, void* out, int32_t out_f32, void* stream);
 
 /* Decoder + NB-mixture likelihood (nn/networks.py:314-325, module/spVIPESmodule.py:758-759,
  * :817-824).  Field meanings are documented in spvipes_amd/csrc/spv_decoder.h (DecParams has
@@ -95,8 +108,7 @@ int spv_gemm_bf16(int32_t a_kmajor, const uint16_t* A_hi, const uint16_t* A_lo, 
 typedef struct spv_dec_params {
   const void* X; int64_t ldx; const int32_t* rows; int32_t col_off; int32_t count_is_u16;
   int32_t B, G, Bp, Gp;
-  const uint16_t* Wm_hi; const uint16_t* Wm_lo; int32_t KMp; int32_t ksteps_m;
-  const uint16_t* Am_hi; const uint16_t* Am_lo;
+  const void* logits; int32_t n_gene_tiles; int32_t logits_f32; /* tiled mixing logits, f16 | f32 (see below) */
   const uint16_t* Wps_hi; const uint16_t* Wps_lo;
   const uint16_t* Aps_hi; const uint16_t* Aps_lo;
   const void* gene_tab;      /* float4 [Gp]              */
@@ -107,7 +119,7 @@ typedef struct spv_dec_params {
   float* part_max_p; float* part_sum_p; float* part_max_s; float* part_sum_s;
   float* rec_part; float* tp_part; float* ts_part;
   float* dtheta_part;
-  void* dL; void* tP; void* tS; int64_t ldg; int32_t grads_f32;
+  void* dL; void* tP; void* tS; int32_t grads_f32;              /* tiled like logits; bf16 | f32 */
 } spv_dec_params;
 
 /* theta = exp(px_r) and the per-(count, gene) lgamma / digamma table (module/spVIPESmodule.py:758
@@ -118,12 +130,20 @@ int spv_dec_tables(const float* px_r, int32_t G, int32_t Gp, void* gene_tab, voi
  * (the cast away of const on those four pointers is deliberate: they are this call's outputs). */
 int spv_dec_lse(const spv_dec_params* p, const float* library, void* stream);
 
-/* rec_part/tp_part/ts_part [gene_splits][Bp], dtheta_part [Bp/128][Gp]; when train != 0 also the
- * per-element gradients dL, tP, tS [Bp][ldg] (bf16, or fp32 when grads_f32). nsplit: 1 | 3. */
-int spv_dec_nb_fwd(const spv_dec_params* p, int32_t nsplit, int32_t train, void* stream);
+/* rec_part/tp_part/ts_part [gene_splits][Bp], dtheta_part [Bp/32][Gp]; when train != 0 also the
+ * per-element gradients dL, tP, tS (accumulator-tile order; bf16, or fp32 when grads_f32). */
+int spv_dec_nb_fwd(const spv_dec_params* p, int32_t train, void* stream);
 
 /* in place: tP <- tP - softmax_p * Tp[b],  tS <- tS - softmax_s * Ts[b]  */
 int spv_dec_softmax_bwd(const spv_dec_params* p, const float* Tp, const float* Ts, void* stream);
+
+/* One Adam step (torch.optim.Adam semantics, L2 weight decay folded into the gradient) over a
+ * flat fp32 parameter buffer; grad_scale multiplies g first (1/world for data-parallel means).
+ * bc1 = 1 - beta1^t, bc2 = 1 - beta2^t.  Replaces scvi TrainingPlan's optimiser step
+ * (constructed at model/base/training_mixin.py:111). */
+int spv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, float bc1, float bc2, float grad_scale,
+                  void* stream);
 
 #ifdef __cplusplus
 }

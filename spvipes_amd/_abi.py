@@ -27,15 +27,14 @@ class SpvDecParams(C.Structure):
     _fields_ = [
         ("X", C.c_void_p), ("ldx", C.c_int64), ("rows", C.c_void_p), ("col_off", C.c_int32), ("count_is_u16", C.c_int32),
         ("B", C.c_int32), ("G", C.c_int32), ("Bp", C.c_int32), ("Gp", C.c_int32),
-        ("Wm_hi", C.c_void_p), ("Wm_lo", C.c_void_p), ("KMp", C.c_int32), ("ksteps_m", C.c_int32),
-        ("Am_hi", C.c_void_p), ("Am_lo", C.c_void_p),
+        ("logits", C.c_void_p), ("n_gene_tiles", C.c_int32), ("logits_f32", C.c_int32),
         ("Wps_hi", C.c_void_p), ("Wps_lo", C.c_void_p), ("Aps_hi", C.c_void_p), ("Aps_lo", C.c_void_p),
         ("gene_tab", C.c_void_p), ("cnt_tab", C.c_void_p),
         ("a_p", C.c_void_p), ("a_s", C.c_void_p), ("lse_p", C.c_void_p), ("lse_s", C.c_void_p), ("w_row", C.c_void_p),
         ("gene_splits", C.c_int32), ("genes_per_split", C.c_int32),
         ("part_max_p", C.c_void_p), ("part_sum_p", C.c_void_p), ("part_max_s", C.c_void_p), ("part_sum_s", C.c_void_p),
         ("rec_part", C.c_void_p), ("tp_part", C.c_void_p), ("ts_part", C.c_void_p), ("dtheta_part", C.c_void_p),
-        ("dL", C.c_void_p), ("tP", C.c_void_p), ("tS", C.c_void_p), ("ldg", C.c_int64), ("grads_f32", C.c_int32),
+        ("dL", C.c_void_p), ("tP", C.c_void_p), ("tS", C.c_void_p), ("grads_f32", C.c_int32),
     ]
 
 
@@ -49,11 +48,15 @@ _SIGNATURES = {
     "spv_enc_fc1_wgrad": (C.c_int, [C.POINTER(SpvCounts), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                     C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "spv_gemm_bf16": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
-                                C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]),
+                                C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
     "spv_dec_tables": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "spv_dec_lse": (C.c_int, [C.POINTER(SpvDecParams), C.c_void_p, C.c_void_p]),
-    "spv_dec_nb_fwd": (C.c_int, [C.POINTER(SpvDecParams), C.c_int32, C.c_int32, C.c_void_p]),
+    "spv_dec_nb_fwd": (C.c_int, [C.POINTER(SpvDecParams), C.c_int32, C.c_void_p]),
+    "spv_dec_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                 C.c_void_p, C.c_int32, C.c_void_p]),
     "spv_dec_softmax_bwd": (C.c_int, [C.POINTER(SpvDecParams), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "spv_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float,
+                                C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -86,6 +89,37 @@ def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = load().spv_last_error()
         raise SpvError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")
+
+
+# ---- optional per-entry-point timing with HIP events on the launch stream (bench.py roofline) ----
+_PROFILE = None  # None = off; else {entry point name: [(start_event, end_event), ...]}
+
+
+def profile_start(names) -> None:
+    global _PROFILE
+    _PROFILE = {n: [] for n in names}
+
+
+def profile_stop() -> dict:
+    """Returns {name: [milliseconds per call]} and switches profiling off (synchronises)."""
+    global _PROFILE
+    prof, _PROFILE = _PROFILE or {}, None
+    torch.cuda.synchronize()
+    return {n: [s.elapsed_time(e) for s, e in evs] for n, evs in prof.items()}
+
+
+def call(name: str, *args) -> None:
+    """Invoke one C-ABI entry point on torch's current stream; raise on a non-zero status."""
+    fn = getattr(load(), name)
+    if _PROFILE is not None and name in _PROFILE:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = fn(*args)
+        e.record()
+        _PROFILE[name].append((s, e))
+    else:
+        rc = fn(*args)
+    check(rc, name)
 
 
 def stream_ptr() -> int:

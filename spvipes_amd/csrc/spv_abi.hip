@@ -147,17 +147,17 @@ extern "C" int spv_enc_fc1_wgrad(const spv_counts* x, int32_t B, int32_t G, cons
 // ---------------------------------------------------------------------------------------------
 // plain GEMM
 // ---------------------------------------------------------------------------------------------
-template <bool A_KMAJ, int NSPLIT>
+template <bool A_KMAJ, int NSPLIT, int A_SRC>
 static int gemm_dispatch(const GemmParams& p, int splits, hipStream_t s) {
-  if (p.N <= 32) return launch_gemm<GemmCfg<128, 32, 4, 1, A_KMAJ, true, SRC_PLAIN, SRC_PLAIN, unsigned short, NSPLIT>>(p, splits, s);
-  return launch_gemm<GemmCfg<64, 320, 2, 2, A_KMAJ, true, SRC_PLAIN, SRC_PLAIN, unsigned short, NSPLIT>>(p, splits, s);
+  if (p.N <= 32) return launch_gemm<GemmCfg<128, 32, 4, 1, A_KMAJ, true, A_SRC, SRC_PLAIN, unsigned short, NSPLIT>>(p, splits, s);
+  return launch_gemm<GemmCfg<64, 320, 2, 2, A_KMAJ, true, A_SRC, SRC_PLAIN, unsigned short, NSPLIT>>(p, splits, s);
 }
 
 extern "C" int spv_gemm_bf16(int32_t a_kmajor, const uint16_t* A_hi, const uint16_t* A_lo, int64_t lda, const uint16_t* B_hi,
                              const uint16_t* B_lo, int64_t ldb, float* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
-                             int32_t nsplit, int32_t splits, int64_t slab_stride, void* stream) {
+                             int32_t nsplit, int32_t splits, int64_t slab_stride, int32_t a_tiles, void* stream) {
   if (!A_hi || !B_hi || !C) return fail(SPV_ERR_ARG, "spv_gemm_bf16: null pointer%s");
-  if (M <= 0 || N <= 0 || K <= 0 || splits <= 0 || (lda % 8) || (ldb % 8)) return fail(SPV_ERR_ARG, "spv_gemm_bf16: bad shape%s");
+  if (M <= 0 || N <= 0 || K <= 0 || splits <= 0 || (!a_tiles && (lda % 8)) || (ldb % 8) || a_tiles < 0) return fail(SPV_ERR_ARG, "spv_gemm_bf16: bad shape%s");
   if (nsplit != 1 && nsplit != 3) return fail(SPV_ERR_ARG, "spv_gemm_bf16: nsplit must be 1 or 3%s");
   if (nsplit == 3 && (!A_lo || !B_lo)) return fail(SPV_ERR_ARG, "spv_gemm_bf16: nsplit=3 needs lo images%s");
   const int bn = (N <= 32) ? 32 : 320;
@@ -170,9 +170,15 @@ extern "C" int spv_gemm_bf16(int32_t a_kmajor, const uint16_t* A_hi, const uint1
   const int ktiles = (K + 31) / 32;
   p.k_per_split = ((ktiles + splits - 1) / splits) * 32;
   p.epi = EPI_STORE;
+  p.tiles_inner = a_tiles;
   hipStream_t s = (hipStream_t)stream;
-  if (a_kmajor) { if (nsplit == 3) gemm_dispatch<true, 3>(p, splits, s); else gemm_dispatch<true, 1>(p, splits, s); }
-  else { if (nsplit == 3) gemm_dispatch<false, 3>(p, splits, s); else gemm_dispatch<false, 1>(p, splits, s); }
+  if (a_tiles) {
+    if (a_kmajor) { if (nsplit == 3) gemm_dispatch<true, 3, SRC_TILED>(p, splits, s); else gemm_dispatch<true, 1, SRC_TILED>(p, splits, s); }
+    else { if (nsplit == 3) gemm_dispatch<false, 3, SRC_TILED>(p, splits, s); else gemm_dispatch<false, 1, SRC_TILED>(p, splits, s); }
+  } else {
+    if (a_kmajor) { if (nsplit == 3) gemm_dispatch<true, 3, SRC_PLAIN>(p, splits, s); else gemm_dispatch<true, 1, SRC_PLAIN>(p, splits, s); }
+    else { if (nsplit == 3) gemm_dispatch<false, 3, SRC_PLAIN>(p, splits, s); else gemm_dispatch<false, 1, SRC_PLAIN>(p, splits, s); }
+  }
   return launch_status("spv_gemm_bf16");
 }
 
@@ -183,15 +189,14 @@ static int to_dec(const spv_dec_params* q, DecParams& p) {
   if (!q) return fail(SPV_ERR_ARG, "decoder: null params%s");
   p.X = q->X; p.ldx = q->ldx; p.rows = q->rows; p.col_off = q->col_off; p.count_is_u16 = q->count_is_u16;
   p.B = q->B; p.G = q->G; p.Bp = q->Bp; p.Gp = q->Gp;
-  p.Wm_hi = q->Wm_hi; p.Wm_lo = q->Wm_lo; p.KMp = q->KMp; p.ksteps_m = q->ksteps_m;
-  p.Am_hi = q->Am_hi; p.Am_lo = q->Am_lo;
+  p.logits = q->logits; p.n_gene_tiles = q->n_gene_tiles; p.logits_f32 = q->logits_f32;
   p.Wps_hi = q->Wps_hi; p.Wps_lo = q->Wps_lo; p.Aps_hi = q->Aps_hi; p.Aps_lo = q->Aps_lo;
   p.gene_tab = (const float4*)q->gene_tab; p.cnt_tab = (const float2*)q->cnt_tab;
   p.a_p = q->a_p; p.a_s = q->a_s; p.lse_p = q->lse_p; p.lse_s = q->lse_s; p.w_row = q->w_row;
   p.gene_splits = q->gene_splits; p.genes_per_split = q->genes_per_split;
   p.part_max_p = q->part_max_p; p.part_sum_p = q->part_sum_p; p.part_max_s = q->part_max_s; p.part_sum_s = q->part_sum_s;
   p.rec_part = q->rec_part; p.tp_part = q->tp_part; p.ts_part = q->ts_part; p.dtheta_part = q->dtheta_part;
-  p.dL = q->dL; p.tP = q->tP; p.tS = q->tS; p.ldg = q->ldg; p.grads_f32 = q->grads_f32;
+  p.dL = q->dL; p.tP = q->tP; p.tS = q->tS; p.grads_f32 = q->grads_f32;
   if (p.B <= 0 || p.G <= 0 || p.Bp < p.B || p.Gp < p.G || (p.Bp % DEC_CELLS_PER_WG) || (p.Gp % 32))
     return fail(SPV_ERR_ARG, "decoder: Bp must be a multiple of 128 and Gp of 32%s");
   if (p.gene_splits <= 0 || (p.genes_per_split % 32) || (long)p.gene_splits * p.genes_per_split < p.G)
@@ -221,44 +226,50 @@ extern "C" int spv_dec_lse(const spv_dec_params* q, const float* library, void* 
   return launch_status("spv_dec_lse");
 }
 
-template <int NSPLIT, bool TRAIN, typename GT>
-static int nb_launch(const DecParams& p, hipStream_t s) {
-  const size_t lds = (size_t)32 * (p.KMp + WM_PAD) * 2 * (NSPLIT == 3 ? 2 : 1) + 4 * 32 * sizeof(float);
+template <bool TRAIN, typename GT>
+static void nb_launch(const DecParams& p, hipStream_t s) {
   dim3 grid(p.Bp / DEC_CELLS_PER_WG, p.gene_splits);
-  if constexpr (NSPLIT == 3) {
-    hipLaunchKernelGGL((dec_nb_kernel<1, 3, TRAIN, GT>), grid, dim3(256), lds, s, p);
-  } else {
-    switch (p.ksteps_m) {
-      case 17: hipLaunchKernelGGL((dec_nb_kernel<17, 1, TRAIN, GT>), grid, dim3(256), lds, s, p); break;
-      case 18: hipLaunchKernelGGL((dec_nb_kernel<18, 1, TRAIN, GT>), grid, dim3(256), lds, s, p); break;
-      case 19: hipLaunchKernelGGL((dec_nb_kernel<19, 1, TRAIN, GT>), grid, dim3(256), lds, s, p); break;
-      case 20: hipLaunchKernelGGL((dec_nb_kernel<20, 1, TRAIN, GT>), grid, dim3(256), lds, s, p); break;
-      default: return fail(SPV_ERR_UNSUPPORTED, "spv_dec_nb_fwd: ksteps_m must be 17..20 in bf16 mode%s");
-    }
-  }
-  return SPV_OK;
+  if (p.logits_f32) hipLaunchKernelGGL((dec_nb_kernel<TRAIN, GT, float>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((dec_nb_kernel<TRAIN, GT, _Float16>), grid, dim3(256), 0, s, p);
 }
 
-extern "C" int spv_dec_nb_fwd(const spv_dec_params* q, int32_t nsplit, int32_t train, void* stream) {
+extern "C" int spv_dec_nb_fwd(const spv_dec_params* q, int32_t train, void* stream) {
   DecParams p;
   int rc = to_dec(q, p);
   if (rc != SPV_OK) return rc;
-  if (!p.X || !p.Wm_hi || !p.Am_hi || !p.gene_tab || !p.cnt_tab || !p.a_p || !p.a_s || !p.w_row || !p.rec_part)
+  if (!p.X || !p.logits || !p.gene_tab || !p.cnt_tab || !p.a_p || !p.a_s || !p.w_row || !p.rec_part)
     return fail(SPV_ERR_ARG, "spv_dec_nb_fwd: null pointer%s");
-  if (nsplit != 1 && nsplit != 3) return fail(SPV_ERR_ARG, "spv_dec_nb_fwd: nsplit must be 1 or 3%s");
-  if (nsplit == 3 && (!p.Wm_lo || !p.Am_lo)) return fail(SPV_ERR_ARG, "spv_dec_nb_fwd: nsplit=3 needs lo images%s");
-  if ((p.KMp % 16) || p.ksteps_m * 16 > p.KMp || p.ksteps_m <= 0) return fail(SPV_ERR_ARG, "spv_dec_nb_fwd: bad KMp / ksteps_m%s");
-  if (train && (!p.dL || !p.tP || !p.tS || !p.tp_part || !p.ts_part || !p.dtheta_part || p.ldg < p.Gp || (p.ldg % 8)))
+  if (p.n_gene_tiles != p.Gp / 32) return fail(SPV_ERR_ARG, "spv_dec_nb_fwd: n_gene_tiles must be Gp / 32%s");
+  if (train && (!p.dL || !p.tP || !p.tS || !p.tp_part || !p.ts_part || !p.dtheta_part))
     return fail(SPV_ERR_ARG, "spv_dec_nb_fwd: training outputs missing%s");
   hipStream_t s = (hipStream_t)stream;
   if (train) {
-    if (p.grads_f32) rc = (nsplit == 3) ? nb_launch<3, true, float>(p, s) : nb_launch<1, true, float>(p, s);
-    else rc = (nsplit == 3) ? nb_launch<3, true, bf16_t>(p, s) : nb_launch<1, true, bf16_t>(p, s);
+    if (p.grads_f32) nb_launch<true, float>(p, s);
+    else nb_launch<true, bf16_t>(p, s);
   } else {
-    rc = (nsplit == 3) ? nb_launch<3, false, bf16_t>(p, s) : nb_launch<1, false, bf16_t>(p, s);
+    nb_launch<false, bf16_t>(p, s);
   }
-  if (rc != SPV_OK) return rc;
   return launch_status("spv_dec_nb_fwd");
+}
+
+extern "C" int spv_dec_logits(const uint16_t* Am_hi, const uint16_t* Am_lo, const uint16_t* Wm_hi, const uint16_t* Wm_lo,
+                              int32_t K, int32_t Bp, int32_t Gp, int32_t nsplit, void* out, int32_t out_f32, void* stream) {
+  if (!Am_hi || !Wm_hi || !out) return fail(SPV_ERR_ARG, "spv_dec_logits: null pointer%s");
+  if (K <= 0 || (K % 32) || Bp <= 0 || Gp <= 0 || (Bp % 128) || (Gp % 128)) return fail(SPV_ERR_ARG, "spv_dec_logits: bad shape%s");
+  if (nsplit != 1 && nsplit != 3) return fail(SPV_ERR_ARG, "spv_dec_logits: nsplit must be 1 or 3%s");
+  if (nsplit == 3 && (!Am_lo || !Wm_lo)) return fail(SPV_ERR_ARG, "spv_dec_logits: nsplit=3 needs lo images%s");
+  // genes on MFMA rows (M), cells on MFMA columns (N): the orientation the likelihood kernel consumes
+  GemmParams p{};
+  p.A = Wm_hi; p.A_lo = Wm_lo; p.lda = K;
+  p.B = Am_hi; p.B_lo = Am_lo; p.ldb = K;
+  p.C = (float*)out; p.ldc = 0; p.slab_stride = 0;
+  p.M = Gp; p.N = Bp; p.K = K; p.k_per_split = K;
+  p.epi = out_f32 ? EPI_TILED_F32 : EPI_TILED_F16;
+  p.tiles_inner = Gp / 32;
+  hipStream_t s = (hipStream_t)stream;
+  if (nsplit == 3) launch_gemm<GemmCfg<128, 128, 2, 2, false, false, SRC_PLAIN, SRC_PLAIN, unsigned short, 3>>(p, 1, s);
+  else launch_gemm<GemmCfg<128, 128, 2, 2, false, false, SRC_PLAIN, SRC_PLAIN, unsigned short, 1>>(p, 1, s);
+  return launch_status("spv_dec_logits");
 }
 
 extern "C" int spv_dec_softmax_bwd(const spv_dec_params* q, const float* Tp, const float* Ts, void* stream) {
@@ -266,9 +277,55 @@ extern "C" int spv_dec_softmax_bwd(const spv_dec_params* q, const float* Tp, con
   int rc = to_dec(q, p);
   if (rc != SPV_OK) return rc;
   if (!Tp || !Ts || !p.tP || !p.tS || !p.lse_p || !p.lse_s) return fail(SPV_ERR_ARG, "spv_dec_softmax_bwd: null pointer%s");
+  if (p.n_gene_tiles != p.Gp / 32) return fail(SPV_ERR_ARG, "spv_dec_softmax_bwd: n_gene_tiles must be Gp / 32%s");
   dim3 grid(p.Bp / DEC_CELLS_PER_WG, p.gene_splits);
   hipStream_t s = (hipStream_t)stream;
   if (p.grads_f32) hipLaunchKernelGGL(dec_softmax_bwd_kernel<float>, grid, dim3(256), 0, s, p, Tp, Ts);
   else hipLaunchKernelGGL(dec_softmax_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, p, Tp, Ts);
   return launch_status("spv_dec_softmax_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------
+// optimiser: Adam over one flat fp32 parameter buffer (scvi TrainingPlan defaults are passed by the
+// host: lr 1e-3, eps 0.01, weight_decay 1e-6 -- training_mixin.py:111).  torch.optim.Adam semantics.
+// ---------------------------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2, float gscale) {
+  const long stride = (long)gridDim.x * blockDim.x * 4;
+  const float step = lr / bc1, isq = rsqrtf(bc2);
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 4 <= n) {
+      f4v pp = *reinterpret_cast<f4v*>(p + i), gg = *reinterpret_cast<const f4v*>(g + i);
+      f4v mm = *reinterpret_cast<f4v*>(m + i), vv = *reinterpret_cast<f4v*>(v + i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float gr = gg[j] * gscale + wd * pp[j];
+        mm[j] = b1 * mm[j] + (1.f - b1) * gr;
+        vv[j] = b2 * vv[j] + (1.f - b2) * gr * gr;
+        pp[j] -= step * mm[j] / (sqrtf(vv[j]) * isq + eps);
+      }
+      *reinterpret_cast<f4v*>(p + i) = pp; *reinterpret_cast<f4v*>(m + i) = mm; *reinterpret_cast<f4v*>(v + i) = vv;
+    } else {
+      for (long k = i; k < n; ++k) {
+        const float gr = g[k] * gscale + wd * p[k];
+        m[k] = b1 * m[k] + (1.f - b1) * gr;
+        v[k] = b2 * v[k] + (1.f - b2) * gr * gr;
+        p[k] -= step * m[k] / (sqrtf(v[k]) * isq + eps);
+      }
+    }
+  }
+}
+
+extern "C" int spv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, float bc1, float bc2, float grad_scale, void* stream) {
+  if (!p || !g || !m || !v || n < 0) return fail(SPV_ERR_ARG, "spv_adam_step: bad arguments%s");
+  if (n == 0) return SPV_OK;
+  if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15)
+    return fail(SPV_ERR_ARG, "spv_adam_step: buffers must be 16-byte aligned%s");
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, lr, beta1, beta2, eps,
+                     weight_decay, bc1, bc2, grad_scale);
+  return launch_status("spv_adam_step");
 }

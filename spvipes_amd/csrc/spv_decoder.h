@@ -17,9 +17,10 @@
 //     per-cell reductions over genes (softmax statistics, rec_b, the row sums the softmax
 //     backward needs) are in-lane accumulations across the gene loop; only the per-gene sum for
 //     d px_r crosses lanes.
-//   * No [B,G] fp32 intermediate ever exists in HBM.  The forward pass emits, per (cell, gene), the
-//     three gradients the backward GEMMs need (d/d logits, d/d log mu1, d/d log mu2) as bf16/fp32
-//     so that the backward pass re-evaluates no transcendental.
+//   * The only [B,G] arrays in HBM are 16-bit: the mixing logits (one plain MFMA GEMM, f16) and,
+//     in training, the three per-element gradients the backward GEMMs need (d/d logits,
+//     d/d log mu1, d/d log mu2, bf16) so that the backward pass re-evaluates no transcendental.
+//     ("fp32" precision mode keeps all four as fp32.)
 //   * lgamma / digamma terms depend only on (count, gene): they come from a per-step table
 //     tab[c][g] = { lgamma(x+theta_g) - lgamma(theta_g) - lgamma(x+1),  psi(x+theta_g) - psi(theta_g) },
 //     x = log1p(c), built by nb_tables_kernel for c < NB_CMAX; larger counts are evaluated inline.
@@ -40,8 +41,7 @@ struct DecParams {
   int B, G;          // logical cells in the minibatch / genes of the group
   int Bp, Gp;        // padded extents of the packed images (multiples of 128)
   // packed operands (bf16, zero padded)
-  const bf16_t* Wm_hi; const bf16_t* Wm_lo; int KMp; int ksteps_m;   // [Gp][KMp]  mixture weights | bias
-  const bf16_t* Am_hi; const bf16_t* Am_lo;                           // [Bp][KMp]  relu(BN(.)) | z | 1
+  const void* logits; int n_gene_tiles; int logits_f32;               // tiled [Bp/32][Gp/32][64][16] mixing logits (f16 | f32)
   const bf16_t* Wps_hi; const bf16_t* Wps_lo;                         // [Gp][48]   W'_p|c_p|0.. W'_s|c_s|0..
   const bf16_t* Aps_hi; const bf16_t* Aps_lo;                         // [Bp][48]   z_p|1|0..   z_s|1|0..
   // per gene / per cell vectors
@@ -54,8 +54,8 @@ struct DecParams {
   int gene_splits; int genes_per_split;      // multiples of 32
   float* part_max_p; float* part_sum_p; float* part_max_s; float* part_sum_s;  // [splits][Bp]  (lse)
   float* rec_part; float* tp_part; float* ts_part;                             // [splits][Bp]  (nb)
-  float* dtheta_part;           // [Bp/128][Gp]
-  void* dL; void* tP; void* tS; long ldg; int grads_f32;                       // [Bp][Gp] bf16 or f32
+  float* dtheta_part;           // [Bp/32][Gp]  one partial row per 32-cell tile
+  void* dL; void* tP; void* tS; int grads_f32;                                 // tiled like logits; bf16 or f32
 };
 
 // ---- per-gene tables ----------------------------------------------------------
@@ -108,6 +108,34 @@ __device__ __forceinline__ void load_counts16(const DecParams& p, int cell, int 
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (g + j < p.G) c[4 * qq + j] = src[j];
       }
+    }
+  }
+}
+
+// 4 consecutive genes g..g+3 of one cell (row = index into the resident count matrix)
+__device__ __forceinline__ void load_counts4(const DecParams& p, long row, int g, bool cell_ok, float (&c)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c[j] = 0.f;
+  if (!cell_ok || g >= p.G) return;
+  if (p.count_is_u16) {
+    const unsigned short* src = reinterpret_cast<const unsigned short*>(p.X) + row * p.ldx + p.col_off + g;
+    if (g + 4 <= p.G && (reinterpret_cast<uintptr_t>(src) & 7) == 0) {
+      const u2v raw = *reinterpret_cast<const u2v*>(src);
+      c[0] = (float)(raw[0] & 0xFFFFu); c[1] = (float)(raw[0] >> 16);
+      c[2] = (float)(raw[1] & 0xFFFFu); c[3] = (float)(raw[1] >> 16);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (g + j < p.G) c[j] = (float)src[j];
+    }
+  } else {
+    const float* src = reinterpret_cast<const float*>(p.X) + row * p.ldx + p.col_off + g;
+    if (g + 4 <= p.G && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+      const f4v raw = *reinterpret_cast<const f4v*>(src);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) c[j] = raw[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (g + j < p.G) c[j] = src[j];
     }
   }
 }
@@ -208,110 +236,137 @@ __global__ void dec_lse_combine_kernel(const float* pmp, const float* psp, const
   a_p[b] = lib - lp; a_s[b] = lib - ls;
 }
 
+// Counts >= NB_CMAX fall outside the (count, gene) table: the hot loop looks them up clamped to the
+// last row and this out-of-line helper returns the difference to the exact value,
+//   { lgamma(x+theta) - lgamma(theta) - lgamma(x+1),  psi(x+theta) - psi(theta) } - table[NB_CMAX-1][g].
+// Both terms enter the result additively, so the fix-up is a plain add, made once per chunk in a
+// rolled loop behind a wave-uniform test (one copy of the lgamma code, outside the hot chain).
+__device__ __forceinline__ float2 gamma_terms_fixup(const DecParams& p, int g, float c) {
+  const float theta = p.gene_tab[g].x, x = log1p_count(c);
+  const LgammaDigamma a = lgamma_digamma(theta), b = lgamma_digamma(x + theta), d = lgamma_digamma(x + 1.0f);
+  const float2 t = p.cnt_tab[(long)(NB_CMAX - 1) * p.Gp + g];
+  return make_float2(b.lg - a.lg - d.lg - t.x, b.dg - a.dg - t.y);
+}
+
 // ---- pass 2: NB-mixture log-likelihood, its row sums and (TRAIN) its per-element gradients ----
+// The mixing logits arrive precomputed (one plain MFMA GEMM, f16 or f32 [Bp][ld]); keeping that
+// K = 292 contraction out of this kernel frees ~100 registers per lane, and this kernel is bound by
+// VALU/transcendental issue, which wants waves, not registers.
 template <typename GT>
-__device__ __forceinline__ void store4(void* base, long ld, int cell, int g, const float (&v)[4]);
+__device__ __forceinline__ void store4(void* base, long off, const float (&v)[4]);
 template <>
-__device__ __forceinline__ void store4<bf16_t>(void* base, long ld, int cell, int g, const float (&v)[4]) {
+__device__ __forceinline__ void store4<bf16_t>(void* base, long off, const float (&v)[4]) {
   u2v w;
   w[0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
   w[1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-  *reinterpret_cast<u2v*>(reinterpret_cast<bf16_t*>(base) + (long)cell * ld + g) = w;
+  *reinterpret_cast<u2v*>(reinterpret_cast<bf16_t*>(base) + off) = w;
 }
 template <>
-__device__ __forceinline__ void store4<float>(void* base, long ld, int cell, int g, const float (&v)[4]) {
-  *reinterpret_cast<f4v*>(reinterpret_cast<float*>(base) + (long)cell * ld + g) = f4v{v[0], v[1], v[2], v[3]};
+__device__ __forceinline__ void store4<float>(void* base, long off, const float (&v)[4]) {
+  *reinterpret_cast<f4v*>(reinterpret_cast<float*>(base) + off) = f4v{v[0], v[1], v[2], v[3]};
 }
 
-constexpr int WM_PAD = 8;  // LDS pitch of the mixture-weight tile = KMp + 8 (conflict-free 16-B row reads)
+template <typename LT>
+__device__ __forceinline__ void load4(const void* base, long off, float (&v)[4]);
+template <>
+__device__ __forceinline__ void load4<_Float16>(const void* base, long off, float (&v)[4]) {
+  typedef __attribute__((ext_vector_type(4))) _Float16 h4v;
+  const h4v x = *reinterpret_cast<const h4v*>(reinterpret_cast<const _Float16*>(base) + off);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = (float)x[j];
+}
+template <>
+__device__ __forceinline__ void load4<bf16_t>(const void* base, long off, float (&v)[4]) {
+  const u2v x = *reinterpret_cast<const u2v*>(reinterpret_cast<const bf16_t*>(base) + off);
+  v[0] = bf2f(x[0] & 0xFFFF); v[1] = bf2f(x[0] >> 16); v[2] = bf2f(x[1] & 0xFFFF); v[3] = bf2f(x[1] >> 16);
+}
+template <>
+__device__ __forceinline__ void load4<float>(const void* base, long off, float (&v)[4]) {
+  const f4v x = *reinterpret_cast<const f4v*>(reinterpret_cast<const float*>(base) + off);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = x[j];
+}
 
-template <int KSTEPS, int NSPLIT, bool TRAIN, typename GT>
-__global__ __launch_bounds__(256) void dec_nb_kernel(DecParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int pitch = p.KMp + WM_PAD;
-  bf16_t* sW = reinterpret_cast<bf16_t*>(smem_raw);              // [32][pitch] hi
-  bf16_t* sW_lo = sW + 32 * pitch;                               // [32][pitch] lo (NSPLIT == 3)
-  float* sdth = reinterpret_cast<float*>(sW + 32 * pitch * (NSPLIT == 3 ? 2 : 1));  // [4 waves][32 genes]
+// sum of v[q] over the 32 lanes of a wave half for all 16 q at once ("transposing" butterfly,
+// 16 shuffles instead of 80): afterwards lane l holds the total of q = 8 b4 + 4 b3 + 2 b2 + b1
+// (b_i = bit i of l), duplicated in lanes l and l ^ 1.
+__device__ __forceinline__ float half_sum16(const float (&v)[16], int lane) {
+  float a[8];
+  const bool u4 = lane & 16;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float send = u4 ? v[i] : v[i + 8], keep = u4 ? v[i + 8] : v[i];
+    a[i] = keep + __shfl_xor(send, 16, 64);
+  }
+  float b[4];
+  const bool u3 = lane & 8;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float send = u3 ? a[i] : a[i + 4], keep = u3 ? a[i + 4] : a[i];
+    b[i] = keep + __shfl_xor(send, 8, 64);
+  }
+  float c[2];
+  const bool u2 = lane & 4;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float send = u2 ? b[i] : b[i + 2], keep = u2 ? b[i + 2] : b[i];
+    c[i] = keep + __shfl_xor(send, 4, 64);
+  }
+  const bool u1 = lane & 2;
+  const float send = u1 ? c[0] : c[1], keep = u1 ? c[1] : c[0];
+  float d = keep + __shfl_xor(send, 2, 64);
+  d += __shfl_xor(d, 1, 64);
+  return d;
+}
 
+template <bool TRAIN, typename GT, typename LT>
+__global__ __launch_bounds__(256, TRAIN ? 3 : 4) void dec_nb_kernel(DecParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, r = lane & 31;
-  const int cell0 = blockIdx.x * DEC_CELLS_PER_WG + 32 * wave;
+  const int cell_tile = blockIdx.x * (DEC_CELLS_PER_WG / 32) + wave;
+  const int cell0 = cell_tile * 32;
   const int cell = cell0 + r;
   const bool cell_ok = cell < p.B;
   const int split = blockIdx.y;
-  const int ksteps = (NSPLIT == 1) ? KSTEPS : p.ksteps_m;
 
-  // resident cell-side fragments
-  PsFrags cf;
-  load_ps_cell_frags(p, cell0, lane, cf);
-  s8v bm[(NSPLIT == 1) ? KSTEPS : 1];
-  if constexpr (NSPLIT == 1) {
-#pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) bm[s] = *reinterpret_cast<const s8v*>(p.Am_hi + (long)cell * p.KMp + 16 * s + 8 * h);
-  }
   const float ap = p.a_p[cell], as_ = p.a_s[cell];
   const float w = p.w_row[cell];
+  const long row_of_cell = cell_ok ? (p.rows ? (long)p.rows[cell] : (long)cell) : 0;
   float rec = 0.f, tp_sum = 0.f, ts_sum = 0.f;
 
   const int gbeg = split * p.genes_per_split;
   int gend = gbeg + p.genes_per_split;
   if (gend > p.Gp) gend = p.Gp;
   for (int g0 = gbeg; g0 < gend; g0 += 32) {
-    if (g0 >= p.G) break;  // uniform over the workgroup
-    __syncthreads();
-    // stage the mixture-weight tile: 32 rows x KMp bf16, 16-byte chunks
-    {
-      const int cpr = p.KMp / 8;
-      for (int c = tid; c < 32 * cpr; c += 256) {
-        const int row = c / cpr, cc = c % cpr;
-        *reinterpret_cast<u4v*>(sW + row * pitch + 8 * cc) = *reinterpret_cast<const u4v*>(p.Wm_hi + (long)(g0 + row) * p.KMp + 8 * cc);
-        if constexpr (NSPLIT == 3)
-          *reinterpret_cast<u4v*>(sW_lo + row * pitch + 8 * cc) = *reinterpret_cast<const u4v*>(p.Wm_lo + (long)(g0 + row) * p.KMp + 8 * cc);
-      }
-    }
-    float cnt[16];
-    load_counts16(p, cell, g0, h, cell_ok, cnt);
+    if (g0 >= p.G) break;
     f16v yp, ys;
-    ps_tiles(p, g0, lane, cf, yp, ys);
-    __syncthreads();
-    f16v lg;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) lg[q] = 0.f;
-    if constexpr (NSPLIT == 1) {
-#pragma unroll
-      for (int s = 0; s < KSTEPS; ++s) lg = mfma32(frag_natural(sW, pitch, 0, 16 * s, lane), bm[s], lg);
-    } else {
-      for (int s = 0; s < ksteps; ++s) {
-        const long bo = (long)cell * p.KMp + 16 * s + 8 * h;
-        const s8v b_hi = *reinterpret_cast<const s8v*>(p.Am_hi + bo), b_lo = *reinterpret_cast<const s8v*>(p.Am_lo + bo);
-        lg = mfma32_split<3>(frag_natural(sW, pitch, 0, 16 * s, lane), frag_natural(sW_lo, pitch, 0, 16 * s, lane), b_hi, b_lo, lg);
-      }
+    {
+      PsFrags cf;  // re-read per tile (3 KB per wave, L1-resident): 24 fewer live registers
+      load_ps_cell_frags(p, cell0, lane, cf);
+      ps_tiles(p, g0, lane, cf, yp, ys);
     }
-
-    float dth[16];
-#pragma unroll
+    // four chunks of 4 consecutive genes; a ROLLED loop (registers 0..3 of the accumulators are the
+    // current chunk, the tiles are rotated by 4 each trip) so that only one chunk's temporaries live
+#pragma unroll 1
     for (int qq = 0; qq < 4; ++qq) {
-      float o_dl[4], o_tp[4], o_ts[4];
+      float o_dl[4], o_tp[4], o_ts[4], ell4[4], cnt4[4], dth4[4];
+      const int gq = g0 + 8 * qq + 4 * h;
+      load_counts4(p, row_of_cell, gq, cell_ok, cnt4);
+      // [cells][genes] arrays live in accumulator-tile order (spv_gemm.h SRC_TILED): this lane's 16
+      // registers of tile (cell_tile, g0/32) are contiguous, chunk qq = registers 4qq..4qq+3
+      const long toff = (((long)cell_tile * p.n_gene_tiles + (g0 >> 5)) * 64 + lane) * 16 + 4 * qq;
+      load4<LT>(p.logits, toff, ell4);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int q = 4 * qq + j;
-        const int g = g0 + crow(q, h);
+        const int g = gq + j;
         const bool ok = cell_ok && (g < p.G);
         const float4 gt = p.gene_tab[g];
         const float theta = gt.x, lt = gt.y, ith = gt.z;
-        const float c = cnt[q];
+        const float c = cnt4[j];
         const float x = log1p_count(c);
-        float F = 0.f, Psi = 0.f;
-        if (c > 0.f) {
-          if (c < (float)NB_CMAX) {
-            const float2 t = p.cnt_tab[(long)(int)c * p.Gp + g];
-            F = t.x; Psi = t.y;
-          } else {
-            const LgammaDigamma a = lgamma_digamma(theta), b = lgamma_digamma(x + theta), d = lgamma_digamma(x + 1.0f);
-            F = b.lg - a.lg - d.lg; Psi = b.dg - a.dg;
-          }
-        }
-        const float ell = lg[q];
-        const float mu1 = fast_exp(yp[q] + ap), mu2 = fast_exp(ys[q] + as_);
+        const float2 tt = p.cnt_tab[(long)(int)fminf(c, (float)(NB_CMAX - 1)) * p.Gp + g];
+        const float F = tt.x, Psi = tt.y;
+        const float ell = ell4[j];
+        const float mu1 = fast_exp(yp[j] + ap), mu2 = fast_exp(ys[j] + as_);
         const float S1 = theta + mu1 + SPV_EPS_NB, S2 = theta + mu2 + SPV_EPS_NB;
         const float L1 = fast_log(S1), L2 = fast_log(S2);
         const float e1 = mu1 + SPV_EPS_NB, e2 = mu2 + SPV_EPS_NB;
@@ -338,30 +393,40 @@ __global__ __launch_bounds__(256) void dec_nb_kernel(DecParams p) {
           o_ts[j] = wk * t2;
           tp_sum += o_tp[j];
           ts_sum += o_ts[j];
-          dth[q] = wk * (r1 * dn1 + r2 * dn2 + Psi);
+          dth4[j] = wk * (r1 * dn1 + r2 * dn2 + Psi);
+        }
+      }
+      if (__builtin_expect(__any(fmaxf(fmaxf(cnt4[0], cnt4[1]), fmaxf(cnt4[2], cnt4[3])) >= (float)NB_CMAX), 0)) {
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) {
+          const float cj = (j == 0) ? cnt4[0] : (j == 1) ? cnt4[1] : (j == 2) ? cnt4[2] : cnt4[3];
+          if (cj >= (float)NB_CMAX && cell_ok && gq + j < p.G) {
+            const float2 fx = gamma_terms_fixup(p, gq + j, cj);
+            rec -= fx.x;
+            if constexpr (TRAIN) {
+              const float dv = -w * fx.y;
+              dth4[0] += (j == 0) ? dv : 0.f; dth4[1] += (j == 1) ? dv : 0.f;
+              dth4[2] += (j == 2) ? dv : 0.f; dth4[3] += (j == 3) ? dv : 0.f;
+            }
+          }
         }
       }
       if constexpr (TRAIN) {
-        if (cell < p.Bp) {
-          const int g = g0 + 8 * qq + 4 * h;
-          store4<GT>(p.dL, p.ldg, cell, g, o_dl);
-          store4<GT>(p.tP, p.ldg, cell, g, o_tp);
-          store4<GT>(p.tS, p.ldg, cell, g, o_ts);
-        }
+        store4<GT>(p.dL, toff, o_dl);
+        store4<GT>(p.tP, toff, o_tp);
+        store4<GT>(p.tS, toff, o_ts);
+        // per-gene sums over this wave's 32 cells: 4 values x 32 lanes -> lane keeps gene 2*b4 + b3
+        const bool u4 = lane & 16, u3 = lane & 8;
+        const float a0 = (u4 ? dth4[2] : dth4[0]) + __shfl_xor(u4 ? dth4[0] : dth4[2], 16, 64);
+        const float a1 = (u4 ? dth4[3] : dth4[1]) + __shfl_xor(u4 ? dth4[1] : dth4[3], 16, 64);
+        float s = (u3 ? a1 : a0) + __shfl_xor(u3 ? a0 : a1, 8, 64);
+        s += __shfl_xor(s, 4, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 1, 64);
+        if ((lane & 7) == 0) p.dtheta_part[(long)cell_tile * p.Gp + gq + 2 * ((lane >> 4) & 1) + ((lane >> 3) & 1)] = s;
       }
-    }
-    if constexpr (TRAIN) {
-      // per-gene sum over this wave's 32 cells, then over the 4 waves (fixed order: deterministic)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const float s = half_sum(dth[q]);
-        if (r == 0) sdth[wave * 32 + crow(q, h)] = s;
-      }
-      __syncthreads();
-      if (tid < 32) {
-        const float s = (sdth[tid] + sdth[32 + tid]) + (sdth[64 + tid] + sdth[96 + tid]);
-        p.dtheta_part[(long)blockIdx.x * p.Gp + g0 + tid] = s;
-      }
+      yp = __builtin_shufflevector(yp, yp, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3);
+      ys = __builtin_shufflevector(ys, ys, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3);
     }
   }
   rec += other_half(rec);
@@ -373,6 +438,7 @@ __global__ __launch_bounds__(256) void dec_nb_kernel(DecParams p) {
   }
 }
 
+
 // ---- backward helper: finish the softmax backward in place -------------------------------------
 //   d/dy_k[b,g] = t_k[b,g] - softmax_k[b,g] * T_k[b],   T_k[b] = sum_g t_k[b,g]
 // (t_k came out of dec_nb_kernel with a_k = library - lse_k held fixed; the second term is the
@@ -380,7 +446,8 @@ __global__ __launch_bounds__(256) void dec_nb_kernel(DecParams p) {
 template <typename GT>
 __global__ __launch_bounds__(256) void dec_softmax_bwd_kernel(DecParams p, const float* Tp, const float* Ts) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
-  const int cell0 = blockIdx.x * DEC_CELLS_PER_WG + 32 * wave;
+  const int cell_tile = blockIdx.x * (DEC_CELLS_PER_WG / 32) + wave;
+  const int cell0 = cell_tile * 32;
   const int cell = cell0 + r;
   const int split = blockIdx.y;
   PsFrags cf;
@@ -394,21 +461,13 @@ __global__ __launch_bounds__(256) void dec_softmax_bwd_kernel(DecParams p, const
     if (g0 >= p.G) break;
     f16v yp, ys;
     ps_tiles(p, g0, lane, cf, yp, ys);
+    const long tbase = (((long)cell_tile * p.n_gene_tiles + (g0 >> 5)) * 64 + lane) * 16;
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
       const int g = g0 + 8 * qq + 4 * h;
       float vp[4], vs[4];
-      if constexpr (sizeof(GT) == 2) {
-        const u2v a = *reinterpret_cast<const u2v*>(reinterpret_cast<const bf16_t*>(p.tP) + (long)cell * p.ldg + g);
-        const u2v b = *reinterpret_cast<const u2v*>(reinterpret_cast<const bf16_t*>(p.tS) + (long)cell * p.ldg + g);
-        vp[0] = bf2f(a[0] & 0xFFFF); vp[1] = bf2f(a[0] >> 16); vp[2] = bf2f(a[1] & 0xFFFF); vp[3] = bf2f(a[1] >> 16);
-        vs[0] = bf2f(b[0] & 0xFFFF); vs[1] = bf2f(b[0] >> 16); vs[2] = bf2f(b[1] & 0xFFFF); vs[3] = bf2f(b[1] >> 16);
-      } else {
-        const f4v a = *reinterpret_cast<const f4v*>(reinterpret_cast<const float*>(p.tP) + (long)cell * p.ldg + g);
-        const f4v b = *reinterpret_cast<const f4v*>(reinterpret_cast<const float*>(p.tS) + (long)cell * p.ldg + g);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { vp[j] = a[j]; vs[j] = b[j]; }
-      }
+      load4<GT>(p.tP, tbase + 4 * qq, vp);
+      load4<GT>(p.tS, tbase + 4 * qq, vs);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int q = 4 * qq + j;
@@ -416,8 +475,8 @@ __global__ __launch_bounds__(256) void dec_softmax_bwd_kernel(DecParams p, const
         vp[j] = ok ? vp[j] - fast_exp(yp[q] - lp) * tpb : 0.f;
         vs[j] = ok ? vs[j] - fast_exp(ys[q] - ls) * tsb : 0.f;
       }
-      store4<GT>(p.tP, p.ldg, cell, g, vp);
-      store4<GT>(p.tS, p.ldg, cell, g, vs);
+      store4<GT>(p.tP, tbase + 4 * qq, vp);
+      store4<GT>(p.tS, tbase + 4 * qq, vs);
     }
   }
 }

@@ -13,6 +13,12 @@
 //               it also produces the per-cell sum of log1p(x) (the library, :435).
 //               As a k-major B operand (k = cell, n = gene) it feeds the fc1 weight gradient.
 //
+//   SRC_TILED : a [cells][genes] array kept in "accumulator-tile" order
+//               T[cell/32][gene/32][lane = cell%32 + 32h][q],  gene%32 = (q&3) + 8(q>>2) + 4h,
+//               i.e. each 32x32 tile is stored exactly as the 64 lanes x 16 registers of the MFMA
+//               that produced it (genes on MFMA rows, cells on MFMA columns): producers write and
+//               consumers read 2 KiB contiguous per tile instead of 32 strided 64-byte row pieces.
+//
 // 256 threads = 4 waves arranged WM x WN; each wave owns (BM/WM) x (BN/WN) of the tile as TM x TN
 // MFMA 32x32 tiles.  BK = 32.  Global->register prefetch of tile t+1 overlaps the MFMAs of tile t
 // (register staging: the count operand has to pass through VALU for log1p anyway).
@@ -21,8 +27,8 @@
 
 namespace spv {
 
-enum { SRC_PLAIN = 0, SRC_COUNTS = 1 };
-enum { EPI_STORE = 0, EPI_ATOMIC = 1 };
+enum { SRC_PLAIN = 0, SRC_COUNTS = 1, SRC_TILED = 2 };
+enum { EPI_STORE = 0, EPI_ATOMIC = 1, EPI_TILED_F16 = 2, EPI_TILED_F32 = 3 };
 
 struct GemmParams {
   const void* A; const void* A_lo; long lda;
@@ -36,6 +42,7 @@ struct GemmParams {
   int M, N, K;
   int k_per_split;   // multiple of 32
   int epi;
+  int tiles_inner;   // gene tiles per cell tile of a SRC_TILED operand / EPI_TILED_* output (= Gp / 32)
 };
 
 __host__ __device__ constexpr int kmajor_pitch(int cols) {
@@ -73,7 +80,8 @@ template <typename Cfg, bool KMAJ, int SRC, int EXT /*BM or BN*/>
 struct Stager {
   static constexpr int FAST8 = KMAJ ? EXT / 8 : Cfg::BK / 8;   // chunks along the contiguous dim
   static constexpr int SLOW = KMAJ ? Cfg::BK : EXT;            // rows of the LDS image
-  static constexpr int NCH = (SLOW * FAST8 + 255) / 256;
+  static constexpr int NCHUNKS = (SRC == SRC_TILED) ? (EXT / 32) * 128 : SLOW * FAST8;
+  static constexpr int NCH = (NCHUNKS + 255) / 256;
   static constexpr int PITCH = KMAJ ? kmajor_pitch(EXT) : NAT_PITCH;
   // per-chunk register payload
   u4v hi[NCH], lo[NCH];
@@ -82,9 +90,14 @@ struct Stager {
   // slow/fast coordinates of chunk i for this thread
   __device__ __forceinline__ static void coord(int i, int tid, int& s, int& f, bool& ok) {
     const int c = tid + 256 * i;
-    ok = c < SLOW * FAST8;
-    s = c / FAST8;
-    f = c % FAST8;
+    ok = c < NCHUNKS;
+    if constexpr (SRC == SRC_TILED) {
+      s = c >> 7;    // 32x32 tile along EXT
+      f = c & 127;   // (lane << 1) | register half
+    } else {
+      s = c / FAST8;
+      f = c % FAST8;
+    }
   }
 
   // tile origin: `ext0` along the M/N dimension, `k0` along K
@@ -97,7 +110,13 @@ struct Stager {
       lo[i] = u4v{0u, 0u, 0u, 0u};
       csum[i] = 0.f;
       if (!ok) continue;
-      if constexpr (SRC == SRC_PLAIN) {
+      if constexpr (SRC == SRC_TILED) {
+        // k-major (k = cell, ext = gene): tile (k0/32, ext0/32 + s); natural (ext = cell, k = gene): (ext0/32 + s, k0/32)
+        const long ct = KMAJ ? k0 / 32 : ext0 / 32 + s, gt = KMAJ ? ext0 / 32 + s : k0 / 32;
+        const long off = ((ct * p.tiles_inner + gt) * 64 + (f >> 1)) * 16 + 8 * (f & 1);
+        hi[i] = *reinterpret_cast<const u4v*>(reinterpret_cast<const bf16_t*>(ptr) + off);
+        if constexpr (Cfg::NSPLIT == 3) lo[i] = *reinterpret_cast<const u4v*>(reinterpret_cast<const bf16_t*>(ptr_lo) + off);
+      } else if constexpr (SRC == SRC_PLAIN) {
         // natural: mem[ext0 + s][k0 + 8f]; k-major: mem[k0 + s][ext0 + 8f]; producer-padded
         const long off = KMAJ ? (long)(k0 + s) * ld + ext0 + 8 * f : (long)(ext0 + s) * ld + k0 + 8 * f;
         hi[i] = *reinterpret_cast<const u4v*>(reinterpret_cast<const bf16_t*>(ptr) + off);
@@ -159,6 +178,19 @@ struct Stager {
       int s, f; bool ok;
       coord(i, tid, s, f, ok);
       if (!ok) continue;
+      if constexpr (SRC == SRC_TILED) {
+        // registers 8qh..8qh+7 of lane (r, h): genes 16qh + 4h + {0..3} and 16qh + 8 + 4h + {0..3} of cell r
+        const int lane = f >> 1, qh = f & 1, r = lane & 31, h = lane >> 5;
+        const int g = 16 * qh + 4 * h;
+        const int o = KMAJ ? r * PITCH + 32 * s + g : (32 * s + r) * PITCH + g;
+        *reinterpret_cast<u2v*>(img_hi + o) = u2v{hi[i][0], hi[i][1]};
+        *reinterpret_cast<u2v*>(img_hi + o + 8) = u2v{hi[i][2], hi[i][3]};
+        if constexpr (Cfg::NSPLIT == 3) {
+          *reinterpret_cast<u2v*>(img_lo + o) = u2v{lo[i][0], lo[i][1]};
+          *reinterpret_cast<u2v*>(img_lo + o + 8) = u2v{lo[i][2], lo[i][3]};
+        }
+        continue;
+      }
       *reinterpret_cast<u4v*>(img_hi + s * PITCH + 8 * f) = hi[i];
       if constexpr (Cfg::NSPLIT == 3) *reinterpret_cast<u4v*>(img_lo + s * PITCH + 8 * f) = lo[i];
     }
@@ -247,6 +279,32 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   // ---- epilogue ---------------------------------------------------------------
   float* C = p.C + (long)split * p.slab_stride;
   const int h = lane >> 5, r = lane & 31;
+  if (p.epi == EPI_TILED_F16 || p.epi == EPI_TILED_F32) {
+    // M = genes, N = cells: every 32x32 accumulator tile goes out as 64 lanes x 16 registers
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j) {
+        const long gt = (m0 + wm * (Cfg::BM / Cfg::WM) + 32 * i) / 32, ct = (n0 + wn * (Cfg::BN / Cfg::WN) + 32 * j) / 32;
+        const long off = ((ct * p.tiles_inner + gt) * 64 + lane) * 16;
+        if (p.epi == EPI_TILED_F32) {
+#pragma unroll
+          for (int q = 0; q < 16; q += 4)
+            *reinterpret_cast<f4v*>(p.C + off + q) = f4v{acc[i][j][q], acc[i][j][q + 1], acc[i][j][q + 2], acc[i][j][q + 3]};
+        } else {
+          typedef __attribute__((ext_vector_type(8))) _Float16 h8v;
+          _Float16* dst = reinterpret_cast<_Float16*>(p.C) + off;
+#pragma unroll
+          for (int q = 0; q < 16; q += 8) {
+            h8v v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (_Float16)acc[i][j][q + e];
+            *reinterpret_cast<h8v*>(dst + q) = v;
+          }
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll

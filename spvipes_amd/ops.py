@@ -74,7 +74,6 @@ def _pack(src: torch.Tensor, dst_hi: torch.Tensor, dst_lo: Optional[torch.Tensor
           extra_one: bool = False, dst_row_off: int = 0, dst_col_off: int = 0, rows_cover: Optional[int] = None,
           cslot: Optional[int] = None) -> None:
     """fp32 [R][C] -> bf16 hi/lo block of a padded image (see spv_pack_bf16)."""
-    lib = _abi.load()
     if src.dtype != torch.float32 or src.dim() != 2 or src.stride(1) != 1:
         raise _abi.SpvError("pack source must be fp32 [R][C] with unit column stride")
     R, Cc = src.shape
@@ -82,9 +81,8 @@ def _pack(src: torch.Tensor, dst_hi: torch.Tensor, dst_lo: Optional[torch.Tensor
     Rp = rows_cover if rows_cover is not None else dst_hi.shape[0] - dst_row_off
     cs = cslot if cslot is not None else ld_dst - dst_col_off
     off = dst_row_off * ld_dst * 2
-    check(lib.spv_pack_bf16(ptr(src), src.stride(0), R, Cc, ptr(extra_col), int(extra_one), ptr(dst_hi) + off,
-                            (ptr(dst_lo) + off) if dst_lo is not None else None, ld_dst, dst_col_off, Rp, cs, stream_ptr()),
-          "spv_pack_bf16")
+    _abi.call("spv_pack_bf16", ptr(src), src.stride(0), R, Cc, ptr(extra_col), int(extra_one), ptr(dst_hi) + off,
+                            (ptr(dst_lo) + off) if dst_lo is not None else None, ld_dst, dst_col_off, Rp, cs, stream_ptr())
 
 
 def _bf16_image(ws: Workspace, name: str, rows: int, cols: int, lo: bool):
@@ -108,7 +106,6 @@ class EncoderFC1(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, counts: GroupCounts, rows, B: int, w_priv, b_priv, w_sh, b_sh, nsplit: int, ws: Workspace):
-        lib = _abi.load()
         H, G = w_priv.shape
         N1 = 2 * H
         bn = 32 if N1 <= 32 else (128 if N1 <= 128 else 256)
@@ -123,8 +120,8 @@ class EncoderFC1(torch.autograd.Function):
         h1 = torch.empty((B, N1), dtype=torch.float32, device=w_priv.device)
         library = torch.empty((B,), dtype=torch.float32, device=w_priv.device)
         cs = counts.c_struct(rows)
-        check(lib.spv_enc_fc1_fwd(C.byref(cs), B, G, ptr(W_hi), ptr(W_lo), Gp, N1, ptr(bias), nsplit, splits, ptr(slabs),
-                                  ptr(rowsum), ptr(h1), ptr(library), stream_ptr()), "spv_enc_fc1_fwd")
+        _abi.call("spv_enc_fc1_fwd", C.byref(cs), B, G, ptr(W_hi), ptr(W_lo), Gp, N1, ptr(bias), nsplit, splits, ptr(slabs),
+                                  ptr(rowsum), ptr(h1), ptr(library), stream_ptr())
         ctx.counts, ctx.rows, ctx.B, ctx.nsplit, ctx.ws, ctx.H, ctx.G = counts, rows, B, nsplit, ws, H, G
         ctx.save_for_backward(h1)
         ctx.mark_non_differentiable(library)
@@ -132,7 +129,6 @@ class EncoderFC1(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dh1, _dlib):
-        lib = _abi.load()
         (h1,) = ctx.saved_tensors
         B, H, G, ws, nsplit = ctx.B, ctx.H, ctx.G, ctx.ws, ctx.nsplit
         N1 = 2 * H
@@ -142,8 +138,7 @@ class EncoderFC1(torch.autograd.Function):
         _pack(dpre, dh_hi, dh_lo)
         dW = torch.empty((N1, G), dtype=torch.float32, device=dh1.device)
         cs = ctx.counts.c_struct(ctx.rows)
-        check(lib.spv_enc_fc1_wgrad(C.byref(cs), B, G, ptr(dh_hi), ptr(dh_lo), N1p, N1, nsplit, ptr(dW), G, stream_ptr()),
-              "spv_enc_fc1_wgrad")
+        _abi.call("spv_enc_fc1_wgrad", C.byref(cs), B, G, ptr(dh_hi), ptr(dh_lo), N1p, N1, nsplit, ptr(dW), G, stream_ptr())
         db = dpre.sum(0)
         return None, None, None, dW[:H], db[:H], dW[H:], db[H:], None, None
 
@@ -162,12 +157,11 @@ def _gene_splits(Bp: int, Gp: int) -> Tuple[int, int]:
 
 
 def _gemm(a_kmajor: bool, A_hi, A_lo, lda, B_hi, B_lo, ldb, M, N, K, nsplit, splits, ws: Workspace, name: str,
-          b_col_off: int = 0) -> torch.Tensor:
-    lib = _abi.load()
+          b_col_off: int = 0, a_tiles: int = 0) -> torch.Tensor:
     out = ws.get(name, (splits, M, N), torch.float32)
     b_off = b_col_off * 2
-    check(lib.spv_gemm_bf16(int(a_kmajor), ptr(A_hi), ptr(A_lo), lda, ptr(B_hi) + b_off, (ptr(B_lo) + b_off) if B_lo is not None else None,
-                            ldb, ptr(out), N, M, N, K, nsplit, splits, M * N, stream_ptr()), "spv_gemm_bf16")
+    _abi.call("spv_gemm_bf16", int(a_kmajor), ptr(A_hi), ptr(A_lo), lda, ptr(B_hi) + b_off, (ptr(B_lo) + b_off) if B_lo is not None else None,
+                            ldb, ptr(out), N, M, N, K, nsplit, splits, M * N, a_tiles, stream_ptr())
     return out[0] if splits == 1 else out.sum(0)
 
 
@@ -179,7 +173,6 @@ class DecoderNBLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, counts: GroupCounts, rows, B: int, zp, zs, m, Wp, cp, Ws, cs_, Wm, bm, px_r, library, w_row,
                 nsplit: int, train: bool, ws: Workspace):
-        lib = _abi.load()
         dev = zp.device
         G = counts.G
         n_p, n_s = zp.shape[1], zs.shape[1]
@@ -189,7 +182,6 @@ class DecoderNBLoss(torch.autograd.Function):
         KMp = 320  # one 320-wide N tile of the backward GEMMs; K steps beyond `ksteps` are never issued
         if KM > KMp:
             raise _abi.SpvError("mixture input wider than 320 columns is not supported")
-        ksteps = -(-KM // 16)
         Bp, Gp = round_up(B, DEC_CELLS_PER_WG), round_up(G, 128)
         lo = True  # the small regressor operands always travel as hi/lo pairs
         mlo = nsplit == 3
@@ -208,7 +200,7 @@ class DecoderNBLoss(torch.autograd.Function):
         # ---- tables / per-cell vectors -----------------------------------------------------------
         gene_tab = ws.get("dec_gene_tab", (Gp, 4), torch.float32)
         cnt_tab = ws.get("dec_cnt_tab", (NB_CMAX, Gp, 2), torch.float32)
-        check(lib.spv_dec_tables(ptr(f32(px_r)), G, Gp, ptr(gene_tab), ptr(cnt_tab), stream_ptr()), "spv_dec_tables")
+        _abi.call("spv_dec_tables", ptr(f32(px_r)), G, Gp, ptr(gene_tab), ptr(cnt_tab), stream_ptr())
         splits, per = _gene_splits(Bp, Gp)
         vec = lambda n: ws.get(n, (Bp,), torch.float32)
         part = lambda n: ws.get(n, (splits, Bp), torch.float32)
@@ -221,23 +213,25 @@ class DecoderNBLoss(torch.autograd.Function):
             dL = ws.get("dec_dL_" + gname, (Bp, Gp), gdt, zero=True)
             tP = ws.get("dec_tP_" + gname, (Bp, Gp), gdt, zero=True)
             tS = ws.get("dec_tS_" + gname, (Bp, Gp), gdt, zero=True)
-            dth = ws.get("dec_dtheta", (Bp // DEC_CELLS_PER_WG, Gp), torch.float32, zero=True)
+            dth = ws.get("dec_dtheta", (Bp // 32, Gp), torch.float32, zero=True)
         else:
             dL = tP = tS = dth = None
         lse_p, lse_s, a_p, a_s = vec("dec_lse_p"), vec("dec_lse_s"), vec("dec_a_p"), vec("dec_a_s")
+        # mixing logits [Bp][Gp]: f16 in bf16 mode, fp32 in fp32 mode (one plain MFMA GEMM, K = KMp)
+        logits = ws.get("dec_logits_" + ("f32" if mlo else "f16"), (Bp, Gp), torch.float32 if mlo else torch.float16)
+        _abi.call("spv_dec_logits", ptr(Am_hi), ptr(Am_lo), ptr(Wm_hi), ptr(Wm_lo), KMp, Bp, Gp, nsplit, ptr(logits), int(mlo), stream_ptr())
         cst = counts.c_struct(rows)
         P = SpvDecParams(
             X=cst.X, ldx=cst.ld, rows=cst.rows, col_off=cst.col_off, count_is_u16=int(cst.dtype == _abi.SPV_COUNT_U16),
-            B=B, G=G, Bp=Bp, Gp=Gp, Wm_hi=ptr(Wm_hi), Wm_lo=ptr(Wm_lo), KMp=KMp, ksteps_m=ksteps,
-            Am_hi=ptr(Am_hi), Am_lo=ptr(Am_lo), Wps_hi=ptr(Wps_hi), Wps_lo=ptr(Wps_lo), Aps_hi=ptr(Aps_hi), Aps_lo=ptr(Aps_lo),
+            B=B, G=G, Bp=Bp, Gp=Gp, logits=ptr(logits), n_gene_tiles=Gp // 32, logits_f32=int(mlo), Wps_hi=ptr(Wps_hi), Wps_lo=ptr(Wps_lo), Aps_hi=ptr(Aps_hi), Aps_lo=ptr(Aps_lo),
             gene_tab=ptr(gene_tab), cnt_tab=ptr(cnt_tab), a_p=ptr(a_p), a_s=ptr(a_s), lse_p=ptr(lse_p), lse_s=ptr(lse_s),
             w_row=ptr(w_pad), gene_splits=splits, genes_per_split=per,
             part_max_p=ptr(part("dec_pmp")), part_sum_p=ptr(part("dec_psp")), part_max_s=ptr(part("dec_pms")), part_sum_s=ptr(part("dec_pss")),
             rec_part=ptr(part("dec_rec")), tp_part=ptr(part("dec_tp")), ts_part=ptr(part("dec_ts")),
-            dtheta_part=ptr(dth), dL=ptr(dL), tP=ptr(tP), tS=ptr(tS), ldg=Gp, grads_f32=int(grads_f32),
+            dtheta_part=ptr(dth), dL=ptr(dL), tP=ptr(tP), tS=ptr(tS), grads_f32=int(grads_f32),
         )
-        check(lib.spv_dec_lse(C.byref(P), ptr(f32(library)), stream_ptr()), "spv_dec_lse")
-        check(lib.spv_dec_nb_fwd(C.byref(P), nsplit, int(train), stream_ptr()), "spv_dec_nb_fwd")
+        _abi.call("spv_dec_lse", C.byref(P), ptr(f32(library)), stream_ptr())
+        _abi.call("spv_dec_nb_fwd", C.byref(P), int(train), stream_ptr())
         rec = part("dec_rec").sum(0)[:B]
         loss = (rec * w_row).sum()
         if train:
@@ -251,7 +245,6 @@ class DecoderNBLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_loss, _g_rec):
-        lib = _abi.load()
         if ctx.done:
             raise _abi.SpvError("DecoderNBLoss.backward may run once per forward (gradient buffers are consumed in place)")
         ctx.done = True
@@ -259,7 +252,7 @@ class DecoderNBLoss(torch.autograd.Function):
         B, G, Bp, Gp, n_p, n_s, KM, KMp, n_m = ctx.dims
         ws, nsplit, P = ctx.ws, ctx.nsplit, ctx.P
         Wm_hi, Wm_lo, Am_hi, Am_lo, Wps_hi, Wps_lo, Aps_hi, Aps_lo, dL, tP, tS, dth, lse_p, lse_s, gene_tab = ctx.keep
-        check(lib.spv_dec_softmax_bwd(C.byref(P), ptr(ctx.Tp), ptr(ctx.Ts), stream_ptr()), "spv_dec_softmax_bwd")
+        _abi.call("spv_dec_softmax_bwd", C.byref(P), ptr(ctx.Tp), ptr(ctx.Ts), stream_ptr())
         if ctx.grads_f32:  # fp32 mode: split the stored fp32 gradients into hi/lo images for the MFMA GEMMs
             def split(t, name):
                 hi, lo = _bf16_image(ws, name, Bp, Gp, True)
@@ -272,13 +265,14 @@ class DecoderNBLoss(torch.autograd.Function):
             dL_hi, tP_hi, tS_hi, dL_lo, tP_lo, tS_lo = dL, tP, tS, None, None, None
         ksp = max(1, min(8, (Gp // 32) // 16))  # K splits of the contractions over genes
         # contraction over cells:  d W[g][k] = sum_b dY[b][g] * A[b][k]
-        dWm = _gemm(True, dL_hi, dL_lo, Gp, Am_hi, Am_lo, KMp, G, KMp, Bp, nsplit, 1, ws, "dec_dWm")
-        dWp = _gemm(True, tP_hi, tP_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KP, Bp, nsplit, 1, ws, "dec_dWp")
-        dWs = _gemm(True, tS_hi, tS_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KS, Bp, nsplit, 1, ws, "dec_dWs", b_col_off=DEC_KP)
+        csp = max(1, min(4, (Bp // 32) // 16))  # K splits of the contractions over cells
+        dWm = _gemm(True, dL_hi, dL_lo, Gp, Am_hi, Am_lo, KMp, G, KMp, Bp, nsplit, min(csp, 2), ws, "dec_dWm", a_tiles=Gp // 32)
+        dWp = _gemm(True, tP_hi, tP_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KP, Bp, nsplit, csp, ws, "dec_dWp", a_tiles=Gp // 32)
+        dWs = _gemm(True, tS_hi, tS_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KS, Bp, nsplit, csp, ws, "dec_dWs", b_col_off=DEC_KP, a_tiles=Gp // 32)
         # contraction over genes:  d A[b][k] = sum_g dY[b][g] * W[g][k]
-        dAm = _gemm(False, dL_hi, dL_lo, Gp, Wm_hi, Wm_lo, KMp, B, KMp, G, nsplit, ksp, ws, "dec_dAm")
-        dAp = _gemm(False, tP_hi, tP_lo, Gp, Wps_hi, Wps_lo, DEC_KPS, B, DEC_KP, G, nsplit, ksp, ws, "dec_dAp")
-        dAs = _gemm(False, tS_hi, tS_lo, Gp, Wps_hi, Wps_lo, DEC_KPS, B, DEC_KS, G, nsplit, ksp, ws, "dec_dAs", b_col_off=DEC_KP)
+        dAm = _gemm(False, dL_hi, dL_lo, Gp, Wm_hi, Wm_lo, KMp, B, KMp, G, nsplit, ksp, ws, "dec_dAm", a_tiles=Gp // 32)
+        dAp = _gemm(False, tP_hi, tP_lo, Gp, Wps_hi, Wps_lo, DEC_KPS, B, DEC_KP, G, nsplit, ksp, ws, "dec_dAp", a_tiles=Gp // 32)
+        dAs = _gemm(False, tS_hi, tS_lo, Gp, Wps_hi, Wps_lo, DEC_KPS, B, DEC_KS, G, nsplit, ksp, ws, "dec_dAs", b_col_off=DEC_KP, a_tiles=Gp // 32)
         g = g_loss
         d_m = dAm[:, :n_m] * g
         d_zp = (dAm[:, n_m:n_m + n_p] + dAp[:, :n_p]) * g
