@@ -81,9 +81,10 @@ int spv_enc_fc1_wgrad(const spv_counts* x, int32_t B, int32_t G,
                       int32_t nsplit, float* dW, int64_t ldc, void* stream);
 
 /* "Accumulator-tile" order of the [cells][genes] arrays exchanged between the decoder kernels
- * (mixing logits, dL, tP, tS):  T[cell/32][gene/32][lane][q], lane = cell%32 + 32 h,
- * gene%32 = (q&3) + 8 (q>>2) + 4 h, q = 0..15 -- each 32x32 tile is stored as the 64 lanes x 16
- * registers of the MFMA accumulator that produced it, 2 KiB contiguous.  n_gene_tiles = Gp / 32. */
+ * (mixing logits, dL, tP, tS):  T[cell/32][gene/32][qq][lane][j], lane = cell%32 + 32 h,
+ * gene%32 = 8 qq + 4 h + j, qq, j = 0..3 -- each 32x32 tile is stored as the MFMA accumulator that
+ * produced it (genes on MFMA rows, register 4 qq + j), register-group major, so one wave
+ * instruction moves 512 contiguous bytes.  n_gene_tiles = Gp / 32. */
 
 /* Plain bf16 MFMA GEMM, fp32 out:  C[M][N] (+)= sum_k A(m,k) B(k,n).
  *   a_kmajor == 0: A is mem[m][k] (k contiguous); a_kmajor == 1: A is mem[k][m];

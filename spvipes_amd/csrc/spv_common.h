@@ -47,8 +47,10 @@ __device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
   lo = f2bf(x - bf2f(hi));
 }
 
-__device__ __forceinline__ float fast_log(float x) { return __logf(x); }
-__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+// raw v_log_f32 / v_exp_f32 (base 2, ~1 ulp, no denormal rescue code around them: every operand on
+// the hot path is a normal number or may flush to zero)
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // log1p of a raw count as the reference computes it: torch.log(1 + x) in fp32

@@ -351,9 +351,9 @@ __global__ __launch_bounds__(256, TRAIN ? 3 : 4) void dec_nb_kernel(DecParams p)
       float o_dl[4], o_tp[4], o_ts[4], ell4[4], cnt4[4], dth4[4];
       const int gq = g0 + 8 * qq + 4 * h;
       load_counts4(p, row_of_cell, gq, cell_ok, cnt4);
-      // [cells][genes] arrays live in accumulator-tile order (spv_gemm.h SRC_TILED): this lane's 16
-      // registers of tile (cell_tile, g0/32) are contiguous, chunk qq = registers 4qq..4qq+3
-      const long toff = (((long)cell_tile * p.n_gene_tiles + (g0 >> 5)) * 64 + lane) * 16 + 4 * qq;
+      // [cells][genes] arrays live in accumulator-tile order (spv_gemm.h SRC_TILED): registers
+      // 4qq..4qq+3 of all 64 lanes of tile (cell_tile, g0/32) are 512 contiguous bytes
+      const long toff = ((long)cell_tile * p.n_gene_tiles + (g0 >> 5)) * 1024 + (qq * 64 + lane) * 4;
       load4<LT>(p.logits, toff, ell4);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -461,13 +461,13 @@ __global__ __launch_bounds__(256) void dec_softmax_bwd_kernel(DecParams p, const
     if (g0 >= p.G) break;
     f16v yp, ys;
     ps_tiles(p, g0, lane, cf, yp, ys);
-    const long tbase = (((long)cell_tile * p.n_gene_tiles + (g0 >> 5)) * 64 + lane) * 16;
+    const long tbase = ((long)cell_tile * p.n_gene_tiles + (g0 >> 5)) * 1024 + lane * 4;
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
       const int g = g0 + 8 * qq + 4 * h;
       float vp[4], vs[4];
-      load4<GT>(p.tP, tbase + 4 * qq, vp);
-      load4<GT>(p.tS, tbase + 4 * qq, vs);
+      load4<GT>(p.tP, tbase + 256 * qq, vp);
+      load4<GT>(p.tS, tbase + 256 * qq, vs);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int q = 4 * qq + j;
@@ -475,8 +475,8 @@ __global__ __launch_bounds__(256) void dec_softmax_bwd_kernel(DecParams p, const
         vp[j] = ok ? vp[j] - fast_exp(yp[q] - lp) * tpb : 0.f;
         vs[j] = ok ? vs[j] - fast_exp(ys[q] - ls) * tsb : 0.f;
       }
-      store4<GT>(p.tP, tbase + 4 * qq, vp);
-      store4<GT>(p.tS, tbase + 4 * qq, vs);
+      store4<GT>(p.tP, tbase + 256 * qq, vp);
+      store4<GT>(p.tS, tbase + 256 * qq, vs);
     }
   }
 }

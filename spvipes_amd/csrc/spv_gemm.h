@@ -14,10 +14,11 @@
 //               As a k-major B operand (k = cell, n = gene) it feeds the fc1 weight gradient.
 //
 //   SRC_TILED : a [cells][genes] array kept in "accumulator-tile" order
-//               T[cell/32][gene/32][lane = cell%32 + 32h][q],  gene%32 = (q&3) + 8(q>>2) + 4h,
-//               i.e. each 32x32 tile is stored exactly as the 64 lanes x 16 registers of the MFMA
-//               that produced it (genes on MFMA rows, cells on MFMA columns): producers write and
-//               consumers read 2 KiB contiguous per tile instead of 32 strided 64-byte row pieces.
+//               T[cell/32][gene/32][qq][lane = cell%32 + 32h][j],  gene%32 = 8 qq + 4 h + j,
+//               i.e. each 32x32 tile is stored as the MFMA accumulator that produced it (genes on
+//               MFMA rows, cells on MFMA columns; register q = 4 qq + j), register-group major: one
+//               wave instruction moving registers 4qq..4qq+3 of every lane touches 64 x 8 B = 512
+//               contiguous bytes (16-bit elements) instead of 32 strided row pieces.
 //
 // 256 threads = 4 waves arranged WM x WN; each wave owns (BM/WM) x (BN/WN) of the tile as TM x TN
 // MFMA 32x32 tiles.  BK = 32.  Global->register prefetch of tile t+1 overlaps the MFMAs of tile t
@@ -93,7 +94,7 @@ struct Stager {
     ok = c < NCHUNKS;
     if constexpr (SRC == SRC_TILED) {
       s = c >> 7;    // 32x32 tile along EXT
-      f = c & 127;   // (lane << 1) | register half
+      f = c & 127;   // (qq << 5) | lane pair
     } else {
       s = c / FAST8;
       f = c % FAST8;
@@ -113,7 +114,7 @@ struct Stager {
       if constexpr (SRC == SRC_TILED) {
         // k-major (k = cell, ext = gene): tile (k0/32, ext0/32 + s); natural (ext = cell, k = gene): (ext0/32 + s, k0/32)
         const long ct = KMAJ ? k0 / 32 : ext0 / 32 + s, gt = KMAJ ? ext0 / 32 + s : k0 / 32;
-        const long off = ((ct * p.tiles_inner + gt) * 64 + (f >> 1)) * 16 + 8 * (f & 1);
+        const long off = (ct * p.tiles_inner + gt) * 1024 + 8 * f;  // 16 B = registers 4qq..4qq+3 of lanes 2lp, 2lp+1
         hi[i] = *reinterpret_cast<const u4v*>(reinterpret_cast<const bf16_t*>(ptr) + off);
         if constexpr (Cfg::NSPLIT == 3) lo[i] = *reinterpret_cast<const u4v*>(reinterpret_cast<const bf16_t*>(ptr_lo) + off);
       } else if constexpr (SRC == SRC_PLAIN) {
@@ -179,15 +180,15 @@ struct Stager {
       coord(i, tid, s, f, ok);
       if (!ok) continue;
       if constexpr (SRC == SRC_TILED) {
-        // registers 8qh..8qh+7 of lane (r, h): genes 16qh + 4h + {0..3} and 16qh + 8 + 4h + {0..3} of cell r
-        const int lane = f >> 1, qh = f & 1, r = lane & 31, h = lane >> 5;
-        const int g = 16 * qh + 4 * h;
+        // genes 8qq + 4h + {0..3} of the two cells r, r+1 held by lanes 2lp and 2lp+1
+        const int qq = f >> 5, lane = (f & 31) * 2, r = lane & 31, h = lane >> 5;
+        const int g = 8 * qq + 4 * h;
         const int o = KMAJ ? r * PITCH + 32 * s + g : (32 * s + r) * PITCH + g;
         *reinterpret_cast<u2v*>(img_hi + o) = u2v{hi[i][0], hi[i][1]};
-        *reinterpret_cast<u2v*>(img_hi + o + 8) = u2v{hi[i][2], hi[i][3]};
+        *reinterpret_cast<u2v*>(img_hi + o + PITCH) = u2v{hi[i][2], hi[i][3]};
         if constexpr (Cfg::NSPLIT == 3) {
           *reinterpret_cast<u2v*>(img_lo + o) = u2v{lo[i][0], lo[i][1]};
-          *reinterpret_cast<u2v*>(img_lo + o + 8) = u2v{lo[i][2], lo[i][3]};
+          *reinterpret_cast<u2v*>(img_lo + o + PITCH) = u2v{lo[i][2], lo[i][3]};
         }
         continue;
       }
@@ -286,20 +287,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 #pragma unroll
       for (int j = 0; j < Cfg::TN; ++j) {
         const long gt = (m0 + wm * (Cfg::BM / Cfg::WM) + 32 * i) / 32, ct = (n0 + wn * (Cfg::BN / Cfg::WN) + 32 * j) / 32;
-        const long off = ((ct * p.tiles_inner + gt) * 64 + lane) * 16;
-        if (p.epi == EPI_TILED_F32) {
+        const long off = (ct * p.tiles_inner + gt) * 1024 + lane * 4;
 #pragma unroll
-          for (int q = 0; q < 16; q += 4)
-            *reinterpret_cast<f4v*>(p.C + off + q) = f4v{acc[i][j][q], acc[i][j][q + 1], acc[i][j][q + 2], acc[i][j][q + 3]};
-        } else {
-          typedef __attribute__((ext_vector_type(8))) _Float16 h8v;
-          _Float16* dst = reinterpret_cast<_Float16*>(p.C) + off;
-#pragma unroll
-          for (int q = 0; q < 16; q += 8) {
-            h8v v;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (_Float16)acc[i][j][q + e];
-            *reinterpret_cast<h8v*>(dst + q) = v;
+        for (int qq = 0; qq < 4; ++qq) {
+          const int q = 4 * qq;
+          if (p.epi == EPI_TILED_F32) {
+            *reinterpret_cast<f4v*>(p.C + off + qq * 256) = f4v{acc[i][j][q], acc[i][j][q + 1], acc[i][j][q + 2], acc[i][j][q + 3]};
+          } else {
+            typedef __attribute__((ext_vector_type(4))) _Float16 h4v;
+            const h4v v = {(_Float16)acc[i][j][q], (_Float16)acc[i][j][q + 1], (_Float16)acc[i][j][q + 2], (_Float16)acc[i][j][q + 3]};
+            *reinterpret_cast<h4v*>(reinterpret_cast<_Float16*>(p.C) + off + qq * 256) = v;
           }
         }
       }

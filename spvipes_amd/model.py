@@ -1,0 +1,207 @@
+"""scvi-tools-style user surface of the MI355X hot path: ``setup_anndata`` / ``train`` /
+``get_latent_representation`` / ``get_loadings`` / ``save`` / ``load``.
+
+Mirrors /root/reference/src/spVIPES/model/spvipes.py (class ``spVIPES``: ctor :216-283,
+``setup_anndata`` :285-422, ``get_latent_representation`` :424-650, ``get_loadings`` :652-677) and
+model/base/training_mixin.py (``train`` :19-123).  anndata / scvi-tools / Lightning are not part of
+this build: the AnnData object is duck-typed (``.X`` dense array, ``.obs`` mapping of columns,
+``.uns`` dict, ``.n_obs``) and ``prepare_adatas``' output schema is the input contract --
+``uns["groups_lengths" | "groups_var_indices" | "groups_obs_indices" | ...]``, ``obs["groups"]``,
+``obs["indices"]`` (data/prepare_adatas.py:97-132).
+
+What stays out: ``process_transport_plan`` (Leiden + Hungarian preprocessing, needs
+scanpy) -- cluster matching expects ``obs["processed_transport_labels"]`` to be present already.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _abi
+from .data import MinibatchSampler, to_group_counts
+from .module import spVIPESmodule
+from .train import Trainer, default_max_epochs
+
+_SETUP_KEY = "_spvipes_amd_setup"
+
+
+def _codes(column) -> np.ndarray:
+    """Categorical codes the way scvi's CategoricalObsField produces them (sorted unique values)."""
+    arr = np.asarray(column)
+    _, inv = np.unique(arr, return_inverse=True)
+    return inv.astype(np.float32)
+
+
+class spVIPES:
+    """Shared-private VAE with Product-of-Experts integration, HIP-accelerated.  Constructor arguments as
+    the reference (:216-224); ``precision`` ("bf16" | "fp32") and ``device`` are this build's additions."""
+
+    def __init__(self, adata, n_hidden: int = 128, n_dimensions_shared: int = 25, n_dimensions_private: int = 10,
+                 dropout_rate: float = 0.1, precision: str = "bf16", device: Optional[str] = None, **model_kwargs):
+        if _SETUP_KEY not in adata.uns:
+            raise ValueError("Please run `spVIPES.setup_anndata(adata, groups_key=...)` before creating the model")
+        if not torch.cuda.is_available():
+            raise _abi.SpvError("spvipes_amd needs an MI355X: there is no CPU fallback for the hot path")
+        _abi.load()
+        self.adata = adata
+        self.device = torch.device(device or "cuda:0")
+        self.n_dimensions_private, self.n_dimensions_shared = n_dimensions_private, n_dimensions_shared
+        setup = adata.uns[_SETUP_KEY]
+        self._setup = setup
+        groups_lengths = adata.uns["groups_lengths"]
+        var_idx = [np.asarray(v) for v in adata.uns["groups_var_indices"]]
+        self.obs_idx = [np.asarray(v) for v in adata.uns["groups_obs_indices"]]
+        plan_key = setup.get("transport_plan_key")
+        transport_plan = None
+        if plan_key:
+            if adata.uns.get(plan_key) is None:
+                raise ValueError(f"Transport plan not found in adata.uns['{plan_key}']")
+            transport_plan = torch.tensor(np.asarray(adata.uns[plan_key]), dtype=torch.float32, device=self.device)
+        pair_data = "processed_transport_labels" not in adata.obs  # :249
+        use_labels = setup.get("label_key") is not None  # :251
+        self.module = spVIPESmodule(
+            groups_lengths=groups_lengths, groups_obs_names=adata.uns.get("groups_obs_names"),
+            groups_var_names=adata.uns.get("groups_var_names"), groups_var_indices=var_idx, groups_obs_indices=self.obs_idx,
+            transport_plan=transport_plan, pair_data=pair_data, use_labels=use_labels,
+            n_labels=(len(np.unique(np.asarray(adata.obs[setup["label_key"]]))) if use_labels else None), n_batch=1,
+            n_hidden=n_hidden, n_dimensions_shared=n_dimensions_shared, n_dimensions_private=n_dimensions_private,
+            dropout_rate=dropout_rate, precision=precision, **model_kwargs,
+        ).to(self.device)
+        # resident per-group count matrices: rows = the group's cells (obs order), columns = its own genes
+        X = np.asarray(adata.X if setup.get("layer") is None else adata.layers[setup["layer"]])
+        self.counts = [to_group_counts(X[self.obs_idx[g]][:, var_idx[g]], self.device) for g in range(2)]
+        obs = adata.obs
+        self._labels = [torch.tensor(_codes(obs[setup["label_key"]])[self.obs_idx[g]], device=self.device) for g in range(2)] if use_labels else None
+        self._components = ([torch.tensor(_codes(obs["processed_transport_labels"])[self.obs_idx[g]], device=self.device) for g in range(2)]
+                            if (transport_plan is not None and not pair_data) else None)
+        self._plan_indices = [torch.tensor(np.asarray(obs["indices"])[self.obs_idx[g]].astype(np.float32), device=self.device) for g in range(2)]
+        self.is_trained_ = False
+        self.history: Dict[str, List[float]] = {}
+
+    # ------------------------------------------------------------------------------------------
+    @classmethod
+    def setup_anndata(cls, adata, groups_key: str, match_clusters: bool = False, transport_plan_key: Optional[str] = None,
+                      label_key: Optional[str] = None, batch_key: Optional[str] = None, layer: Optional[str] = None, **kwargs) -> None:
+        """Registers the fields the model reads (:355-422).  Same arguments, priorities and errors."""
+        if batch_key is not None:
+            raise NotImplementedError("batch covariates are outside the accelerated path")
+        if groups_key not in adata.obs:
+            raise KeyError(f"groups_key '{groups_key}' not found in adata.obs")
+        if transport_plan_key is not None:
+            if transport_plan_key not in adata.uns:
+                raise ValueError(f"Transport plan key '{transport_plan_key}' not found in adata.uns")
+            adata.uns["transport_plan"] = adata.uns[transport_plan_key]
+            if match_clusters and "processed_transport_labels" not in adata.obs:
+                raise NotImplementedError(
+                    "match_clusters=True needs obs['processed_transport_labels'] (the reference derives it with "
+                    "scanpy Leiden + Hungarian matching in process_transport_plan, which is outside this build)")
+            if "indices" not in adata.obs:
+                raise ValueError("'indices' must be present in adata.obs when using a transport plan")
+        if label_key is not None and label_key not in adata.obs:
+            raise KeyError(f"label_key '{label_key}' not found in adata.obs")
+        for k in ("groups_lengths", "groups_var_indices", "groups_obs_indices"):
+            if k not in adata.uns:
+                raise ValueError(f"adata.uns['{k}'] missing: build the AnnData with prepare_adatas (or the same schema)")
+        adata.uns[_SETUP_KEY] = {"groups_key": groups_key, "match_clusters": match_clusters, "transport_plan_key": transport_plan_key,
+                                 "label_key": label_key, "layer": layer}
+
+    # ------------------------------------------------------------------------------------------
+    def _local_rows(self, g: int, indices: Sequence[int]) -> np.ndarray:
+        """adata row numbers -> rows of group g's resident matrix."""
+        pos = np.full(self.adata.n_obs, -1, dtype=np.int64)
+        pos[self.obs_idx[g]] = np.arange(len(self.obs_idx[g]))
+        loc = pos[np.asarray(indices)]
+        if (loc < 0).any():
+            raise ValueError(f"group_indices_list[{g}] contains cells that do not belong to group {g}")
+        return loc
+
+    def _minibatch(self, rows: Sequence[torch.Tensor]):
+        out = []
+        for g, r in enumerate(rows):
+            rl = r.long()
+            d = {"counts": self.counts[g], "rows": r, "indices": self._plan_indices[g][rl].unsqueeze(1), "groups": None, "batch": None}
+            if self._labels is not None:
+                d["labels"] = self._labels[g][rl].unsqueeze(1)
+            if self._components is not None:
+                d["processed_transport_labels"] = self._components[g][rl].unsqueeze(1)
+            out.append(d)
+        return tuple(out)
+
+    def train(self, group_indices_list: List[List[int]], batch_size: Optional[int] = 128, max_epochs: Optional[int] = None,
+              use_gpu=None, train_size: float = 0.9, validation_size: Optional[float] = None, early_stopping: bool = False,
+              plan_kwargs: Optional[dict] = None, n_steps_kl_warmup: Optional[int] = None, n_epochs_kl_warmup: Optional[int] = 400,
+              seed: int = 0, **trainer_kwargs) -> None:
+        """training_mixin.py:19-123 (signature kept; ``use_gpu``/``early_stopping`` accepted and ignored)."""
+        if max_epochs is None:
+            max_epochs = default_max_epochs(self.adata.n_obs)
+        plan_kwargs = dict(plan_kwargs or {})
+        local = [self._local_rows(g, group_indices_list[g]) for g in range(2)]
+        sampler = MinibatchSampler([len(l) for l in local], batch_size, self.device, seed=seed, train_size=train_size,
+                                   validation_size=validation_size, group_indices_list=local)
+        trainer = Trainer(self.module, self.counts, lr=plan_kwargs.get("lr", 1e-3), eps=plan_kwargs.get("eps", 0.01),
+                          weight_decay=plan_kwargs.get("weight_decay", 1e-6), n_epochs_kl_warmup=n_epochs_kl_warmup,
+                          n_steps_kl_warmup=n_steps_kl_warmup)
+        trainer.minibatch = self._minibatch  # labels / components / plan indices of this AnnData
+        self.history = trainer.fit(sampler, max_epochs, log_every=trainer_kwargs.get("log_every", 1))
+        self.is_trained_ = True
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def get_latent_representation(self, group_indices_list: List[List[int]], adata=None, indices=None, normalized: bool = False,
+                                  give_mean: bool = True, mc_samples: int = 5000, batch_size: Optional[int] = None,
+                                  drop_last: Optional[bool] = None) -> dict:
+        """model/spvipes.py:424-650.  Returns the SAMPLED ``log_z`` (as the reference does) as
+        {"shared","private","shared_reordered","private_reordered"} -> {0: ndarray, 1: ndarray}."""
+        if normalized:
+            raise NotImplementedError("normalized=True is broken in the reference (nothing is collected for the shared latents, :542-544)")
+        batch_size = batch_size or 128
+        drop_last = bool(drop_last) if drop_last is not None else False
+        n1, n2 = (len(g) for g in group_indices_list)
+        local = [self._local_rows(g, group_indices_list[g]) for g in range(2)]
+        use_cycling = self.module.use_transport_plan and self.module.pair_data and not drop_last and not self.module.use_labels
+        if use_cycling:  # :578-626
+            mn, mx = min(n1, n2), max(n1, n2)
+            if mn == 0:
+                raise ValueError("One of the groups is empty")
+            chunks = [([local[0][(s + i) % n1] for i in range(mn)], [local[1][(s + i) % n2] for i in range(mn)]) for s in range(0, mx, mn)]
+        else:
+            chunks = [(local[0], local[1])]
+        res = {k: [] for k in ("s0", "s1", "p0", "p1", "i1")}
+        was_training = self.module.training
+        self.module.eval()
+        for c0, c1 in chunks:
+            it0 = list(MinibatchSampler.sequential(c0, batch_size, self.device))
+            it1 = list(MinibatchSampler.sequential(c1, batch_size, self.device))
+            if drop_last:
+                it0 = [b for b in it0 if len(b) == batch_size]
+                it1 = [b for b in it1 if len(b) == batch_size]
+            n_steps = max(len(it0), len(it1))  # ConcatDataLoader: the longer loader leads, the shorter one is cycled
+            for s in range(n_steps):
+                rows = [it0[s % len(it0)], it1[s % len(it1)]]
+                tensors = self._minibatch(rows)
+                out = self.module.inference(**self.module._get_inference_input(tensors))
+                res["s0"].append(out["poe_stats"][0]["logtheta_log_z"].cpu())
+                res["s1"].append(out["poe_stats"][1]["logtheta_log_z"].cpu())
+                res["p0"].append(out["private_stats"][0]["log_z"].cpu())
+                res["p1"].append(out["private_stats"][1]["log_z"].cpu())
+                res["i1"].append(tensors[1]["indices"].cpu())
+        self.module.train(was_training)
+        i1 = torch.cat(res["i1"]).numpy().flatten()[:n2]
+        p = {0: torch.cat(res["p0"]).numpy()[:n1], 1: torch.cat(res["p1"]).numpy()[:n2]}
+        s = {0: torch.cat(res["s0"]).numpy()[:n1], 1: torch.cat(res["s1"]).numpy()[:n2]}
+        order = np.argsort(i1)
+        return {"shared": s, "private": p, "shared_reordered": {0: s[0], 1: s[1][order]}, "private_reordered": {0: p[0], 1: p[1][order]}}
+
+    def get_loadings(self) -> dict:
+        """:652-677 (plain arrays instead of DataFrames: pandas indices need var_names, which duck-typed inputs may lack)."""
+        return {(i, t): self.module.get_loadings(i, t) for i in range(2) for t in ("private", "shared")}
+
+    # ------------------------------------------------------------------------------------------
+    def save(self, path: str) -> None:
+        """state_dict with the reference's parameter names (loads into the reference module and back)."""
+        torch.save({k: v.detach().cpu() for k, v in self.module.state_dict().items()}, path)
+
+    def load_state(self, path: str) -> None:
+        self.module.load_state_dict(torch.load(path, map_location=self.device))

@@ -255,7 +255,7 @@ class spVIPESmodule(nn.Module):
         log_z = loc + scale * eps
         return OrderedDict([
             ("logtheta_loc", loc), ("logtheta_logvar", logvar), ("logtheta_scale", scale),
-            ("log_z", log_z), ("theta", F.softmax(log_z, -1)), ("qz", torch.distributions.Normal(loc, scale)),
+            ("log_z", log_z), ("theta", F.softmax(log_z, -1)), ("qz", torch.distributions.Normal(loc, scale, validate_args=False)),
         ])
 
     def inference(self, x, batch_index, groups, global_indices, noise: Optional[dict] = None,
@@ -319,7 +319,7 @@ class spVIPESmodule(nn.Module):
             z_private, z_shared = log_z[:, n_s: n_p + n_s], log_z[:, :n_s]  # :753-754
             out[str(g)] = {
                 "px": LazyNBMixture(g, z_private, z_shared, library[g]),
-                "pz": torch.distributions.Normal(torch.zeros_like(log_z), torch.ones_like(log_z)),
+                "pz": torch.distributions.Normal(torch.zeros_like(log_z), torch.ones_like(log_z), validate_args=False),
             }
         return {"private_shared": {}, "private_poe": out}
 

@@ -274,11 +274,13 @@ class DecoderNBLoss(torch.autograd.Function):
         dAp = _gemm(False, tP_hi, tP_lo, Gp, Wps_hi, Wps_lo, DEC_KPS, B, DEC_KP, G, nsplit, ksp, ws, "dec_dAp", a_tiles=Gp // 32)
         dAs = _gemm(False, tS_hi, tS_lo, Gp, Wps_hi, Wps_lo, DEC_KPS, B, DEC_KS, G, nsplit, ksp, ws, "dec_dAs", b_col_off=DEC_KP, a_tiles=Gp // 32)
         g = g_loss
-        d_m = dAm[:, :n_m] * g
-        d_zp = (dAm[:, n_m:n_m + n_p] + dAp[:, :n_p]) * g
-        d_zs = (dAm[:, n_m + n_p:n_m + n_p + n_s] + dAs[:, :n_s]) * g
-        d_Wm, d_bm = dWm[:, :KM - 1] * g, dWm[:, KM - 1] * g
-        d_Wp, d_cp = dWp[:, :n_p] * g, dWp[:, n_p] * g
-        d_Ws, d_cs = dWs[:, :n_s] * g, dWs[:, n_s] * g
+        for t in (dWm, dWp, dWs, dAm, dAp, dAs):  # scale the contiguous GEMM outputs once, slice afterwards
+            t.mul_(g)
+        d_m = dAm[:, :n_m]
+        d_zp = dAm[:, n_m:n_m + n_p] + dAp[:, :n_p]
+        d_zs = dAm[:, n_m + n_p:n_m + n_p + n_s] + dAs[:, :n_s]
+        d_Wm, d_bm = dWm[:, :KM - 1], dWm[:, KM - 1]
+        d_Wp, d_cp = dWp[:, :n_p], dWp[:, n_p]
+        d_Ws, d_cs = dWs[:, :n_s], dWs[:, n_s]
         d_pxr = torch.exp(px_r) * dth.sum(0)[:G] * g  # theta = exp(px_r): d/d px_r = theta * d/d theta
         return (None, None, None, d_zp, d_zs, d_m, d_Wp, d_cp, d_Ws, d_cs, d_Wm, d_bm, d_pxr, None, None, None, None, None)

@@ -78,7 +78,7 @@ def _finish(loc: Tensor, logvar: Tensor, scale: Tensor, eps: Optional[Tensor], c
     log_z = loc + qscale * eps
     return OrderedDict([
         ("logtheta_loc", loc), ("logtheta_logvar", logvar), ("logtheta_scale", scale),
-        ("logtheta_qz", torch.distributions.Normal(loc, qscale)), ("logtheta_log_z", log_z),
+        ("logtheta_qz", torch.distributions.Normal(loc, qscale, validate_args=False)), ("logtheta_log_z", log_z),
         ("logtheta_theta", F.softmax(log_z, -1)),
     ])
 
@@ -90,8 +90,8 @@ def label_based_poe(shared_stats: Dict[int, dict], labels: Dict[int, Tensor], no
         partner, mode = label_partner(labels[g], labels[o])
         loc, logvar = own["logtheta_loc"], own["logtheta_logvar"]
         pidx = partner.clamp(min=0)
-        o_var = torch.exp(other["logtheta_logvar"][pidx])
-        o_loc = other["logtheta_loc"][pidx]
+        o_var = torch.exp(other["logtheta_logvar"].index_select(0, pidx))
+        o_loc = other["logtheta_loc"].index_select(0, pidx)
         m = mode.unsqueeze(1)
         one = torch.ones_like(o_var)
         t = torch.where(m == 0, 1.0 / o_var, torch.where(m == 1, one, one * 0.36787944117144233))
@@ -117,8 +117,8 @@ def paired_poe(shared_stats: Dict[int, dict], plan_block: Tensor, noise: dict) -
     out = {}
     for g, o in ((0, 1), (1, 0)):
         own, other = shared_stats[g], shared_stats[o]
-        o_var = torch.exp(other["logtheta_logvar"][part[g]])
-        j_loc, j_logvar = _fuse(own["logtheta_loc"], own["logtheta_logvar"], 1.0 / o_var, other["logtheta_loc"][part[g]] / o_var)
+        o_var = torch.exp(other["logtheta_logvar"].index_select(0, part[g]))
+        j_loc, j_logvar = _fuse(own["logtheta_loc"], own["logtheta_logvar"], 1.0 / o_var, other["logtheta_loc"].index_select(0, part[g]) / o_var)
         out[g] = _finish(j_loc, j_logvar, torch.exp(0.5 * j_logvar), noise.get(f"poe_{g}"), clamp=True)
     return out
 
@@ -157,10 +157,10 @@ def cluster_based_poe(shared_stats: Dict[int, dict], plan_block: Tensor, process
         own = shared_stats[g]
         pidx = partner.clamp(min=0)
         v_self = torch.exp(E[g]["logtheta_logvar"])
-        v_oth = torch.exp(E[o]["logtheta_logvar"][pidx])
+        v_oth = torch.exp(E[o]["logtheta_logvar"].index_select(0, pidx))
         m = mode.unsqueeze(1)
         t = torch.where(m == 0, 1.0 / v_oth, torch.ones_like(v_oth))
-        u = torch.where(m == 0, E[o]["logtheta_loc"][pidx] / v_oth, torch.zeros_like(v_oth))
+        u = torch.where(m == 0, E[o]["logtheta_loc"].index_select(0, pidx) / v_oth, torch.zeros_like(v_oth))
         joint = 1.0 / (1.0 + (1.0 / v_self + t))
         j_loc = (E[g]["logtheta_loc"] / v_self + u) * joint
         j_logvar = torch.log(joint)

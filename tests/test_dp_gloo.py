@@ -1,0 +1,76 @@
+"""CPU, world_size 2, gloo: the data-parallel mechanics of spvipes_amd.train -- parameters re-homed into one
+flat buffer, gradients accumulated into one flat buffer, ONE all-reduce per step, 1/world folded into the
+optimiser scale.  (The HIP kernels themselves need the GPU; tests/test_gpu_parity.py covers them.)"""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from spvipes_amd.train import FlatParams
+
+
+def _net():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+
+
+def _batch(rank):
+    g = torch.Generator().manual_seed(100 + rank)
+    return torch.randn(6, 5, generator=g), torch.randn(6, 3, generator=g)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net = _net()
+    fp = FlatParams(net)
+    dist.broadcast(fp.flat, src=0)
+    x, y = _batch(rank)
+    fp.zero_grad()
+    ((net(x) - y) ** 2).mean().backward()
+    assert all(p.grad.data_ptr() >= fp.grad.data_ptr() for p in fp.params)  # grads landed in the flat buffer
+    dist.all_reduce(fp.grad, op=dist.ReduceOp.SUM)  # the step's single collective
+    mean_grad = fp.grad / world
+    fp.flat.add_(mean_grad, alpha=-0.1)  # any optimiser acting on the flat buffers
+    q.put((rank, mean_grad.clone(), fp.flat.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_allreduce_equals_mean_of_rank_gradients():
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference: mean of the two ranks' gradients on the same two minibatches
+    grads = []
+    for r in range(world):
+        net = _net()
+        x, y = _batch(r)
+        ((net(x) - y) ** 2).mean().backward()
+        grads.append(torch.cat([torch.nn.functional.pad(p.grad.flatten(), (0, (-p.numel()) % 4)) for p in net.parameters()]))
+    want = (grads[0] + grads[1]) / world
+    for rank, mean_grad, flat in got:
+        torch.testing.assert_close(mean_grad, want, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(got[0][2], got[1][2], rtol=0, atol=0)  # replicas stay bit-identical
+
+
+def test_flat_params_are_views_and_survive_load_state_dict():
+    net = _net()
+    ref = {k: v.clone() for k, v in net.state_dict().items()}
+    fp = FlatParams(net)
+    for k, v in net.state_dict().items():
+        torch.testing.assert_close(v, ref[k])
+    net.load_state_dict({k: v + 1 for k, v in ref.items()})
+    assert abs(float(fp.flat[0]) - float(ref["0.weight"].flatten()[0]) - 1) < 1e-6  # still the same storage

@@ -1,0 +1,158 @@
+"""GPU: optimiser kernel, training loop, user API, and size-independent properties at benchmark sizes."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    from spvipes_amd import _abi
+    _abi.load()
+    return torch.device("cuda:0")
+
+
+def test_hip_adam_matches_torch_adam(dev):
+    from spvipes_amd.train import FlatParams, HipAdam
+    torch.manual_seed(0)
+    mk = lambda: torch.nn.Sequential(torch.nn.Linear(13, 17), torch.nn.Linear(17, 5)).to(dev)
+    a, b = mk(), mk()
+    b.load_state_dict(a.state_dict())
+    fp = FlatParams(a)
+    mine = HipAdam(fp, lr=1e-3, eps=0.01, weight_decay=1e-6)
+    ref = torch.optim.Adam(b.parameters(), lr=1e-3, eps=0.01, weight_decay=1e-6)
+    for step in range(5):
+        x = torch.randn(9, 13, device=dev)
+        fp.zero_grad()
+        a(x).pow(2).sum().backward()
+        mine.step()
+        ref.zero_grad()
+        b(x).pow(2).sum().backward()
+        ref.step()
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        torch.testing.assert_close(pa, pb, rtol=1e-5, atol=1e-7)
+
+
+class DuckAnnData:
+    """The fields of prepare_adatas' output that the model reads (data/prepare_adatas.py:97-132)."""
+
+    def __init__(self, X, obs, uns):
+        self.X, self.obs, self.uns, self.layers = X, obs, uns, {}
+        self.n_obs, self.n_vars = X.shape
+
+
+def _duck(n=(300, 260), G=(96, 80), seed=0, with_plan=False):
+    rng = np.random.default_rng(seed)
+    X = np.zeros((n[0] + n[1], G[0] + G[1]), np.float32)
+    X[: n[0], : G[0]] = rng.poisson(2.0, (n[0], G[0])) * (rng.random((n[0], G[0])) < 0.3)
+    X[n[0]:, G[0]:] = rng.poisson(2.0, (n[1], G[1])) * (rng.random((n[1], G[1])) < 0.3)
+    X[: n[0], 0] += 1
+    X[n[0]:, G[0]] += 1
+    obs = {"groups": np.array(["a"] * n[0] + ["b"] * n[1]), "indices": np.concatenate([np.arange(n[0]), np.arange(n[1])]).astype(np.int32),
+           "cell_type": np.concatenate([rng.integers(0, 4, n[0]), rng.integers(1, 5, n[1])])}
+    uns = {"groups_lengths": {0: G[0], 1: G[1]}, "groups_var_indices": [np.arange(G[0]), G[0] + np.arange(G[1])],
+           "groups_obs_indices": [np.arange(n[0]), n[0] + np.arange(n[1])], "groups_obs_names": None, "groups_var_names": None}
+    if with_plan:
+        uns["plan"] = (rng.random(n) * (rng.random(n) < 0.1)).astype(np.float32)
+    return DuckAnnData(X, obs, uns)
+
+
+def test_user_api_train_and_latents(dev):
+    from spvipes_amd.model import spVIPES
+    ad = _duck()
+    spVIPES.setup_anndata(ad, groups_key="groups", label_key="cell_type")
+    torch.manual_seed(0)
+    model = spVIPES(ad, n_hidden=32, n_dimensions_shared=10, n_dimensions_private=5, precision="fp32")
+    gi = [list(ad.uns["groups_obs_indices"][0]), list(ad.uns["groups_obs_indices"][1])]
+    model.train(gi, batch_size=64, max_epochs=8, train_size=1.0, n_epochs_kl_warmup=None, plan_kwargs={"lr": 5e-3})
+    h = model.history["train_loss"]  # constant KL weight: the loss is the negative ELBO and must go down
+    assert len(h) == 8 and all(np.isfinite(h)) and h[-1] < h[0], h
+    lat = model.get_latent_representation(gi, batch_size=64)
+    assert set(lat) == {"shared", "private", "shared_reordered", "private_reordered"}
+    assert lat["shared"][0].shape == (300, 10) and lat["shared"][1].shape == (260, 10)
+    assert lat["private"][0].shape == (300, 5) and lat["private_reordered"][1].shape == (260, 5)
+    assert all(np.isfinite(v).all() for d in lat.values() for v in d.values())
+    load = model.get_loadings()
+    assert load[(0, "shared")].shape == (96, 10) and load[(1, "private")].shape == (80, 5)
+
+
+def test_user_api_paired_transport_plan_cycling(dev):
+    from spvipes_amd.model import spVIPES
+    ad = _duck(n=(96, 64), with_plan=True)
+    spVIPES.setup_anndata(ad, groups_key="groups", transport_plan_key="plan")
+    model = spVIPES(ad, n_hidden=16, n_dimensions_shared=6, n_dimensions_private=3, precision="fp32")
+    assert model.module.pair_data and model.module.use_transport_plan and not model.module.use_labels
+    gi = [list(ad.uns["groups_obs_indices"][0]), list(ad.uns["groups_obs_indices"][1])]
+    model.train(gi, batch_size=32, max_epochs=2, train_size=1.0)
+    lat = model.get_latent_representation(gi, batch_size=32)  # unequal groups -> cycling path (:578-626)
+    assert lat["shared"][0].shape == (96, 6) and lat["shared"][1].shape == (64, 6)
+
+
+def test_setup_errors_match_reference(dev):
+    from spvipes_amd.model import spVIPES
+    ad = _duck()
+    with pytest.raises(ValueError):
+        spVIPES.setup_anndata(ad, groups_key="groups", transport_plan_key="missing")
+    with pytest.raises(ValueError):
+        spVIPES(ad)  # setup_anndata not run
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_full_size_invariances(dev, precision):
+    """BASELINE config-1 sizes (4096 cells x 10000 genes): properties that need no oracle run --
+    (a) permuting the cells of the minibatch permutes the per-cell reconstruction terms,
+    (b) permuting genes (counts columns and every per-gene parameter row together) leaves them unchanged,
+    (c) the weighted loss is linear in the cell weights."""
+    from spvipes_amd import ops
+    from spvipes_amd.data import make_synthetic_group
+    B, G, n_p, n_s = 4096, 10000, 10, 25
+    grp = make_synthetic_group(0, B, G, dev)
+    nsplit = 3 if precision == "fp32" else 1
+    g = torch.Generator(device=dev).manual_seed(0)
+    r = lambda *s, sc=1.0: torch.randn(*s, generator=g, device=dev) * sc
+    t = dict(zp=r(B, n_p), zs=r(B, n_s), m=torch.relu(r(B, 256)), Wp=r(G, n_p, sc=0.5), cp=r(G, sc=0.3), Ws=r(G, n_s, sc=0.3),
+             cs=r(G, sc=0.3), Wm=r(G, 256 + n_p + n_s, sc=0.05), bm=r(G, sc=0.2), px_r=r(G))
+    Xf = torch.from_numpy(grp.counts.X.cpu().numpy().view(np.uint16).astype(np.float32)).to(dev)
+    lib = torch.log(torch.log1p(Xf).sum(1))
+    w = torch.rand(B, generator=g, device=dev) / B
+    ws = ops.Workspace(dev)
+    rows = torch.arange(B, dtype=torch.int32, device=dev)
+
+    def run(rows, t, lib, w, counts=grp.counts):
+        with torch.no_grad():
+            loss, rec = ops.DecoderNBLoss.apply(counts, rows, B, *t.values(), lib, w, nsplit, False, ws)
+        return float(loss), rec.clone()
+
+    base_loss, base_rec = run(rows, t, lib, w)
+    assert torch.isfinite(base_rec).all()
+    tol = 1e-5 if precision == "fp32" else 2e-4
+    perm = torch.randperm(B, generator=g, device=dev)
+    tp = dict(t, zp=t["zp"][perm], zs=t["zs"][perm], m=t["m"][perm])
+    _, rec_p = run(perm.to(torch.int32), tp, lib[perm], w[perm])
+    torch.testing.assert_close(rec_p, base_rec[perm], rtol=tol, atol=tol * 1e3)
+    gp = torch.randperm(G, generator=g, device=dev)
+    tg = dict(t, Wp=t["Wp"][gp], cp=t["cp"][gp], Ws=t["Ws"][gp], cs=t["cs"][gp], Wm=t["Wm"][gp], bm=t["bm"][gp], px_r=t["px_r"][gp])
+    Xg = ops.GroupCounts(grp.counts.X[:, gp.cpu().to(dev)].contiguous(), G, 0)
+    _, rec_g = run(rows, tg, lib, w, counts=Xg)
+    torch.testing.assert_close(rec_g, base_rec, rtol=max(tol, 5e-5), atol=max(tol, 5e-5) * 1e3)
+    l2, _ = run(rows, t, lib, 2.0 * w)
+    assert abs(l2 - 2 * base_loss) <= 1e-5 * abs(base_loss)
+
+
+def test_training_step_runs_at_benchmark_size_and_learns(dev):
+    from spvipes_amd.data import MinibatchSampler, make_synthetic_group
+    from spvipes_amd.module import spVIPESmodule
+    from spvipes_amd.train import Trainer
+    torch.manual_seed(0)
+    groups = [make_synthetic_group(g, 8192, 2000, dev) for g in range(2)]
+    module = spVIPESmodule({0: 2000, 1: 2000}, use_labels=True, n_hidden=64, n_dimensions_shared=10, n_dimensions_private=5).to(dev)
+    trainer = Trainer(module, [g.counts for g in groups], labels=[g.labels for g in groups])
+    sampler = MinibatchSampler([8192, 8192], 1024, dev, seed=0)
+    module.train()
+    losses = []
+    for ep in range(3):
+        for rows in sampler.epoch():
+            losses.append(float(trainer.step(rows, kl_weight=1.0).loss.detach()))
+    assert np.isfinite(losses).all() and np.mean(losses[-4:]) < np.mean(losses[:4])

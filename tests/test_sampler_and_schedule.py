@@ -1,0 +1,49 @@
+"""CPU: host logic of the train loop -- sampler epoch semantics, KL warm-up, epochs heuristic."""
+import numpy as np
+import torch
+
+from spvipes_amd.data import MinibatchSampler
+from spvipes_amd.train import default_max_epochs, kl_weight_at
+
+CPU = torch.device("cpu")
+
+
+def test_split_follows_randomstate_permutation():
+    s = MinibatchSampler([10, 7], 2, CPU, seed=0, train_size=0.8)
+    rs = np.random.RandomState(seed=0)
+    p0, p1 = rs.permutation(np.arange(10)), rs.permutation(np.arange(7))
+    assert s.val_idx[0].tolist() == p0[:2].tolist() and s.train_idx[0].tolist() == p0[2:].tolist()
+    assert s.val_idx[1].tolist() == p1[:1].tolist() and s.train_idx[1].tolist() == p1[1:].tolist()  # ceil(0.8*7)=6 train
+
+
+def test_epoch_length_drop_last_and_cycle_replay():
+    s = MinibatchSampler([23, 9], 4, CPU, seed=1)
+    assert s.batches_per_group == [5, 2] and s.steps_per_epoch == 5
+    ep = list(s.epoch())
+    assert len(ep) == 5 and all(b[0].numel() == 4 and b[1].numel() == 4 for b in ep)
+    big = torch.cat([b[0] for b in ep])
+    assert big.unique().numel() == 20  # drop_last: 20 of 23 cells, no repeats within the epoch
+    # the smaller group replays the batches of its first pass, in order (itertools.cycle)
+    assert torch.equal(ep[2][1], ep[0][1]) and torch.equal(ep[3][1], ep[1][1]) and torch.equal(ep[4][1], ep[0][1])
+    ep2 = list(s.epoch())
+    assert not torch.equal(torch.cat([b[0] for b in ep2]), big)  # reshuffled every epoch
+
+
+def test_ranks_get_disjoint_shards():
+    a = MinibatchSampler([40, 40], 4, CPU, seed=0, rank=0, world=2)
+    b = MinibatchSampler([40, 40], 4, CPU, seed=0, rank=1, world=2)
+    for g in range(2):
+        assert len(a.train_idx[g]) == len(b.train_idx[g]) == 20
+        assert not set(a.train_idx[g].tolist()) & set(b.train_idx[g].tolist())
+
+
+def test_sequential_eval_order_keeps_last_partial_batch():
+    out = list(MinibatchSampler.sequential([5, 3, 9, 1, 7], 2, CPU))
+    assert [o.tolist() for o in out] == [[5, 3], [9, 1], [7]]
+
+
+def test_kl_warmup_and_epoch_heuristic():
+    assert kl_weight_at(0, 0, 400, None) == 0.0 and kl_weight_at(200, 0, 400, None) == 0.5 and kl_weight_at(999, 0, 400, None) == 1.0
+    assert kl_weight_at(5, 50, 400, 100) == 0.5  # steps take precedence
+    assert kl_weight_at(3, 7, None, None) == 1.0
+    assert default_max_epochs(50_000) == 160 and default_max_epochs(1_000) == 400  # training_mixin.py:89-91
