@@ -146,6 +146,122 @@ int spv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
                   float beta2, float eps, float weight_decay, float bc1, float bc2, float grad_scale,
                   void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Small dense primitives for the [B, <=256] layers (encoder tails nn/networks.py:120-129, decoder
+ * trunk nn/networks.py:322-323) and their backward.  fp32, batched: one launch serves up to
+ * SPV_MAXP independent problems (2 groups x {private, shared} x {mu, logvar} heads).  All arrays row-major.
+ * ------------------------------------------------------------------------------------------- */
+#define SPV_MAXP 8
+
+typedef struct spv_linear_prob {
+  const float* X; int64_t ldx;     /* [B][K]                                     */
+  const float* W;                  /* [N][K] (torch Linear weight)               */
+  const float* bias;               /* [N] or NULL                                */
+  float* Y; int64_t ldy;           /* [B][N] forward output (read again by the backward masks) */
+  const float* dY; int64_t lddy;   /* backward: upstream gradient [B][N]         */
+  float* dX; int64_t lddx;         /* backward: [B][K]                           */
+  float* dW; float* db;            /* backward: [N][K], [N] (db may be NULL)     */
+  int32_t N, K;
+} spv_linear_prob;
+typedef struct spv_linear_batch {
+  spv_linear_prob p[SPV_MAXP];
+  int32_t nprob, B;
+  int32_t relu;       /* forward: Y = relu(.); backward: dY masked with (Y > 0)                      */
+  float drop_p;       /* inverted dropout after the relu (0 = none); backward rescales where Y > 0   */
+  uint64_t seed;      /* counter-based mask: (seed, problem, element)                                */
+  int32_t accumulate; /* dgrad: dX += instead of dX =                                                */
+} spv_linear_batch;
+int spv_linear_fwd(const spv_linear_batch* a, void* stream);    /* Y = dropout(relu(X W^T + b))      */
+int spv_linear_dgrad(const spv_linear_batch* a, void* stream);  /* dX (+)= mask(dY) W                */
+int spv_linear_wgrad(const spv_linear_batch* a, void* stream);  /* dW = mask(dY)^T X, db = colsum    */
+
+typedef struct spv_bn_prob {
+  const float* X; int64_t ldx;     /* [B][N], N <= 256                                              */
+  float* Y; int64_t ldy;
+  const float* gamma; const float* beta;
+  float* running_mean; float* running_var;   /* updated in training (momentum, unbiased variance)   */
+  float* stats;                    /* [N][2] saved (mean, 1/sqrt(var+eps))                          */
+  float* part;                     /* workspace [ceil(B/256)][N][2]                                 */
+  const float* dY; int64_t lddy;   /* backward                                                     */
+  float* dX; int64_t lddx;
+  float* dgamma; float* dbeta;
+  int32_t N;
+} spv_bn_prob;
+typedef struct spv_bn_batch {
+  spv_bn_prob p[SPV_MAXP];
+  int32_t nprob, B, training, relu;  /* relu: Y = relu(bn(X)) and the backward masks dY with (Y > 0) */
+  float eps, momentum;
+} spv_bn_batch;
+int spv_bn_fwd(const spv_bn_batch* a, void* stream);
+int spv_bn_bwd(const spv_bn_batch* a, void* stream);
+
+/* post = BatchNorm output [B][2n] = (loc | logvar): scale = exp(logvar/2), log_z = loc + scale*eps,
+ * theta = softmax(log_z), kl_b = KL(N(loc,scale) || N(0,1)) summed over n (nn/networks.py:125-129,
+ * module/spVIPESmodule.py:841-854).  Backward: d_post from the (nullable) upstream gradients. */
+typedef struct spv_sample_prob {
+  const float* post; int32_t n;
+  const float* eps;
+  float* scale; float* logz; float* theta; float* kl;
+  const float* g_loc; const float* g_logvar; const float* g_scale; const float* g_logz; const float* g_kl;
+  float* d_post;
+} spv_sample_prob;
+typedef struct spv_sample_batch { spv_sample_prob p[SPV_MAXP]; int32_t nprob, B; } spv_sample_batch;
+int spv_enc_sample_fwd(const spv_sample_batch* a, void* stream);
+int spv_enc_sample_bwd(const spv_sample_batch* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Label-based Product of Experts on device (module/spVIPESmodule.py:583-718 + _poe2 :282-379).
+ * ------------------------------------------------------------------------------------------- */
+#define SPV_POE_LMAX 4096   /* label codes are integers in [0, SPV_POE_LMAX) */
+
+/* rank-within-label pairing of two minibatches; labels are float32 codes (as the reference carries
+ * them); order*: int32 scratch [B*]; partner*: int32 [B*] (-1 = none); mode*: int32 [B*]
+ * (0 partner, 1 ones/zeros padding, 2 label absent from the other group); *err != 0 on a bad code. */
+int spv_poe_partner(const float* labels0, const float* labels1, int32_t B0, int32_t B1, int32_t* order0, int32_t* order1,
+                    int32_t* partner0, int32_t* mode0, int32_t* partner1, int32_t* mode1, int32_t* err, void* stream);
+
+typedef struct spv_poe_args {
+  const float* stats[2]; int64_t ld[2];   /* shared encoders' (loc | logvar) rows, [B][ld], logvar at column n */
+  const int32_t* partner[2]; const int32_t* mode[2];
+  const float* eps[2];                     /* [B][n] */
+  float* loc[2]; float* logvar[2]; float* scale[2]; float* logz[2]; float* theta[2]; float* kl[2];
+  const float* g_loc[2]; const float* g_logvar[2]; const float* g_scale[2]; const float* g_logz[2]; const float* g_kl[2];
+  float* d_stats[2];                       /* backward output, same layout as stats, ZERO-INITIALISED by the caller */
+  int32_t B[2]; int32_t n;
+} spv_poe_args;
+int spv_poe_fuse_fwd(const spv_poe_args* a, void* stream);
+int spv_poe_fuse_bwd(const spv_poe_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Decoder preparation: latent slicing (spVIPESmodule.py:733-754) and BatchNorm folding of the two
+ * factor regressors (nn/networks.py:314,318) into the packed operand image of the decoder kernels.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct spv_zsplit_args {
+  const float* priv[2]; const float* poe[2];   /* private log_z [B][n_p], PoE log_z [B][n_s] */
+  float* zcat[2];                               /* [B][n_p + n_s] = [z_private | z_shared]    */
+  const float* d_zcat[2]; float* d_priv[2]; float* d_poe[2];
+  int32_t B, n_p, n_s, ngroups;
+} spv_zsplit_args;
+int spv_zsplit_fwd(const spv_zsplit_args* a, void* stream);
+int spv_zsplit_bwd(const spv_zsplit_args* a, void* stream);
+
+typedef struct spv_fold_prob {
+  const float* W; const float* gamma; const float* beta;   /* [G][K], [G], [G]            */
+  float* running_mean; float* running_var;                 /* [G]                         */
+  const float* zsum; const float* zz;                      /* [K] column sums of z, [K][K] z^T z */
+  const float* z; int64_t ldz;                             /* [B][ldz] (backward)         */
+  float* stat;                                             /* [G][2] saved (mean, var)    */
+  uint16_t* img_hi; uint16_t* img_lo; int64_t ld_img; int32_t col_off; int32_t slot;   /* packed [Gp][ld_img] */
+  const float* dWeff; int64_t ld_dw;                       /* backward in: [G][ld_dw], col K = d c */
+  float* dW; float* dgamma; float* dbeta;                  /* backward out                */
+  float* red_part;                                         /* [ceil(G/256)][K + K*K]      */
+  float* dz; int64_t lddz;                                 /* backward out (+=): [B][lddz] */
+  int32_t G, Gp, K;
+} spv_fold_prob;
+typedef struct spv_fold_batch { spv_fold_prob p[SPV_MAXP]; int32_t nprob, B, training; float eps, momentum; } spv_fold_batch;
+int spv_bn_fold_fwd(const spv_fold_batch* a, void* stream);
+int spv_bn_fold_bwd(const spv_fold_batch* a, void* stream);   /* fold backward + the z-statistics backward */
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,67 @@ class SpvDecParams(C.Structure):
     ]
 
 
+SPV_MAXP = 8
+
+
+class SpvLinearProb(C.Structure):
+    _fields_ = [("X", C.c_void_p), ("ldx", C.c_int64), ("W", C.c_void_p), ("bias", C.c_void_p), ("Y", C.c_void_p), ("ldy", C.c_int64),
+                ("dY", C.c_void_p), ("lddy", C.c_int64), ("dX", C.c_void_p), ("lddx", C.c_int64), ("dW", C.c_void_p), ("db", C.c_void_p),
+                ("N", C.c_int32), ("K", C.c_int32)]
+
+
+class SpvLinearBatch(C.Structure):
+    _fields_ = [("p", SpvLinearProb * SPV_MAXP), ("nprob", C.c_int32), ("B", C.c_int32), ("relu", C.c_int32), ("drop_p", C.c_float),
+                ("seed", C.c_uint64), ("accumulate", C.c_int32)]
+
+
+class SpvBnProb(C.Structure):
+    _fields_ = [("X", C.c_void_p), ("ldx", C.c_int64), ("Y", C.c_void_p), ("ldy", C.c_int64), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("stats", C.c_void_p), ("part", C.c_void_p),
+                ("dY", C.c_void_p), ("lddy", C.c_int64), ("dX", C.c_void_p), ("lddx", C.c_int64), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
+                ("N", C.c_int32)]
+
+
+class SpvBnBatch(C.Structure):
+    _fields_ = [("p", SpvBnProb * SPV_MAXP), ("nprob", C.c_int32), ("B", C.c_int32), ("training", C.c_int32), ("relu", C.c_int32),
+                ("eps", C.c_float), ("momentum", C.c_float)]
+
+
+class SpvSampleProb(C.Structure):
+    _fields_ = [("post", C.c_void_p), ("n", C.c_int32), ("eps", C.c_void_p), ("scale", C.c_void_p), ("logz", C.c_void_p), ("theta", C.c_void_p),
+                ("kl", C.c_void_p), ("g_loc", C.c_void_p), ("g_logvar", C.c_void_p), ("g_scale", C.c_void_p), ("g_logz", C.c_void_p),
+                ("g_kl", C.c_void_p), ("d_post", C.c_void_p)]
+
+
+class SpvSampleBatch(C.Structure):
+    _fields_ = [("p", SpvSampleProb * SPV_MAXP), ("nprob", C.c_int32), ("B", C.c_int32)]
+
+
+class SpvPoeArgs(C.Structure):
+    _fields_ = [("stats", C.c_void_p * 2), ("ld", C.c_int64 * 2), ("partner", C.c_void_p * 2), ("mode", C.c_void_p * 2), ("eps", C.c_void_p * 2),
+                ("loc", C.c_void_p * 2), ("logvar", C.c_void_p * 2), ("scale", C.c_void_p * 2), ("logz", C.c_void_p * 2), ("theta", C.c_void_p * 2),
+                ("kl", C.c_void_p * 2), ("g_loc", C.c_void_p * 2), ("g_logvar", C.c_void_p * 2), ("g_scale", C.c_void_p * 2),
+                ("g_logz", C.c_void_p * 2), ("g_kl", C.c_void_p * 2), ("d_stats", C.c_void_p * 2), ("B", C.c_int32 * 2), ("n", C.c_int32)]
+
+
+class SpvZsplitArgs(C.Structure):
+    _fields_ = [("priv", C.c_void_p * 2), ("poe", C.c_void_p * 2), ("zcat", C.c_void_p * 2), ("d_zcat", C.c_void_p * 2),
+                ("d_priv", C.c_void_p * 2), ("d_poe", C.c_void_p * 2), ("B", C.c_int32), ("n_p", C.c_int32), ("n_s", C.c_int32), ("ngroups", C.c_int32)]
+
+
+class SpvFoldProb(C.Structure):
+    _fields_ = [("W", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
+                ("zsum", C.c_void_p), ("zz", C.c_void_p), ("z", C.c_void_p), ("ldz", C.c_int64), ("stat", C.c_void_p),
+                ("img_hi", C.c_void_p), ("img_lo", C.c_void_p), ("ld_img", C.c_int64), ("col_off", C.c_int32), ("slot", C.c_int32),
+                ("dWeff", C.c_void_p), ("ld_dw", C.c_int64), ("dW", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
+                ("red_part", C.c_void_p), ("dz", C.c_void_p), ("lddz", C.c_int64), ("G", C.c_int32), ("Gp", C.c_int32), ("K", C.c_int32)]
+
+
+class SpvFoldBatch(C.Structure):
+    _fields_ = [("p", SpvFoldProb * SPV_MAXP), ("nprob", C.c_int32), ("B", C.c_int32), ("training", C.c_int32), ("eps", C.c_float),
+                ("momentum", C.c_float)]
+
+
 _SIGNATURES = {
     "spv_version": (C.c_int, []),
     "spv_last_error": (C.c_char_p, []),
@@ -55,6 +116,21 @@ _SIGNATURES = {
     "spv_dec_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                  C.c_void_p, C.c_int32, C.c_void_p]),
     "spv_dec_softmax_bwd": (C.c_int, [C.POINTER(SpvDecParams), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "spv_linear_fwd": (C.c_int, [C.POINTER(SpvLinearBatch), C.c_void_p]),
+    "spv_linear_dgrad": (C.c_int, [C.POINTER(SpvLinearBatch), C.c_void_p]),
+    "spv_linear_wgrad": (C.c_int, [C.POINTER(SpvLinearBatch), C.c_void_p]),
+    "spv_bn_fwd": (C.c_int, [C.POINTER(SpvBnBatch), C.c_void_p]),
+    "spv_bn_bwd": (C.c_int, [C.POINTER(SpvBnBatch), C.c_void_p]),
+    "spv_enc_sample_fwd": (C.c_int, [C.POINTER(SpvSampleBatch), C.c_void_p]),
+    "spv_enc_sample_bwd": (C.c_int, [C.POINTER(SpvSampleBatch), C.c_void_p]),
+    "spv_poe_partner": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+    "spv_poe_fuse_fwd": (C.c_int, [C.POINTER(SpvPoeArgs), C.c_void_p]),
+    "spv_poe_fuse_bwd": (C.c_int, [C.POINTER(SpvPoeArgs), C.c_void_p]),
+    "spv_zsplit_fwd": (C.c_int, [C.POINTER(SpvZsplitArgs), C.c_void_p]),
+    "spv_zsplit_bwd": (C.c_int, [C.POINTER(SpvZsplitArgs), C.c_void_p]),
+    "spv_bn_fold_fwd": (C.c_int, [C.POINTER(SpvFoldBatch), C.c_void_p]),
+    "spv_bn_fold_bwd": (C.c_int, [C.POINTER(SpvFoldBatch), C.c_void_p]),
     "spv_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float,
                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
 }

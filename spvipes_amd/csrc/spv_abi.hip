@@ -3,6 +3,7 @@
 #include "spv_common.h"
 #include "spv_gemm.h"
 #include "spv_decoder.h"
+#include "spv_small.h"
 
 #include <cstdio>
 #include <cstring>
@@ -328,4 +329,186 @@ extern "C" int spv_adam_step(float* p, const float* g, float* m, float* v, int64
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, lr, beta1, beta2, eps,
                      weight_decay, bc1, bc2, grad_scale);
   return launch_status("spv_adam_step");
+}
+
+// ---------------------------------------------------------------------------------------------
+// small dense primitives (spv_small.h)
+// ---------------------------------------------------------------------------------------------
+static int check_linear(const spv_linear_batch* a, const char* who) {
+  if (!a || a->nprob <= 0 || a->nprob > SPV_MAXP || a->B <= 0) return fail(SPV_ERR_ARG, "%s: bad batch", who);
+  if (a->drop_p < 0.f || a->drop_p >= 1.f) return fail(SPV_ERR_ARG, "%s: dropout probability outside [0,1)", who);
+  for (int i = 0; i < a->nprob; ++i)
+    if (a->p[i].N <= 0 || a->p[i].K <= 0 || !a->p[i].W) return fail(SPV_ERR_ARG, "%s: bad problem", who);
+  return SPV_OK;
+}
+static void linear_extents(const spv_linear_batch* a, int& nmax, int& kmax) {
+  nmax = kmax = 0;
+  for (int i = 0; i < a->nprob; ++i) { nmax = a->p[i].N > nmax ? a->p[i].N : nmax; kmax = a->p[i].K > kmax ? a->p[i].K : kmax; }
+}
+
+extern "C" int spv_linear_fwd(const spv_linear_batch* a, void* stream) {
+  int rc = check_linear(a, "spv_linear_fwd");
+  if (rc) return rc;
+  for (int i = 0; i < a->nprob; ++i) if (!a->p[i].X || !a->p[i].Y) return fail(SPV_ERR_ARG, "spv_linear_fwd: null pointer%s");
+  int nmax, kmax; linear_extents(a, nmax, kmax);
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3((a->B + 31) / 32, (nmax + 31) / 32, a->nprob), dim3(256), 0, (hipStream_t)stream, *a);
+  return launch_status("spv_linear_fwd");
+}
+extern "C" int spv_linear_dgrad(const spv_linear_batch* a, void* stream) {
+  int rc = check_linear(a, "spv_linear_dgrad");
+  if (rc) return rc;
+  for (int i = 0; i < a->nprob; ++i)
+    if (!a->p[i].dY || !a->p[i].dX || ((a->relu || a->drop_p > 0.f) && !a->p[i].Y)) return fail(SPV_ERR_ARG, "spv_linear_dgrad: null pointer%s");
+  int nmax, kmax; linear_extents(a, nmax, kmax);
+  hipLaunchKernelGGL(linear_dgrad_kernel, dim3((a->B + 31) / 32, (kmax + 31) / 32, a->nprob), dim3(256), 0, (hipStream_t)stream, *a);
+  return launch_status("spv_linear_dgrad");
+}
+extern "C" int spv_linear_wgrad(const spv_linear_batch* a, void* stream) {
+  int rc = check_linear(a, "spv_linear_wgrad");
+  if (rc) return rc;
+  for (int i = 0; i < a->nprob; ++i)
+    if (!a->p[i].dY || !a->p[i].X || !a->p[i].dW || ((a->relu || a->drop_p > 0.f) && !a->p[i].Y)) return fail(SPV_ERR_ARG, "spv_linear_wgrad: null pointer%s");
+  int nmax, kmax; linear_extents(a, nmax, kmax);
+  hipLaunchKernelGGL(linear_wgrad_kernel, dim3((nmax + 31) / 32, (kmax + 31) / 32, a->nprob), dim3(256), 0, (hipStream_t)stream, *a);
+  return launch_status("spv_linear_wgrad");
+}
+
+static int check_bn(const spv_bn_batch* a, const char* who) {
+  if (!a || a->nprob <= 0 || a->nprob > SPV_MAXP || a->B <= 0) return fail(SPV_ERR_ARG, "%s: bad batch", who);
+  for (int i = 0; i < a->nprob; ++i) {
+    const spv_bn_prob& q = a->p[i];
+    if (q.N <= 0 || q.N > 256 || !q.X || !q.gamma || !q.beta || !q.running_mean || !q.running_var || !q.stats || !q.part)
+      return fail(SPV_ERR_ARG, "%s: bad problem (N <= 256, non-null pointers)", who);
+  }
+  return SPV_OK;
+}
+extern "C" int spv_bn_fwd(const spv_bn_batch* a, void* stream) {
+  int rc = check_bn(a, "spv_bn_fwd");
+  if (rc) return rc;
+  for (int i = 0; i < a->nprob; ++i) if (!a->p[i].Y) return fail(SPV_ERR_ARG, "spv_bn_fwd: null output%s");
+  dim3 grid((a->B + BN_ROWS - 1) / BN_ROWS, a->nprob);
+  hipStream_t s = (hipStream_t)stream;
+  if (a->training) hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(256), 0, s, *a);
+  hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(256), 0, s, *a);
+  return launch_status("spv_bn_fwd");
+}
+extern "C" int spv_bn_bwd(const spv_bn_batch* a, void* stream) {
+  int rc = check_bn(a, "spv_bn_bwd");
+  if (rc) return rc;
+  for (int i = 0; i < a->nprob; ++i)
+    if (!a->p[i].dY || !a->p[i].dX || !a->p[i].dgamma || !a->p[i].dbeta || (a->relu && !a->p[i].Y)) return fail(SPV_ERR_ARG, "spv_bn_bwd: null pointer%s");
+  dim3 grid((a->B + BN_ROWS - 1) / BN_ROWS, a->nprob);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, s, *a);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, s, *a);
+  return launch_status("spv_bn_bwd");
+}
+
+static int check_sample(const spv_sample_batch* a, const char* who) {
+  if (!a || a->nprob <= 0 || a->nprob > SPV_MAXP || a->B <= 0) return fail(SPV_ERR_ARG, "%s: bad batch", who);
+  for (int i = 0; i < a->nprob; ++i)
+    if (a->p[i].n <= 0 || !a->p[i].post || !a->p[i].eps || !a->p[i].scale) return fail(SPV_ERR_ARG, "%s: bad problem", who);
+  return SPV_OK;
+}
+extern "C" int spv_enc_sample_fwd(const spv_sample_batch* a, void* stream) {
+  int rc = check_sample(a, "spv_enc_sample_fwd");
+  if (rc) return rc;
+  for (int i = 0; i < a->nprob; ++i) if (!a->p[i].logz || !a->p[i].theta || !a->p[i].kl) return fail(SPV_ERR_ARG, "spv_enc_sample_fwd: null output%s");
+  hipLaunchKernelGGL(enc_sample_fwd_kernel, dim3((a->B + 255) / 256, a->nprob), dim3(256), 0, (hipStream_t)stream, *a);
+  return launch_status("spv_enc_sample_fwd");
+}
+extern "C" int spv_enc_sample_bwd(const spv_sample_batch* a, void* stream) {
+  int rc = check_sample(a, "spv_enc_sample_bwd");
+  if (rc) return rc;
+  for (int i = 0; i < a->nprob; ++i) if (!a->p[i].d_post) return fail(SPV_ERR_ARG, "spv_enc_sample_bwd: null output%s");
+  hipLaunchKernelGGL(enc_sample_bwd_kernel, dim3((a->B + 255) / 256, a->nprob), dim3(256), 0, (hipStream_t)stream, *a);
+  return launch_status("spv_enc_sample_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------
+// PoE (label) and decoder preparation
+// ---------------------------------------------------------------------------------------------
+extern "C" int spv_poe_partner(const float* labels0, const float* labels1, int32_t B0, int32_t B1, int32_t* order0, int32_t* order1,
+                               int32_t* partner0, int32_t* mode0, int32_t* partner1, int32_t* mode1, int32_t* err, void* stream) {
+  if (!labels0 || !labels1 || !order0 || !order1 || !partner0 || !partner1 || !mode0 || !mode1 || !err || B0 <= 0 || B1 <= 0)
+    return fail(SPV_ERR_ARG, "spv_poe_partner: bad arguments%s");
+  hipLaunchKernelGGL(poe_partner_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, labels0, labels1, B0, B1, order0, order1, partner0,
+                     mode0, partner1, mode1, err);
+  return launch_status("spv_poe_partner");
+}
+static int check_poe(const spv_poe_args* a, const char* who) {
+  if (!a || a->n <= 0 || a->B[0] <= 0 || a->B[1] <= 0) return fail(SPV_ERR_ARG, "%s: bad shape", who);
+  for (int g = 0; g < 2; ++g)
+    if (!a->stats[g] || !a->partner[g] || !a->mode[g] || !a->eps[g] || !a->loc[g] || !a->scale[g] || a->ld[g] < 2 * a->n)
+      return fail(SPV_ERR_ARG, "%s: null pointer / bad pitch", who);
+  return SPV_OK;
+}
+extern "C" int spv_poe_fuse_fwd(const spv_poe_args* a, void* stream) {
+  int rc = check_poe(a, "spv_poe_fuse_fwd");
+  if (rc) return rc;
+  for (int g = 0; g < 2; ++g) if (!a->logvar[g] || !a->logz[g] || !a->theta[g] || !a->kl[g]) return fail(SPV_ERR_ARG, "spv_poe_fuse_fwd: null output%s");
+  const int Bm = a->B[0] > a->B[1] ? a->B[0] : a->B[1];
+  hipLaunchKernelGGL(poe_fuse_fwd_kernel, dim3((Bm + 255) / 256, 2), dim3(256), 0, (hipStream_t)stream, *a);
+  return launch_status("spv_poe_fuse_fwd");
+}
+extern "C" int spv_poe_fuse_bwd(const spv_poe_args* a, void* stream) {
+  int rc = check_poe(a, "spv_poe_fuse_bwd");
+  if (rc) return rc;
+  for (int g = 0; g < 2; ++g) if (!a->d_stats[g]) return fail(SPV_ERR_ARG, "spv_poe_fuse_bwd: null output%s");
+  const int Bm = a->B[0] > a->B[1] ? a->B[0] : a->B[1];
+  hipLaunchKernelGGL(poe_fuse_bwd_kernel, dim3((Bm + 255) / 256, 2), dim3(256), 0, (hipStream_t)stream, *a);
+  return launch_status("spv_poe_fuse_bwd");
+}
+
+extern "C" int spv_zsplit_fwd(const spv_zsplit_args* a, void* stream) {
+  if (!a || a->B <= 0 || a->n_p <= 0 || a->n_s <= 0 || a->ngroups <= 0 || a->ngroups > 2) return fail(SPV_ERR_ARG, "spv_zsplit_fwd: bad shape%s");
+  for (int g = 0; g < a->ngroups; ++g) if (!a->priv[g] || !a->poe[g] || !a->zcat[g]) return fail(SPV_ERR_ARG, "spv_zsplit_fwd: null pointer%s");
+  const long tot = (long)a->B * (a->n_p + a->n_s);
+  hipLaunchKernelGGL(zsplit_fwd_kernel, dim3((unsigned)((tot + 255) / 256), a->ngroups), dim3(256), 0, (hipStream_t)stream, *a);
+  return launch_status("spv_zsplit_fwd");
+}
+extern "C" int spv_zsplit_bwd(const spv_zsplit_args* a, void* stream) {
+  if (!a || a->B <= 0 || a->n_p <= 0 || a->n_s <= 0 || a->ngroups <= 0 || a->ngroups > 2) return fail(SPV_ERR_ARG, "spv_zsplit_bwd: bad shape%s");
+  for (int g = 0; g < a->ngroups; ++g) if (!a->d_zcat[g] || !a->d_priv[g] || !a->d_poe[g]) return fail(SPV_ERR_ARG, "spv_zsplit_bwd: null pointer%s");
+  const long tot = (long)a->B * (a->n_p + a->n_s);
+  hipLaunchKernelGGL(zsplit_bwd_kernel, dim3((unsigned)((tot + 255) / 256), a->ngroups), dim3(256), 0, (hipStream_t)stream, *a);
+  return launch_status("spv_zsplit_bwd");
+}
+
+static int check_fold(const spv_fold_batch* a, const char* who) {
+  if (!a || a->nprob <= 0 || a->nprob > SPV_MAXP || a->B <= 0) return fail(SPV_ERR_ARG, "%s: bad batch", who);
+  for (int i = 0; i < a->nprob; ++i) {
+    const spv_fold_prob& q = a->p[i];
+    if (q.K <= 0 || q.K > FOLD_KMAX || q.G <= 0 || q.Gp < q.G || !q.W || !q.gamma || !q.beta || !q.running_mean || !q.running_var || !q.stat ||
+        (a->training && (!q.zsum || !q.zz)))
+      return fail(SPV_ERR_ARG, "%s: bad problem (K <= 32, non-null pointers)", who);
+  }
+  return SPV_OK;
+}
+extern "C" int spv_bn_fold_fwd(const spv_fold_batch* a, void* stream) {
+  int rc = check_fold(a, "spv_bn_fold_fwd");
+  if (rc) return rc;
+  int gmax = 0;
+  for (int i = 0; i < a->nprob; ++i) {
+    const spv_fold_prob& q = a->p[i];
+    if (!q.img_hi || !q.img_lo || q.slot < q.K + 1 || q.col_off + q.slot > q.ld_img) return fail(SPV_ERR_ARG, "spv_bn_fold_fwd: bad image slot%s");
+    gmax = q.Gp > gmax ? q.Gp : gmax;
+  }
+  hipLaunchKernelGGL(bn_fold_fwd_kernel, dim3((gmax + 255) / 256, a->nprob), dim3(256), 0, (hipStream_t)stream, *a);
+  return launch_status("spv_bn_fold_fwd");
+}
+extern "C" int spv_bn_fold_bwd(const spv_fold_batch* a, void* stream) {
+  int rc = check_fold(a, "spv_bn_fold_bwd");
+  if (rc) return rc;
+  int gmax = 0;
+  for (int i = 0; i < a->nprob; ++i) {
+    const spv_fold_prob& q = a->p[i];
+    if (!q.dWeff || !q.dW || !q.dgamma || !q.dbeta || q.ld_dw < q.K + 1 || (a->training && (!q.red_part || !q.z || !q.dz)))
+      return fail(SPV_ERR_ARG, "spv_bn_fold_bwd: null pointer%s");
+    gmax = q.G > gmax ? q.G : gmax;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_fold_bwd_kernel, dim3((gmax + 255) / 256, a->nprob), dim3(256), 0, s, *a);
+  if (a->training) hipLaunchKernelGGL(zstats_bwd_kernel, dim3((a->B + 255) / 256, a->nprob), dim3(256), 0, s, *a);
+  return launch_status("spv_bn_fold_bwd");
 }

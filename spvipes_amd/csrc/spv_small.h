@@ -1,0 +1,630 @@
+// Small dense primitives for the [B, <=256] parts of the step (encoder tails, decoder trunk):
+// fp32 VALU kernels, LDS tiled, batched over up to SPV_MAXP independent problems per launch
+// (the two groups x {private, shared} encoders run as ONE launch per stage).
+//
+// They replace the stock torch ops of nn/networks.py:120-129 (fc2, mu/logvar heads + BatchNorm1d),
+// nn/networks.py:322-323 (sigmoid_decoder trunk) and their autograd: a step needs ~35 of these
+// launches instead of ~900 eager kernels.  fp32 throughout: the latent means the north-star
+// checks come out of these layers.
+#pragma once
+#include "../../include/spvipes_hip.h"
+#include "spv_common.h"
+
+namespace spv {
+
+constexpr int SM_T = 32;        // tile edge
+constexpr int SM_PITCH = 36;    // LDS row pitch in floats (144 B: 16-B aligned, breaks the 128-B bank period)
+
+typedef spv_linear_prob LinearProb;    // field meanings: include/spvipes_hip.h
+typedef spv_linear_batch LinearBatch;
+
+__device__ __forceinline__ unsigned hash_u32(unsigned long long x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+  return (unsigned)x;
+}
+// keep-probability test of inverted dropout, counter-based (seed, problem, element) -> reproducible
+__device__ __forceinline__ bool dropout_keep(unsigned long long seed, int prob, long idx, float p) {
+  const unsigned u = hash_u32(seed + 0x9E3779B97F4A7C15ULL * (unsigned long long)(idx * SPV_MAXP + prob + 1));
+  return (float)(u >> 8) * (1.0f / 16777216.0f) >= p;
+}
+
+// Y = act(X W^T + b): tile 32 rows x 32 cols per workgroup, 4 outputs per thread
+__global__ __launch_bounds__(256) void linear_fwd_kernel(LinearBatch a) {
+  const LinearProb& q = a.p[blockIdx.z];
+  const int n0 = blockIdx.y * SM_T, b0 = blockIdx.x * SM_T;
+  if (n0 >= q.N) return;
+  __shared__ __attribute__((aligned(16))) float sX[SM_T * SM_PITCH], sW[SM_T * SM_PITCH];
+  const int tid = threadIdx.x, r = tid >> 3, cg = (tid & 7) * 4;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < q.K; k0 += SM_T) {
+    {  // stage 32x32 of X and of W (rows n0.., cols k0..): one float4 per thread per matrix
+      const int rr = tid >> 3, kk = (tid & 7) * 4;
+      f4v vx = {0.f, 0.f, 0.f, 0.f}, vw = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = k0 + kk + j;
+        if (k < q.K) {
+          if (b0 + rr < a.B) vx[j] = q.X[(long)(b0 + rr) * q.ldx + k];
+          if (n0 + rr < q.N) vw[j] = q.W[(long)(n0 + rr) * q.K + k];
+        }
+      }
+      *reinterpret_cast<f4v*>(&sX[rr * SM_PITCH + kk]) = vx;
+      *reinterpret_cast<f4v*>(&sW[rr * SM_PITCH + kk]) = vw;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < SM_T; kk += 4) {
+      const f4v x = *reinterpret_cast<const f4v*>(&sX[r * SM_PITCH + kk]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f4v w = *reinterpret_cast<const f4v*>(&sW[(cg + i) * SM_PITCH + kk]);
+        acc[i] += x[0] * w[0] + x[1] * w[1] + x[2] * w[2] + x[3] * w[3];
+      }
+    }
+    __syncthreads();
+  }
+  const int b = b0 + r;
+  if (b >= a.B) return;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + cg + i;
+    if (n >= q.N) continue;
+    float v = acc[i] + (q.bias ? q.bias[n] : 0.f);
+    if (a.relu) v = fmaxf(v, 0.f);
+    if (a.drop_p > 0.f) v = dropout_keep(a.seed, blockIdx.z, (long)b * q.N + n, a.drop_p) ? v * (1.0f / (1.0f - a.drop_p)) : 0.f;
+    q.Y[(long)b * q.ldy + n] = v;
+  }
+}
+
+__device__ __forceinline__ float masked_dy(const LinearBatch& a, const LinearProb& q, int b, int n) {
+  float g = q.dY[(long)b * q.lddy + n];
+  if (a.relu || a.drop_p > 0.f) g = (q.Y[(long)b * q.ldy + n] > 0.f) ? g * (a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f) : 0.f;
+  return g;
+}
+
+// dX = mask(dY) W : tile 32 rows x 32 k-cols
+__global__ __launch_bounds__(256) void linear_dgrad_kernel(LinearBatch a) {
+  const LinearProb& q = a.p[blockIdx.z];
+  const int k0 = blockIdx.y * SM_T, b0 = blockIdx.x * SM_T;
+  if (k0 >= q.K) return;
+  __shared__ __attribute__((aligned(16))) float sG[SM_T * SM_PITCH], sW[SM_T * SM_PITCH];
+  const int tid = threadIdx.x, r = tid >> 3, cg = (tid & 7) * 4;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int n0 = 0; n0 < q.N; n0 += SM_T) {
+    {
+      const int rr = tid >> 3, cc = (tid & 7) * 4;
+      f4v vg = {0.f, 0.f, 0.f, 0.f}, vw = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (b0 + rr < a.B && n0 + cc + j < q.N) vg[j] = masked_dy(a, q, b0 + rr, n0 + cc + j);   // sG[b][n]
+        if (n0 + rr < q.N && k0 + cc + j < q.K) vw[j] = q.W[(long)(n0 + rr) * q.K + k0 + cc + j];  // sW[n][k]
+      }
+      *reinterpret_cast<f4v*>(&sG[rr * SM_PITCH + cc]) = vg;
+      *reinterpret_cast<f4v*>(&sW[rr * SM_PITCH + cc]) = vw;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int n = 0; n < SM_T; ++n) {
+      const float g = sG[r * SM_PITCH + n];
+      const f4v w = *reinterpret_cast<const f4v*>(&sW[n * SM_PITCH + cg]);
+      acc[0] += g * w[0]; acc[1] += g * w[1]; acc[2] += g * w[2]; acc[3] += g * w[3];
+    }
+    __syncthreads();
+  }
+  const int b = b0 + r;
+  if (b >= a.B) return;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = k0 + cg + i;
+    if (k >= q.K) continue;
+    float* dst = q.dX + (long)b * q.lddx + k;
+    *dst = a.accumulate ? *dst + acc[i] : acc[i];
+  }
+}
+
+// dW = mask(dY)^T X, db = colsum(mask(dY)): tile 32 n x 32 k, loop over the batch (fixed order)
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(LinearBatch a) {
+  const LinearProb& q = a.p[blockIdx.z];
+  const int n0 = blockIdx.x * SM_T, k0 = blockIdx.y * SM_T;
+  if (n0 >= q.N || k0 >= q.K) return;
+  __shared__ __attribute__((aligned(16))) float sG[SM_T * SM_PITCH], sX[SM_T * SM_PITCH];
+  const int tid = threadIdx.x, nn = tid >> 3, cg = (tid & 7) * 4;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f}, bsum = 0.f;
+  for (int b0 = 0; b0 < a.B; b0 += SM_T) {
+    {
+      const int rr = tid >> 3, cc = (tid & 7) * 4;
+      f4v vg = {0.f, 0.f, 0.f, 0.f}, vx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (b0 + rr < a.B && n0 + cc + j < q.N) vg[j] = masked_dy(a, q, b0 + rr, n0 + cc + j);        // sG[b][n]
+        if (b0 + rr < a.B && k0 + cc + j < q.K) vx[j] = q.X[(long)(b0 + rr) * q.ldx + k0 + cc + j];   // sX[b][k]
+      }
+      *reinterpret_cast<f4v*>(&sG[rr * SM_PITCH + cc]) = vg;
+      *reinterpret_cast<f4v*>(&sX[rr * SM_PITCH + cc]) = vx;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int b = 0; b < SM_T; ++b) {
+      const float g = sG[b * SM_PITCH + nn];
+      const f4v x = *reinterpret_cast<const f4v*>(&sX[b * SM_PITCH + cg]);
+      acc[0] += g * x[0]; acc[1] += g * x[1]; acc[2] += g * x[2]; acc[3] += g * x[3];
+      bsum += g;
+    }
+    __syncthreads();
+  }
+  const int n = n0 + nn;
+  if (n >= q.N) return;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (k0 + cg + i < q.K) q.dW[(long)n * q.K + k0 + cg + i] = acc[i];
+  if (q.db && blockIdx.y == 0 && cg == 0) q.db[n] = bsum;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm1d over the batch dimension, batched problems, N <= 256 columns
+// ---------------------------------------------------------------------------------------------
+typedef spv_bn_prob BnProb;
+typedef spv_bn_batch BnBatch;
+constexpr int BN_ROWS = 256;
+
+__global__ __launch_bounds__(256) void bn_stats_kernel(BnBatch a) {
+  const BnProb& q = a.p[blockIdx.y];
+  const int j = threadIdx.x;
+  if (j >= q.N) return;
+  const int b0 = blockIdx.x * BN_ROWS, b1 = min(b0 + BN_ROWS, a.B);
+  float s = 0.f;
+  for (int b = b0; b < b1; ++b) s += q.X[(long)b * q.ldx + j];
+  const float mean = s / (float)(b1 - b0);
+  float m2 = 0.f;
+  for (int b = b0; b < b1; ++b) { const float d = q.X[(long)b * q.ldx + j] - mean; m2 += d * d; }
+  q.part[((long)blockIdx.x * q.N + j) * 2] = mean;
+  q.part[((long)blockIdx.x * q.N + j) * 2 + 1] = m2;
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(BnBatch a) {
+  const BnProb& q = a.p[blockIdx.y];
+  __shared__ float s_mean[256], s_inv[256];
+  const int j = threadIdx.x;
+  const int nblk = (a.B + BN_ROWS - 1) / BN_ROWS;
+  if (j < q.N) {
+    float mean, var;
+    if (a.training) {  // Chan's parallel combination of the per-block (count, mean, M2)
+      float tot = 0.f;
+      for (int k = 0; k < nblk; ++k) tot += q.part[((long)k * q.N + j) * 2] * (float)(min((k + 1) * BN_ROWS, a.B) - k * BN_ROWS);
+      mean = tot / (float)a.B;
+      float m2 = 0.f;
+      for (int k = 0; k < nblk; ++k) {
+        const float cnt = (float)(min((k + 1) * BN_ROWS, a.B) - k * BN_ROWS), d = q.part[((long)k * q.N + j) * 2] - mean;
+        m2 += q.part[((long)k * q.N + j) * 2 + 1] + cnt * d * d;
+      }
+      var = m2 / (float)a.B;
+      if (blockIdx.x == 0) {  // torch: running stats take the UNBIASED variance
+        q.running_mean[j] = (1.f - a.momentum) * q.running_mean[j] + a.momentum * mean;
+        q.running_var[j] = (1.f - a.momentum) * q.running_var[j] + a.momentum * var * ((float)a.B / fmaxf((float)a.B - 1.f, 1.f));
+      }
+    } else {
+      mean = q.running_mean[j];
+      var = q.running_var[j];
+    }
+    const float inv = rsqrtf(var + a.eps);
+    s_mean[j] = mean; s_inv[j] = inv;
+    if (blockIdx.x == 0) { q.stats[2 * j] = mean; q.stats[2 * j + 1] = inv; }
+  }
+  __syncthreads();
+  const int b0 = blockIdx.x * BN_ROWS, b1 = min(b0 + BN_ROWS, a.B);
+  const long total = (long)(b1 - b0) * q.N;
+  for (long i = threadIdx.x; i < total; i += 256) {
+    const int b = b0 + (int)(i / q.N), c = (int)(i % q.N);
+    float v = (q.X[(long)b * q.ldx + c] - s_mean[c]) * s_inv[c] * q.gamma[c] + q.beta[c];
+    if (a.relu) v = fmaxf(v, 0.f);
+    q.Y[(long)b * q.ldy + c] = v;
+  }
+}
+
+__device__ __forceinline__ float bn_masked_dy(const BnBatch& a, const BnProb& q, int b, int j) {
+  const float g = q.dY[(long)b * q.lddy + j];
+  return (a.relu && !(q.Y[(long)b * q.ldy + j] > 0.f)) ? 0.f : g;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBatch a) {
+  const BnProb& q = a.p[blockIdx.y];
+  const int j = threadIdx.x;
+  if (j >= q.N) return;
+  const int b0 = blockIdx.x * BN_ROWS, b1 = min(b0 + BN_ROWS, a.B);
+  const float mean = q.stats[2 * j], inv = q.stats[2 * j + 1];
+  float sg = 0.f, sgx = 0.f;
+  for (int b = b0; b < b1; ++b) {
+    const float g = bn_masked_dy(a, q, b, j);
+    sg += g;
+    sgx += g * (q.X[(long)b * q.ldx + j] - mean) * inv;
+  }
+  q.part[((long)blockIdx.x * q.N + j) * 2] = sg;
+  q.part[((long)blockIdx.x * q.N + j) * 2 + 1] = sgx;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBatch a) {
+  const BnProb& q = a.p[blockIdx.y];
+  __shared__ float s_sg[256], s_sgx[256];
+  const int j = threadIdx.x;
+  const int nblk = (a.B + BN_ROWS - 1) / BN_ROWS;
+  if (j < q.N) {
+    float sg = 0.f, sgx = 0.f;
+    for (int k = 0; k < nblk; ++k) { sg += q.part[((long)k * q.N + j) * 2]; sgx += q.part[((long)k * q.N + j) * 2 + 1]; }
+    s_sg[j] = sg; s_sgx[j] = sgx;
+    if (blockIdx.x == 0) { q.dgamma[j] = sgx; q.dbeta[j] = sg; }
+  }
+  __syncthreads();
+  const int b0 = blockIdx.x * BN_ROWS, b1 = min(b0 + BN_ROWS, a.B);
+  const long total = (long)(b1 - b0) * q.N;
+  const float invB = 1.0f / (float)a.B;
+  for (long i = threadIdx.x; i < total; i += 256) {
+    const int b = b0 + (int)(i / q.N), c = (int)(i % q.N);
+    const float mean = q.stats[2 * c], inv = q.stats[2 * c + 1];
+    const float g = bn_masked_dy(a, q, b, c);
+    float dx;
+    if (a.training) {
+      const float xhat = (q.X[(long)b * q.ldx + c] - mean) * inv;
+      dx = q.gamma[c] * inv * (g - s_sg[c] * invB - xhat * s_sgx[c] * invB);
+    } else {
+      dx = q.gamma[c] * inv * g;
+    }
+    q.dX[(long)b * q.lddx + c] = dx;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Encoder head sampling (nn/networks.py:125-129) + KL to N(0,1) (module/spVIPESmodule.py:841-854), batched
+//   post = BatchNorm output [B][2n] = (loc | logvar);  scale = exp(logvar/2);  log_z = loc + scale*eps;
+//   theta = softmax(log_z);  kl_b = sum_d 0.5 (scale^2 + loc^2 - 1 - logvar)
+// backward: d post from (g_loc, g_logvar, g_scale, g_logz, g_kl) (any may be null)
+// ---------------------------------------------------------------------------------------------
+typedef spv_sample_prob SampleProb;
+typedef spv_sample_batch SampleBatch;
+
+__global__ __launch_bounds__(256) void enc_sample_fwd_kernel(SampleBatch a) {
+  const SampleProb& q = a.p[blockIdx.y];
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= a.B) return;
+  const int n = q.n;
+  const float* row = q.post + (long)b * 2 * n;
+  float mx = -INFINITY, kl = 0.f;
+  for (int d = 0; d < n; ++d) {
+    const float loc = row[d], lv = row[n + d];
+    const float sc = expf(0.5f * lv);
+    const float z = loc + sc * q.eps[(long)b * n + d];
+    q.scale[(long)b * n + d] = sc;
+    q.logz[(long)b * n + d] = z;
+    mx = fmaxf(mx, z);
+    kl += 0.5f * (sc * sc + loc * loc - 1.0f - lv);
+  }
+  float sum = 0.f;
+  for (int d = 0; d < n; ++d) sum += expf(q.logz[(long)b * n + d] - mx);
+  const float inv = 1.0f / sum;
+  for (int d = 0; d < n; ++d) q.theta[(long)b * n + d] = expf(q.logz[(long)b * n + d] - mx) * inv;
+  q.kl[b] = kl;
+}
+
+__global__ __launch_bounds__(256) void enc_sample_bwd_kernel(SampleBatch a) {
+  const SampleProb& q = a.p[blockIdx.y];
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= a.B) return;
+  const int n = q.n;
+  const float* row = q.post + (long)b * 2 * n;
+  const float gk = q.g_kl ? q.g_kl[b] : 0.f;
+  for (int d = 0; d < n; ++d) {
+    const long i = (long)b * n + d;
+    const float loc = row[d], sc = q.scale[i];
+    const float gz = q.g_logz ? q.g_logz[i] : 0.f;
+    const float gl = (q.g_loc ? q.g_loc[i] : 0.f) + gz + gk * loc;
+    const float gs = (q.g_scale ? q.g_scale[i] : 0.f) + gz * q.eps[i] + gk * sc;
+    const float gv = (q.g_logvar ? q.g_logvar[i] : 0.f) + 0.5f * sc * gs - 0.5f * gk;
+    q.d_post[(long)b * 2 * n + d] = gl;
+    q.d_post[(long)b * 2 * n + n + d] = gv;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Label-based Product of Experts (module/spVIPESmodule.py:583-718 + _poe2 :282-379), on device.
+//
+// Pairing: cell i of group g with label L and rank k among the same-label cells of its minibatch
+// (batch order) is fused with the k-th cell of label L in the other minibatch (mode 0); if L occurs
+// there but k >= its count the missing expert is the ones/zeros padding of _poe2 (mode 1); if L does
+// not occur there it is the dummy expert loc = 0, logvar = 1 (mode 2).  The reference finds this with
+// a Python loop and three .item() syncs per cell (:685-701); here one wave per group walks its
+// minibatch in 64-cell chunks with ballots and a running per-label counter in LDS.
+// ---------------------------------------------------------------------------------------------
+constexpr int POE_LMAX = 4096;   // label codes must be integers in [0, POE_LMAX)
+
+__global__ __launch_bounds__(128) void poe_partner_kernel(const float* lab0, const float* lab1, int B0, int B1, int* order0,
+                                                          int* order1, int* partner0, int* mode0, int* partner1, int* mode1, int* err) {
+  __shared__ int cnt[2][POE_LMAX], start[2][POE_LMAX];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float* lab = w ? lab1 : lab0;
+  const int B = w ? B1 : B0;
+  int* order = w ? order1 : order0;
+  int* rank = w ? partner1 : partner0;  // the partner arrays double as scratch for the ranks
+  for (int l = lane; l < POE_LMAX; l += 64) cnt[w][l] = 0;
+  __syncthreads();
+  // rank within label, stable in batch order
+  for (int c0 = 0; c0 < B; c0 += 64) {
+    const int i = c0 + lane;
+    const bool act = i < B;
+    int L = act ? (int)lab[i] : -1;
+    if (act && (L < 0 || L >= POE_LMAX)) { *err = 1; L = 0; }
+    unsigned long long todo = __ballot(act);
+    int my_rank = 0;
+    while (todo) {
+      const int src = __ffsll((long long)todo) - 1;
+      const int cur = __shfl(L, src, 64);
+      const unsigned long long same = __ballot(act && L == cur);
+      const int base = cnt[w][cur];
+      if (act && L == cur) my_rank = base + __popcll(same & ((1ull << lane) - 1ull));
+      if (lane == src) cnt[w][cur] = base + __popcll(same);
+      todo &= ~same;
+    }
+    if (act) rank[i] = my_rank;
+  }
+  __syncthreads();
+  // exclusive prefix of the label counts -> first slot of each label in `order`
+  {
+    int run = 0;
+    for (int l0 = 0; l0 < POE_LMAX; l0 += 64) {
+      const int c = cnt[w][l0 + lane];
+      int inc = c;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off, 64); if (lane >= off) inc += t; }
+      start[w][l0 + lane] = run + inc - c;
+      run += __shfl(inc, 63, 64);
+    }
+  }
+  __syncthreads();
+  for (int i = lane; i < B; i += 64) { const int L = min(max((int)lab[i], 0), POE_LMAX - 1); order[start[w][L] + rank[i]] = i; }
+  __threadfence();  // `order` travels through global memory to the other wave of this workgroup
+  __syncthreads();
+  // partner / mode against the other group's tables
+  {
+    const int o = 1 - w;
+    const int* order_o = o ? order1 : order0;
+    int* partner = w ? partner1 : partner0;
+    int* mode = w ? mode1 : mode0;
+    for (int i = lane; i < B; i += 64) {
+      const int L = min(max((int)lab[i], 0), POE_LMAX - 1), k = rank[i], co = cnt[o][L];
+      const int m = (k < co) ? 0 : (co > 0 ? 1 : 2);
+      const int pr = (m == 0) ? order_o[start[o][L] + k] : -1;
+      mode[i] = m;
+      partner[i] = pr;  // overwrites rank[i]: read above
+    }
+  }
+}
+
+typedef spv_poe_args PoeArgs;
+
+__global__ __launch_bounds__(256) void poe_fuse_fwd_kernel(PoeArgs a) {
+  const int g = blockIdx.y, o = 1 - g;
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= a.B[g]) return;
+  const int n = a.n, m = a.mode[g][b], pr = a.partner[g][b];
+  const float* own = a.stats[g] + (long)b * a.ld[g];           // (loc | logvar) rows of the shared encoder
+  const float* oth = a.stats[o] + (long)(pr < 0 ? 0 : pr) * a.ld[o];
+  float kl = 0.f, mx = -INFINITY;
+  for (int d = 0; d < n; ++d) {
+    const float loc = own[d], inv = expf(-own[n + d]);
+    float t, u;
+    if (m == 0) { t = expf(-oth[n + d]); u = oth[d] * t; }
+    else { t = (m == 1) ? 1.0f : 0.36787944117144233f; u = 0.f; }
+    const float J = 1.0f / (1.0f + (inv + t));
+    const float jl = (loc * inv + u) * J, jv = logf(J), sc = sqrtf(expf(jv));
+    const float z = jl + sc * a.eps[g][(long)b * n + d];
+    const long i = (long)b * n + d;
+    a.loc[g][i] = jl; a.logvar[g][i] = jv; a.scale[g][i] = sc; a.logz[g][i] = z;
+    mx = fmaxf(mx, z);
+    kl += 0.5f * (sc * sc + jl * jl - 1.0f - logf(sc * sc));
+  }
+  float sum = 0.f;
+  for (int d = 0; d < n; ++d) sum += expf(a.logz[g][(long)b * n + d] - mx);
+  for (int d = 0; d < n; ++d) a.theta[g][(long)b * n + d] = expf(a.logz[g][(long)b * n + d] - mx) / sum;
+  a.kl[g][b] = kl;
+}
+
+// d_stats[g] (same [B][ld] layout as stats[g], ZERO-INITIALISED by the caller) receives the gradient of a
+// cell's own expert and, through its partner, of the other group's cell: at most two adds per element.
+__global__ __launch_bounds__(256) void poe_fuse_bwd_kernel(PoeArgs a) {
+  const int g = blockIdx.y, o = 1 - g;
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= a.B[g]) return;
+  const int n = a.n, m = a.mode[g][b], pr = a.partner[g][b];
+  const float* own = a.stats[g] + (long)b * a.ld[g];
+  const float* oth = a.stats[o] + (long)(pr < 0 ? 0 : pr) * a.ld[o];
+  float* d_own = a.d_stats[g] + (long)b * a.ld[g];
+  float* d_oth = a.d_stats[o] + (long)(pr < 0 ? 0 : pr) * a.ld[o];
+  const float gk = a.g_kl[g] ? a.g_kl[g][b] : 0.f;
+  for (int d = 0; d < n; ++d) {
+    const long i = (long)b * n + d;
+    const float loc = own[d], inv = expf(-own[n + d]);
+    float t = (m == 1) ? 1.0f : 0.36787944117144233f, u = 0.f, lo = 0.f;
+    if (m == 0) { lo = oth[d]; t = expf(-oth[n + d]); u = lo * t; }
+    const float J = 1.0f / (1.0f + (inv + t));
+    const float jl = a.loc[g][i], sc = a.scale[g][i];
+    const float gz = a.g_logz[g] ? a.g_logz[g][i] : 0.f;
+    const float Gl = (a.g_loc[g] ? a.g_loc[g][i] : 0.f) + gz + gk * jl;
+    const float Gs = (a.g_scale[g] ? a.g_scale[g][i] : 0.f) + gz * a.eps[g][i] + gk * (sc - 1.0f / sc);
+    const float Gv = (a.g_logvar[g] ? a.g_logvar[g][i] : 0.f) + 0.5f * sc * Gs;
+    const float dN = Gl * J, dP = -J * (Gl * jl + Gv);
+    atomicAdd(&d_own[d], dN * inv);
+    atomicAdd(&d_own[n + d], -inv * (dN * loc + dP));
+    if (m == 0) {
+      atomicAdd(&d_oth[d], dN * t);
+      atomicAdd(&d_oth[n + d], -t * (dP + dN * lo));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Decoder preparation (module/spVIPESmodule.py:733-754 + the BatchNorm of the two factor regressors,
+// nn/networks.py:314,318 with scvi FCLayers' BatchNorm1d(eps 1e-3, momentum 0.01)).
+// ---------------------------------------------------------------------------------------------
+typedef spv_zsplit_args ZsplitArgs;
+
+// Z = cat(private_log_z, poe_log_z); z_private = Z[:, n_s:n_s+n_p], z_shared = Z[:, :n_s]  (the A6 quirk)
+// zcat = [z_private | z_shared] (input of the mixing trunk, nn/networks.py:322)
+__global__ __launch_bounds__(256) void zsplit_fwd_kernel(ZsplitArgs a) {
+  const int g = blockIdx.y;
+  const int nt = a.n_p + a.n_s;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)a.B * nt) return;
+  const int b = (int)(i / nt), c = (int)(i % nt);  // column of zcat
+  const int zc = (c < a.n_p) ? a.n_s + c : c - a.n_p;  // column of Z
+  const float v = (zc < a.n_p) ? a.priv[g][(long)b * a.n_p + zc] : a.poe[g][(long)b * a.n_s + zc - a.n_p];
+  a.zcat[g][i] = v;
+}
+__global__ __launch_bounds__(256) void zsplit_bwd_kernel(ZsplitArgs a) {
+  const int g = blockIdx.y;
+  const int nt = a.n_p + a.n_s;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)a.B * nt) return;
+  const int b = (int)(i / nt), zc = (int)(i % nt);  // column of Z
+  const int c = (zc < a.n_s) ? a.n_p + zc : zc - a.n_s;  // column of zcat holding it (Z is n_p + n_s wide: each column used once)
+  const float v = a.d_zcat[g][(long)b * nt + c];
+  if (zc < a.n_p) a.d_priv[g][(long)b * a.n_p + zc] = v;
+  else a.d_poe[g][(long)b * a.n_s + zc - a.n_p] = v;
+}
+
+typedef spv_fold_prob FoldProb;
+typedef spv_fold_batch FoldBatch;
+constexpr int FOLD_KMAX = 32;
+
+// per gene: BatchNorm over the batch of the linear map z -> w_g . z folded into W'_g = inv * w_g and
+// c_g = beta_g - inv * mean_g, with mean_g = w_g . zbar, var_g = w_g^T C w_g (biased), inv = gamma_g / sqrt(var_g + eps);
+// written straight into the packed bf16 hi/lo operand image.  zc[0..K) = column sums of z, zc[K..) = z^T z.
+__global__ __launch_bounds__(256) void bn_fold_fwd_kernel(FoldBatch a) {
+  const FoldProb& q = a.p[blockIdx.y];
+  __shared__ float s_zbar[FOLD_KMAX], s_C[FOLD_KMAX * FOLD_KMAX];
+  const int K = q.K;
+  if (a.training) {
+    const float invB = 1.0f / (float)a.B;
+    for (int i = threadIdx.x; i < K; i += 256) s_zbar[i] = q.zsum[i] * invB;
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * K; i += 256) s_C[i] = q.zz[i] * invB - s_zbar[i / K] * s_zbar[i % K];
+    __syncthreads();
+  }
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= q.Gp) return;
+  bf16_t* hi = q.img_hi + (long)g * q.ld_img + q.col_off;
+  bf16_t* lo = q.img_lo + (long)g * q.ld_img + q.col_off;
+  if (g >= q.G) {
+    for (int k = 0; k < q.slot; ++k) { hi[k] = 0; lo[k] = 0; }
+    return;
+  }
+  float w[FOLD_KMAX];
+  for (int k = 0; k < K; ++k) w[k] = q.W[(long)g * K + k];
+  float mean, var;
+  if (a.training) {
+    mean = 0.f; var = 0.f;
+    for (int k = 0; k < K; ++k) {
+      mean += w[k] * s_zbar[k];
+      float v = 0.f;
+      for (int l = 0; l < K; ++l) v += s_C[k * K + l] * w[l];
+      var += w[k] * v;
+    }
+    var = fmaxf(var, 0.f);
+    q.running_mean[g] = (1.f - a.momentum) * q.running_mean[g] + a.momentum * mean;
+    q.running_var[g] = (1.f - a.momentum) * q.running_var[g] + a.momentum * var * ((float)a.B / fmaxf((float)a.B - 1.f, 1.f));
+  } else {
+    mean = q.running_mean[g]; var = q.running_var[g];
+  }
+  const float inv = q.gamma[g] * rsqrtf(var + a.eps);
+  q.stat[2 * g] = mean; q.stat[2 * g + 1] = var;
+  for (int k = 0; k < q.slot; ++k) {
+    const float v = (k < K) ? w[k] * inv : (k == K ? q.beta[g] - mean * inv : 0.f);
+    bf16_t h, l;
+    split_bf16(v, h, l);
+    hi[k] = h; lo[k] = l;
+  }
+}
+
+// backward of the fold: from dW' [G][ld_dw] (columns 0..K-1 = d W'_g, column K = d c_g) to dW, d gamma, d beta and
+// per-block partial sums of d zbar [K] and d C [K][K]
+__global__ __launch_bounds__(256) void bn_fold_bwd_kernel(FoldBatch a) {
+  const FoldProb& q = a.p[blockIdx.y];
+  __shared__ float s_zbar[FOLD_KMAX], s_C[FOLD_KMAX * FOLD_KMAX], s_w[256 * FOLD_KMAX], s_dm[256], s_dv[256];
+  const int K = q.K;
+  const int nred = K + K * K;
+  if (a.training) {
+    const float invB = 1.0f / (float)a.B;
+    for (int i = threadIdx.x; i < K; i += 256) s_zbar[i] = q.zsum[i] * invB;
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * K; i += 256) s_C[i] = q.zz[i] * invB - s_zbar[i / K] * s_zbar[i % K];
+  }
+  __syncthreads();
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  float dmean = 0.f, dvar = 0.f;
+  float w[FOLD_KMAX];
+  for (int k = 0; k < K; ++k) w[k] = 0.f;
+  if (g < q.G) {
+    for (int k = 0; k < K; ++k) w[k] = q.W[(long)g * K + k];
+    const float mean = q.stat[2 * g], var = q.stat[2 * g + 1];
+    const float rs = rsqrtf(var + a.eps), gam = q.gamma[g], inv = gam * rs;
+    const float* gW = q.dWeff + (long)g * q.ld_dw;
+    const float gc = gW[K];
+    float dinv = -gc * mean;
+    for (int k = 0; k < K; ++k) dinv += gW[k] * w[k];
+    q.dbeta[g] = gc;
+    q.dgamma[g] = dinv * rs;
+    if (a.training) {
+      dmean = -gc * inv;
+      dvar = dinv * gam * (-0.5f) * rs * rs * rs;
+      for (int k = 0; k < K; ++k) {
+        float v = 0.f;
+        for (int l = 0; l < K; ++l) v += s_C[k * K + l] * w[l];
+        q.dW[(long)g * K + k] = gW[k] * inv + dmean * s_zbar[k] + 2.0f * dvar * v;
+      }
+    } else {
+      for (int k = 0; k < K; ++k) q.dW[(long)g * K + k] = gW[k] * inv;
+    }
+  }
+  if (!a.training) return;
+  // block partials of d zbar[k] = sum_g dmean_g w_gk and d C[k][l] = sum_g dvar_g w_gk w_gl, summed in gene order
+  for (int k = 0; k < K; ++k) s_w[threadIdx.x * FOLD_KMAX + k] = w[k];
+  s_dm[threadIdx.x] = dmean; s_dv[threadIdx.x] = dvar;
+  __syncthreads();
+  for (int i = threadIdx.x; i < nred; i += 256) {
+    float acc = 0.f;
+    if (i < K) {
+      for (int t = 0; t < 256; ++t) acc += s_dm[t] * s_w[t * FOLD_KMAX + i];
+    } else {
+      const int k = (i - K) / K, l = (i - K) % K;
+      for (int t = 0; t < 256; ++t) acc += s_dv[t] * s_w[t * FOLD_KMAX + k] * s_w[t * FOLD_KMAX + l];
+    }
+    q.red_part[(long)blockIdx.x * nred + i] = acc;
+  }
+}
+
+// d z[b][k] (+)= d zbar[k] / B + (1/B) sum_l (dC + dC^T)[k][l] (z[b][l] - zbar[l]);   red = sum over blocks of red_part
+__global__ __launch_bounds__(256) void zstats_bwd_kernel(FoldBatch a) {
+  const FoldProb& q = a.p[blockIdx.y];
+  __shared__ float s_zbar[FOLD_KMAX], s_dz[FOLD_KMAX], s_S[FOLD_KMAX * FOLD_KMAX], s_red[FOLD_KMAX + FOLD_KMAX * FOLD_KMAX];
+  const int K = q.K, nred = K + K * K;
+  const int nblk = (q.G + 255) / 256;
+  const float invB = 1.0f / (float)a.B;
+  for (int i = threadIdx.x; i < nred; i += 256) {
+    float s = 0.f;
+    for (int k = 0; k < nblk; ++k) s += q.red_part[(long)k * nred + i];
+    s_red[i] = s;
+  }
+  for (int i = threadIdx.x; i < K; i += 256) s_zbar[i] = q.zsum[i] * invB;
+  __syncthreads();
+  for (int i = threadIdx.x; i < K; i += 256) s_dz[i] = s_red[i] * invB;
+  for (int i = threadIdx.x; i < K * K; i += 256) s_S[i] = (s_red[K + i] + s_red[K + (i % K) * K + i / K]) * invB;
+  __syncthreads();
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= a.B) return;
+  float zc[FOLD_KMAX];
+  for (int l = 0; l < K; ++l) zc[l] = q.z[(long)b * q.ldz + l] - s_zbar[l];
+  for (int k = 0; k < K; ++k) {
+    float v = s_dz[k];
+    for (int l = 0; l < K; ++l) v += s_S[k * K + l] * zc[l];
+    q.dz[(long)b * q.lddz + k] += v;
+  }
+}
+
+}  // namespace spv

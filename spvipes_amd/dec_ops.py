@@ -1,0 +1,269 @@
+"""The whole decoder side of the step for BOTH groups as one autograd node: latent slicing, BatchNorm
+folding of the two factor regressors, mixing trunk, operand packing, logits GEMM, softmax statistics,
+NB-mixture likelihood -- and the hand-written backward of all of it.
+
+Reference arithmetic replaced (file:line into /root/reference/src/spVIPES):
+    module/spVIPESmodule.py:733-759 (generative), nn/networks.py:314-325 (LinearDecoderSPVIPE.forward),
+    module/spVIPESmodule.py:817-824 (reconstruction term of loss)
+
+Launches per step (2 groups): 10 small batched kernels + per group {5 packs, tables, logits GEMM, lse x2,
+likelihood} forward; backward per group {softmax fix, 6 GEMMs} + 8 small batched kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Sequence
+
+import torch
+
+from . import _abi
+from ._abi import (DEC_CELLS_PER_WG, DEC_KP, DEC_KPS, DEC_KS, NB_CMAX, SpvBnBatch, SpvDecParams, SpvFoldBatch, SpvZsplitArgs, ptr,
+                   round_up, stream_ptr)
+from .nn_ops import _add_lin, _fptr, _lin_batch
+from .ops import N_HIDDEN_MIX, GroupCounts, Workspace, _bf16_image, _gemm, _gene_splits, _pack
+
+N_DEC_PARAMS = 13  # Wp, gamma_p, beta_p, Ws, gamma_s, beta_s, Wa, ba, gamma_a, beta_a, Wm, bm, px_r
+KMP = 320
+
+
+def decoder_params(dec, px_r) -> List[torch.Tensor]:
+    fp, fs, tr, mx = dec.factor_regressor_private, dec.factor_regressor_shared, dec.sigmoid_decoder, dec.mixture
+    return [fp.linear.weight, fp.bn.weight, fp.bn.bias, fs.linear.weight, fs.bn.weight, fs.bn.bias,
+            tr.linear.weight, tr.linear.bias, tr.bn.weight, tr.bn.bias, mx.linear.weight, mx.linear.bias, px_r]
+
+
+class DecoderFused(torch.autograd.Function):
+    """inputs : per group (private_log_z [B,n_p], poe_log_z [B,n_s]) then per group its 13 parameters
+    outputs: (sum_g sum_b w_b rec_gb, rec_0 [B], rec_1 [B])   -- rec_g detached"""
+
+    @staticmethod
+    def forward(ctx, counts: Sequence[GroupCounts], rows, B: int, decoders, library: Sequence[torch.Tensor], w_row: torch.Tensor,
+                training: bool, nsplit: int, ws: Sequence[Workspace], *tensors):
+        NG = 2
+        lat = [(tensors[2 * g], tensors[2 * g + 1]) for g in range(NG)]
+        par = [tensors[2 * NG + g * N_DEC_PARAMS: 2 * NG + (g + 1) * N_DEC_PARAMS] for g in range(NG)]
+        dev = lat[0][0].device
+        n_p, n_s = lat[0][0].shape[1], lat[0][1].shape[1]
+        nt = n_p + n_s
+        if n_p + 1 > DEC_KP or n_s + 1 > DEC_KS:
+            raise _abi.SpvError(f"decoder kernels support n_private <= {DEC_KP - 1} and n_shared <= {DEC_KS - 1}")
+        n_m = par[0][6].shape[0]
+        KM = n_m + nt + 1
+        if KM > KMP:
+            raise _abi.SpvError("mixture input wider than 320 columns is not supported")
+        need_grad = any(ctx.needs_input_grad)  # (grad mode is off inside Function.forward)
+        Bp = round_up(B, DEC_CELLS_PER_WG)
+        Gs = [c.G for c in counts]
+        Gps = [round_up(G, 128) for G in Gs]
+        mlo = nsplit == 3
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        cont = lambda t: t if (t.is_contiguous() and t.dtype == torch.float32) else t.contiguous().float()
+        # ---- 1. latent slicing: zcat = [z_private | z_shared] --------------------------------------
+        zcat = [new(B, nt) for _ in range(NG)]
+        za = SpvZsplitArgs()
+        za.B, za.n_p, za.n_s, za.ngroups = B, n_p, n_s, NG
+        keep = []
+        for g in range(NG):
+            pz, qz = cont(lat[g][0]), cont(lat[g][1])
+            keep += [pz, qz]
+            za.priv[g], za.poe[g], za.zcat[g] = ptr(pz), ptr(qz), ptr(zcat[g])
+        _abi.call("spv_zsplit_fwd", C.byref(za), stream_ptr())
+        # ---- 2. batch statistics of z (column sums and z^T z) for the BatchNorm fold ---------------
+        zsum = [[new(n_p), new(n_s)] for _ in range(NG)]
+        zz = [[new(n_p, n_p), new(n_s, n_s)] for _ in range(NG)]
+        if training:
+            b = _lin_batch(B)
+            for g in range(NG):
+                for k, (off, n) in enumerate(((0, n_p), (n_p, n_s))):
+                    _add_lin(b, N=n, K=n, W=ptr(zz[g][k]), X=_fptr(zcat[g], off), ldx=nt, dY=_fptr(zcat[g], off), lddy=nt, dW=ptr(zz[g][k]), db=ptr(zsum[g][k]))
+            _abi.call("spv_linear_wgrad", C.byref(b), stream_ptr())
+        # ---- 3. fold the regressors' BatchNorm into the packed [Gp][48] operand image ---------------
+        Wps = [_bf16_image(ws[g], "dec_Wps", Gps[g], DEC_KPS, True) for g in range(NG)]
+        fstat = [[new(Gs[g], 2), new(Gs[g], 2)] for g in range(NG)]
+        fb = SpvFoldBatch()
+        fb.nprob, fb.B, fb.training, fb.eps, fb.momentum = 0, B, int(training), 1e-3, 0.01
+        for g in range(NG):
+            fp, fs = decoders[g].factor_regressor_private, decoders[g].factor_regressor_shared
+            for k, (reg, W, gam, bet, off, slot, n, zoff) in enumerate(((fp, par[g][0], par[g][1], par[g][2], 0, DEC_KP, n_p, 0),
+                                                                        (fs, par[g][3], par[g][4], par[g][5], DEC_KP, DEC_KS, n_s, n_p))):
+                q = fb.p[fb.nprob]
+                q.W, q.gamma, q.beta, q.running_mean, q.running_var = ptr(W), ptr(gam), ptr(bet), ptr(reg.bn.running_mean), ptr(reg.bn.running_var)
+                q.zsum, q.zz, q.z, q.ldz, q.stat = ptr(zsum[g][k]), ptr(zz[g][k]), _fptr(zcat[g], zoff), nt, ptr(fstat[g][k])
+                q.img_hi, q.img_lo, q.ld_img, q.col_off, q.slot = ptr(Wps[g][0]), ptr(Wps[g][1]), DEC_KPS, off, slot
+                q.G, q.Gp, q.K = Gs[g], Gps[g], n
+                fb.nprob += 1
+        _abi.call("spv_bn_fold_fwd", C.byref(fb), stream_ptr())
+        # ---- 4. mixing trunk: m = relu(BN(zcat Wa^T + ba)) -------------------------------------------
+        pre_a = [new(B, n_m) for _ in range(NG)]
+        m = [new(B, n_m) for _ in range(NG)]
+        tstat = [new(n_m, 2) for _ in range(NG)]
+        b = _lin_batch(B)
+        for g in range(NG):
+            _add_lin(b, N=n_m, K=nt, W=ptr(par[g][6]), bias=ptr(par[g][7]), X=ptr(zcat[g]), ldx=nt, Y=ptr(pre_a[g]), ldy=n_m)
+        _abi.call("spv_linear_fwd", C.byref(b), stream_ptr())
+        nblk = -(-B // 256)
+        bn = SpvBnBatch()
+        bn.nprob, bn.B, bn.training, bn.relu, bn.eps, bn.momentum = NG, B, int(training), 1, 1e-3, 0.01
+        for g in range(NG):
+            tb = decoders[g].sigmoid_decoder.bn
+            q = bn.p[g]
+            q.X, q.ldx, q.Y, q.ldy, q.gamma, q.beta = ptr(pre_a[g]), n_m, ptr(m[g]), n_m, ptr(par[g][8]), ptr(par[g][9])
+            q.running_mean, q.running_var, q.stats, q.N = ptr(tb.running_mean), ptr(tb.running_var), ptr(tstat[g]), n_m
+            q.part = ptr(ws[g].get("trunk_bn_part", (nblk, n_m, 2), torch.float32))
+        _abi.call("spv_bn_fwd", C.byref(bn), stream_ptr())
+        # ---- 5. per group: operand images, tables, logits GEMM, softmax statistics, likelihood ------
+        w_pad = ws[0].get("dec_w_row", (Bp,), torch.float32, zero=True)
+        w_pad[:B].copy_(w_row)
+        grads_f32 = bool(need_grad and mlo)
+        gdt, gname = (torch.float32, "f32") if grads_f32 else (torch.int16, "bf16")
+        P, rec, saved_g = [], [], []
+        loss = None
+        for g in range(NG):
+            G, Gp, wsg = Gs[g], Gps[g], ws[g]
+            Wm_hi, Wm_lo = _bf16_image(wsg, "dec_Wm", Gp, KMP, mlo)
+            _pack(cont(par[g][10]), Wm_hi, Wm_lo, extra_col=cont(par[g][11]))
+            Am_hi, Am_lo = _bf16_image(wsg, "dec_Am", Bp, KMP, mlo)
+            _pack(m[g], Am_hi, Am_lo, dst_col_off=0, cslot=n_m)
+            _pack(zcat[g], Am_hi, Am_lo, extra_one=True, dst_col_off=n_m, cslot=KMP - n_m)
+            Aps_hi, Aps_lo = _bf16_image(wsg, "dec_Aps", Bp, DEC_KPS, True)
+            _pack(zcat[g][:, :n_p], Aps_hi, Aps_lo, extra_one=True, dst_col_off=0, cslot=DEC_KP)
+            _pack(zcat[g][:, n_p:], Aps_hi, Aps_lo, extra_one=True, dst_col_off=DEC_KP, cslot=DEC_KS)
+            gene_tab = wsg.get("dec_gene_tab", (Gp, 4), torch.float32)
+            cnt_tab = wsg.get("dec_cnt_tab", (NB_CMAX, Gp, 2), torch.float32)
+            _abi.call("spv_dec_tables", ptr(cont(par[g][12])), G, Gp, ptr(gene_tab), ptr(cnt_tab), stream_ptr())
+            logits = wsg.get("dec_logits_" + ("f32" if mlo else "f16"), (Bp, Gp), torch.float32 if mlo else torch.float16)
+            _abi.call("spv_dec_logits", ptr(Am_hi), ptr(Am_lo), ptr(Wm_hi), ptr(Wm_lo), KMP, Bp, Gp, nsplit, ptr(logits), int(mlo), stream_ptr())
+            splits, per = _gene_splits(Bp, Gp)
+            vec = lambda nme: wsg.get(nme, (Bp,), torch.float32)
+            part = lambda nme: wsg.get(nme, (splits, Bp), torch.float32)
+            if need_grad:
+                dL = wsg.get("dec_dL_" + gname, (Bp, Gp), gdt, zero=True)
+                tP = wsg.get("dec_tP_" + gname, (Bp, Gp), gdt, zero=True)
+                tS = wsg.get("dec_tS_" + gname, (Bp, Gp), gdt, zero=True)
+                dth = wsg.get("dec_dtheta", (Bp // 32, Gp), torch.float32, zero=True)
+            else:
+                dL = tP = tS = dth = None
+            lse_p, lse_s, a_p, a_s = vec("dec_lse_p"), vec("dec_lse_s"), vec("dec_a_p"), vec("dec_a_s")
+            cst = counts[g].c_struct(rows[g])
+            p = SpvDecParams(
+                X=cst.X, ldx=cst.ld, rows=cst.rows, col_off=cst.col_off, count_is_u16=int(cst.dtype == _abi.SPV_COUNT_U16),
+                B=B, G=G, Bp=Bp, Gp=Gp, logits=ptr(logits), n_gene_tiles=Gp // 32, logits_f32=int(mlo),
+                Wps_hi=ptr(Wps[g][0]), Wps_lo=ptr(Wps[g][1]), Aps_hi=ptr(Aps_hi), Aps_lo=ptr(Aps_lo),
+                gene_tab=ptr(gene_tab), cnt_tab=ptr(cnt_tab), a_p=ptr(a_p), a_s=ptr(a_s), lse_p=ptr(lse_p), lse_s=ptr(lse_s),
+                w_row=ptr(w_pad), gene_splits=splits, genes_per_split=per,
+                part_max_p=ptr(part("dec_pmp")), part_sum_p=ptr(part("dec_psp")), part_max_s=ptr(part("dec_pms")), part_sum_s=ptr(part("dec_pss")),
+                rec_part=ptr(part("dec_rec")), tp_part=ptr(part("dec_tp")), ts_part=ptr(part("dec_ts")),
+                dtheta_part=ptr(dth), dL=ptr(dL), tP=ptr(tP), tS=ptr(tS), grads_f32=int(grads_f32),
+            )
+            _abi.call("spv_dec_lse", C.byref(p), ptr(cont(library[g].flatten())), stream_ptr())
+            _abi.call("spv_dec_nb_fwd", C.byref(p), int(need_grad), stream_ptr())
+            r = part("dec_rec").sum(0)[:B]
+            rec.append(r)
+            l = (r * w_row).sum()
+            loss = l if loss is None else loss + l
+            P.append(p)
+            if need_grad:
+                saved_g.append(dict(Wm=(Wm_hi, Wm_lo), Am=(Am_hi, Am_lo), Aps=(Aps_hi, Aps_lo), dL=dL, tP=tP, tS=tS, dth=dth,
+                                    Tp=part("dec_tp").sum(0), Ts=part("dec_ts").sum(0)))
+        if need_grad:
+            ctx.P, ctx.saved_g, ctx.ws, ctx.decoders, ctx.training, ctx.nsplit = P, saved_g, ws, decoders, training, nsplit
+            ctx.dims = (B, Bp, Gs, Gps, n_p, n_s, n_m, KM)
+            ctx.grads_f32, ctx.done, ctx.keep = grads_f32, False, keep
+            ctx.Wps, ctx.fb = Wps, fb
+            ctx.small = (zcat, zsum, zz, fstat, pre_a, m, tstat)
+            ctx.save_for_backward(*tensors)
+        for r in rec:
+            ctx.mark_non_differentiable(r)
+        return (loss, *rec)
+
+    @staticmethod
+    def backward(ctx, g_loss, *_g_rec):
+        if ctx.done:
+            raise _abi.SpvError("DecoderFused.backward may run once per forward (gradient buffers are consumed in place)")
+        ctx.done = True
+        NG = 2
+        tensors = ctx.saved_tensors
+        par = [tensors[2 * NG + g * N_DEC_PARAMS: 2 * NG + (g + 1) * N_DEC_PARAMS] for g in range(NG)]
+        B, Bp, Gs, Gps, n_p, n_s, n_m, KM = ctx.dims
+        nt = n_p + n_s
+        ws, nsplit, training = ctx.ws, ctx.nsplit, ctx.training
+        zcat, zsum, zz, fstat, pre_a, m, tstat = ctx.small
+        dev = zcat[0].device
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        d_zcat, dWm, dWp, dWs, dAm, d_pxr = [], [], [], [], [], []
+        for g in range(NG):
+            G, Gp, wsg, S, P = Gs[g], Gps[g], ws[g], ctx.saved_g[g], ctx.P[g]
+            _abi.call("spv_dec_softmax_bwd", C.byref(P), ptr(S["Tp"]), ptr(S["Ts"]), stream_ptr())
+            if ctx.grads_f32:
+                def split(t, name):
+                    hi, lo = _bf16_image(wsg, name, Bp, Gp, True)
+                    _pack(t, hi, lo)
+                    return hi, lo
+                (dL_hi, dL_lo), (tP_hi, tP_lo), (tS_hi, tS_lo) = split(S["dL"], "dec_dL_split"), split(S["tP"], "dec_tP_split"), split(S["tS"], "dec_tS_split")
+            else:
+                dL_hi, tP_hi, tS_hi, dL_lo, tP_lo, tS_lo = S["dL"], S["tP"], S["tS"], None, None, None
+            T = Gp // 32
+            ksp = max(1, min(8, T // 16))
+            csp = max(1, min(4, (Bp // 32) // 16))
+            (Wm_hi, Wm_lo), (Am_hi, Am_lo), (Aps_hi, Aps_lo) = S["Wm"], S["Am"], S["Aps"]
+            a = _gemm(True, dL_hi, dL_lo, Gp, Am_hi, Am_lo, KMP, G, KMP, Bp, nsplit, min(csp, 2), wsg, "dec_dWm", a_tiles=T)
+            b_ = _gemm(True, tP_hi, tP_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KP, Bp, nsplit, csp, wsg, "dec_dWp", a_tiles=T)
+            c = _gemm(True, tS_hi, tS_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KS, Bp, nsplit, csp, wsg, "dec_dWs", b_col_off=DEC_KP, a_tiles=T)
+            d = _gemm(False, dL_hi, dL_lo, Gp, Wm_hi, Wm_lo, KMP, B, KMP, G, nsplit, ksp, wsg, "dec_dAm", a_tiles=T)
+            e = _gemm(False, tP_hi, tP_lo, Gp, ctx.Wps[g][0], ctx.Wps[g][1], DEC_KPS, B, DEC_KP, G, nsplit, ksp, wsg, "dec_dAp", a_tiles=T)
+            f = _gemm(False, tS_hi, tS_lo, Gp, ctx.Wps[g][0], ctx.Wps[g][1], DEC_KPS, B, DEC_KS, G, nsplit, ksp, wsg, "dec_dAs", b_col_off=DEC_KP, a_tiles=T)
+            for t in (a, b_, c, d, e, f):
+                t.mul_(g_loss)
+            dWm.append(a); dWp.append(b_); dWs.append(c); dAm.append(d)
+            # gradient reaching zcat directly: through the logits GEMM (columns n_m..) and the two regressors
+            d_zcat.append((d[:, n_m:n_m + nt] + torch.cat([e[:, :n_p], f[:, :n_s]], dim=1)).contiguous())
+            d_pxr.append(torch.exp(par[g][12]) * S["dth"].sum(0)[:G] * g_loss)
+        # ---- trunk backward (BatchNorm + relu, Linear) ----------------------------------------------
+        nblk = -(-B // 256)
+        d_pre = [new(B, n_m) for _ in range(NG)]
+        d_gam_a, d_bet_a = [new(n_m) for _ in range(NG)], [new(n_m) for _ in range(NG)]
+        bn = SpvBnBatch()
+        bn.nprob, bn.B, bn.training, bn.relu, bn.eps, bn.momentum = NG, B, int(training), 1, 1e-3, 0.01
+        for g in range(NG):
+            tb = ctx.decoders[g].sigmoid_decoder.bn
+            q = bn.p[g]
+            q.X, q.ldx, q.Y, q.ldy, q.gamma, q.beta = ptr(pre_a[g]), n_m, ptr(m[g]), n_m, ptr(par[g][8]), ptr(par[g][9])
+            q.running_mean, q.running_var, q.stats, q.N = ptr(tb.running_mean), ptr(tb.running_var), ptr(tstat[g]), n_m
+            q.part = ptr(ws[g].get("trunk_bn_part", (nblk, n_m, 2), torch.float32))
+            q.dY, q.lddy, q.dX, q.lddx, q.dgamma, q.dbeta = ptr(dAm[g]), KMP, ptr(d_pre[g]), n_m, ptr(d_gam_a[g]), ptr(d_bet_a[g])
+        _abi.call("spv_bn_bwd", C.byref(bn), stream_ptr())
+        dWa, dba = [new(n_m, nt) for _ in range(NG)], [new(n_m) for _ in range(NG)]
+        bw, bd = _lin_batch(B), _lin_batch(B, accumulate=True)
+        for g in range(NG):
+            _add_lin(bw, N=n_m, K=nt, W=ptr(par[g][6]), X=ptr(zcat[g]), ldx=nt, dY=ptr(d_pre[g]), lddy=n_m, dW=ptr(dWa[g]), db=ptr(dba[g]))
+            _add_lin(bd, N=n_m, K=nt, W=ptr(par[g][6]), dY=ptr(d_pre[g]), lddy=n_m, dX=ptr(d_zcat[g]), lddx=nt)
+        _abi.call("spv_linear_wgrad", C.byref(bw), stream_ptr())
+        _abi.call("spv_linear_dgrad", C.byref(bd), stream_ptr())
+        # ---- BatchNorm-fold backward (+ the z statistics it used) ------------------------------------
+        fb = ctx.fb
+        dWraw = [[new(Gs[g], n_p), new(Gs[g], n_s)] for g in range(NG)]
+        dgam = [[new(Gs[g]), new(Gs[g])] for g in range(NG)]
+        dbet = [[new(Gs[g]), new(Gs[g])] for g in range(NG)]
+        i = 0
+        for g in range(NG):
+            for k, (dweff, ld, n, zoff) in enumerate(((dWp[g], DEC_KP, n_p, 0), (dWs[g], DEC_KS, n_s, n_p))):
+                q = fb.p[i]
+                q.dWeff, q.ld_dw, q.dW, q.dgamma, q.dbeta = ptr(dweff), ld, ptr(dWraw[g][k]), ptr(dgam[g][k]), ptr(dbet[g][k])
+                q.red_part = ptr(ws[g].get(f"fold_red_{k}", (-(-Gs[g] // 256), n + n * n), torch.float32))
+                q.dz, q.lddz = _fptr(d_zcat[g], zoff), nt
+                i += 1
+        _abi.call("spv_bn_fold_bwd", C.byref(fb), stream_ptr())
+        # ---- latent slicing backward ------------------------------------------------------------------
+        d_priv, d_poe = [new(B, n_p) for _ in range(NG)], [new(B, n_s) for _ in range(NG)]
+        za = SpvZsplitArgs()
+        za.B, za.n_p, za.n_s, za.ngroups = B, n_p, n_s, NG
+        for g in range(NG):
+            za.d_zcat[g], za.d_priv[g], za.d_poe[g] = ptr(d_zcat[g]), ptr(d_priv[g]), ptr(d_poe[g])
+        _abi.call("spv_zsplit_bwd", C.byref(za), stream_ptr())
+        grads = []
+        for g in range(NG):
+            grads += [d_priv[g], d_poe[g]]
+        for g in range(NG):
+            grads += [dWraw[g][0], dgam[g][0], dbet[g][0], dWraw[g][1], dgam[g][1], dbet[g][1], dWa[g], dba[g], d_gam_a[g], d_bet_a[g],
+                      dWm[g][:, :KM - 1], dWm[g][:, KM - 1], d_pxr[g]]
+        return (None,) * 9 + tuple(grads)

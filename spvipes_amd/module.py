@@ -30,7 +30,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _abi
-from .ops import N_HIDDEN_MIX, DecoderNBLoss, EncoderFC1, GroupCounts, Workspace
+from .ops import N_HIDDEN_MIX, EncoderFC1, GroupCounts, Workspace
 
 X_KEY, BATCH_KEY = "X", "batch"  # scvi.REGISTRY_KEYS.X_KEY / BATCH_KEY
 
@@ -93,31 +93,8 @@ class LazyNBMixture:
     """What ``generative`` hands to ``loss`` in place of scvi's NegativeBinomialMixture: the decoder
     inputs; the likelihood itself is evaluated by the fused HIP kernel inside ``loss``."""
 
-    def __init__(self, group: int, z_private, z_shared, library):
-        self.group, self.z_private, self.z_shared, self.library = group, z_private, z_shared, library
-
-
-def _fold_bn_linear(z: torch.Tensor, lin: nn.Linear, bn: nn.BatchNorm1d, training: bool):
-    """BatchNorm1d(z @ W^T) == z @ W'^T + c.  In training mode the batch mean / (biased) variance of
-    column g of z W^T are W_g . mean(z) and W_g^T cov(z) W_g, so no [B, G] tensor is formed; the
-    running statistics get torch's update (unbiased variance, bn.momentum)."""
-    W = lin.weight
-    if training:
-        B = z.shape[0]
-        zbar = z.mean(0)
-        zc = z - zbar
-        cov = zc.t() @ zc / B
-        mean = W @ zbar
-        var = ((W @ cov) * W).sum(1)
-        with torch.no_grad():
-            mom = bn.momentum
-            bn.running_mean.mul_(1 - mom).add_(mom * mean)
-            bn.running_var.mul_(1 - mom).add_(mom * var * (B / max(B - 1, 1)))
-            bn.num_batches_tracked += 1
-    else:
-        mean, var = bn.running_mean, bn.running_var
-    inv = bn.weight * torch.rsqrt(var + bn.eps)
-    return W * inv[:, None], bn.bias - mean * inv
+    def __init__(self, group: int, private_log_z, poe_log_z, library):
+        self.group, self.private_log_z, self.poe_log_z, self.library = group, private_log_z, poe_log_z, library
 
 
 class spVIPESmodule(nn.Module):
@@ -264,32 +241,74 @@ class spVIPESmodule(nn.Module):
         standard-normal draws ("enc_{g}_private", "enc_{g}_shared", "poe_{g}") for parity tests."""
         from . import poe as P
 
+        from .nn_ops import EncoderSpec, EncoderTails, PoELabel
+
         noise = noise or {}
         private_stats, shared_stats, library = {}, {}, {}
-        self._step_inputs = {}
+        self._step_inputs, self._kl_private, self._kl_poe = {}, {}, {}
+        h1s, eps_enc = {}, {}
+        H = self.n_hidden
         for g, group in x.items():
             counts, rows, B = self._counts_of(g, group)
             self._step_inputs[g] = (counts, rows, B)
             ep, es = self.encoders[g]["private"], self.encoders[g]["shared"]
             ws = self._workspace(g, counts.X.device)
             h1, lib = EncoderFC1.apply(counts, rows, B, ep.fc1.weight, ep.fc1.bias, es.fc1.weight, es.fc1.bias, self.nsplit, ws)
-            H = self.n_hidden
             dev = h1.device
             e_p = noise.get(f"enc_{g}_private")
             e_s = noise.get(f"enc_{g}_shared")
-            e_p = torch.randn(B, self.n_dimensions_private, device=dev) if e_p is None else e_p
-            e_s = torch.randn(B, self.n_dimensions_shared, device=dev) if e_s is None else e_s
-            dm = dropout_masks or {}
-            private_stats[g] = self._encoder_tail(ep, h1[:, :H], e_p, dm.get(f"enc_{g}_private"))
-            shared_stats[g] = self._encoder_tail(es, h1[:, H:], e_s, dm.get(f"enc_{g}_shared"))
+            eps_enc[g] = (torch.randn(B, self.n_dimensions_private, device=dev) if e_p is None else e_p,
+                          torch.randn(B, self.n_dimensions_shared, device=dev) if e_s is None else e_s)
+            h1s[g] = h1
             library[g] = lib.unsqueeze(1)
+        groups_ = sorted(x.keys())
+        same_B = len({self._step_inputs[g][2] for g in groups_}) == 1
+        if dropout_masks is None and same_B:
+            # all four encoder tails (fc2, dropout, heads, BatchNorm, draw, KL) as a few batched HIP launches
+            specs, eps_list = [], []
+            for g in groups_:
+                specs += [EncoderSpec(self.encoders[g]["private"], g, 0), EncoderSpec(self.encoders[g]["shared"], g, H)]
+                eps_list += [eps_enc[g][0], eps_enc[g][1]]
+            flat = [p for s in specs for p in s.params()]
+            self._seed_counter = getattr(self, "_seed_counter", 0) + 1
+            outs = EncoderTails.apply(specs, eps_list, self.training, float(self.dropout_rate), self._seed_counter,
+                                      self._workspace(groups_[0], h1s[groups_[0]].device), *[h1s[g] for g in groups_], *flat)
+            for i, s in enumerate(specs):
+                loc, logvar, scale, log_z, theta, kl = outs[6 * i: 6 * i + 6]
+                st = OrderedDict([("logtheta_loc", loc), ("logtheta_logvar", logvar), ("logtheta_scale", scale), ("log_z", log_z),
+                                  ("theta", theta), ("qz", torch.distributions.Normal(loc, scale, validate_args=False))])
+                if i % 2 == 0:
+                    private_stats[s.h1_group] = st
+                    self._kl_private[s.h1_group] = kl
+                else:
+                    shared_stats[s.h1_group] = st
+        else:  # ragged minibatches (inference only) or injected dropout masks: per-encoder torch glue
+            dm = dropout_masks or {}
+            for g in groups_:
+                private_stats[g] = self._encoder_tail(self.encoders[g]["private"], h1s[g][:, :H], eps_enc[g][0], dm.get(f"enc_{g}_private"))
+                shared_stats[g] = self._encoder_tail(self.encoders[g]["shared"], h1s[g][:, H:], eps_enc[g][1], dm.get(f"enc_{g}_shared"))
 
         labels = processed_labels = None
         if self.use_labels and "labels" in kwargs:
             labels = dict(enumerate(kwargs["labels"]))
         if self.use_transport_plan and not self.pair_data:
             processed_labels = kwargs.get("processed_labels")
-        poe_stats = self._supervised_poe(shared_stats, global_indices, processed_labels, labels, noise, P)
+        if self.use_labels and labels is not None:
+            # label-based PoE (priority as spVIPESmodule.py:492-493): pairing + fusion + draw + KL in HIP
+            dev = shared_stats[0]["logtheta_loc"].device
+            e = [noise.get(f"poe_{g}") for g in (0, 1)]
+            e = [torch.randn_like(shared_stats[g]["logtheta_loc"]) if e[g] is None else e[g] for g in (0, 1)]
+            o = PoELabel.apply([labels[0], labels[1]], e, self._workspace(0, dev), shared_stats[0]["logtheta_loc"], shared_stats[0]["logtheta_logvar"],
+                               shared_stats[1]["logtheta_loc"], shared_stats[1]["logtheta_logvar"])
+            poe_stats = {}
+            for g in (0, 1):
+                loc, logvar, scale, log_z, theta, kl = o[6 * g: 6 * g + 6]
+                poe_stats[g] = OrderedDict([("logtheta_loc", loc), ("logtheta_logvar", logvar), ("logtheta_scale", scale),
+                                            ("logtheta_qz", torch.distributions.Normal(loc, scale, validate_args=False)),
+                                            ("logtheta_log_z", log_z), ("logtheta_theta", theta)])
+                self._kl_poe[g] = kl
+        else:
+            poe_stats = self._supervised_poe(shared_stats, global_indices, processed_labels, labels, noise, P)
         return {"private_stats": private_stats, "shared_stats": shared_stats, "poe_stats": poe_stats, "library": library}
 
     def _supervised_poe(self, shared_stats, global_indices, processed_labels, labels, noise, P):
@@ -312,33 +331,19 @@ class spVIPESmodule(nn.Module):
             raise ValueError(
                 f"Number of groups passed to `generative` is shared:{len(shared_stats.keys())}, private:{len(private_stats.keys())}, the only supported value is 2"
             )
-        n_s, n_p = self.n_dimensions_shared, self.n_dimensions_private
         out = {}
         for g in (0, 1):
-            log_z = torch.cat((private_stats[g]["log_z"], poe_stats[g]["logtheta_log_z"]), dim=-1)  # :733,:737
-            z_private, z_shared = log_z[:, n_s: n_p + n_s], log_z[:, :n_s]  # :753-754
+            # Z = cat(private_log_z, poe_log_z) and the slicing quirk of :733,:753-754 happen inside the fused
+            # decoder op (spv_zsplit_fwd); the lazy object only carries the two latents and the library
             out[str(g)] = {
-                "px": LazyNBMixture(g, z_private, z_shared, library[g]),
-                "pz": torch.distributions.Normal(torch.zeros_like(log_z), torch.ones_like(log_z), validate_args=False),
+                "px": LazyNBMixture(g, private_stats[g]["log_z"], poe_stats[g]["logtheta_log_z"], library[g]),
+                "pz": None,
             }
         return {"private_shared": {}, "private_poe": out}
 
-    def _reconstruction(self, g: int, px: LazyNBMixture, w_row: torch.Tensor):
-        """-sum_g log NBMixture for group g through the fused HIP decoder/likelihood kernels."""
-        dec = self.decoders[g]
-        counts, rows, B = self._step_inputs[g]
-        zp, zs = px.z_private, px.z_shared
-        Wp, cp = _fold_bn_linear(zp, dec.factor_regressor_private.linear, dec.factor_regressor_private.bn, self.training)
-        Ws, cs = _fold_bn_linear(zs, dec.factor_regressor_shared.linear, dec.factor_regressor_shared.bn, self.training)
-        zcat = torch.cat([zp, zs], dim=1)  # nn/networks.py:322
-        m = F.relu(dec.sigmoid_decoder.bn(dec.sigmoid_decoder.linear(zcat)))
-        mix = dec.mixture.linear
-        train = torch.is_grad_enabled()
-        return DecoderNBLoss.apply(counts, rows, B, zp, zs, m, Wp, cp, Ws, cs, mix.weight, mix.bias, self.px_r[g],
-                                   px.library.flatten(), w_row, self.nsplit, train, self._workspace(g, zp.device))
-
     def loss(self, tensors_by_group, inference_outputs, generative_outputs, kl_weight: float = 1.0):
         """spVIPESmodule.py:809-899."""
+        from .dec_ops import DecoderFused, decoder_params
         from .poe import kl_normal_std
 
         B0, B1 = self._step_inputs[0][2], self._step_inputs[1][2]
@@ -346,15 +351,17 @@ class spVIPESmodule(nn.Module):
             raise RuntimeError(f"The size of tensor a ({B0}) must match the size of tensor b ({B1}) at non-singleton dimension 0")
         dev = inference_outputs["library"][0].device
         w = torch.full((B0,), 1.0 / B0, device=dev)
-        rec_sum, rec = [], []
-        for g in (0, 1):
-            s, r = self._reconstruction(g, generative_outputs["private_poe"][str(g)]["px"], w)
-            rec_sum.append(s)
-            rec.append(r)
+        px = [generative_outputs["private_poe"][str(g)]["px"] for g in (0, 1)]
+        lat = [t for g in (0, 1) for t in (px[g].private_log_z, px[g].poe_log_z)]
+        params = [t for g in (0, 1) for t in decoder_params(self.decoders[g], self.px_r[g])]
+        res = DecoderFused.apply([self._step_inputs[g][0] for g in (0, 1)], [self._step_inputs[g][1] for g in (0, 1)], B0,
+                                 [self.decoders[g] for g in (0, 1)], [px[g].library for g in (0, 1)], w, self.training, self.nsplit,
+                                 [self._workspace(g, dev) for g in (0, 1)], *lat, *params)
+        rec_total, rec = res[0], [res[1], res[2]]
         pr, po = inference_outputs["private_stats"], inference_outputs["poe_stats"]
-        kl_p = [kl_normal_std(pr[g]["logtheta_loc"], pr[g]["logtheta_scale"]) for g in (0, 1)]
-        kl_q = [kl_normal_std(po[g]["logtheta_loc"], po[g]["logtheta_qz"].scale) for g in (0, 1)]
-        loss = rec_sum[0] + rec_sum[1] + torch.mean(kl_weight * kl_p[0] + kl_weight * kl_q[0] + kl_weight * kl_p[1] + kl_weight * kl_q[1])
+        kl_p = [self._kl_private[g] if g in self._kl_private else kl_normal_std(pr[g]["logtheta_loc"], pr[g]["logtheta_scale"]) for g in (0, 1)]
+        kl_q = [self._kl_poe[g] if g in self._kl_poe else kl_normal_std(po[g]["logtheta_loc"], po[g]["logtheta_qz"].scale) for g in (0, 1)]
+        loss = rec_total + torch.mean(kl_weight * kl_p[0] + kl_weight * kl_q[0] + kl_weight * kl_p[1] + kl_weight * kl_q[1])
         return LossOutput(
             loss=loss,
             reconstruction_loss={"reconst_loss_groups_1_poe": rec[0], "reconst_loss_groups_2_poe": rec[1]},

@@ -1,0 +1,277 @@
+"""Autograd wrappers over the small dense HIP primitives (csrc/spv_small.h): the [B, <=256] layers of the
+step -- both encoders' tails of both groups, and the decoder trunk -- run as a handful of batched
+launches with a hand-written backward instead of hundreds of eager torch kernels.
+
+Reference arithmetic replaced (file:line into /root/reference/src/spVIPES):
+    EncoderTails   nn/networks.py:120-129 (fc2+relu, dropout, mu / logvar heads with BatchNorm1d, rsample,
+                   softmax) and the private KL of module/spVIPESmodule.py:841-854
+    TrunkBN        nn/networks.py:322-323 (sigmoid_decoder: Linear -> BatchNorm1d(eps 1e-3, momentum 0.01) -> ReLU)
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _abi
+from ._abi import SpvBnBatch, SpvLinearBatch, SpvSampleBatch, ptr, stream_ptr
+
+
+def _lin_batch(B: int, relu: bool = False, drop_p: float = 0.0, seed: int = 0, accumulate: bool = False) -> SpvLinearBatch:
+    b = SpvLinearBatch()
+    b.nprob, b.B, b.relu, b.drop_p, b.seed, b.accumulate = 0, B, int(relu), float(drop_p), int(seed), int(accumulate)
+    return b
+
+
+def _add_lin(b: SpvLinearBatch, *, N: int, K: int, W=None, X=None, ldx=0, bias=None, Y=None, ldy=0, dY=None, lddy=0, dX=None, lddx=0,
+             dW=None, db=None) -> None:
+    q = b.p[b.nprob]
+    q.X, q.ldx, q.W, q.bias, q.Y, q.ldy = X, ldx, W, bias, Y, ldy
+    q.dY, q.lddy, q.dX, q.lddx, q.dW, q.db, q.N, q.K = dY, lddy, dX, lddx, dW, db, N, K
+    b.nprob += 1
+
+
+def _fptr(t: torch.Tensor, col: int = 0) -> int:
+    """device address of t[0, col] for a row-major fp32 matrix (or of t[col] for a vector)."""
+    return t.data_ptr() + 4 * col
+
+
+class EncoderSpec:
+    """Parameters and buffers of one reference ``Encoder`` (nn/networks.py:47-83) after fc1."""
+
+    def __init__(self, enc, h1_group: int, h1_col: int):
+        self.enc, self.h1_group, self.h1_col = enc, h1_group, h1_col
+        self.n = enc.n_topics
+
+    def params(self) -> List[torch.Tensor]:
+        e = self.enc
+        return [e.fc2.weight, e.fc2.bias, e.mu_encoder[0].weight, e.mu_encoder[0].bias, e.lvar_encoder[0].weight, e.lvar_encoder[0].bias,
+                e.mu_encoder[1].weight, e.mu_encoder[1].bias, e.lvar_encoder[1].weight, e.lvar_encoder[1].bias]
+
+
+N_ENC_PARAMS = 10
+
+
+class EncoderTails(torch.autograd.Function):
+    """All encoders' tails in 4 forward / 7 backward launches.
+
+    inputs : h1 per group ([B, 2H]: private | shared halves), then per encoder its 10 parameters
+    outputs: per encoder (loc, logvar, scale, log_z, theta, kl)  -- theta is not differentiable here
+    """
+
+    @staticmethod
+    def forward(ctx, specs: Sequence[EncoderSpec], eps: Sequence[torch.Tensor], training: bool, drop_p: float, seed: int, ws, *tensors):
+        n_groups = max(s.h1_group for s in specs) + 1
+        h1 = tensors[:n_groups]
+        par = [tensors[n_groups + i * N_ENC_PARAMS: n_groups + (i + 1) * N_ENC_PARAMS] for i in range(len(specs))]
+        B, H = h1[0].shape[0], specs[0].enc.fc2.weight.shape[0]
+        dev = h1[0].device
+        for t in h1:
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise _abi.SpvError("EncoderTails expects contiguous fp32 h1")
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        h2 = [new(B, H) for _ in specs]
+        pre = [new(B, 2 * s.n) for s in specs]
+        post = [new(B, 2 * s.n) for s in specs]
+        stats = [new(2, s.n, 2) for s in specs]
+        nblk = -(-B // 256)
+        dp = float(drop_p) if training else 0.0
+        # 1. fc2 + relu (+ dropout)
+        b = _lin_batch(B, relu=True, drop_p=dp, seed=seed)
+        for s, p, y in zip(specs, par, h2):
+            _add_lin(b, N=H, K=H, W=ptr(p[0]), bias=ptr(p[1]), X=_fptr(h1[s.h1_group], s.h1_col), ldx=h1[s.h1_group].shape[1], Y=ptr(y), ldy=H)
+        _abi.call("spv_linear_fwd", C.byref(b), stream_ptr())
+        # 2. mu / logvar heads into the two halves of `pre`
+        b = _lin_batch(B)
+        for s, p, x, y in zip(specs, par, h2, pre):
+            _add_lin(b, N=s.n, K=H, W=ptr(p[2]), bias=ptr(p[3]), X=ptr(x), ldx=H, Y=_fptr(y, 0), ldy=2 * s.n)
+            _add_lin(b, N=s.n, K=H, W=ptr(p[4]), bias=ptr(p[5]), X=ptr(x), ldx=H, Y=_fptr(y, s.n), ldy=2 * s.n)
+        _abi.call("spv_linear_fwd", C.byref(b), stream_ptr())
+        # 3. BatchNorm1d (torch defaults eps 1e-5, momentum 0.1: nn/networks.py:76,82)
+        bn = SpvBnBatch()
+        bn.nprob, bn.B, bn.training, bn.relu, bn.eps, bn.momentum = 0, B, int(training), 0, 1e-5, 0.1
+        parts = []
+        for s, p, x, y, st in zip(specs, par, pre, post, stats):
+            for half, (g, be, mod) in enumerate(((p[6], p[7], s.enc.mu_encoder[1]), (p[8], p[9], s.enc.lvar_encoder[1]))):
+                part = ws.get(f"tail_bn_part_{len(parts)}", (nblk, s.n, 2), torch.float32)
+                parts.append(part)
+                q = bn.p[bn.nprob]
+                q.X, q.ldx, q.Y, q.ldy = _fptr(x, half * s.n), 2 * s.n, _fptr(y, half * s.n), 2 * s.n
+                q.gamma, q.beta, q.running_mean, q.running_var = ptr(g), ptr(be), ptr(mod.running_mean), ptr(mod.running_var)
+                q.stats, q.part, q.N = ptr(st[half]), ptr(part), s.n
+                bn.nprob += 1
+        _abi.call("spv_bn_fwd", C.byref(bn), stream_ptr())
+        # 4. scale, reparameterised draw, softmax, KL
+        scale = [new(B, s.n) for s in specs]
+        logz = [new(B, s.n) for s in specs]
+        theta = [new(B, s.n) for s in specs]
+        kl = [new(B) for _ in specs]
+        sb = SpvSampleBatch()
+        sb.nprob, sb.B = len(specs), B
+        for i, s in enumerate(specs):
+            q = sb.p[i]
+            q.post, q.n, q.eps, q.scale, q.logz, q.theta, q.kl = ptr(post[i]), s.n, ptr(eps[i].contiguous()), ptr(scale[i]), ptr(logz[i]), ptr(theta[i]), ptr(kl[i])
+        _abi.call("spv_enc_sample_fwd", C.byref(sb), stream_ptr())
+        ctx.specs, ctx.training, ctx.dp, ctx.seed, ctx.ws, ctx.n_groups, ctx.B, ctx.H = specs, training, dp, seed, ws, n_groups, B, H
+        ctx.eps = [e.contiguous() for e in eps]
+        ctx.save_for_backward(*tensors, *h2, *pre, *post, *stats, *scale)
+        outs = []
+        for i, s in enumerate(specs):
+            outs += [post[i][:, :s.n], post[i][:, s.n:], scale[i], logz[i], theta[i], kl[i]]
+            ctx.mark_non_differentiable(theta[i])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *g):
+        specs, B, H, ws, n_groups = ctx.specs, ctx.B, ctx.H, ctx.ws, ctx.n_groups
+        E = len(specs)
+        saved = ctx.saved_tensors
+        n_in = n_groups + E * N_ENC_PARAMS
+        tensors = saved[:n_in]
+        h1 = tensors[:n_groups]
+        par = [tensors[n_groups + i * N_ENC_PARAMS: n_groups + (i + 1) * N_ENC_PARAMS] for i in range(E)]
+        h2, pre, post, stats, scale = (saved[n_in + k * E: n_in + (k + 1) * E] for k in range(5))
+        dev = h1[0].device
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        cont = lambda t: None if t is None else t.contiguous()
+        # 1. sampling / KL backward -> d_post
+        d_post = [new(B, 2 * s.n) for s in specs]
+        sb = SpvSampleBatch()
+        sb.nprob, sb.B = E, B
+        keep = []
+        for i, s in enumerate(specs):
+            gl, gv, gs, gz, _gt, gk = (cont(t) for t in g[6 * i: 6 * i + 6])
+            keep += [gl, gv, gs, gz, gk]
+            q = sb.p[i]
+            q.post, q.n, q.eps, q.scale = ptr(post[i]), s.n, ptr(ctx.eps[i]), ptr(scale[i])
+            q.g_loc, q.g_logvar, q.g_scale, q.g_logz, q.g_kl, q.d_post = ptr(gl), ptr(gv), ptr(gs), ptr(gz), ptr(gk), ptr(d_post[i])
+        _abi.call("spv_enc_sample_bwd", C.byref(sb), stream_ptr())
+        # 2. BatchNorm backward -> d_pre, d gamma / beta
+        d_pre = [new(B, 2 * s.n) for s in specs]
+        d_gb = [[new(s.n) for _ in range(4)] for s in specs]  # d gamma_mu, d beta_mu, d gamma_lv, d beta_lv
+        nblk = -(-B // 256)
+        bn = SpvBnBatch()
+        bn.nprob, bn.B, bn.training, bn.relu, bn.eps, bn.momentum = 0, B, int(ctx.training), 0, 1e-5, 0.1
+        k = 0
+        for i, (s, p) in enumerate(zip(specs, par)):
+            for half, (gam, be, mod) in enumerate(((p[6], p[7], s.enc.mu_encoder[1]), (p[8], p[9], s.enc.lvar_encoder[1]))):
+                q = bn.p[bn.nprob]
+                q.X, q.ldx, q.Y, q.ldy = _fptr(pre[i], half * s.n), 2 * s.n, _fptr(post[i], half * s.n), 2 * s.n
+                q.gamma, q.beta, q.running_mean, q.running_var = ptr(gam), ptr(be), ptr(mod.running_mean), ptr(mod.running_var)
+                q.stats, q.part, q.N = ptr(stats[i][half]), ptr(ws.get(f"tail_bn_part_{k}", (nblk, s.n, 2), torch.float32)), s.n
+                q.dY, q.lddy, q.dX, q.lddx = _fptr(d_post[i], half * s.n), 2 * s.n, _fptr(d_pre[i], half * s.n), 2 * s.n
+                q.dgamma, q.dbeta = ptr(d_gb[i][2 * half]), ptr(d_gb[i][2 * half + 1])
+                bn.nprob += 1
+                k += 1
+        _abi.call("spv_bn_bwd", C.byref(bn), stream_ptr())
+        # 3. head weight gradients
+        dWmu, dbmu, dWlv, dblv = ([new(s.n, H) for s in specs], [new(s.n) for s in specs], [new(s.n, H) for s in specs], [new(s.n) for s in specs])
+        b = _lin_batch(B)
+        for i, s in enumerate(specs):
+            _add_lin(b, N=s.n, K=H, W=ptr(par[i][2]), X=ptr(h2[i]), ldx=H, dY=_fptr(d_pre[i], 0), lddy=2 * s.n, dW=ptr(dWmu[i]), db=ptr(dbmu[i]))
+            _add_lin(b, N=s.n, K=H, W=ptr(par[i][4]), X=ptr(h2[i]), ldx=H, dY=_fptr(d_pre[i], s.n), lddy=2 * s.n, dW=ptr(dWlv[i]), db=ptr(dblv[i]))
+        _abi.call("spv_linear_wgrad", C.byref(b), stream_ptr())
+        # 4. d h2 = d_pre_mu Wmu + d_pre_lv Wlv
+        dh2 = [new(B, H) for _ in specs]
+        for half, acc in ((0, False), (1, True)):
+            b = _lin_batch(B, accumulate=acc)
+            for i, s in enumerate(specs):
+                _add_lin(b, N=s.n, K=H, W=ptr(par[i][2 + 2 * half]), dY=_fptr(d_pre[i], half * s.n), lddy=2 * s.n, dX=ptr(dh2[i]), lddx=H)
+            _abi.call("spv_linear_dgrad", C.byref(b), stream_ptr())
+        # 5./6. fc2 backward (relu + dropout mask recovered from the saved h2 > 0)
+        dW2, db2 = [new(H, H) for _ in specs], [new(H) for _ in specs]
+        dh1 = [torch.zeros_like(t) for t in h1]
+        bw = _lin_batch(B, relu=True, drop_p=ctx.dp)
+        bd = _lin_batch(B, relu=True, drop_p=ctx.dp)
+        for i, s in enumerate(specs):
+            x, ldx = _fptr(h1[s.h1_group], s.h1_col), h1[s.h1_group].shape[1]
+            _add_lin(bw, N=H, K=H, W=ptr(par[i][0]), X=x, ldx=ldx, Y=ptr(h2[i]), ldy=H, dY=ptr(dh2[i]), lddy=H, dW=ptr(dW2[i]), db=ptr(db2[i]))
+            _add_lin(bd, N=H, K=H, W=ptr(par[i][0]), Y=ptr(h2[i]), ldy=H, dY=ptr(dh2[i]), lddy=H, dX=_fptr(dh1[s.h1_group], s.h1_col), lddx=ldx)
+        _abi.call("spv_linear_wgrad", C.byref(bw), stream_ptr())
+        _abi.call("spv_linear_dgrad", C.byref(bd), stream_ptr())
+        grads: List[Optional[torch.Tensor]] = list(dh1)
+        for i in range(E):
+            grads += [dW2[i], db2[i], dWmu[i], dbmu[i], dWlv[i], dblv[i], d_gb[i][0], d_gb[i][1], d_gb[i][2], d_gb[i][3]]
+        return (None, None, None, None, None, None, *grads)
+
+
+# ------------------------------------------------------------------------------------------------
+# label-based Product of Experts
+# ------------------------------------------------------------------------------------------------
+def _loc_logvar_block(loc: torch.Tensor, logvar: torch.Tensor):
+    """(base pointer, row pitch) of a [B][>=2n] block holding loc | logvar side by side; copies if the two
+    are not already adjacent views of one buffer (they are when they come out of EncoderTails)."""
+    n = loc.shape[1]
+    if (loc.dtype == torch.float32 and loc.stride(1) == 1 and logvar.stride(1) == 1 and loc.stride(0) == logvar.stride(0)
+            and logvar.data_ptr() == loc.data_ptr() + 4 * n and loc.stride(0) >= 2 * n):
+        return loc, loc.data_ptr(), loc.stride(0)
+    blk = torch.cat([loc, logvar], dim=1).contiguous()
+    return blk, blk.data_ptr(), 2 * n
+
+
+class PoELabel(torch.autograd.Function):
+    """Both groups' label-based PoE in 2 forward launches (pairing + fusion/draw/KL) and 1 backward launch.
+    inputs : loc0, logvar0, loc1, logvar1 (shared-encoder statistics); outputs per group
+    (loc*, logvar*, scale*, log_z, theta, kl) -- theta not differentiable."""
+
+    @staticmethod
+    def forward(ctx, labels: Sequence[torch.Tensor], eps: Sequence[torch.Tensor], ws, loc0, logvar0, loc1, logvar1):
+        from ._abi import SpvPoeArgs
+        dev = loc0.device
+        n = loc0.shape[1]
+        Bs = [loc0.shape[0], loc1.shape[0]]
+        i32 = lambda name, k: ws.get(name, (k,), torch.int32)
+        lab = [l.flatten().contiguous().float() for l in labels]
+        order = [i32(f"poe_order{g}", Bs[g]) for g in range(2)]
+        partner = [torch.empty(Bs[g], dtype=torch.int32, device=dev) for g in range(2)]
+        mode = [torch.empty(Bs[g], dtype=torch.int32, device=dev) for g in range(2)]
+        err = ws.get("poe_err", (1,), torch.int32, zero=True)
+        _abi.call("spv_poe_partner", ptr(lab[0]), ptr(lab[1]), Bs[0], Bs[1], ptr(order[0]), ptr(order[1]), ptr(partner[0]), ptr(mode[0]),
+                  ptr(partner[1]), ptr(mode[1]), ptr(err), stream_ptr())
+        blocks = [_loc_logvar_block(loc0, logvar0), _loc_logvar_block(loc1, logvar1)]
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        out = {k: [new(Bs[g], n) for g in range(2)] for k in ("loc", "logvar", "scale", "logz", "theta")}
+        kl = [new(Bs[g]) for g in range(2)]
+        eps = [e.contiguous() for e in eps]
+        a = SpvPoeArgs()
+        a.n = n
+        for g in range(2):
+            a.stats[g], a.ld[g], a.partner[g], a.mode[g], a.eps[g], a.B[g] = blocks[g][1], blocks[g][2], ptr(partner[g]), ptr(mode[g]), ptr(eps[g]), Bs[g]
+            a.loc[g], a.logvar[g], a.scale[g], a.logz[g], a.theta[g] = (ptr(out[k][g]) for k in ("loc", "logvar", "scale", "logz", "theta"))
+            a.kl[g] = ptr(kl[g])
+        _abi.call("spv_poe_fuse_fwd", C.byref(a), stream_ptr())
+        ctx.blocks, ctx.eps, ctx.partner, ctx.mode, ctx.n, ctx.Bs, ctx.err = blocks, eps, partner, mode, n, Bs, err
+        ctx.save_for_backward(out["loc"][0], out["loc"][1], out["scale"][0], out["scale"][1])
+        res = []
+        for g in range(2):
+            res += [out["loc"][g], out["logvar"][g], out["scale"][g], out["logz"][g], out["theta"][g], kl[g]]
+            ctx.mark_non_differentiable(out["theta"][g])
+        return tuple(res)
+
+    @staticmethod
+    def backward(ctx, *g):
+        from ._abi import SpvPoeArgs
+        loc = ctx.saved_tensors[0:2]
+        scale = ctx.saved_tensors[2:4]
+        n, Bs = ctx.n, ctx.Bs
+        dev = loc[0].device
+        cont = lambda t: None if t is None else t.contiguous()
+        a = SpvPoeArgs()
+        a.n = n
+        d = [torch.zeros(Bs[k], 2 * n, dtype=torch.float32, device=dev) for k in range(2)]
+        keep = []
+        for k in range(2):
+            gl, gv, gs, gz, _gt, gk = (cont(t) for t in g[6 * k: 6 * k + 6])
+            keep += [gl, gv, gs, gz, gk]
+            a.stats[k], a.ld[k], a.partner[k], a.mode[k], a.eps[k], a.B[k] = ctx.blocks[k][1], ctx.blocks[k][2], ptr(ctx.partner[k]), ptr(ctx.mode[k]), ptr(ctx.eps[k]), Bs[k]
+            a.loc[k], a.scale[k] = ptr(loc[k]), ptr(scale[k])
+            a.g_loc[k], a.g_logvar[k], a.g_scale[k], a.g_logz[k], a.g_kl[k] = ptr(gl), ptr(gv), ptr(gs), ptr(gz), ptr(gk)
+        # d_stats must use the same pitch as stats: allocate [B][ld] when the inputs were views of a wider buffer
+        for k in range(2):
+            ld = ctx.blocks[k][2]
+            if ld != 2 * n:
+                d[k] = torch.zeros(Bs[k], ld, dtype=torch.float32, device=dev)
+            a.d_stats[k] = ptr(d[k])
+        _abi.call("spv_poe_fuse_bwd", C.byref(a), stream_ptr())
+        return (None, None, None, d[0][:, :n], d[0][:, n:2 * n], d[1][:, :n], d[1][:, n:2 * n])
