@@ -173,7 +173,9 @@ typedef struct spv_linear_batch {
 } spv_linear_batch;
 int spv_linear_fwd(const spv_linear_batch* a, void* stream);    /* Y = dropout(relu(X W^T + b))      */
 int spv_linear_dgrad(const spv_linear_batch* a, void* stream);  /* dX (+)= mask(dY) W                */
-int spv_linear_wgrad(const spv_linear_batch* a, void* stream);  /* dW = mask(dY)^T X, db = colsum    */
+/* dW = mask(dY)^T X, db = colsum(mask(dY)); wpart: fp32 workspace of >= nprob * 16 * Nmax * (Kmax + 1)
+ * elements (the batch is reduced in 16 slices, then summed in slice order)                          */
+int spv_linear_wgrad(const spv_linear_batch* a, float* wpart, int64_t wpart_elems, void* stream);
 
 typedef struct spv_bn_prob {
   const float* X; int64_t ldx;     /* [B][N], N <= 256                                              */
@@ -181,7 +183,7 @@ typedef struct spv_bn_prob {
   const float* gamma; const float* beta;
   float* running_mean; float* running_var;   /* updated in training (momentum, unbiased variance)   */
   float* stats;                    /* [N][2] saved (mean, 1/sqrt(var+eps))                          */
-  float* part;                     /* workspace [ceil(B/256)][N][2]                                 */
+  float* part;                     /* workspace [ceil(B/64)][N][2]                                  */
   const float* dY; int64_t lddy;   /* backward                                                     */
   float* dX; int64_t lddx;
   float* dgamma; float* dbeta;

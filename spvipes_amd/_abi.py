@@ -39,6 +39,7 @@ class SpvDecParams(C.Structure):
 
 
 SPV_MAXP = 8
+BN_ROWS = 64  # rows per workgroup of the BatchNorm kernels (sizes their partial-sum workspace)
 
 
 class SpvLinearProb(C.Structure):
@@ -118,7 +119,7 @@ _SIGNATURES = {
     "spv_dec_softmax_bwd": (C.c_int, [C.POINTER(SpvDecParams), C.c_void_p, C.c_void_p, C.c_void_p]),
     "spv_linear_fwd": (C.c_int, [C.POINTER(SpvLinearBatch), C.c_void_p]),
     "spv_linear_dgrad": (C.c_int, [C.POINTER(SpvLinearBatch), C.c_void_p]),
-    "spv_linear_wgrad": (C.c_int, [C.POINTER(SpvLinearBatch), C.c_void_p]),
+    "spv_linear_wgrad": (C.c_int, [C.POINTER(SpvLinearBatch), C.c_void_p, C.c_int64, C.c_void_p]),
     "spv_bn_fwd": (C.c_int, [C.POINTER(SpvBnBatch), C.c_void_p]),
     "spv_bn_bwd": (C.c_int, [C.POINTER(SpvBnBatch), C.c_void_p]),
     "spv_enc_sample_fwd": (C.c_int, [C.POINTER(SpvSampleBatch), C.c_void_p]),

@@ -363,13 +363,18 @@ extern "C" int spv_linear_dgrad(const spv_linear_batch* a, void* stream) {
   hipLaunchKernelGGL(linear_dgrad_kernel, dim3((a->B + 31) / 32, (kmax + 31) / 32, a->nprob), dim3(256), 0, (hipStream_t)stream, *a);
   return launch_status("spv_linear_dgrad");
 }
-extern "C" int spv_linear_wgrad(const spv_linear_batch* a, void* stream) {
+extern "C" int spv_linear_wgrad(const spv_linear_batch* a, float* wpart, int64_t wpart_elems, void* stream) {
   int rc = check_linear(a, "spv_linear_wgrad");
   if (rc) return rc;
   for (int i = 0; i < a->nprob; ++i)
     if (!a->p[i].dY || !a->p[i].X || !a->p[i].dW || ((a->relu || a->drop_p > 0.f) && !a->p[i].Y)) return fail(SPV_ERR_ARG, "spv_linear_wgrad: null pointer%s");
+  if (!wpart) return fail(SPV_ERR_ARG, "spv_linear_wgrad: workspace missing%s");
   int nmax, kmax; linear_extents(a, nmax, kmax);
-  hipLaunchKernelGGL(linear_wgrad_kernel, dim3((nmax + 31) / 32, (kmax + 31) / 32, a->nprob), dim3(256), 0, (hipStream_t)stream, *a);
+  const long prob_stride = (long)WG_SLICES * nmax * (kmax + 1);
+  if (wpart_elems < prob_stride * a->nprob) return fail(SPV_ERR_ARG, "spv_linear_wgrad: workspace too small%s");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(linear_wgrad_kernel, dim3((nmax + 31) / 32, (kmax + 31) / 32, a->nprob * WG_SLICES), dim3(256), 0, s, *a, wpart, prob_stride);
+  hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((unsigned)(((long)nmax * (kmax + 1) + 255) / 256), a->nprob), dim3(256), 0, s, *a, wpart, prob_stride);
   return launch_status("spv_linear_wgrad");
 }
 

@@ -122,22 +122,28 @@ __global__ __launch_bounds__(256) void linear_dgrad_kernel(LinearBatch a) {
   }
 }
 
-// dW = mask(dY)^T X, db = colsum(mask(dY)): tile 32 n x 32 k, loop over the batch (fixed order)
-__global__ __launch_bounds__(256) void linear_wgrad_kernel(LinearBatch a) {
-  const LinearProb& q = a.p[blockIdx.z];
+// dW = mask(dY)^T X, db = colsum(mask(dY)): tile 32 n x 32 k; the batch is cut into WG_SLICES slices (one
+// workgroup each, partial tiles into `wpart`), summed in slice order by linear_wgrad_reduce_kernel
+constexpr int WG_SLICES = 16;
+
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(LinearBatch a, float* wpart, long prob_stride) {
+  const int prob = blockIdx.z / WG_SLICES, slice = blockIdx.z % WG_SLICES;
+  const LinearProb& q = a.p[prob];
   const int n0 = blockIdx.x * SM_T, k0 = blockIdx.y * SM_T;
   if (n0 >= q.N || k0 >= q.K) return;
   __shared__ __attribute__((aligned(16))) float sG[SM_T * SM_PITCH], sX[SM_T * SM_PITCH];
   const int tid = threadIdx.x, nn = tid >> 3, cg = (tid & 7) * 4;
   float acc[4] = {0.f, 0.f, 0.f, 0.f}, bsum = 0.f;
-  for (int b0 = 0; b0 < a.B; b0 += SM_T) {
+  const int per = ((a.B + WG_SLICES * SM_T - 1) / (WG_SLICES * SM_T)) * SM_T;
+  const int bbeg = slice * per, bend = min(bbeg + per, a.B);
+  for (int b0 = bbeg; b0 < bend; b0 += SM_T) {
     {
       const int rr = tid >> 3, cc = (tid & 7) * 4;
       f4v vg = {0.f, 0.f, 0.f, 0.f}, vx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (b0 + rr < a.B && n0 + cc + j < q.N) vg[j] = masked_dy(a, q, b0 + rr, n0 + cc + j);        // sG[b][n]
-        if (b0 + rr < a.B && k0 + cc + j < q.K) vx[j] = q.X[(long)(b0 + rr) * q.ldx + k0 + cc + j];   // sX[b][k]
+        if (b0 + rr < bend && n0 + cc + j < q.N) vg[j] = masked_dy(a, q, b0 + rr, n0 + cc + j);        // sG[b][n]
+        if (b0 + rr < bend && k0 + cc + j < q.K) vx[j] = q.X[(long)(b0 + rr) * q.ldx + k0 + cc + j];   // sX[b][k]
       }
       *reinterpret_cast<f4v*>(&sG[rr * SM_PITCH + cc]) = vg;
       *reinterpret_cast<f4v*>(&sX[rr * SM_PITCH + cc]) = vx;
@@ -154,10 +160,26 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(LinearBatch a) {
   }
   const int n = n0 + nn;
   if (n >= q.N) return;
+  // partial layout per problem: [slice][N][K + 1] (last column = bias partial)
+  float* dst = wpart + prob * prob_stride + ((long)slice * q.N + n) * (q.K + 1);
 #pragma unroll
   for (int i = 0; i < 4; ++i)
-    if (k0 + cg + i < q.K) q.dW[(long)n * q.K + k0 + cg + i] = acc[i];
-  if (q.db && blockIdx.y == 0 && cg == 0) q.db[n] = bsum;
+    if (k0 + cg + i < q.K) dst[k0 + cg + i] = acc[i];
+  if (blockIdx.y == 0 && cg == 0) dst[q.K] = bsum;
+}
+
+__global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(LinearBatch a, const float* wpart, long prob_stride) {
+  const LinearProb& q = a.p[blockIdx.y];
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long tot = (long)q.N * (q.K + 1);
+  if (i >= tot) return;
+  const float* src = wpart + blockIdx.y * prob_stride + i;
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < WG_SLICES; ++k) s += src[(long)k * tot];
+  const int n = (int)(i / (q.K + 1)), c = (int)(i % (q.K + 1));
+  if (c < q.K) q.dW[(long)n * q.K + c] = s;
+  else if (q.db) q.db[n] = s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -165,20 +187,41 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(LinearBatch a) {
 // ---------------------------------------------------------------------------------------------
 typedef spv_bn_prob BnProb;
 typedef spv_bn_batch BnBatch;
-constexpr int BN_ROWS = 256;
+constexpr int BN_ROWS = 64;   // rows per workgroup (B = 4096 -> 64 workgroups per problem)
+
+// column c = tid % NC, row slot = tid / NC (NC = N rounded up to a power of two): every thread strides over the
+// block's rows; the per-slot partials are then summed in slot order (deterministic)
+__device__ __forceinline__ int pow2_at_least(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 
 __global__ __launch_bounds__(256) void bn_stats_kernel(BnBatch a) {
   const BnProb& q = a.p[blockIdx.y];
-  const int j = threadIdx.x;
-  if (j >= q.N) return;
+  __shared__ float s_acc[256], s_mean[256];
+  const int NC = pow2_at_least(q.N), RS = 256 / NC;  // N <= 256
+  const int c = threadIdx.x % NC, slot = threadIdx.x / NC;
   const int b0 = blockIdx.x * BN_ROWS, b1 = min(b0 + BN_ROWS, a.B);
   float s = 0.f;
-  for (int b = b0; b < b1; ++b) s += q.X[(long)b * q.ldx + j];
-  const float mean = s / (float)(b1 - b0);
+  if (c < q.N) for (int b = b0 + slot; b < b1; b += RS) s += q.X[(long)b * q.ldx + c];
+  s_acc[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < q.N) {
+    float t = 0.f;
+    for (int k = 0; k < RS; ++k) t += s_acc[k * NC + threadIdx.x];
+    s_mean[threadIdx.x] = t / (float)(b1 - b0);
+  }
+  __syncthreads();
   float m2 = 0.f;
-  for (int b = b0; b < b1; ++b) { const float d = q.X[(long)b * q.ldx + j] - mean; m2 += d * d; }
-  q.part[((long)blockIdx.x * q.N + j) * 2] = mean;
-  q.part[((long)blockIdx.x * q.N + j) * 2 + 1] = m2;
+  if (c < q.N) {
+    const float mean = s_mean[c];
+    for (int b = b0 + slot; b < b1; b += RS) { const float d = q.X[(long)b * q.ldx + c] - mean; m2 += d * d; }
+  }
+  s_acc[threadIdx.x] = m2;
+  __syncthreads();
+  if (threadIdx.x < q.N) {
+    float t = 0.f;
+    for (int k = 0; k < RS; ++k) t += s_acc[k * NC + threadIdx.x];
+    q.part[((long)blockIdx.x * q.N + threadIdx.x) * 2] = s_mean[threadIdx.x];
+    q.part[((long)blockIdx.x * q.N + threadIdx.x) * 2 + 1] = t;
+  }
 }
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(BnBatch a) {
@@ -212,10 +255,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnBatch a) {
   }
   __syncthreads();
   const int b0 = blockIdx.x * BN_ROWS, b1 = min(b0 + BN_ROWS, a.B);
-  const long total = (long)(b1 - b0) * q.N;
-  for (long i = threadIdx.x; i < total; i += 256) {
-    const int b = b0 + (int)(i / q.N), c = (int)(i % q.N);
-    float v = (q.X[(long)b * q.ldx + c] - s_mean[c]) * s_inv[c] * q.gamma[c] + q.beta[c];
+  const int NC = pow2_at_least(q.N), RS = 256 / NC;
+  const int c = threadIdx.x % NC, slot = threadIdx.x / NC;
+  if (c >= q.N) return;
+  const float mean = s_mean[c], sc = s_inv[c] * q.gamma[c], be = q.beta[c];
+  for (int b = b0 + slot; b < b1; b += RS) {
+    float v = (q.X[(long)b * q.ldx + c] - mean) * sc + be;
     if (a.relu) v = fmaxf(v, 0.f);
     q.Y[(long)b * q.ldy + c] = v;
   }
@@ -228,18 +273,27 @@ __device__ __forceinline__ float bn_masked_dy(const BnBatch& a, const BnProb& q,
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBatch a) {
   const BnProb& q = a.p[blockIdx.y];
-  const int j = threadIdx.x;
-  if (j >= q.N) return;
+  __shared__ float s_g[256], s_gx[256];
+  const int NC = pow2_at_least(q.N), RS = 256 / NC;
+  const int c = threadIdx.x % NC, slot = threadIdx.x / NC;
   const int b0 = blockIdx.x * BN_ROWS, b1 = min(b0 + BN_ROWS, a.B);
-  const float mean = q.stats[2 * j], inv = q.stats[2 * j + 1];
   float sg = 0.f, sgx = 0.f;
-  for (int b = b0; b < b1; ++b) {
-    const float g = bn_masked_dy(a, q, b, j);
-    sg += g;
-    sgx += g * (q.X[(long)b * q.ldx + j] - mean) * inv;
+  if (c < q.N) {
+    const float mean = q.stats[2 * c], inv = q.stats[2 * c + 1];
+    for (int b = b0 + slot; b < b1; b += RS) {
+      const float g = bn_masked_dy(a, q, b, c);
+      sg += g;
+      sgx += g * (q.X[(long)b * q.ldx + c] - mean) * inv;
+    }
   }
-  q.part[((long)blockIdx.x * q.N + j) * 2] = sg;
-  q.part[((long)blockIdx.x * q.N + j) * 2 + 1] = sgx;
+  s_g[threadIdx.x] = sg; s_gx[threadIdx.x] = sgx;
+  __syncthreads();
+  if (threadIdx.x < q.N) {
+    float t0 = 0.f, t1 = 0.f;
+    for (int k = 0; k < RS; ++k) { t0 += s_g[k * NC + threadIdx.x]; t1 += s_gx[k * NC + threadIdx.x]; }
+    q.part[((long)blockIdx.x * q.N + threadIdx.x) * 2] = t0;
+    q.part[((long)blockIdx.x * q.N + threadIdx.x) * 2 + 1] = t1;
+  }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBatch a) {
@@ -255,18 +309,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBatch a) {
   }
   __syncthreads();
   const int b0 = blockIdx.x * BN_ROWS, b1 = min(b0 + BN_ROWS, a.B);
-  const long total = (long)(b1 - b0) * q.N;
   const float invB = 1.0f / (float)a.B;
-  for (long i = threadIdx.x; i < total; i += 256) {
-    const int b = b0 + (int)(i / q.N), c = (int)(i % q.N);
-    const float mean = q.stats[2 * c], inv = q.stats[2 * c + 1];
+  const int NC = pow2_at_least(q.N), RS = 256 / NC;
+  const int c = threadIdx.x % NC, slot = threadIdx.x / NC;
+  if (c >= q.N) return;
+  const float mean = q.stats[2 * c], inv = q.stats[2 * c + 1], gi = q.gamma[c] * inv;
+  const float msg = s_sg[c] * invB, msgx = s_sgx[c] * invB;
+  for (int b = b0 + slot; b < b1; b += RS) {
     const float g = bn_masked_dy(a, q, b, c);
     float dx;
     if (a.training) {
       const float xhat = (q.X[(long)b * q.ldx + c] - mean) * inv;
-      dx = q.gamma[c] * inv * (g - s_sg[c] * invB - xhat * s_sgx[c] * invB);
+      dx = gi * (g - msg - xhat * msgx);
     } else {
-      dx = q.gamma[c] * inv * g;
+      dx = gi * g;
     }
     q.dX[(long)b * q.lddx + c] = dx;
   }
@@ -515,8 +571,7 @@ __global__ __launch_bounds__(256) void bn_fold_fwd_kernel(FoldBatch a) {
     for (int k = 0; k < q.slot; ++k) { hi[k] = 0; lo[k] = 0; }
     return;
   }
-  float w[FOLD_KMAX];
-  for (int k = 0; k < K; ++k) w[k] = q.W[(long)g * K + k];
+  const float* w = q.W + (long)g * K;  // K <= 32 floats, L1-resident: re-read instead of a runtime-indexed register array
   float mean, var;
   if (a.training) {
     mean = 0.f; var = 0.f;
@@ -558,10 +613,9 @@ __global__ __launch_bounds__(256) void bn_fold_bwd_kernel(FoldBatch a) {
   __syncthreads();
   const int g = blockIdx.x * 256 + threadIdx.x;
   float dmean = 0.f, dvar = 0.f;
-  float w[FOLD_KMAX];
-  for (int k = 0; k < K; ++k) w[k] = 0.f;
+  float* w = s_w + threadIdx.x * FOLD_KMAX;  // this thread's weight row lives in LDS
+  for (int k = 0; k < K; ++k) w[k] = (g < q.G) ? q.W[(long)g * K + k] : 0.f;
   if (g < q.G) {
-    for (int k = 0; k < K; ++k) w[k] = q.W[(long)g * K + k];
     const float mean = q.stat[2 * g], var = q.stat[2 * g + 1];
     const float rs = rsqrtf(var + a.eps), gam = q.gamma[g], inv = gam * rs;
     const float* gW = q.dWeff + (long)g * q.ld_dw;
@@ -584,7 +638,6 @@ __global__ __launch_bounds__(256) void bn_fold_bwd_kernel(FoldBatch a) {
   }
   if (!a.training) return;
   // block partials of d zbar[k] = sum_g dmean_g w_gk and d C[k][l] = sum_g dvar_g w_gk w_gl, summed in gene order
-  for (int k = 0; k < K; ++k) s_w[threadIdx.x * FOLD_KMAX + k] = w[k];
   s_dm[threadIdx.x] = dmean; s_dv[threadIdx.x] = dvar;
   __syncthreads();
   for (int i = threadIdx.x; i < nred; i += 256) {
@@ -618,11 +671,10 @@ __global__ __launch_bounds__(256) void zstats_bwd_kernel(FoldBatch a) {
   __syncthreads();
   const int b = blockIdx.x * 256 + threadIdx.x;
   if (b >= a.B) return;
-  float zc[FOLD_KMAX];
-  for (int l = 0; l < K; ++l) zc[l] = q.z[(long)b * q.ldz + l] - s_zbar[l];
+  const float* zrow = q.z + (long)b * q.ldz;
   for (int k = 0; k < K; ++k) {
     float v = s_dz[k];
-    for (int l = 0; l < K; ++l) v += s_S[k * K + l] * zc[l];
+    for (int l = 0; l < K; ++l) v += s_S[k * K + l] * (zrow[l] - s_zbar[l]);
     q.dz[(long)b * q.lddz + k] += v;
   }
 }

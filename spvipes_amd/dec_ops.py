@@ -19,7 +19,7 @@ import torch
 from . import _abi
 from ._abi import (DEC_CELLS_PER_WG, DEC_KP, DEC_KPS, DEC_KS, NB_CMAX, SpvBnBatch, SpvDecParams, SpvFoldBatch, SpvZsplitArgs, ptr,
                    round_up, stream_ptr)
-from .nn_ops import _add_lin, _fptr, _lin_batch
+from .nn_ops import _add_lin, _fptr, _lin_batch, _wgrad, grad_out
 from .ops import N_HIDDEN_MIX, GroupCounts, Workspace, _bf16_image, _gemm, _gene_splits, _pack
 
 N_DEC_PARAMS = 13  # Wp, gamma_p, beta_p, Ws, gamma_s, beta_s, Wa, ba, gamma_a, beta_a, Wm, bm, px_r
@@ -76,7 +76,7 @@ class DecoderFused(torch.autograd.Function):
             for g in range(NG):
                 for k, (off, n) in enumerate(((0, n_p), (n_p, n_s))):
                     _add_lin(b, N=n, K=n, W=ptr(zz[g][k]), X=_fptr(zcat[g], off), ldx=nt, dY=_fptr(zcat[g], off), lddy=nt, dW=ptr(zz[g][k]), db=ptr(zsum[g][k]))
-            _abi.call("spv_linear_wgrad", C.byref(b), stream_ptr())
+            _wgrad(b, ws if not isinstance(ws, (list, tuple)) else ws[0])
         # ---- 3. fold the regressors' BatchNorm into the packed [Gp][48] operand image ---------------
         Wps = [_bf16_image(ws[g], "dec_Wps", Gps[g], DEC_KPS, True) for g in range(NG)]
         fstat = [[new(Gs[g], 2), new(Gs[g], 2)] for g in range(NG)]
@@ -101,7 +101,7 @@ class DecoderFused(torch.autograd.Function):
         for g in range(NG):
             _add_lin(b, N=n_m, K=nt, W=ptr(par[g][6]), bias=ptr(par[g][7]), X=ptr(zcat[g]), ldx=nt, Y=ptr(pre_a[g]), ldy=n_m)
         _abi.call("spv_linear_fwd", C.byref(b), stream_ptr())
-        nblk = -(-B // 256)
+        nblk = -(-B // _abi.BN_ROWS)
         bn = SpvBnBatch()
         bn.nprob, bn.B, bn.training, bn.relu, bn.eps, bn.momentum = NG, B, int(training), 1, 1e-3, 0.01
         for g in range(NG):
@@ -219,9 +219,10 @@ class DecoderFused(torch.autograd.Function):
             d_zcat.append((d[:, n_m:n_m + nt] + torch.cat([e[:, :n_p], f[:, :n_s]], dim=1)).contiguous())
             d_pxr.append(torch.exp(par[g][12]) * S["dth"].sum(0)[:G] * g_loss)
         # ---- trunk backward (BatchNorm + relu, Linear) ----------------------------------------------
-        nblk = -(-B // 256)
+        nblk = -(-B // _abi.BN_ROWS)
         d_pre = [new(B, n_m) for _ in range(NG)]
-        d_gam_a, d_bet_a = [new(n_m) for _ in range(NG)], [new(n_m) for _ in range(NG)]
+        pg = [[grad_out(par[g][j]) for j in range(10)] for g in range(NG)]  # small-layer parameters: Wp..beta_a
+        d_gam_a, d_bet_a = [pg[g][8][0] for g in range(NG)], [pg[g][9][0] for g in range(NG)]
         bn = SpvBnBatch()
         bn.nprob, bn.B, bn.training, bn.relu, bn.eps, bn.momentum = NG, B, int(training), 1, 1e-3, 0.01
         for g in range(NG):
@@ -232,18 +233,18 @@ class DecoderFused(torch.autograd.Function):
             q.part = ptr(ws[g].get("trunk_bn_part", (nblk, n_m, 2), torch.float32))
             q.dY, q.lddy, q.dX, q.lddx, q.dgamma, q.dbeta = ptr(dAm[g]), KMP, ptr(d_pre[g]), n_m, ptr(d_gam_a[g]), ptr(d_bet_a[g])
         _abi.call("spv_bn_bwd", C.byref(bn), stream_ptr())
-        dWa, dba = [new(n_m, nt) for _ in range(NG)], [new(n_m) for _ in range(NG)]
+        dWa, dba = [pg[g][6][0] for g in range(NG)], [pg[g][7][0] for g in range(NG)]
         bw, bd = _lin_batch(B), _lin_batch(B, accumulate=True)
         for g in range(NG):
             _add_lin(bw, N=n_m, K=nt, W=ptr(par[g][6]), X=ptr(zcat[g]), ldx=nt, dY=ptr(d_pre[g]), lddy=n_m, dW=ptr(dWa[g]), db=ptr(dba[g]))
             _add_lin(bd, N=n_m, K=nt, W=ptr(par[g][6]), dY=ptr(d_pre[g]), lddy=n_m, dX=ptr(d_zcat[g]), lddx=nt)
-        _abi.call("spv_linear_wgrad", C.byref(bw), stream_ptr())
+        _wgrad(bw, ws if not isinstance(ws, (list, tuple)) else ws[0])
         _abi.call("spv_linear_dgrad", C.byref(bd), stream_ptr())
         # ---- BatchNorm-fold backward (+ the z statistics it used) ------------------------------------
         fb = ctx.fb
-        dWraw = [[new(Gs[g], n_p), new(Gs[g], n_s)] for g in range(NG)]
-        dgam = [[new(Gs[g]), new(Gs[g])] for g in range(NG)]
-        dbet = [[new(Gs[g]), new(Gs[g])] for g in range(NG)]
+        dWraw = [[pg[g][0][0], pg[g][3][0]] for g in range(NG)]
+        dgam = [[pg[g][1][0], pg[g][4][0]] for g in range(NG)]
+        dbet = [[pg[g][2][0], pg[g][5][0]] for g in range(NG)]
         i = 0
         for g in range(NG):
             for k, (dweff, ld, n, zoff) in enumerate(((dWp[g], DEC_KP, n_p, 0), (dWs[g], DEC_KS, n_s, n_p))):
@@ -264,6 +265,5 @@ class DecoderFused(torch.autograd.Function):
         for g in range(NG):
             grads += [d_priv[g], d_poe[g]]
         for g in range(NG):
-            grads += [dWraw[g][0], dgam[g][0], dbet[g][0], dWraw[g][1], dgam[g][1], dbet[g][1], dWa[g], dba[g], d_gam_a[g], d_bet_a[g],
-                      dWm[g][:, :KM - 1], dWm[g][:, KM - 1], d_pxr[g]]
+            grads += [pg[g][j][1] for j in range(10)] + [dWm[g][:, :KM - 1], dWm[g][:, KM - 1], d_pxr[g]]
         return (None,) * 9 + tuple(grads)

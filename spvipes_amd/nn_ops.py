@@ -32,6 +32,31 @@ def _add_lin(b: SpvLinearBatch, *, N: int, K: int, W=None, X=None, ldx=0, bias=N
     b.nprob += 1
 
 
+# When True (set by train.Trainer around its step), parameter gradients of the small layers are written
+# straight into the parameters' pre-allocated, zeroed ``.grad`` views of the flat gradient buffer and the
+# autograd node returns None for them: every parameter receives exactly one contribution per step, so a
+# store equals an accumulation, and ~60 tiny "grad += g" kernels per step disappear.
+GRAD_SINK = False
+
+
+def grad_out(param: torch.Tensor):
+    """(tensor the kernel writes, value the autograd node returns) for one parameter's gradient."""
+    g = param.grad
+    if GRAD_SINK and g is not None and g.is_contiguous() and g.dtype == torch.float32:
+        return g, None
+    t = torch.empty_like(param, dtype=torch.float32)
+    return t, t
+
+
+def _wgrad(b: SpvLinearBatch, ws) -> None:
+    """spv_linear_wgrad with its slice-partial workspace (16 batch slices, summed in fixed order)."""
+    nmax = max(b.p[i].N for i in range(b.nprob))
+    kmax = max(b.p[i].K for i in range(b.nprob))
+    n = b.nprob * 16 * nmax * (kmax + 1)
+    part = ws.get("wgrad_part", (n,), torch.float32)
+    _abi.call("spv_linear_wgrad", C.byref(b), ptr(part), n, stream_ptr())
+
+
 def _fptr(t: torch.Tensor, col: int = 0) -> int:
     """device address of t[0, col] for a row-major fp32 matrix (or of t[col] for a vector)."""
     return t.data_ptr() + 4 * col
@@ -75,7 +100,7 @@ class EncoderTails(torch.autograd.Function):
         pre = [new(B, 2 * s.n) for s in specs]
         post = [new(B, 2 * s.n) for s in specs]
         stats = [new(2, s.n, 2) for s in specs]
-        nblk = -(-B // 256)
+        nblk = -(-B // _abi.BN_ROWS)
         dp = float(drop_p) if training else 0.0
         # 1. fc2 + relu (+ dropout)
         b = _lin_batch(B, relu=True, drop_p=dp, seed=seed)
@@ -149,8 +174,10 @@ class EncoderTails(torch.autograd.Function):
         _abi.call("spv_enc_sample_bwd", C.byref(sb), stream_ptr())
         # 2. BatchNorm backward -> d_pre, d gamma / beta
         d_pre = [new(B, 2 * s.n) for s in specs]
-        d_gb = [[new(s.n) for _ in range(4)] for s in specs]  # d gamma_mu, d beta_mu, d gamma_lv, d beta_lv
-        nblk = -(-B // 256)
+        # parameter gradients: (write target, autograd return value) per parameter of each encoder
+        pg = [[grad_out(par[i][j]) for j in range(N_ENC_PARAMS)] for i in range(E)]
+        d_gb = [[pg[i][6][0], pg[i][7][0], pg[i][8][0], pg[i][9][0]] for i in range(E)]  # d gamma_mu, d beta_mu, d gamma_lv, d beta_lv
+        nblk = -(-B // _abi.BN_ROWS)
         bn = SpvBnBatch()
         bn.nprob, bn.B, bn.training, bn.relu, bn.eps, bn.momentum = 0, B, int(ctx.training), 0, 1e-5, 0.1
         k = 0
@@ -166,12 +193,12 @@ class EncoderTails(torch.autograd.Function):
                 k += 1
         _abi.call("spv_bn_bwd", C.byref(bn), stream_ptr())
         # 3. head weight gradients
-        dWmu, dbmu, dWlv, dblv = ([new(s.n, H) for s in specs], [new(s.n) for s in specs], [new(s.n, H) for s in specs], [new(s.n) for s in specs])
+        dWmu, dbmu, dWlv, dblv = ([pg[i][2][0] for i in range(E)], [pg[i][3][0] for i in range(E)], [pg[i][4][0] for i in range(E)], [pg[i][5][0] for i in range(E)])
         b = _lin_batch(B)
         for i, s in enumerate(specs):
             _add_lin(b, N=s.n, K=H, W=ptr(par[i][2]), X=ptr(h2[i]), ldx=H, dY=_fptr(d_pre[i], 0), lddy=2 * s.n, dW=ptr(dWmu[i]), db=ptr(dbmu[i]))
             _add_lin(b, N=s.n, K=H, W=ptr(par[i][4]), X=ptr(h2[i]), ldx=H, dY=_fptr(d_pre[i], s.n), lddy=2 * s.n, dW=ptr(dWlv[i]), db=ptr(dblv[i]))
-        _abi.call("spv_linear_wgrad", C.byref(b), stream_ptr())
+        _wgrad(b, ws if not isinstance(ws, (list, tuple)) else ws[0])
         # 4. d h2 = d_pre_mu Wmu + d_pre_lv Wlv
         dh2 = [new(B, H) for _ in specs]
         for half, acc in ((0, False), (1, True)):
@@ -180,7 +207,7 @@ class EncoderTails(torch.autograd.Function):
                 _add_lin(b, N=s.n, K=H, W=ptr(par[i][2 + 2 * half]), dY=_fptr(d_pre[i], half * s.n), lddy=2 * s.n, dX=ptr(dh2[i]), lddx=H)
             _abi.call("spv_linear_dgrad", C.byref(b), stream_ptr())
         # 5./6. fc2 backward (relu + dropout mask recovered from the saved h2 > 0)
-        dW2, db2 = [new(H, H) for _ in specs], [new(H) for _ in specs]
+        dW2, db2 = [pg[i][0][0] for i in range(E)], [pg[i][1][0] for i in range(E)]
         dh1 = [torch.zeros_like(t) for t in h1]
         bw = _lin_batch(B, relu=True, drop_p=ctx.dp)
         bd = _lin_batch(B, relu=True, drop_p=ctx.dp)
@@ -188,11 +215,11 @@ class EncoderTails(torch.autograd.Function):
             x, ldx = _fptr(h1[s.h1_group], s.h1_col), h1[s.h1_group].shape[1]
             _add_lin(bw, N=H, K=H, W=ptr(par[i][0]), X=x, ldx=ldx, Y=ptr(h2[i]), ldy=H, dY=ptr(dh2[i]), lddy=H, dW=ptr(dW2[i]), db=ptr(db2[i]))
             _add_lin(bd, N=H, K=H, W=ptr(par[i][0]), Y=ptr(h2[i]), ldy=H, dY=ptr(dh2[i]), lddy=H, dX=_fptr(dh1[s.h1_group], s.h1_col), lddx=ldx)
-        _abi.call("spv_linear_wgrad", C.byref(bw), stream_ptr())
+        _wgrad(bw, ws if not isinstance(ws, (list, tuple)) else ws[0])
         _abi.call("spv_linear_dgrad", C.byref(bd), stream_ptr())
         grads: List[Optional[torch.Tensor]] = list(dh1)
         for i in range(E):
-            grads += [dW2[i], db2[i], dWmu[i], dbmu[i], dWlv[i], dblv[i], d_gb[i][0], d_gb[i][1], d_gb[i][2], d_gb[i][3]]
+            grads += [pg[i][j][1] for j in range(N_ENC_PARAMS)]
         return (None, None, None, None, None, None, *grads)
 
 

@@ -116,9 +116,15 @@ class Trainer:
         """forward + loss + backward + (all-reduce) + Adam for one minibatch; returns the LossOutput."""
         if kl_weight is None:
             kl_weight = kl_weight_at(self.epoch, self.global_step, self.n_epochs_kl_warmup, self.n_steps_kl_warmup)
+        from . import nn_ops
+
         self.fp.grad.zero_()
         _, _, lo = self.module(self.minibatch(rows), loss_kwargs={"kl_weight": kl_weight})
-        lo.loss.backward()
+        nn_ops.GRAD_SINK = True  # small-layer gradients land directly in the flat buffer (see nn_ops.grad_out)
+        try:
+            lo.loss.backward()
+        finally:
+            nn_ops.GRAD_SINK = False
         if self.world > 1:
             dist.all_reduce(self.fp.grad, op=dist.ReduceOp.SUM)  # the step's only collective
         self.opt.step(grad_scale=1.0 / self.world)
