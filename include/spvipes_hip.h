@@ -75,7 +75,7 @@ int spv_enc_fc1_fwd(const spv_counts* x, int32_t B, int32_t G,
                     float* slabs, float* rowsum_ws, float* h1, float* library, void* stream);
 
 /* fc1 weight gradient (autograd of nn/networks.py:119):  dW1[N1][G] = dh^T @ log1p(X[rows]).
- *   dh_hi/lo : bf16 [Bp32][ld_dh] (ld_dh >= round_up(N1,128), zero padded)  */
+ *   dh_hi/lo : bf16 [round_up(B,64)][ld_dh] (ld_dh >= round_up(N1,128), zero padded)  */
 int spv_enc_fc1_wgrad(const spv_counts* x, int32_t B, int32_t G,
                       const uint16_t* dh_hi, const uint16_t* dh_lo, int64_t ld_dh, int32_t N1,
                       int32_t nsplit, float* dW, int64_t ldc, void* stream);
@@ -90,7 +90,8 @@ int spv_enc_fc1_wgrad(const spv_counts* x, int32_t B, int32_t G,
  *   a_kmajor == 0: A is mem[m][k] (k contiguous); a_kmajor == 1: A is mem[k][m];
  *   a_tiles > 0: A is a tiled [cells][genes] array (above) with a_tiles gene tiles per cell tile;
  *                a_kmajor then says whether K runs over cells (1) or over genes (0); lda is unused.
- *   B is always k-major: mem[k][n].   Operands zero padded to tile multiples (64 x 320 / 128 x 32).
+ *   B is always k-major: mem[k][n].   Operands zero padded to tile multiples (64 x 320 / 128 x 32,
+ *   K to a multiple of 64).
  *   splits > 1: C is a stack of `splits` fp32 slabs (slab_stride elements apart), one per K range. */
 int spv_gemm_bf16(int32_t a_kmajor, const uint16_t* A_hi, const uint16_t* A_lo, int64_t lda,
                   const uint16_t* B_hi, const uint16_t* B_lo, int64_t ldb,
@@ -214,13 +215,15 @@ int spv_enc_sample_bwd(const spv_sample_batch* a, void* stream);
 /* ---------------------------------------------------------------------------------------------
  * Label-based Product of Experts on device (module/spVIPESmodule.py:583-718 + _poe2 :282-379).
  * ------------------------------------------------------------------------------------------- */
-#define SPV_POE_LMAX 4096   /* label codes are integers in [0, SPV_POE_LMAX) */
+#define SPV_POE_LMAX 1024   /* label codes are integers in [0, SPV_POE_LMAX) */
 
 /* rank-within-label pairing of two minibatches; labels are float32 codes (as the reference carries
- * them); order*: int32 scratch [B*]; partner*: int32 [B*] (-1 = none); mode*: int32 [B*]
- * (0 partner, 1 ones/zeros padding, 2 label absent from the other group); *err != 0 on a bad code. */
+ * them); order*, rank*: int32 scratch [B*]; tables: int32 scratch [2][2][SPV_POE_LMAX];
+ * partner*: int32 [B*] (-1 = none); mode*: int32 [B*] (0 partner, 1 ones/zeros padding, 2 label
+ * absent from the other group); *err != 0 on a label code outside [0, SPV_POE_LMAX). */
 int spv_poe_partner(const float* labels0, const float* labels1, int32_t B0, int32_t B1, int32_t* order0, int32_t* order1,
-                    int32_t* partner0, int32_t* mode0, int32_t* partner1, int32_t* mode1, int32_t* err, void* stream);
+                    int32_t* rank0, int32_t* rank1, int32_t* tables, int32_t* partner0, int32_t* mode0,
+                    int32_t* partner1, int32_t* mode1, int32_t* err, void* stream);
 
 typedef struct spv_poe_args {
   const float* stats[2]; int64_t ld[2];   /* shared encoders' (loc | logvar) rows, [B][ld], logvar at column n */

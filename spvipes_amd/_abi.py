@@ -125,7 +125,7 @@ _SIGNATURES = {
     "spv_enc_sample_fwd": (C.c_int, [C.POINTER(SpvSampleBatch), C.c_void_p]),
     "spv_enc_sample_bwd": (C.c_int, [C.POINTER(SpvSampleBatch), C.c_void_p]),
     "spv_poe_partner": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "spv_poe_fuse_fwd": (C.c_int, [C.POINTER(SpvPoeArgs), C.c_void_p]),
     "spv_poe_fuse_bwd": (C.c_int, [C.POINTER(SpvPoeArgs), C.c_void_p]),
     "spv_zsplit_fwd": (C.c_int, [C.POINTER(SpvZsplitArgs), C.c_void_p]),

@@ -130,16 +130,16 @@ extern "C" int spv_enc_fc1_wgrad(const spv_counts* x, int32_t B, int32_t G, cons
   p.rowsum = nullptr;
   p.C = dW; p.ldc = ldc; p.slab_stride = 0;
   p.M = N1; p.N = G; p.K = B;
-  p.k_per_split = (B + 31) & ~31;
+  p.k_per_split = (B + 63) & ~63;
   p.epi = EPI_STORE;
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if (x->dtype == SPV_COUNT_U16) {
-    rc = (nsplit == 3) ? launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_COUNTS, unsigned short, 3>>(p, 1, s)
-                       : launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_COUNTS, unsigned short, 1>>(p, 1, s);
+    rc = (nsplit == 3) ? launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_COUNTS, unsigned short, 3, 64>>(p, 1, s)
+                       : launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_COUNTS, unsigned short, 1, 64>>(p, 1, s);
   } else if (x->dtype == SPV_COUNT_F32) {
-    rc = (nsplit == 3) ? launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_COUNTS, float, 3>>(p, 1, s)
-                       : launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_COUNTS, float, 1>>(p, 1, s);
+    rc = (nsplit == 3) ? launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_COUNTS, float, 3, 64>>(p, 1, s)
+                       : launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_COUNTS, float, 1, 64>>(p, 1, s);
   } else return fail(SPV_ERR_ARG, "spv_enc_fc1_wgrad: unknown count dtype%s");
   (void)rc;
   return launch_status("spv_enc_fc1_wgrad");
@@ -150,8 +150,8 @@ extern "C" int spv_enc_fc1_wgrad(const spv_counts* x, int32_t B, int32_t G, cons
 // ---------------------------------------------------------------------------------------------
 template <bool A_KMAJ, int NSPLIT, int A_SRC>
 static int gemm_dispatch(const GemmParams& p, int splits, hipStream_t s) {
-  if (p.N <= 32) return launch_gemm<GemmCfg<128, 32, 4, 1, A_KMAJ, true, A_SRC, SRC_PLAIN, unsigned short, NSPLIT>>(p, splits, s);
-  return launch_gemm<GemmCfg<64, 320, 2, 2, A_KMAJ, true, A_SRC, SRC_PLAIN, unsigned short, NSPLIT>>(p, splits, s);
+  if (p.N <= 32) return launch_gemm<GemmCfg<128, 32, 4, 1, A_KMAJ, true, A_SRC, SRC_PLAIN, unsigned short, NSPLIT, 64>>(p, splits, s);
+  return launch_gemm<GemmCfg<64, 320, 2, 2, A_KMAJ, true, A_SRC, SRC_PLAIN, unsigned short, NSPLIT, 64>>(p, splits, s);
 }
 
 extern "C" int spv_gemm_bf16(int32_t a_kmajor, const uint16_t* A_hi, const uint16_t* A_lo, int64_t lda, const uint16_t* B_hi,
@@ -168,8 +168,8 @@ extern "C" int spv_gemm_bf16(int32_t a_kmajor, const uint16_t* A_hi, const uint1
   p.B = B_hi; p.B_lo = B_lo; p.ldb = ldb;
   p.C = C; p.ldc = ldc; p.slab_stride = slab_stride;
   p.M = M; p.N = N; p.K = K;
-  const int ktiles = (K + 31) / 32;
-  p.k_per_split = ((ktiles + splits - 1) / splits) * 32;
+  const int ktiles = (K + 63) / 64;  // BK = 64: operands are padded to multiples of 64 along K
+  p.k_per_split = ((ktiles + splits - 1) / splits) * 64;
   p.epi = EPI_STORE;
   p.tiles_inner = a_tiles;
   hipStream_t s = (hipStream_t)stream;
@@ -412,21 +412,21 @@ extern "C" int spv_bn_bwd(const spv_bn_batch* a, void* stream) {
 static int check_sample(const spv_sample_batch* a, const char* who) {
   if (!a || a->nprob <= 0 || a->nprob > SPV_MAXP || a->B <= 0) return fail(SPV_ERR_ARG, "%s: bad batch", who);
   for (int i = 0; i < a->nprob; ++i)
-    if (a->p[i].n <= 0 || !a->p[i].post || !a->p[i].eps || !a->p[i].scale) return fail(SPV_ERR_ARG, "%s: bad problem", who);
+    if (a->p[i].n <= 0 || a->p[i].n > 32 || !a->p[i].post || !a->p[i].eps || !a->p[i].scale) return fail(SPV_ERR_ARG, "%s: bad problem", who);
   return SPV_OK;
 }
 extern "C" int spv_enc_sample_fwd(const spv_sample_batch* a, void* stream) {
   int rc = check_sample(a, "spv_enc_sample_fwd");
   if (rc) return rc;
   for (int i = 0; i < a->nprob; ++i) if (!a->p[i].logz || !a->p[i].theta || !a->p[i].kl) return fail(SPV_ERR_ARG, "spv_enc_sample_fwd: null output%s");
-  hipLaunchKernelGGL(enc_sample_fwd_kernel, dim3((a->B + 255) / 256, a->nprob), dim3(256), 0, (hipStream_t)stream, *a);
+  hipLaunchKernelGGL(enc_sample_fwd_kernel, dim3((a->B + 7) / 8, a->nprob), dim3(256), 0, (hipStream_t)stream, *a);
   return launch_status("spv_enc_sample_fwd");
 }
 extern "C" int spv_enc_sample_bwd(const spv_sample_batch* a, void* stream) {
   int rc = check_sample(a, "spv_enc_sample_bwd");
   if (rc) return rc;
   for (int i = 0; i < a->nprob; ++i) if (!a->p[i].d_post) return fail(SPV_ERR_ARG, "spv_enc_sample_bwd: null output%s");
-  hipLaunchKernelGGL(enc_sample_bwd_kernel, dim3((a->B + 255) / 256, a->nprob), dim3(256), 0, (hipStream_t)stream, *a);
+  hipLaunchKernelGGL(enc_sample_bwd_kernel, dim3((a->B + 7) / 8, a->nprob), dim3(256), 0, (hipStream_t)stream, *a);
   return launch_status("spv_enc_sample_bwd");
 }
 
@@ -434,15 +434,19 @@ extern "C" int spv_enc_sample_bwd(const spv_sample_batch* a, void* stream) {
 // PoE (label) and decoder preparation
 // ---------------------------------------------------------------------------------------------
 extern "C" int spv_poe_partner(const float* labels0, const float* labels1, int32_t B0, int32_t B1, int32_t* order0, int32_t* order1,
-                               int32_t* partner0, int32_t* mode0, int32_t* partner1, int32_t* mode1, int32_t* err, void* stream) {
-  if (!labels0 || !labels1 || !order0 || !order1 || !partner0 || !partner1 || !mode0 || !mode1 || !err || B0 <= 0 || B1 <= 0)
+                               int32_t* rank0, int32_t* rank1, int32_t* tables, int32_t* partner0, int32_t* mode0, int32_t* partner1,
+                               int32_t* mode1, int32_t* err, void* stream) {
+  if (!labels0 || !labels1 || !order0 || !order1 || !rank0 || !rank1 || !tables || !partner0 || !partner1 || !mode0 || !mode1 || !err || B0 <= 0 || B1 <= 0)
     return fail(SPV_ERR_ARG, "spv_poe_partner: bad arguments%s");
-  hipLaunchKernelGGL(poe_partner_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, labels0, labels1, B0, B1, order0, order1, partner0,
-                     mode0, partner1, mode1, err);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(poe_rank_kernel, dim3(2), dim3(512), 0, s, labels0, labels1, B0, B1, order0, order1, rank0, rank1, tables, err);
+  const int Bm = B0 > B1 ? B0 : B1;
+  hipLaunchKernelGGL(poe_lookup_kernel, dim3((Bm + 255) / 256, 2), dim3(256), 0, s, labels0, labels1, B0, B1, order0, order1, rank0, rank1,
+                     tables, partner0, mode0, partner1, mode1);
   return launch_status("spv_poe_partner");
 }
 static int check_poe(const spv_poe_args* a, const char* who) {
-  if (!a || a->n <= 0 || a->B[0] <= 0 || a->B[1] <= 0) return fail(SPV_ERR_ARG, "%s: bad shape", who);
+  if (!a || a->n <= 0 || a->n > 32 || a->B[0] <= 0 || a->B[1] <= 0) return fail(SPV_ERR_ARG, "%s: bad shape (latent dimension <= 32)", who);
   for (int g = 0; g < 2; ++g)
     if (!a->stats[g] || !a->partner[g] || !a->mode[g] || !a->eps[g] || !a->loc[g] || !a->scale[g] || a->ld[g] < 2 * a->n)
       return fail(SPV_ERR_ARG, "%s: null pointer / bad pitch", who);
@@ -453,7 +457,7 @@ extern "C" int spv_poe_fuse_fwd(const spv_poe_args* a, void* stream) {
   if (rc) return rc;
   for (int g = 0; g < 2; ++g) if (!a->logvar[g] || !a->logz[g] || !a->theta[g] || !a->kl[g]) return fail(SPV_ERR_ARG, "spv_poe_fuse_fwd: null output%s");
   const int Bm = a->B[0] > a->B[1] ? a->B[0] : a->B[1];
-  hipLaunchKernelGGL(poe_fuse_fwd_kernel, dim3((Bm + 255) / 256, 2), dim3(256), 0, (hipStream_t)stream, *a);
+  hipLaunchKernelGGL(poe_fuse_fwd_kernel, dim3((Bm + 7) / 8, 2), dim3(256), 0, (hipStream_t)stream, *a);
   return launch_status("spv_poe_fuse_fwd");
 }
 extern "C" int spv_poe_fuse_bwd(const spv_poe_args* a, void* stream) {
@@ -461,7 +465,7 @@ extern "C" int spv_poe_fuse_bwd(const spv_poe_args* a, void* stream) {
   if (rc) return rc;
   for (int g = 0; g < 2; ++g) if (!a->d_stats[g]) return fail(SPV_ERR_ARG, "spv_poe_fuse_bwd: null output%s");
   const int Bm = a->B[0] > a->B[1] ? a->B[0] : a->B[1];
-  hipLaunchKernelGGL(poe_fuse_bwd_kernel, dim3((Bm + 255) / 256, 2), dim3(256), 0, (hipStream_t)stream, *a);
+  hipLaunchKernelGGL(poe_fuse_bwd_kernel, dim3((Bm + 7) / 8, 2), dim3(256), 0, (hipStream_t)stream, *a);
   return launch_status("spv_poe_fuse_bwd");
 }
 

@@ -21,7 +21,7 @@
 //               contiguous bytes (16-bit elements) instead of 32 strided row pieces.
 //
 // 256 threads = 4 waves arranged WM x WN; each wave owns (BM/WM) x (BN/WN) of the tile as TM x TN
-// MFMA 32x32 tiles.  BK = 32.  Global->register prefetch of tile t+1 overlaps the MFMAs of tile t
+// MFMA 32x32 tiles.  BK = 32 or 64.  Global->register prefetch of tile t+1 overlaps the MFMAs of tile t
 // (register staging: the count operand has to pass through VALU for log1p anyway).
 #pragma once
 #include "spv_common.h"
@@ -53,11 +53,12 @@ __host__ __device__ constexpr int kmajor_pitch(int cols) {
   while ((p % 64) != 16 && (p % 64) != 48) p += 4;
   return p * 2;
 }
-constexpr int NAT_PITCH = 40;  // 32 k + 8 pad (80 B rows, 16-B aligned)
+__host__ __device__ constexpr int nat_pitch(int bk) { return bk + 8; }  // BK k + 8 pad (16-B aligned rows, conflict-free 16-B reads)
 
-template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ_, bool B_KMAJ_, int A_SRC_, int B_SRC_, typename CT_, int NSPLIT_>
+template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ_, bool B_KMAJ_, int A_SRC_, int B_SRC_, typename CT_, int NSPLIT_, int BK_ = 32>
 struct GemmCfg {
-  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BK = 32;
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BK = BK_;
+  static constexpr int NAT_PITCH = nat_pitch(BK_);
   static constexpr bool A_KMAJ = A_KMAJ_, B_KMAJ = B_KMAJ_;
   static constexpr int A_SRC = A_SRC_, B_SRC = B_SRC_, NSPLIT = NSPLIT_;
   typedef CT_ CT;
@@ -81,9 +82,9 @@ template <typename Cfg, bool KMAJ, int SRC, int EXT /*BM or BN*/>
 struct Stager {
   static constexpr int FAST8 = KMAJ ? EXT / 8 : Cfg::BK / 8;   // chunks along the contiguous dim
   static constexpr int SLOW = KMAJ ? Cfg::BK : EXT;            // rows of the LDS image
-  static constexpr int NCHUNKS = (SRC == SRC_TILED) ? (EXT / 32) * 128 : SLOW * FAST8;
+  static constexpr int NCHUNKS = (SRC == SRC_TILED) ? (EXT / 32) * (Cfg::BK / 32) * 128 : SLOW * FAST8;
   static constexpr int NCH = (NCHUNKS + 255) / 256;
-  static constexpr int PITCH = KMAJ ? kmajor_pitch(EXT) : NAT_PITCH;
+  static constexpr int PITCH = KMAJ ? kmajor_pitch(EXT) : Cfg::NAT_PITCH;
   // per-chunk register payload
   u4v hi[NCH], lo[NCH];
   float csum[NCH];
@@ -93,7 +94,7 @@ struct Stager {
     const int c = tid + 256 * i;
     ok = c < NCHUNKS;
     if constexpr (SRC == SRC_TILED) {
-      s = c >> 7;    // 32x32 tile along EXT
+      s = c >> 7;    // 32x32 tile: (tile along EXT) * (BK/32) + (tile along K)
       f = c & 127;   // (qq << 5) | lane pair
     } else {
       s = c / FAST8;
@@ -113,7 +114,8 @@ struct Stager {
       if (!ok) continue;
       if constexpr (SRC == SRC_TILED) {
         // k-major (k = cell, ext = gene): tile (k0/32, ext0/32 + s); natural (ext = cell, k = gene): (ext0/32 + s, k0/32)
-        const long ct = KMAJ ? k0 / 32 : ext0 / 32 + s, gt = KMAJ ? ext0 / 32 + s : k0 / 32;
+        const int et = s / (Cfg::BK / 32), kt = s % (Cfg::BK / 32);
+        const long ct = KMAJ ? k0 / 32 + kt : ext0 / 32 + et, gt = KMAJ ? ext0 / 32 + et : k0 / 32 + kt;
         const long off = (ct * p.tiles_inner + gt) * 1024 + 8 * f;  // 16 B = registers 4qq..4qq+3 of lanes 2lp, 2lp+1
         hi[i] = *reinterpret_cast<const u4v*>(reinterpret_cast<const bf16_t*>(ptr) + off);
         if constexpr (Cfg::NSPLIT == 3) lo[i] = *reinterpret_cast<const u4v*>(reinterpret_cast<const bf16_t*>(ptr_lo) + off);
@@ -123,57 +125,67 @@ struct Stager {
         hi[i] = *reinterpret_cast<const u4v*>(reinterpret_cast<const bf16_t*>(ptr) + off);
         if constexpr (Cfg::NSPLIT == 3) lo[i] = *reinterpret_cast<const u4v*>(reinterpret_cast<const bf16_t*>(ptr_lo) + off);
       } else {
-        // counts: slow index = cell, fast index = gene
+        // counts: slow index = cell, fast index = gene.  Only the RAW words are fetched here (u16: 8 counts in
+        // hi[i]; f32: 4 + 4 floats in hi[i], lo[i]); log1p / bf16 split happen in store(), after the MFMAs of
+        // the current tile, so the gather's latency hides under them.  Out-of-range -> 0 -> log1p(0) = 0.
         const int cell = KMAJ ? k0 + s : ext0 + s;
         const int gene = KMAJ ? ext0 + 8 * f : k0 + 8 * f;
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = 0.f;
         if (cell < p.n_cells && gene < p.n_genes) {
           const long row = p.rows ? (long)p.rows[cell] : (long)cell;
           const typename Cfg::CT* src = reinterpret_cast<const typename Cfg::CT*>(ptr) + row * ld + p.col_off + gene;
           const bool full = gene + 8 <= p.n_genes;
           const bool aligned = ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
           if (full && aligned) {
-            if constexpr (sizeof(typename Cfg::CT) == 2) {
-              u4v raw = *reinterpret_cast<const u4v*>(src);
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                v[2 * j] = (float)(raw[j] & 0xFFFFu);
-                v[2 * j + 1] = (float)(raw[j] >> 16);
-              }
-            } else {
-              f4v r0 = *reinterpret_cast<const f4v*>(src);
-              f4v r1 = *reinterpret_cast<const f4v*>(src + 4);
-#pragma unroll
-              for (int j = 0; j < 4; ++j) { v[j] = r0[j]; v[4 + j] = r1[j]; }
-            }
+            hi[i] = *reinterpret_cast<const u4v*>(src);
+            if constexpr (sizeof(typename Cfg::CT) == 4) lo[i] = *reinterpret_cast<const u4v*>(src + 4);
           } else {
+            if constexpr (sizeof(typename Cfg::CT) == 2) {
+              unsigned w[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-              if (gene + j < p.n_genes) v[j] = count_to_float<typename Cfg::CT>(src[j]);
+              for (int j = 0; j < 8; ++j)
+                if (gene + j < p.n_genes) w[j >> 1] |= (unsigned)reinterpret_cast<const unsigned short*>(src)[j] << (16 * (j & 1));
+              hi[i] = u4v{w[0], w[1], w[2], w[3]};
+            } else {
+              unsigned w[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                if (gene + j < p.n_genes) w[j] = __float_as_uint(reinterpret_cast<const float*>(src)[j]);
+              hi[i] = u4v{w[0], w[1], w[2], w[3]};
+              lo[i] = u4v{w[4], w[5], w[6], w[7]};
+            }
           }
         }
-        float sum = 0.f;
-        unsigned hw[4], lw[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float x0 = log1p_count(v[2 * j]), x1 = log1p_count(v[2 * j + 1]);
-          sum += x0 + x1;
-          bf16_t h0, l0, h1, l1;
-          split_bf16(x0, h0, l0);
-          split_bf16(x1, h1, l1);
-          hw[j] = (unsigned)h0 | ((unsigned)h1 << 16);
-          lw[j] = (unsigned)l0 | ((unsigned)l1 << 16);
-        }
-        hi[i] = u4v{hw[0], hw[1], hw[2], hw[3]};
-        if constexpr (Cfg::NSPLIT == 3) lo[i] = u4v{lw[0], lw[1], lw[2], lw[3]};
-        csum[i] = sum;
       }
     }
   }
 
-  __device__ __forceinline__ void store(bf16_t* img_hi, bf16_t* img_lo, int tid) const {
+  // decode one raw count chunk into log1p values, their bf16 hi/lo split and their sum
+  __device__ __forceinline__ static void decode_counts(const u4v& r0, const u4v& r1, u4v& o_hi, u4v& o_lo, float& sum) {
+    float v[8];
+    if constexpr (sizeof(typename Cfg::CT) == 2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[2 * j] = (float)(r0[j] & 0xFFFFu); v[2 * j + 1] = (float)(r0[j] >> 16); }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] = __uint_as_float(r0[j]); v[4 + j] = __uint_as_float(r1[j]); }
+    }
+    sum = 0.f;
+    unsigned hw[4], lw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x0 = log1p_count(v[2 * j]), x1 = log1p_count(v[2 * j + 1]);
+      sum += x0 + x1;
+      bf16_t h0, l0, h1, l1;
+      split_bf16(x0, h0, l0);
+      split_bf16(x1, h1, l1);
+      hw[j] = (unsigned)h0 | ((unsigned)h1 << 16);
+      lw[j] = (unsigned)l0 | ((unsigned)l1 << 16);
+    }
+    o_hi = u4v{hw[0], hw[1], hw[2], hw[3]};
+    o_lo = u4v{lw[0], lw[1], lw[2], lw[3]};
+  }
+
+  __device__ __forceinline__ void store(bf16_t* img_hi, bf16_t* img_lo, int tid) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       int s, f; bool ok;
@@ -183,13 +195,21 @@ struct Stager {
         // genes 8qq + 4h + {0..3} of the two cells r, r+1 held by lanes 2lp and 2lp+1
         const int qq = f >> 5, lane = (f & 31) * 2, r = lane & 31, h = lane >> 5;
         const int g = 8 * qq + 4 * h;
-        const int o = KMAJ ? r * PITCH + 32 * s + g : (32 * s + r) * PITCH + g;
+        const int et = s / (Cfg::BK / 32), kt = s % (Cfg::BK / 32);
+        const int o = KMAJ ? (32 * kt + r) * PITCH + 32 * et + g : (32 * et + r) * PITCH + 32 * kt + g;
         *reinterpret_cast<u2v*>(img_hi + o) = u2v{hi[i][0], hi[i][1]};
         *reinterpret_cast<u2v*>(img_hi + o + PITCH) = u2v{hi[i][2], hi[i][3]};
         if constexpr (Cfg::NSPLIT == 3) {
           *reinterpret_cast<u2v*>(img_lo + o) = u2v{lo[i][0], lo[i][1]};
           *reinterpret_cast<u2v*>(img_lo + o + PITCH) = u2v{lo[i][2], lo[i][3]};
         }
+        continue;
+      }
+      if constexpr (SRC == SRC_COUNTS) {
+        u4v o_hi, o_lo;
+        decode_counts(hi[i], lo[i], o_hi, o_lo, csum[i]);
+        *reinterpret_cast<u4v*>(img_hi + s * PITCH + 8 * f) = o_hi;
+        if constexpr (Cfg::NSPLIT == 3) *reinterpret_cast<u4v*>(img_lo + s * PITCH + 8 * f) = o_lo;
         continue;
       }
       *reinterpret_cast<u4v*>(img_hi + s * PITCH + 8 * f) = hi[i];
@@ -212,7 +232,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   const int split = blockIdx.z;
   const int kbeg = split * p.k_per_split;
   int kend = kbeg + p.k_per_split;
-  const int Kpad = (p.K + 31) & ~31;
+  const int Kpad = (p.K + Cfg::BK - 1) / Cfg::BK * Cfg::BK;
   if (kend > Kpad) kend = Kpad;
 
   f16v acc[Cfg::TM][Cfg::TN];
@@ -336,6 +356,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 template <typename Cfg>
 inline int launch_gemm(const GemmParams& p, int splits, hipStream_t stream) {
   dim3 grid((p.M + Cfg::BM - 1) / Cfg::BM, (p.N + Cfg::BN - 1) / Cfg::BN, splits);
+  if constexpr (Cfg::LDS_BYTES > 65536) {
+    static bool raised = false;  // one-time opt-in to more than 64 KiB of dynamic LDS for this instantiation
+    if (!raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<Cfg>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES); raised = true; }
+  }
   hipLaunchKernelGGL(gemm_kernel<Cfg>, grid, dim3(256), Cfg::LDS_BYTES, stream, p);
   return hipGetLastError() == hipSuccess ? SPV_OK : SPV_ERR_LAUNCH;
 }

@@ -337,46 +337,52 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBatch a) {
 typedef spv_sample_prob SampleProb;
 typedef spv_sample_batch SampleBatch;
 
+// one lane per latent dimension (n <= 32), 32 lanes per cell, 8 cells per 256-thread block
+__device__ __forceinline__ float sum32(float v) {
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float max32(float v) {
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
 __global__ __launch_bounds__(256) void enc_sample_fwd_kernel(SampleBatch a) {
   const SampleProb& q = a.p[blockIdx.y];
-  const int b = blockIdx.x * 256 + threadIdx.x;
-  if (b >= a.B) return;
+  const int b = blockIdx.x * 8 + (threadIdx.x >> 5), d = threadIdx.x & 31;
   const int n = q.n;
-  const float* row = q.post + (long)b * 2 * n;
-  float mx = -INFINITY, kl = 0.f;
-  for (int d = 0; d < n; ++d) {
-    const float loc = row[d], lv = row[n + d];
-    const float sc = expf(0.5f * lv);
-    const float z = loc + sc * q.eps[(long)b * n + d];
-    q.scale[(long)b * n + d] = sc;
-    q.logz[(long)b * n + d] = z;
-    mx = fmaxf(mx, z);
-    kl += 0.5f * (sc * sc + loc * loc - 1.0f - lv);
+  const bool ok = b < a.B && d < n;
+  const long i = (long)b * n + d;
+  float loc = 0.f, lv = 0.f, sc = 0.f, z = -INFINITY, klt = 0.f;
+  if (ok) {
+    loc = q.post[(long)b * 2 * n + d]; lv = q.post[(long)b * 2 * n + n + d];
+    sc = expf(0.5f * lv);
+    z = loc + sc * q.eps[i];
+    klt = 0.5f * (sc * sc + loc * loc - 1.0f - lv);
   }
-  float sum = 0.f;
-  for (int d = 0; d < n; ++d) sum += expf(q.logz[(long)b * n + d] - mx);
-  const float inv = 1.0f / sum;
-  for (int d = 0; d < n; ++d) q.theta[(long)b * n + d] = expf(q.logz[(long)b * n + d] - mx) * inv;
-  q.kl[b] = kl;
+  const float mx = max32(z);
+  const float e = ok ? expf(z - mx) : 0.f;
+  const float sum = sum32(e), kl = sum32(klt);
+  if (ok) { q.scale[i] = sc; q.logz[i] = z; q.theta[i] = e / sum; }
+  if (b < a.B && d == 0) q.kl[b] = kl;
 }
 
 __global__ __launch_bounds__(256) void enc_sample_bwd_kernel(SampleBatch a) {
   const SampleProb& q = a.p[blockIdx.y];
-  const int b = blockIdx.x * 256 + threadIdx.x;
-  if (b >= a.B) return;
+  const int b = blockIdx.x * 8 + (threadIdx.x >> 5), d = threadIdx.x & 31;
   const int n = q.n;
-  const float* row = q.post + (long)b * 2 * n;
+  if (b >= a.B || d >= n) return;
+  const long i = (long)b * n + d;
   const float gk = q.g_kl ? q.g_kl[b] : 0.f;
-  for (int d = 0; d < n; ++d) {
-    const long i = (long)b * n + d;
-    const float loc = row[d], sc = q.scale[i];
-    const float gz = q.g_logz ? q.g_logz[i] : 0.f;
-    const float gl = (q.g_loc ? q.g_loc[i] : 0.f) + gz + gk * loc;
-    const float gs = (q.g_scale ? q.g_scale[i] : 0.f) + gz * q.eps[i] + gk * sc;
-    const float gv = (q.g_logvar ? q.g_logvar[i] : 0.f) + 0.5f * sc * gs - 0.5f * gk;
-    q.d_post[(long)b * 2 * n + d] = gl;
-    q.d_post[(long)b * 2 * n + n + d] = gv;
-  }
+  const float loc = q.post[(long)b * 2 * n + d], sc = q.scale[i];
+  const float gz = q.g_logz ? q.g_logz[i] : 0.f;
+  const float gl = (q.g_loc ? q.g_loc[i] : 0.f) + gz + gk * loc;
+  const float gs = (q.g_scale ? q.g_scale[i] : 0.f) + gz * q.eps[i] + gk * sc;
+  const float gv = (q.g_logvar ? q.g_logvar[i] : 0.f) + 0.5f * sc * gs - 0.5f * gk;
+  q.d_post[(long)b * 2 * n + d] = gl;
+  q.d_post[(long)b * 2 * n + n + d] = gv;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -389,22 +395,31 @@ __global__ __launch_bounds__(256) void enc_sample_bwd_kernel(SampleBatch a) {
 // a Python loop and three .item() syncs per cell (:685-701); here one wave per group walks its
 // minibatch in 64-cell chunks with ballots and a running per-label counter in LDS.
 // ---------------------------------------------------------------------------------------------
-constexpr int POE_LMAX = 4096;   // label codes must be integers in [0, POE_LMAX)
+constexpr int POE_LMAX = 1024;   // label codes must be integers in [0, POE_LMAX)
+constexpr int POE_WAVES = 8;
 
-__global__ __launch_bounds__(128) void poe_partner_kernel(const float* lab0, const float* lab1, int B0, int B1, int* order0,
-                                                          int* order1, int* partner0, int* mode0, int* partner1, int* mode1, int* err) {
-  __shared__ int cnt[2][POE_LMAX], start[2][POE_LMAX];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const float* lab = w ? lab1 : lab0;
-  const int B = w ? B1 : B0;
-  int* order = w ? order1 : order0;
-  int* rank = w ? partner1 : partner0;  // the partner arrays double as scratch for the ranks
-  for (int l = lane; l < POE_LMAX; l += 64) cnt[w][l] = 0;
+// stage 1 (one workgroup of 8 waves per group): stable rank of every cell within its label, label counts and
+// first slots, and the cells of each label listed in batch order.  Wave w owns a contiguous segment of the
+// minibatch and counts into its own histogram row; an exclusive prefix over the waves makes the ranks global.
+__global__ __launch_bounds__(512) void poe_rank_kernel(const float* lab0, const float* lab1, int B0, int B1, int* order0, int* order1,
+                                                       int* rank0, int* rank1, int* tables /*[2][2][POE_LMAX]: cnt, start*/, int* err) {
+  __shared__ int hist[POE_WAVES][POE_LMAX];
+  __shared__ int s_scan[512];
+  const int g = blockIdx.x;
+  const float* lab = g ? lab1 : lab0;
+  const int B = g ? B1 : B0;
+  int* order = g ? order1 : order0;
+  int* rank = g ? rank1 : rank0;
+  int* cnt = tables + (g * 2 + 0) * POE_LMAX;
+  int* start = tables + (g * 2 + 1) * POE_LMAX;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int l = tid; l < POE_WAVES * POE_LMAX; l += 512) (&hist[0][0])[l] = 0;
   __syncthreads();
-  // rank within label, stable in batch order
-  for (int c0 = 0; c0 < B; c0 += 64) {
+  const int seg = ((B + POE_WAVES * 64 - 1) / (POE_WAVES * 64)) * 64;
+  const int cbeg = w * seg, cend = min(cbeg + seg, B);
+  for (int c0 = cbeg; c0 < cend; c0 += 64) {
     const int i = c0 + lane;
-    const bool act = i < B;
+    const bool act = i < cend;
     int L = act ? (int)lab[i] : -1;
     if (act && (L < 0 || L >= POE_LMAX)) { *err = 1; L = 0; }
     unsigned long long todo = __ballot(act);
@@ -413,105 +428,121 @@ __global__ __launch_bounds__(128) void poe_partner_kernel(const float* lab0, con
       const int src = __ffsll((long long)todo) - 1;
       const int cur = __shfl(L, src, 64);
       const unsigned long long same = __ballot(act && L == cur);
-      const int base = cnt[w][cur];
+      const int base = hist[w][cur];
       if (act && L == cur) my_rank = base + __popcll(same & ((1ull << lane) - 1ull));
-      if (lane == src) cnt[w][cur] = base + __popcll(same);
+      if (lane == src) hist[w][cur] = base + __popcll(same);
       todo &= ~same;
     }
     if (act) rank[i] = my_rank;
   }
   __syncthreads();
-  // exclusive prefix of the label counts -> first slot of each label in `order`
-  {
-    int run = 0;
-    for (int l0 = 0; l0 < POE_LMAX; l0 += 64) {
-      const int c = cnt[w][l0 + lane];
-      int inc = c;
+  // exclusive prefix over the waves (per label) and the label totals; two labels per thread
+  int tot[2];
 #pragma unroll
-      for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off, 64); if (lane >= off) inc += t; }
-      start[w][l0 + lane] = run + inc - c;
-      run += __shfl(inc, 63, 64);
+  for (int k = 0; k < 2; ++k) {
+    const int l = 2 * tid + k;
+    int run = 0;
+    for (int ww = 0; ww < POE_WAVES; ++ww) { const int t = hist[ww][l]; hist[ww][l] = run; run += t; }
+    tot[k] = run;
+    cnt[l] = run;
+  }
+  // exclusive scan of the totals over the 1024 labels
+  s_scan[tid] = tot[0] + tot[1];
+  __syncthreads();
+  for (int off = 1; off < 512; off <<= 1) {
+    const int v = (tid >= off) ? s_scan[tid - off] : 0;
+    __syncthreads();
+    s_scan[tid] += v;
+    __syncthreads();
+  }
+  const int excl = s_scan[tid] - (tot[0] + tot[1]);
+  start[2 * tid] = excl;
+  start[2 * tid + 1] = excl + tot[0];
+  __threadfence();
+  __syncthreads();
+  for (int c0 = cbeg; c0 < cend; c0 += 64) {
+    const int i = c0 + lane;
+    if (i < cend) {
+      const int L = min(max((int)lab[i], 0), POE_LMAX - 1);
+      const int r = hist[w][L] + rank[i];
+      rank[i] = r;
+      order[start[L] + r] = i;
     }
   }
-  __syncthreads();
-  for (int i = lane; i < B; i += 64) { const int L = min(max((int)lab[i], 0), POE_LMAX - 1); order[start[w][L] + rank[i]] = i; }
-  __threadfence();  // `order` travels through global memory to the other wave of this workgroup
-  __syncthreads();
-  // partner / mode against the other group's tables
-  {
-    const int o = 1 - w;
-    const int* order_o = o ? order1 : order0;
-    int* partner = w ? partner1 : partner0;
-    int* mode = w ? mode1 : mode0;
-    for (int i = lane; i < B; i += 64) {
-      const int L = min(max((int)lab[i], 0), POE_LMAX - 1), k = rank[i], co = cnt[o][L];
-      const int m = (k < co) ? 0 : (co > 0 ? 1 : 2);
-      const int pr = (m == 0) ? order_o[start[o][L] + k] : -1;
-      mode[i] = m;
-      partner[i] = pr;  // overwrites rank[i]: read above
-    }
-  }
+}
+
+// stage 2: partner / mode of every cell from the other group's tables
+__global__ __launch_bounds__(256) void poe_lookup_kernel(const float* lab0, const float* lab1, int B0, int B1, const int* order0,
+                                                         const int* order1, const int* rank0, const int* rank1, const int* tables,
+                                                         int* partner0, int* mode0, int* partner1, int* mode1) {
+  const int g = blockIdx.y, o = 1 - g;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= (g ? B1 : B0)) return;
+  const int L = min(max((int)(g ? lab1 : lab0)[i], 0), POE_LMAX - 1), k = (g ? rank1 : rank0)[i];
+  const int co = tables[(o * 2 + 0) * POE_LMAX + L], so = tables[(o * 2 + 1) * POE_LMAX + L];
+  const int m = (k < co) ? 0 : (co > 0 ? 1 : 2);
+  (g ? mode1 : mode0)[i] = m;
+  (g ? partner1 : partner0)[i] = (m == 0) ? (o ? order1 : order0)[so + k] : -1;
 }
 
 typedef spv_poe_args PoeArgs;
 
 __global__ __launch_bounds__(256) void poe_fuse_fwd_kernel(PoeArgs a) {
   const int g = blockIdx.y, o = 1 - g;
-  const int b = blockIdx.x * 256 + threadIdx.x;
-  if (b >= a.B[g]) return;
-  const int n = a.n, m = a.mode[g][b], pr = a.partner[g][b];
-  const float* own = a.stats[g] + (long)b * a.ld[g];           // (loc | logvar) rows of the shared encoder
-  const float* oth = a.stats[o] + (long)(pr < 0 ? 0 : pr) * a.ld[o];
-  float kl = 0.f, mx = -INFINITY;
-  for (int d = 0; d < n; ++d) {
+  const int b = blockIdx.x * 8 + (threadIdx.x >> 5), d = threadIdx.x & 31;
+  const int n = a.n;
+  const bool ok = b < a.B[g] && d < n;
+  float z = -INFINITY, klt = 0.f, jl = 0.f, jv = 0.f, sc = 0.f;
+  const long i = (long)b * n + d;
+  if (ok) {
+    const int m = a.mode[g][b], pr = a.partner[g][b];
+    const float* own = a.stats[g] + (long)b * a.ld[g];           // (loc | logvar) rows of the shared encoder
+    const float* oth = a.stats[o] + (long)(pr < 0 ? 0 : pr) * a.ld[o];
     const float loc = own[d], inv = expf(-own[n + d]);
     float t, u;
     if (m == 0) { t = expf(-oth[n + d]); u = oth[d] * t; }
     else { t = (m == 1) ? 1.0f : 0.36787944117144233f; u = 0.f; }
     const float J = 1.0f / (1.0f + (inv + t));
-    const float jl = (loc * inv + u) * J, jv = logf(J), sc = sqrtf(expf(jv));
-    const float z = jl + sc * a.eps[g][(long)b * n + d];
-    const long i = (long)b * n + d;
-    a.loc[g][i] = jl; a.logvar[g][i] = jv; a.scale[g][i] = sc; a.logz[g][i] = z;
-    mx = fmaxf(mx, z);
-    kl += 0.5f * (sc * sc + jl * jl - 1.0f - logf(sc * sc));
+    jl = (loc * inv + u) * J; jv = logf(J); sc = sqrtf(expf(jv));
+    z = jl + sc * a.eps[g][i];
+    klt = 0.5f * (sc * sc + jl * jl - 1.0f - logf(sc * sc));
   }
-  float sum = 0.f;
-  for (int d = 0; d < n; ++d) sum += expf(a.logz[g][(long)b * n + d] - mx);
-  for (int d = 0; d < n; ++d) a.theta[g][(long)b * n + d] = expf(a.logz[g][(long)b * n + d] - mx) / sum;
-  a.kl[g][b] = kl;
+  const float mx = max32(z);
+  const float e = ok ? expf(z - mx) : 0.f;
+  const float sum = sum32(e), kl = sum32(klt);
+  if (ok) { a.loc[g][i] = jl; a.logvar[g][i] = jv; a.scale[g][i] = sc; a.logz[g][i] = z; a.theta[g][i] = e / sum; }
+  if (b < a.B[g] && d == 0) a.kl[g][b] = kl;
 }
 
 // d_stats[g] (same [B][ld] layout as stats[g], ZERO-INITIALISED by the caller) receives the gradient of a
 // cell's own expert and, through its partner, of the other group's cell: at most two adds per element.
 __global__ __launch_bounds__(256) void poe_fuse_bwd_kernel(PoeArgs a) {
   const int g = blockIdx.y, o = 1 - g;
-  const int b = blockIdx.x * 256 + threadIdx.x;
-  if (b >= a.B[g]) return;
-  const int n = a.n, m = a.mode[g][b], pr = a.partner[g][b];
+  const int b = blockIdx.x * 8 + (threadIdx.x >> 5), d = threadIdx.x & 31;
+  const int n = a.n;
+  if (b >= a.B[g] || d >= n) return;
+  const int m = a.mode[g][b], pr = a.partner[g][b];
   const float* own = a.stats[g] + (long)b * a.ld[g];
   const float* oth = a.stats[o] + (long)(pr < 0 ? 0 : pr) * a.ld[o];
   float* d_own = a.d_stats[g] + (long)b * a.ld[g];
   float* d_oth = a.d_stats[o] + (long)(pr < 0 ? 0 : pr) * a.ld[o];
   const float gk = a.g_kl[g] ? a.g_kl[g][b] : 0.f;
-  for (int d = 0; d < n; ++d) {
-    const long i = (long)b * n + d;
-    const float loc = own[d], inv = expf(-own[n + d]);
-    float t = (m == 1) ? 1.0f : 0.36787944117144233f, u = 0.f, lo = 0.f;
-    if (m == 0) { lo = oth[d]; t = expf(-oth[n + d]); u = lo * t; }
-    const float J = 1.0f / (1.0f + (inv + t));
-    const float jl = a.loc[g][i], sc = a.scale[g][i];
-    const float gz = a.g_logz[g] ? a.g_logz[g][i] : 0.f;
-    const float Gl = (a.g_loc[g] ? a.g_loc[g][i] : 0.f) + gz + gk * jl;
-    const float Gs = (a.g_scale[g] ? a.g_scale[g][i] : 0.f) + gz * a.eps[g][i] + gk * (sc - 1.0f / sc);
-    const float Gv = (a.g_logvar[g] ? a.g_logvar[g][i] : 0.f) + 0.5f * sc * Gs;
-    const float dN = Gl * J, dP = -J * (Gl * jl + Gv);
-    atomicAdd(&d_own[d], dN * inv);
-    atomicAdd(&d_own[n + d], -inv * (dN * loc + dP));
-    if (m == 0) {
-      atomicAdd(&d_oth[d], dN * t);
-      atomicAdd(&d_oth[n + d], -t * (dP + dN * lo));
-    }
+  const long i = (long)b * n + d;
+  const float loc = own[d], inv = expf(-own[n + d]);
+  float t = (m == 1) ? 1.0f : 0.36787944117144233f, lo = 0.f;
+  if (m == 0) { lo = oth[d]; t = expf(-oth[n + d]); }
+  const float J = 1.0f / (1.0f + (inv + t));
+  const float jl = a.loc[g][i], sc = a.scale[g][i];
+  const float gz = a.g_logz[g] ? a.g_logz[g][i] : 0.f;
+  const float Gl = (a.g_loc[g] ? a.g_loc[g][i] : 0.f) + gz + gk * jl;
+  const float Gs = (a.g_scale[g] ? a.g_scale[g][i] : 0.f) + gz * a.eps[g][i] + gk * (sc - 1.0f / sc);
+  const float Gv = (a.g_logvar[g] ? a.g_logvar[g][i] : 0.f) + 0.5f * sc * Gs;
+  const float dN = Gl * J, dP = -J * (Gl * jl + Gv);
+  atomicAdd(&d_own[d], dN * inv);
+  atomicAdd(&d_own[n + d], -inv * (dN * loc + dP));
+  if (m == 0) {
+    atomicAdd(&d_oth[d], dN * t);
+    atomicAdd(&d_oth[n + d], -t * (dP + dN * lo));
   }
 }
 

@@ -203,15 +203,18 @@ class DecoderFused(torch.autograd.Function):
             else:
                 dL_hi, tP_hi, tS_hi, dL_lo, tP_lo, tS_lo = S["dL"], S["tP"], S["tS"], None, None, None
             T = Gp // 32
-            ksp = max(1, min(8, T // 16))
-            csp = max(1, min(4, (Bp // 32) // 16))
+            # K splits (fp32 slabs, summed in order) sized for >= ~2 workgroups per CU: these GEMMs stream a
+            # [B,G] array once and are latency-bound with fewer resident workgroups
+            bt = Bp // 32
+            ksp_m, ksp_n = max(1, min(T // 8, -(-512 // max(Bp // 64, 1)))), max(1, min(T // 8, -(-512 // max(Bp // 128, 1))))
+            csp_m, csp_n = max(1, min(bt // 8, -(-512 // max(Gp // 64, 1)))), max(1, min(bt // 8, -(-512 // max(Gp // 128, 1))))
             (Wm_hi, Wm_lo), (Am_hi, Am_lo), (Aps_hi, Aps_lo) = S["Wm"], S["Am"], S["Aps"]
-            a = _gemm(True, dL_hi, dL_lo, Gp, Am_hi, Am_lo, KMP, G, KMP, Bp, nsplit, min(csp, 2), wsg, "dec_dWm", a_tiles=T)
-            b_ = _gemm(True, tP_hi, tP_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KP, Bp, nsplit, csp, wsg, "dec_dWp", a_tiles=T)
-            c = _gemm(True, tS_hi, tS_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KS, Bp, nsplit, csp, wsg, "dec_dWs", b_col_off=DEC_KP, a_tiles=T)
-            d = _gemm(False, dL_hi, dL_lo, Gp, Wm_hi, Wm_lo, KMP, B, KMP, G, nsplit, ksp, wsg, "dec_dAm", a_tiles=T)
-            e = _gemm(False, tP_hi, tP_lo, Gp, ctx.Wps[g][0], ctx.Wps[g][1], DEC_KPS, B, DEC_KP, G, nsplit, ksp, wsg, "dec_dAp", a_tiles=T)
-            f = _gemm(False, tS_hi, tS_lo, Gp, ctx.Wps[g][0], ctx.Wps[g][1], DEC_KPS, B, DEC_KS, G, nsplit, ksp, wsg, "dec_dAs", b_col_off=DEC_KP, a_tiles=T)
+            a = _gemm(True, dL_hi, dL_lo, Gp, Am_hi, Am_lo, KMP, G, KMP, Bp, nsplit, csp_m, wsg, "dec_dWm", a_tiles=T)
+            b_ = _gemm(True, tP_hi, tP_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KP, Bp, nsplit, csp_n, wsg, "dec_dWp", a_tiles=T)
+            c = _gemm(True, tS_hi, tS_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KS, Bp, nsplit, csp_n, wsg, "dec_dWs", b_col_off=DEC_KP, a_tiles=T)
+            d = _gemm(False, dL_hi, dL_lo, Gp, Wm_hi, Wm_lo, KMP, B, KMP, G, nsplit, ksp_m, wsg, "dec_dAm", a_tiles=T)
+            e = _gemm(False, tP_hi, tP_lo, Gp, ctx.Wps[g][0], ctx.Wps[g][1], DEC_KPS, B, DEC_KP, G, nsplit, ksp_n, wsg, "dec_dAp", a_tiles=T)
+            f = _gemm(False, tS_hi, tS_lo, Gp, ctx.Wps[g][0], ctx.Wps[g][1], DEC_KPS, B, DEC_KS, G, nsplit, ksp_n, wsg, "dec_dAs", b_col_off=DEC_KP, a_tiles=T)
             for t in (a, b_, c, d, e, f):
                 t.mul_(g_loss)
             dWm.append(a); dWp.append(b_); dWs.append(c); dAm.append(d)

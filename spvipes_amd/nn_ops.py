@@ -254,8 +254,10 @@ class PoELabel(torch.autograd.Function):
         partner = [torch.empty(Bs[g], dtype=torch.int32, device=dev) for g in range(2)]
         mode = [torch.empty(Bs[g], dtype=torch.int32, device=dev) for g in range(2)]
         err = ws.get("poe_err", (1,), torch.int32, zero=True)
-        _abi.call("spv_poe_partner", ptr(lab[0]), ptr(lab[1]), Bs[0], Bs[1], ptr(order[0]), ptr(order[1]), ptr(partner[0]), ptr(mode[0]),
-                  ptr(partner[1]), ptr(mode[1]), ptr(err), stream_ptr())
+        rank = [i32(f"poe_rank{g}", Bs[g]) for g in range(2)]
+        tables = ws.get("poe_tables", (2, 2, 1024), torch.int32)
+        _abi.call("spv_poe_partner", ptr(lab[0]), ptr(lab[1]), Bs[0], Bs[1], ptr(order[0]), ptr(order[1]), ptr(rank[0]), ptr(rank[1]),
+                  ptr(tables), ptr(partner[0]), ptr(mode[0]), ptr(partner[1]), ptr(mode[1]), ptr(err), stream_ptr())
         blocks = [_loc_logvar_block(loc0, logvar0), _loc_logvar_block(loc1, logvar1)]
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         out = {k: [new(Bs[g], n) for g in range(2)] for k in ("loc", "logvar", "scale", "logz", "theta")}

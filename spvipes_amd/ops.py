@@ -133,7 +133,7 @@ class EncoderFC1(torch.autograd.Function):
         B, H, G, ws, nsplit = ctx.B, ctx.H, ctx.G, ctx.ws, ctx.nsplit
         N1 = 2 * H
         dpre = (dh1 * (h1 > 0)).contiguous()
-        Bp, N1p = round_up(B, 32), round_up(N1, 128)
+        Bp, N1p = round_up(B, 64), round_up(N1, 128)
         dh_hi, dh_lo = _bf16_image(ws, "fc1_dh", Bp, N1p, nsplit == 3)
         _pack(dpre, dh_hi, dh_lo)
         dW = torch.empty((N1, G), dtype=torch.float32, device=dh1.device)
