@@ -169,7 +169,8 @@ typedef struct spv_linear_batch {
   int32_t nprob, B;
   int32_t relu;       /* forward: Y = relu(.); backward: dY masked with (Y > 0)                      */
   float drop_p;       /* inverted dropout after the relu (0 = none); backward rescales where Y > 0   */
-  uint64_t seed;      /* counter-based mask: (seed, problem, element)                                */
+  uint64_t seed;      /* counter-based mask: (seed + *seed_ptr, problem, element)                    */
+  const uint64_t* seed_ptr; /* optional device-resident addend (lets a captured hipGraph draw fresh masks) */
   int32_t accumulate; /* dgrad: dX += instead of dX =                                                */
 } spv_linear_batch;
 int spv_linear_fwd(const spv_linear_batch* a, void* stream);    /* Y = dropout(relu(X W^T + b))      */

@@ -50,7 +50,7 @@ class SpvLinearProb(C.Structure):
 
 class SpvLinearBatch(C.Structure):
     _fields_ = [("p", SpvLinearProb * SPV_MAXP), ("nprob", C.c_int32), ("B", C.c_int32), ("relu", C.c_int32), ("drop_p", C.c_float),
-                ("seed", C.c_uint64), ("accumulate", C.c_int32)]
+                ("seed", C.c_uint64), ("seed_ptr", C.c_void_p), ("accumulate", C.c_int32)]
 
 
 class SpvBnProb(C.Structure):

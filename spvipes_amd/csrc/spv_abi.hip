@@ -48,6 +48,31 @@ __global__ void pack_bf16_kernel(const float* src, long ld_src, int R, int C, co
   if (dst_lo) dst_lo[o] = lo;
 }
 
+// 8 consecutive destination columns per thread: one 16-byte store per image
+__global__ void pack_bf16_vec8_kernel(const float* src, long ld_src, int R, int C, const float* extra_col, int extra_one,
+                                      bf16_t* dst_hi, bf16_t* dst_lo, long ld_dst, int dst_col_off, int Rp, int cslot8) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)Rp * cslot8) return;
+  const int r = (int)(idx / cslot8), c0 = (int)(idx % cslot8) * 8;
+  unsigned hw[4] = {0u, 0u, 0u, 0u}, lw[4] = {0u, 0u, 0u, 0u};
+  if (r < R) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c0 + j;
+      float v = 0.f;
+      if (c < C) v = src[(long)r * ld_src + c];
+      else if (c == C) v = extra_col ? extra_col[r] : (extra_one ? 1.0f : 0.f);
+      bf16_t h, l;
+      split_bf16(v, h, l);
+      hw[j >> 1] |= (unsigned)h << (16 * (j & 1));
+      lw[j >> 1] |= (unsigned)l << (16 * (j & 1));
+    }
+  }
+  const long o = (long)r * ld_dst + dst_col_off + c0;
+  *reinterpret_cast<u4v*>(dst_hi + o) = u4v{hw[0], hw[1], hw[2], hw[3]};
+  if (dst_lo) *reinterpret_cast<u4v*>(dst_lo + o) = u4v{lw[0], lw[1], lw[2], lw[3]};
+}
+
 extern "C" int spv_pack_bf16(const float* src, int64_t ld_src, int32_t R, int32_t C, const float* extra_col,
                              int32_t extra_one, uint16_t* dst_hi, uint16_t* dst_lo, int64_t ld_dst,
                              int32_t dst_col_off, int32_t Rp, int32_t cslot, void* stream) {
@@ -56,6 +81,12 @@ extern "C" int spv_pack_bf16(const float* src, int64_t ld_src, int32_t R, int32_
     return fail(SPV_ERR_ARG, "spv_pack_bf16: bad shape%s");
   const long total = (long)Rp * cslot;
   if (total == 0) return SPV_OK;
+  if ((cslot % 8) == 0 && (dst_col_off % 8) == 0 && (ld_dst % 8) == 0 && ((uintptr_t)dst_hi % 16) == 0 && (!dst_lo || ((uintptr_t)dst_lo % 16) == 0)) {
+    const long tot8 = total / 8;
+    hipLaunchKernelGGL(pack_bf16_vec8_kernel, dim3((unsigned)((tot8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (long)ld_src, R, C,
+                       extra_col, extra_one, dst_hi, dst_lo, (long)ld_dst, dst_col_off, Rp, cslot / 8);
+    return launch_status("spv_pack_bf16");
+  }
   hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
                      (long)ld_src, R, C, extra_col, extra_one, dst_hi, dst_lo, (long)ld_dst, dst_col_off, Rp, cslot);
   return launch_status("spv_pack_bf16");

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(LinearBatch a) {
     if (n >= q.N) continue;
     float v = acc[i] + (q.bias ? q.bias[n] : 0.f);
     if (a.relu) v = fmaxf(v, 0.f);
-    if (a.drop_p > 0.f) v = dropout_keep(a.seed, blockIdx.z, (long)b * q.N + n, a.drop_p) ? v * (1.0f / (1.0f - a.drop_p)) : 0.f;
+    if (a.drop_p > 0.f) v = dropout_keep(a.seed + (a.seed_ptr ? *a.seed_ptr : 0ull), blockIdx.z, (long)b * q.N + n, a.drop_p) ? v * (1.0f / (1.0f - a.drop_p)) : 0.f;
     q.Y[(long)b * q.ldy + n] = v;
   }
 }
@@ -200,7 +200,10 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(BnBatch a) {
   const int c = threadIdx.x % NC, slot = threadIdx.x / NC;
   const int b0 = blockIdx.x * BN_ROWS, b1 = min(b0 + BN_ROWS, a.B);
   float s = 0.f;
-  if (c < q.N) for (int b = b0 + slot; b < b1; b += RS) s += q.X[(long)b * q.ldx + c];
+  if (c < q.N) {
+#pragma unroll 4
+    for (int b = b0 + slot; b < b1; b += RS) s += q.X[(long)b * q.ldx + c];
+  }
   s_acc[threadIdx.x] = s;
   __syncthreads();
   if (threadIdx.x < q.N) {
@@ -212,6 +215,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(BnBatch a) {
   float m2 = 0.f;
   if (c < q.N) {
     const float mean = s_mean[c];
+#pragma unroll 4
     for (int b = b0 + slot; b < b1; b += RS) { const float d = q.X[(long)b * q.ldx + c] - mean; m2 += d * d; }
   }
   s_acc[threadIdx.x] = m2;
@@ -259,6 +263,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnBatch a) {
   const int c = threadIdx.x % NC, slot = threadIdx.x / NC;
   if (c >= q.N) return;
   const float mean = s_mean[c], sc = s_inv[c] * q.gamma[c], be = q.beta[c];
+#pragma unroll 4
   for (int b = b0 + slot; b < b1; b += RS) {
     float v = (q.X[(long)b * q.ldx + c] - mean) * sc + be;
     if (a.relu) v = fmaxf(v, 0.f);
@@ -280,6 +285,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBatch a) {
   float sg = 0.f, sgx = 0.f;
   if (c < q.N) {
     const float mean = q.stats[2 * c], inv = q.stats[2 * c + 1];
+#pragma unroll 4
     for (int b = b0 + slot; b < b1; b += RS) {
       const float g = bn_masked_dy(a, q, b, c);
       sg += g;
@@ -315,6 +321,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBatch a) {
   if (c >= q.N) return;
   const float mean = q.stats[2 * c], inv = q.stats[2 * c + 1], gi = q.gamma[c] * inv;
   const float msg = s_sg[c] * invB, msgx = s_sgx[c] * invB;
+#pragma unroll 4
   for (int b = b0 + slot; b < b1; b += RS) {
     const float g = bn_masked_dy(a, q, b, c);
     float dx;

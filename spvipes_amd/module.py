@@ -270,8 +270,12 @@ class spVIPESmodule(nn.Module):
                 specs += [EncoderSpec(self.encoders[g]["private"], g, 0), EncoderSpec(self.encoders[g]["shared"], g, H)]
                 eps_list += [eps_enc[g][0], eps_enc[g][1]]
             flat = [p for s in specs for p in s.params()]
-            self._seed_counter = getattr(self, "_seed_counter", 0) + 1
-            outs = EncoderTails.apply(specs, eps_list, self.training, float(self.dropout_rate), self._seed_counter,
+            dev0 = h1s[groups_[0]].device
+            if getattr(self, "_seed_dev", None) is None or self._seed_dev.device != dev0:
+                self._seed_dev = torch.zeros((), dtype=torch.int64, device=dev0)  # device-resident: survives hipGraph replay
+            if self.training and self.dropout_rate > 0:
+                self._seed_dev.add_(1)
+            outs = EncoderTails.apply(specs, eps_list, self.training, float(self.dropout_rate), self._seed_dev,
                                       self._workspace(groups_[0], h1s[groups_[0]].device), *[h1s[g] for g in groups_], *flat)
             for i, s in enumerate(specs):
                 loc, logvar, scale, log_z, theta, kl = outs[6 * i: 6 * i + 6]

@@ -18,9 +18,14 @@ from . import _abi
 from ._abi import SpvBnBatch, SpvLinearBatch, SpvSampleBatch, ptr, stream_ptr
 
 
-def _lin_batch(B: int, relu: bool = False, drop_p: float = 0.0, seed: int = 0, accumulate: bool = False) -> SpvLinearBatch:
+def _lin_batch(B: int, relu: bool = False, drop_p: float = 0.0, seed=0, accumulate: bool = False) -> SpvLinearBatch:
+    """``seed``: python int, or a device int64 tensor (read by the kernel at run time: hipGraph-safe)."""
     b = SpvLinearBatch()
-    b.nprob, b.B, b.relu, b.drop_p, b.seed, b.accumulate = 0, B, int(relu), float(drop_p), int(seed), int(accumulate)
+    b.nprob, b.B, b.relu, b.drop_p, b.accumulate = 0, B, int(relu), float(drop_p), int(accumulate)
+    if isinstance(seed, torch.Tensor):
+        b.seed, b.seed_ptr = 0, seed.data_ptr()
+    else:
+        b.seed, b.seed_ptr = int(seed), None
     return b
 
 

@@ -96,6 +96,7 @@ class Trainer:
         self.n_epochs_kl_warmup, self.n_steps_kl_warmup = n_epochs_kl_warmup, n_steps_kl_warmup
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.global_step, self.epoch = 0, 0
+        self.graph = None
         self.history: Dict[str, List[float]] = {"train_loss": [], "elbo_train": [], "reconstruction_loss_train": [], "kl_local_train": []}
 
     def minibatch(self, rows: Sequence[torch.Tensor]):
@@ -112,10 +113,7 @@ class Trainer:
             out.append(d)
         return tuple(out)
 
-    def step(self, rows: Sequence[torch.Tensor], kl_weight: Optional[float] = None):
-        """forward + loss + backward + (all-reduce) + Adam for one minibatch; returns the LossOutput."""
-        if kl_weight is None:
-            kl_weight = kl_weight_at(self.epoch, self.global_step, self.n_epochs_kl_warmup, self.n_steps_kl_warmup)
+    def _forward_backward(self, rows, kl_weight):
         from . import nn_ops
 
         self.fp.grad.zero_()
@@ -125,6 +123,40 @@ class Trainer:
             lo.loss.backward()
         finally:
             nn_ops.GRAD_SINK = False
+        return lo
+
+    def capture(self, rows: Sequence[torch.Tensor], warmup: int = 3) -> None:
+        """Capture forward + loss + backward of one step into a hipGraph (``torch.cuda.CUDAGraph``): the ~150
+        launches of a step replay as one submission.  Everything that changes between steps lives in device
+        memory: the row indices (copied into static buffers), the KL weight (0-dim tensor), the dropout seed
+        (module._seed_dev), the noise (graph-safe generator).  The all-reduce and Adam stay outside."""
+        if self.graph is not None:
+            return
+        self._static_rows = [r.clone() for r in rows]
+        self._klw = torch.ones((), dtype=torch.float32, device=self.device)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):  # allocates every workspace buffer before the capture
+                self._forward_backward(self._static_rows, self._klw)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._static_lo = self._forward_backward(self._static_rows, self._klw)
+        self.graph = g
+
+    def step(self, rows: Sequence[torch.Tensor], kl_weight: Optional[float] = None):
+        """forward + loss + backward + (all-reduce) + Adam for one minibatch; returns the LossOutput."""
+        if kl_weight is None:
+            kl_weight = kl_weight_at(self.epoch, self.global_step, self.n_epochs_kl_warmup, self.n_steps_kl_warmup)
+        if self.graph is not None:
+            for s, r in zip(self._static_rows, rows):
+                s.copy_(r)
+            self._klw.fill_(float(kl_weight))
+            self.graph.replay()
+            lo = self._static_lo  # tensors are overwritten by the next replay
+        else:
+            lo = self._forward_backward(rows, kl_weight)
         if self.world > 1:
             dist.all_reduce(self.fp.grad, op=dist.ReduceOp.SUM)  # the step's only collective
         self.opt.step(grad_scale=1.0 / self.world)
