@@ -132,7 +132,7 @@ int spv_dec_tables(const float* px_r, int32_t G, int32_t Gp, void* gene_tab, voi
  * (the cast away of const on those four pointers is deliberate: they are this call's outputs). */
 int spv_dec_lse(const spv_dec_params* p, const float* library, void* stream);
 
-/* rec_part/tp_part/ts_part [gene_splits][Bp], dtheta_part [Bp/32][Gp]; when train != 0 also the
+/* rec_part/tp_part/ts_part [gene_splits][Bp], dtheta_part [Bp/16][Gp] (genes_per_split <= 1024); when train != 0 also the
  * per-element gradients dL, tP, tS (accumulator-tile order; bf16, or fp32 when grads_f32). */
 int spv_dec_nb_fwd(const spv_dec_params* p, int32_t train, void* stream);
 

@@ -260,7 +260,7 @@ extern "C" int spv_dec_lse(const spv_dec_params* q, const float* library, void* 
 
 template <bool TRAIN, typename GT>
 static void nb_launch(const DecParams& p, hipStream_t s) {
-  dim3 grid(p.Bp / DEC_CELLS_PER_WG, p.gene_splits);
+  dim3 grid(p.Bp / 64, p.gene_splits);  // 4 waves x 16 cells per workgroup
   if (p.logits_f32) hipLaunchKernelGGL((dec_nb_kernel<TRAIN, GT, float>), grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL((dec_nb_kernel<TRAIN, GT, _Float16>), grid, dim3(256), 0, s, p);
 }
@@ -272,6 +272,7 @@ extern "C" int spv_dec_nb_fwd(const spv_dec_params* q, int32_t train, void* stre
   if (!p.X || !p.logits || !p.gene_tab || !p.cnt_tab || !p.a_p || !p.a_s || !p.w_row || !p.rec_part)
     return fail(SPV_ERR_ARG, "spv_dec_nb_fwd: null pointer%s");
   if (p.n_gene_tiles != p.Gp / 32) return fail(SPV_ERR_ARG, "spv_dec_nb_fwd: n_gene_tiles must be Gp / 32%s");
+  if (p.genes_per_split > NB_GT_MAX) return fail(SPV_ERR_ARG, "spv_dec_nb_fwd: at most 1024 genes per split%s");
   if (train && (!p.dL || !p.tP || !p.tS || !p.tp_part || !p.ts_part || !p.dtheta_part))
     return fail(SPV_ERR_ARG, "spv_dec_nb_fwd: training outputs missing%s");
   hipStream_t s = (hipStream_t)stream;

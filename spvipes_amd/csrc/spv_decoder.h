@@ -54,7 +54,7 @@ struct DecParams {
   int gene_splits; int genes_per_split;      // multiples of 32
   float* part_max_p; float* part_sum_p; float* part_max_s; float* part_sum_s;  // [splits][Bp]  (lse)
   float* rec_part; float* tp_part; float* ts_part;                             // [splits][Bp]  (nb)
-  float* dtheta_part;           // [Bp/32][Gp]  one partial row per 32-cell tile
+  float* dtheta_part;           // [Bp/16][Gp]  one partial row per 16-cell wave tile
   void* dL; void* tP; void* tS; int grads_f32;                                 // tiled like logits; bf16 or f32
 };
 
@@ -319,125 +319,156 @@ __device__ __forceinline__ float half_sum16(const float (&v)[16], int lane) {
   return d;
 }
 
+// 16x16x32 MFMA formulation: a wave owns 16 cells and walks the genes of its split in chunks of 16; one chunk is
+// exactly one accumulator (lane l: cell l & 15, genes 4 (l >> 4) + j), so nothing but the chunk's own 4 elements
+// per lane is live -- no 32-register tile to carry, no rotation -- and the next chunk's counts / logits are
+// fetched while this one is evaluated.  The [cells][genes] arrays stay in the 32x32 accumulator-tile order.
+typedef __attribute__((ext_vector_type(4))) float f4acc;
+constexpr int NB_GT_MAX = 1024;   // genes per split held in LDS (gene table)
+
 template <bool TRAIN, typename GT, typename LT>
 __global__ __launch_bounds__(256, TRAIN ? 3 : 4) void dec_nb_kernel(DecParams p) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, r = lane & 31;
-  const int cell_tile = blockIdx.x * (DEC_CELLS_PER_WG / 32) + wave;
-  const int cell0 = cell_tile * 32;
-  const int cell = cell0 + r;
+  __shared__ float4 s_gt[NB_GT_MAX];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c16 = lane & 15, gq = lane >> 4;              // cell within the wave's 16, gene group within a chunk
+  const int tile16 = blockIdx.x * 4 + wave;               // 16-cell tile of this wave
+  const int cell = tile16 * 16 + c16;
+  const int cell_tile = tile16 >> 1, ch = tile16 & 1;     // 32-cell storage tile and which half of it
   const bool cell_ok = cell < p.B;
   const int split = blockIdx.y;
+  const int gbeg = split * p.genes_per_split;
+  int gend = gbeg + p.genes_per_split;
+  if (gend > p.Gp) gend = p.Gp;
+  if (gend > ((p.G + 15) & ~15)) gend = (p.G + 15) & ~15;
+  for (int i = tid; i < gend - gbeg; i += 256) s_gt[i] = p.gene_tab[gbeg + i];
+  __syncthreads();
 
+  // resident cell-side fragments: B[k = 8 gq + i][col = cell]
+  const long aoff = (long)cell * DEC_KPS + 8 * gq;
+  s8v bp_hi = *reinterpret_cast<const s8v*>(p.Aps_hi + aoff), bp_lo = *reinterpret_cast<const s8v*>(p.Aps_lo + aoff);
+  if (gq >= 2) {  // the private regressor only has K = 16: its K = 32 MFMA sees zeros beyond
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { bp_hi[i] = 0; bp_lo[i] = 0; }
+  }
+  const s8v bs_hi = *reinterpret_cast<const s8v*>(p.Aps_hi + aoff + DEC_KP), bs_lo = *reinterpret_cast<const s8v*>(p.Aps_lo + aoff + DEC_KP);
   const float ap = p.a_p[cell], as_ = p.a_s[cell];
   const float w = p.w_row[cell];
   const long row_of_cell = cell_ok ? (p.rows ? (long)p.rows[cell] : (long)cell) : 0;
   float rec = 0.f, tp_sum = 0.f, ts_sum = 0.f;
+  // storage offset of this lane inside a 32x32 tile for gene half gh: qq = 2 gh + (gq >> 1), h = gq & 1
+  const int lane_st = (16 * ch + c16 + 32 * (gq & 1)) * 4 + (gq >> 1) * 256;
 
-  const int gbeg = split * p.genes_per_split;
-  int gend = gbeg + p.genes_per_split;
-  if (gend > p.Gp) gend = p.Gp;
-  for (int g0 = gbeg; g0 < gend; g0 += 32) {
-    if (g0 >= p.G) break;
-    f16v yp, ys;
-    {
-      PsFrags cf;  // re-read per tile (3 KB per wave, L1-resident): 24 fewer live registers
-      load_ps_cell_frags(p, cell0, lane, cf);
-      ps_tiles(p, g0, lane, cf, yp, ys);
-    }
-    // four chunks of 4 consecutive genes; a ROLLED loop (registers 0..3 of the accumulators are the
-    // current chunk, the tiles are rotated by 4 each trip) so that only one chunk's temporaries live
-#pragma unroll 1
-    for (int qq = 0; qq < 4; ++qq) {
-      float o_dl[4], o_tp[4], o_ts[4], ell4[4], cnt4[4], dth4[4];
-      const int gq = g0 + 8 * qq + 4 * h;
-      load_counts4(p, row_of_cell, gq, cell_ok, cnt4);
-      // [cells][genes] arrays live in accumulator-tile order (spv_gemm.h SRC_TILED): registers
-      // 4qq..4qq+3 of all 64 lanes of tile (cell_tile, g0/32) are 512 contiguous bytes
-      const long toff = ((long)cell_tile * p.n_gene_tiles + (g0 >> 5)) * 1024 + (qq * 64 + lane) * 4;
-      load4<LT>(p.logits, toff, ell4);
+  float cnt4[4], ell4[4];
+  if (gbeg < gend) {
+    load_counts4(p, row_of_cell, gbeg + 4 * gq, cell_ok, cnt4);
+    load4<LT>(p.logits, ((long)cell_tile * p.n_gene_tiles + (gbeg >> 5)) * 1024 + ((gbeg >> 4) & 1) * 512 + lane_st, ell4);
+  }
+  for (int g0 = gbeg; g0 < gend; g0 += 16) {
+    const long toff = ((long)cell_tile * p.n_gene_tiles + (g0 >> 5)) * 1024 + ((g0 >> 4) & 1) * 512 + lane_st;
+    // ---- y_p, y_s for this chunk: A[row = gene g0 + (lane & 15)][k = 8 gq + i] ------------------------------
+    const long woff = (long)(g0 + c16) * DEC_KPS + 8 * gq;
+    const s8v wp_hi = *reinterpret_cast<const s8v*>(p.Wps_hi + woff), wp_lo = *reinterpret_cast<const s8v*>(p.Wps_lo + woff);
+    const s8v ws_hi = *reinterpret_cast<const s8v*>(p.Wps_hi + woff + DEC_KP), ws_lo = *reinterpret_cast<const s8v*>(p.Wps_lo + woff + DEC_KP);
+    f4acc yp = {0.f, 0.f, 0.f, 0.f}, ys = {0.f, 0.f, 0.f, 0.f};
+    yp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp_hi, bp_lo, yp, 0, 0, 0);
+    yp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp_lo, bp_hi, yp, 0, 0, 0);
+    yp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp_hi, bp_hi, yp, 0, 0, 0);
+    ys = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws_hi, bs_lo, ys, 0, 0, 0);
+    ys = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws_lo, bs_hi, ys, 0, 0, 0);
+    ys = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws_hi, bs_hi, ys, 0, 0, 0);
+    // ---- this chunk's inputs were fetched one trip ago; fetch the next chunk's now ------------------------------
+    float cnt[4], ell[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int g = gq + j;
-        const bool ok = cell_ok && (g < p.G);
-        const float4 gt = p.gene_tab[g];
-        const float theta = gt.x, lt = gt.y, ith = gt.z;
-        const float c = cnt4[j];
-        const float x = log1p_count(c);
-        const float2 tt = p.cnt_tab[(long)(int)fminf(c, (float)(NB_CMAX - 1)) * p.Gp + g];
-        const float F = tt.x, Psi = tt.y;
-        const float ell = ell4[j];
-        const float mu1 = fast_exp(yp[j] + ap), mu2 = fast_exp(ys[j] + as_);
-        const float S1 = theta + mu1 + SPV_EPS_NB, S2 = theta + mu2 + SPV_EPS_NB;
-        const float L1 = fast_log(S1), L2 = fast_log(S2);
-        const float e1 = mu1 + SPV_EPS_NB, e2 = mu2 + SPV_EPS_NB;
-        const float nb1 = theta * (lt - L1) + x * (fast_log(e1) - L1);
-        const float v2 = theta * (lt - L2) + x * (fast_log(e2) - L2) - ell;
-        const float d = nb1 - v2, M = fmaxf(nb1, v2);
-        const float ed = fast_exp(-fabsf(d)), el = fast_exp(-fabsf(ell));
-        const float iol = fast_rcp(1.0f + el);
-        const float logp = M - fmaxf(-ell, 0.f) + fast_log((1.0f + ed) * iol) + F;
-        rec -= ok ? logp : 0.f;
-        if constexpr (TRAIN) {
-          const float iod = fast_rcp(1.0f + ed);
-          const float r1 = (d >= 0.f) ? iod : ed * iod, r2 = 1.0f - r1;
-          const float sig = (ell <= 0.f) ? iol : el * iol;  // sigmoid(-ell)
-          const float iS1 = fast_rcp(S1), iS2 = fast_rcp(S2);
-          const float g1 = x * mu1 * fast_rcp(e1) - (theta + x) * mu1 * iS1;
-          const float g2 = x * mu2 * fast_rcp(e2) - (theta + x) * mu2 * iS2;
-          const float t1 = r1 * g1, t2 = r2 * g2;
-          const float dn1 = (lt - L1) + theta * (ith - iS1) - x * iS1;
-          const float dn2 = (lt - L2) + theta * (ith - iS2) - x * iS2;
-          const float wk = ok ? -w : 0.f;  // loss = sum_b w_b * (-sum_g logp)
-          o_dl[j] = wk * (sig - r2);
-          o_tp[j] = wk * t1;
-          o_ts[j] = wk * t2;
-          tp_sum += o_tp[j];
-          ts_sum += o_ts[j];
-          dth4[j] = wk * (r1 * dn1 + r2 * dn2 + Psi);
-        }
+    for (int j = 0; j < 4; ++j) { cnt[j] = cnt4[j]; ell[j] = ell4[j]; }
+    if (g0 + 16 < gend) {
+      const int gn = g0 + 16;
+      load_counts4(p, row_of_cell, gn + 4 * gq, cell_ok, cnt4);
+      load4<LT>(p.logits, ((long)cell_tile * p.n_gene_tiles + (gn >> 5)) * 1024 + ((gn >> 4) & 1) * 512 + lane_st, ell4);
+    }
+    const int gq0 = g0 + 4 * gq;  // first of this lane's 4 consecutive genes
+    float o_dl[4], o_tp[4], o_ts[4], dth4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int g = gq0 + j;
+      const bool ok = cell_ok && (g < p.G);
+      const float4 gt = s_gt[g - gbeg];
+      const float theta = gt.x, lt = gt.y, ith = gt.z;
+      const float c = cnt[j];
+      const float x = log1p_count(c);
+      const float2 tt = p.cnt_tab[(long)(int)fminf(c, (float)(NB_CMAX - 1)) * p.Gp + g];
+      const float F = tt.x, Psi = tt.y;
+      const float el_ = ell[j];
+      const float mu1 = fast_exp(yp[j] + ap), mu2 = fast_exp(ys[j] + as_);
+      const float S1 = theta + mu1 + SPV_EPS_NB, S2 = theta + mu2 + SPV_EPS_NB;
+      const float L1 = fast_log(S1), L2 = fast_log(S2);
+      const float e1 = mu1 + SPV_EPS_NB, e2 = mu2 + SPV_EPS_NB;
+      const float nb1 = theta * (lt - L1) + x * (fast_log(e1) - L1);
+      const float v2 = theta * (lt - L2) + x * (fast_log(e2) - L2) - el_;
+      const float d = nb1 - v2, M = fmaxf(nb1, v2);
+      const float ed = fast_exp(-fabsf(d)), el = fast_exp(-fabsf(el_));
+      const float iol = fast_rcp(1.0f + el);
+      const float logp = M - fmaxf(-el_, 0.f) + fast_log((1.0f + ed) * iol) + F;
+      rec -= ok ? logp : 0.f;
+      if constexpr (TRAIN) {
+        const float iod = fast_rcp(1.0f + ed);
+        const float r1 = (d >= 0.f) ? iod : ed * iod, r2 = 1.0f - r1;
+        const float sig = (el_ <= 0.f) ? iol : el * iol;  // sigmoid(-logit)
+        const float iS1 = fast_rcp(S1), iS2 = fast_rcp(S2);
+        const float g1 = x * mu1 * fast_rcp(e1) - (theta + x) * mu1 * iS1;
+        const float g2 = x * mu2 * fast_rcp(e2) - (theta + x) * mu2 * iS2;
+        const float t1 = r1 * g1, t2 = r2 * g2;
+        const float dn1 = (lt - L1) + theta * (ith - iS1) - x * iS1;
+        const float dn2 = (lt - L2) + theta * (ith - iS2) - x * iS2;
+        const float wk = ok ? -w : 0.f;  // loss = sum_b w_b * (-sum_g logp)
+        o_dl[j] = wk * (sig - r2);
+        o_tp[j] = wk * t1;
+        o_ts[j] = wk * t2;
+        tp_sum += o_tp[j];
+        ts_sum += o_ts[j];
+        dth4[j] = wk * (r1 * dn1 + r2 * dn2 + Psi);
       }
-      if (__builtin_expect(__any(fmaxf(fmaxf(cnt4[0], cnt4[1]), fmaxf(cnt4[2], cnt4[3])) >= (float)NB_CMAX), 0)) {
+    }
+    if (__builtin_expect(__any(fmaxf(fmaxf(cnt[0], cnt[1]), fmaxf(cnt[2], cnt[3])) >= (float)NB_CMAX), 0)) {
 #pragma unroll 1
-        for (int j = 0; j < 4; ++j) {
-          const float cj = (j == 0) ? cnt4[0] : (j == 1) ? cnt4[1] : (j == 2) ? cnt4[2] : cnt4[3];
-          if (cj >= (float)NB_CMAX && cell_ok && gq + j < p.G) {
-            const float2 fx = gamma_terms_fixup(p, gq + j, cj);
-            rec -= fx.x;
-            if constexpr (TRAIN) {
-              const float dv = -w * fx.y;
-              dth4[0] += (j == 0) ? dv : 0.f; dth4[1] += (j == 1) ? dv : 0.f;
-              dth4[2] += (j == 2) ? dv : 0.f; dth4[3] += (j == 3) ? dv : 0.f;
-            }
+      for (int j = 0; j < 4; ++j) {
+        const float cj = (j == 0) ? cnt[0] : (j == 1) ? cnt[1] : (j == 2) ? cnt[2] : cnt[3];
+        if (cj >= (float)NB_CMAX && cell_ok && gq0 + j < p.G) {
+          const float2 fx = gamma_terms_fixup(p, gq0 + j, cj);
+          rec -= fx.x;
+          if constexpr (TRAIN) {
+            const float dv = -w * fx.y;
+            dth4[0] += (j == 0) ? dv : 0.f; dth4[1] += (j == 1) ? dv : 0.f;
+            dth4[2] += (j == 2) ? dv : 0.f; dth4[3] += (j == 3) ? dv : 0.f;
           }
         }
       }
-      if constexpr (TRAIN) {
-        store4<GT>(p.dL, toff, o_dl);
-        store4<GT>(p.tP, toff, o_tp);
-        store4<GT>(p.tS, toff, o_ts);
-        // per-gene sums over this wave's 32 cells: 4 values x 32 lanes -> lane keeps gene 2*b4 + b3
-        const bool u4 = lane & 16, u3 = lane & 8;
-        const float a0 = (u4 ? dth4[2] : dth4[0]) + __shfl_xor(u4 ? dth4[0] : dth4[2], 16, 64);
-        const float a1 = (u4 ? dth4[3] : dth4[1]) + __shfl_xor(u4 ? dth4[1] : dth4[3], 16, 64);
-        float s = (u3 ? a1 : a0) + __shfl_xor(u3 ? a0 : a1, 8, 64);
-        s += __shfl_xor(s, 4, 64);
-        s += __shfl_xor(s, 2, 64);
-        s += __shfl_xor(s, 1, 64);
-        if ((lane & 7) == 0) p.dtheta_part[(long)cell_tile * p.Gp + gq + 2 * ((lane >> 4) & 1) + ((lane >> 3) & 1)] = s;
-      }
-      yp = __builtin_shufflevector(yp, yp, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3);
-      ys = __builtin_shufflevector(ys, ys, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3);
+    }
+    if constexpr (TRAIN) {
+      store4<GT>(p.dL, toff, o_dl);
+      store4<GT>(p.tP, toff, o_tp);
+      store4<GT>(p.tS, toff, o_ts);
+      // per-gene sums over this wave's 16 cells (lanes sharing gq): 4 values x 16 lanes -> lane keeps gene 2*b3 + b2
+      const bool u3 = lane & 8, u2 = lane & 4;
+      const float a0 = (u3 ? dth4[2] : dth4[0]) + __shfl_xor(u3 ? dth4[0] : dth4[2], 8, 64);
+      const float a1 = (u3 ? dth4[3] : dth4[1]) + __shfl_xor(u3 ? dth4[1] : dth4[3], 8, 64);
+      float s = (u2 ? a1 : a0) + __shfl_xor(u2 ? a0 : a1, 4, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 1, 64);
+      if ((lane & 3) == 0) p.dtheta_part[(long)tile16 * p.Gp + gq0 + 2 * ((lane >> 3) & 1) + ((lane >> 2) & 1)] = s;
     }
   }
-  rec += other_half(rec);
-  if constexpr (TRAIN) { tp_sum += other_half(tp_sum); ts_sum += other_half(ts_sum); }
-  if (h == 0) {
+  // the four gene groups of a cell sit in lanes c16, c16+16, c16+32, c16+48
+  rec += __shfl_xor(rec, 16, 64); rec += __shfl_xor(rec, 32, 64);
+  if constexpr (TRAIN) {
+    tp_sum += __shfl_xor(tp_sum, 16, 64); tp_sum += __shfl_xor(tp_sum, 32, 64);
+    ts_sum += __shfl_xor(ts_sum, 16, 64); ts_sum += __shfl_xor(ts_sum, 32, 64);
+  }
+  if (gq == 0) {
     const long o = (long)split * p.Bp + cell;
     p.rec_part[o] = rec;
     if constexpr (TRAIN) { p.tp_part[o] = tp_sum; p.ts_part[o] = ts_sum; }
   }
 }
-
 
 // ---- backward helper: finish the softmax backward in place -------------------------------------
 //   d/dy_k[b,g] = t_k[b,g] - softmax_k[b,g] * T_k[b],   T_k[b] = sum_g t_k[b,g]

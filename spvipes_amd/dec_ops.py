@@ -140,7 +140,7 @@ class DecoderFused(torch.autograd.Function):
                 dL = wsg.get("dec_dL_" + gname, (Bp, Gp), gdt, zero=True)
                 tP = wsg.get("dec_tP_" + gname, (Bp, Gp), gdt, zero=True)
                 tS = wsg.get("dec_tS_" + gname, (Bp, Gp), gdt, zero=True)
-                dth = wsg.get("dec_dtheta", (Bp // 32, Gp), torch.float32, zero=True)
+                dth = wsg.get("dec_dtheta", (Bp // 16, Gp), torch.float32, zero=True)
             else:
                 dL = tP = tS = dth = None
             lse_p, lse_s, a_p, a_s = vec("dec_lse_p"), vec("dec_lse_s"), vec("dec_a_p"), vec("dec_a_s")

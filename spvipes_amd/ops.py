@@ -150,7 +150,7 @@ def _gene_splits(Bp: int, Gp: int) -> Tuple[int, int]:
     cell_blocks = Bp // DEC_CELLS_PER_WG
     want = max(1, -(-1024 // cell_blocks))  # ~4 workgroups per CU
     tiles = Gp // 32
-    splits = max(1, min(want, tiles))
+    splits = max(1, min(want, tiles), -(-tiles // 32))  # at most 1024 genes per split (the NB kernel keeps them in LDS)
     per = round_up(-(-tiles // splits), 1) * 32
     splits = -(-Gp // per)
     return splits, per
@@ -213,7 +213,7 @@ class DecoderNBLoss(torch.autograd.Function):
             dL = ws.get("dec_dL_" + gname, (Bp, Gp), gdt, zero=True)
             tP = ws.get("dec_tP_" + gname, (Bp, Gp), gdt, zero=True)
             tS = ws.get("dec_tS_" + gname, (Bp, Gp), gdt, zero=True)
-            dth = ws.get("dec_dtheta", (Bp // 32, Gp), torch.float32, zero=True)
+            dth = ws.get("dec_dtheta", (Bp // 16, Gp), torch.float32, zero=True)
         else:
             dL = tP = tS = dth = None
         lse_p, lse_s, a_p, a_s = vec("dec_lse_p"), vec("dec_lse_s"), vec("dec_a_p"), vec("dec_a_s")
