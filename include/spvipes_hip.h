@@ -122,6 +122,7 @@ typedef struct spv_dec_params {
   float* rec_part; float* tp_part; float* ts_part;
   float* dtheta_part;
   void* dL; void* tP; void* tS; int32_t grads_f32;              /* tiled like logits; bf16 | f32 */
+  int32_t nb_splits; int32_t nb_genes_per_split;               /* gene splits of spv_dec_nb_fwd: multiple of 32, <= SPV_NB_GSPL_MAX */
 } spv_dec_params;
 
 /* theta = exp(px_r) and the per-(count, gene) lgamma / digamma table (module/spVIPESmodule.py:758
@@ -132,7 +133,7 @@ int spv_dec_tables(const float* px_r, int32_t G, int32_t Gp, void* gene_tab, voi
  * (the cast away of const on those four pointers is deliberate: they are this call's outputs). */
 int spv_dec_lse(const spv_dec_params* p, const float* library, void* stream);
 
-/* rec_part/tp_part/ts_part [gene_splits][Bp], dtheta_part [Bp/16][Gp] (genes_per_split <= 1024); when train != 0 also the
+/* rec_part/tp_part/ts_part [nb_splits][Bp], dtheta_part [Bp/16][Gp]; when train != 0 also the
  * per-element gradients dL, tP, tS (accumulator-tile order; bf16, or fp32 when grads_f32). */
 int spv_dec_nb_fwd(const spv_dec_params* p, int32_t train, void* stream);
 
@@ -216,6 +217,7 @@ int spv_enc_sample_bwd(const spv_sample_batch* a, void* stream);
 /* ---------------------------------------------------------------------------------------------
  * Label-based Product of Experts on device (module/spVIPESmodule.py:583-718 + _poe2 :282-379).
  * ------------------------------------------------------------------------------------------- */
+#define SPV_NB_GSPL_MAX 160 /* genes per likelihood split: their regressor weights sit in LDS */
 #define SPV_POE_LMAX 1024   /* label codes are integers in [0, SPV_POE_LMAX) */
 
 /* rank-within-label pairing of two minibatches; labels are float32 codes (as the reference carries

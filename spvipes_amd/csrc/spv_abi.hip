@@ -229,6 +229,7 @@ static int to_dec(const spv_dec_params* q, DecParams& p) {
   p.part_max_p = q->part_max_p; p.part_sum_p = q->part_sum_p; p.part_max_s = q->part_max_s; p.part_sum_s = q->part_sum_s;
   p.rec_part = q->rec_part; p.tp_part = q->tp_part; p.ts_part = q->ts_part; p.dtheta_part = q->dtheta_part;
   p.dL = q->dL; p.tP = q->tP; p.tS = q->tS; p.grads_f32 = q->grads_f32;
+  p.nb_splits = q->nb_splits; p.nb_genes_per_split = q->nb_genes_per_split;
   if (p.B <= 0 || p.G <= 0 || p.Bp < p.B || p.Gp < p.G || (p.Bp % DEC_CELLS_PER_WG) || (p.Gp % 32))
     return fail(SPV_ERR_ARG, "decoder: Bp must be a multiple of 128 and Gp of 32%s");
   if (p.gene_splits <= 0 || (p.genes_per_split % 32) || (long)p.gene_splits * p.genes_per_split < p.G)
@@ -258,11 +259,18 @@ extern "C" int spv_dec_lse(const spv_dec_params* q, const float* library, void* 
   return launch_status("spv_dec_lse");
 }
 
+template <bool TRAIN, typename GT, int CM>
+static void nb_launch_mode(const DecParams& p, hipStream_t s) {
+  dim3 grid((p.Bp + NB_CELLS_PER_WG - 1) / NB_CELLS_PER_WG, p.nb_splits);
+  if (p.logits_f32) hipLaunchKernelGGL((dec_nb_kernel<TRAIN, GT, float, CM>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((dec_nb_kernel<TRAIN, GT, _Float16, CM>), grid, dim3(256), 0, s, p);
+}
 template <bool TRAIN, typename GT>
 static void nb_launch(const DecParams& p, hipStream_t s) {
-  dim3 grid(p.Bp / 64, p.gene_splits);  // 4 waves x 16 cells per workgroup
-  if (p.logits_f32) hipLaunchKernelGGL((dec_nb_kernel<TRAIN, GT, float>), grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((dec_nb_kernel<TRAIN, GT, _Float16>), grid, dim3(256), 0, s, p);
+  if (!p.count_is_u16) return nb_launch_mode<TRAIN, GT, CNT_F32>(p, s);
+  const bool aligned = ((reinterpret_cast<uintptr_t>(p.X) & 7) == 0) && (p.ldx % 4 == 0) && (p.col_off % 4 == 0);
+  if (aligned) nb_launch_mode<TRAIN, GT, CNT_U16_ALIGNED>(p, s);
+  else nb_launch_mode<TRAIN, GT, CNT_U16_ANY>(p, s);
 }
 
 extern "C" int spv_dec_nb_fwd(const spv_dec_params* q, int32_t train, void* stream) {
@@ -272,7 +280,9 @@ extern "C" int spv_dec_nb_fwd(const spv_dec_params* q, int32_t train, void* stre
   if (!p.X || !p.logits || !p.gene_tab || !p.cnt_tab || !p.a_p || !p.a_s || !p.w_row || !p.rec_part)
     return fail(SPV_ERR_ARG, "spv_dec_nb_fwd: null pointer%s");
   if (p.n_gene_tiles != p.Gp / 32) return fail(SPV_ERR_ARG, "spv_dec_nb_fwd: n_gene_tiles must be Gp / 32%s");
-  if (p.genes_per_split > NB_GT_MAX) return fail(SPV_ERR_ARG, "spv_dec_nb_fwd: at most 1024 genes per split%s");
+  if (p.nb_splits <= 0 || p.nb_genes_per_split <= 0 || (p.nb_genes_per_split % 32) || p.nb_genes_per_split > NB_GSPL_MAX ||
+      (long)p.nb_splits * p.nb_genes_per_split < p.G)
+    return fail(SPV_ERR_ARG, "spv_dec_nb_fwd: nb_genes_per_split must be a multiple of 32, at most 160, and the splits must cover G%s");
   if (train && (!p.dL || !p.tP || !p.tS || !p.tp_part || !p.ts_part || !p.dtheta_part))
     return fail(SPV_ERR_ARG, "spv_dec_nb_fwd: training outputs missing%s");
   hipStream_t s = (hipStream_t)stream;

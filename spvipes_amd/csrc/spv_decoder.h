@@ -53,9 +53,10 @@ struct DecParams {
   // outputs
   int gene_splits; int genes_per_split;      // multiples of 32
   float* part_max_p; float* part_sum_p; float* part_max_s; float* part_sum_s;  // [splits][Bp]  (lse)
-  float* rec_part; float* tp_part; float* ts_part;                             // [splits][Bp]  (nb)
+  float* rec_part; float* tp_part; float* ts_part;                             // [nb_splits][Bp]  (nb)
   float* dtheta_part;           // [Bp/16][Gp]  one partial row per 16-cell wave tile
   void* dL; void* tP; void* tS; int grads_f32;                                 // tiled like logits; bf16 or f32
+  int nb_splits; int nb_genes_per_split;     // gene splits of the likelihood kernel (multiple of 32, <= NB_GSPL_MAX)
 };
 
 // ---- per-gene tables ----------------------------------------------------------
@@ -79,64 +80,48 @@ __global__ void nb_tables_kernel(const float* px_r, int G, int Gp, float4* gene_
   cnt_tab[(long)c * Gp + g] = make_float2(xt.lg - t.lg - x1.lg, xt.dg - t.dg);
 }
 
-// counts of the 16 accumulator rows of this lane: cell = cell0 + (lane & 31), genes g0 + crow(q, h)
-__device__ __forceinline__ void load_counts16(const DecParams& p, int cell, int g0, int h, bool cell_ok, float (&c)[16]) {
-#pragma unroll
-  for (int q = 0; q < 16; ++q) c[q] = 0.f;
-  if (!cell_ok) return;
-  const long row = p.rows ? (long)p.rows[cell] : (long)cell;
-#pragma unroll
-  for (int qq = 0; qq < 4; ++qq) {
-    const int g = g0 + 8 * qq + 4 * h;  // 4 consecutive genes: registers 4qq .. 4qq+3
-    if (p.count_is_u16) {
-      const unsigned short* src = reinterpret_cast<const unsigned short*>(p.X) + row * p.ldx + p.col_off + g;
-      if (g + 4 <= p.G && (reinterpret_cast<uintptr_t>(src) & 7) == 0) {
-        const u2v raw = *reinterpret_cast<const u2v*>(src);
-        c[4 * qq + 0] = (float)(raw[0] & 0xFFFFu); c[4 * qq + 1] = (float)(raw[0] >> 16);
-        c[4 * qq + 2] = (float)(raw[1] & 0xFFFFu); c[4 * qq + 3] = (float)(raw[1] >> 16);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (g + j < p.G) c[4 * qq + j] = (float)src[j];
-      }
-    } else {
-      const float* src = reinterpret_cast<const float*>(p.X) + row * p.ldx + p.col_off + g;
-      if (g + 4 <= p.G && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
-        const f4v raw = *reinterpret_cast<const f4v*>(src);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) c[4 * qq + j] = raw[j];
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (g + j < p.G) c[4 * qq + j] = src[j];
-      }
-    }
-  }
-}
+// Count words of 4 consecutive genes g..g+3 (g % 4 == 0) of one cell, kept undecoded so that the load
+// needs no wait until its values are used.  The access mode is uniform per launch:
+enum { CNT_U16_ALIGNED = 0, CNT_U16_ANY = 1, CNT_F32 = 2 };
+template <int CM> struct RawCounts;
+template <> struct RawCounts<CNT_U16_ALIGNED> { u2v w; };          // one 8-byte load (matrix base, ld, col_off 4-aligned)
+template <> struct RawCounts<CNT_U16_ANY> { unsigned short w[4]; };
+template <> struct RawCounts<CNT_F32> { float w[4]; };
 
-// 4 consecutive genes g..g+3 of one cell (row = index into the resident count matrix)
-__device__ __forceinline__ void load_counts4(const DecParams& p, long row, int g, bool cell_ok, float (&c)[4]) {
+// branch-free: lanes (or genes) with nothing to read fetch element 0 of the matrix and decode() masks them
+template <int CM>
+__device__ __forceinline__ RawCounts<CM> load_counts4_raw(const DecParams& p, long row, int g, bool cell_ok) {
+  RawCounts<CM> r;
+  const long base = row * p.ldx + p.col_off + g;
+  if constexpr (CM == CNT_U16_ALIGNED) {
+    const bool full = cell_ok && (g + 4 <= p.G);
+    r.w = *reinterpret_cast<const u2v*>(reinterpret_cast<const unsigned short*>(p.X) + (full ? base : 0));
+  } else if constexpr (CM == CNT_U16_ANY) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) c[j] = 0.f;
-  if (!cell_ok || g >= p.G) return;
-  if (p.count_is_u16) {
-    const unsigned short* src = reinterpret_cast<const unsigned short*>(p.X) + row * p.ldx + p.col_off + g;
-    if (g + 4 <= p.G && (reinterpret_cast<uintptr_t>(src) & 7) == 0) {
-      const u2v raw = *reinterpret_cast<const u2v*>(src);
-      c[0] = (float)(raw[0] & 0xFFFFu); c[1] = (float)(raw[0] >> 16);
-      c[2] = (float)(raw[1] & 0xFFFFu); c[3] = (float)(raw[1] >> 16);
-    } else {
+    for (int j = 0; j < 4; ++j) r.w[j] = reinterpret_cast<const unsigned short*>(p.X)[(cell_ok && g + j < p.G) ? base + j : 0];
+  } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) if (g + j < p.G) c[j] = (float)src[j];
+    for (int j = 0; j < 4; ++j) r.w[j] = reinterpret_cast<const float*>(p.X)[(cell_ok && g + j < p.G) ? base + j : 0];
+  }
+  return r;
+}
+template <int CM>
+__device__ __forceinline__ void decode_counts4(const DecParams& p, const RawCounts<CM>& r, long row, int g, bool cell_ok, float (&c)[4]) {
+  if constexpr (CM == CNT_U16_ALIGNED) {
+    const bool full = cell_ok && (g + 4 <= p.G);
+    c[0] = full ? (float)(r.w[0] & 0xFFFFu) : 0.f; c[1] = full ? (float)(r.w[0] >> 16) : 0.f;
+    c[2] = full ? (float)(r.w[1] & 0xFFFFu) : 0.f; c[3] = full ? (float)(r.w[1] >> 16) : 0.f;
+    const bool partial = cell_ok && g < p.G && g + 4 > p.G;  // only where G % 4 != 0: the last genes of the group
+    if (__builtin_expect(__any(partial), 0)) {
+      if (partial) {
+        const unsigned short* src = reinterpret_cast<const unsigned short*>(p.X) + row * p.ldx + p.col_off + g;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) if (g + j < p.G) c[j] = (float)src[j];
+      }
     }
   } else {
-    const float* src = reinterpret_cast<const float*>(p.X) + row * p.ldx + p.col_off + g;
-    if (g + 4 <= p.G && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
-      const f4v raw = *reinterpret_cast<const f4v*>(src);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) c[j] = raw[j];
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) if (g + j < p.G) c[j] = src[j];
-    }
+    for (int j = 0; j < 4; ++j) c[j] = (cell_ok && g + j < p.G) ? (float)r.w[j] : 0.f;
   }
 }
 
@@ -324,149 +309,193 @@ __device__ __forceinline__ float half_sum16(const float (&v)[16], int lane) {
 // per lane is live -- no 32-register tile to carry, no rotation -- and the next chunk's counts / logits are
 // fetched while this one is evaluated.  The [cells][genes] arrays stay in the 32x32 accumulator-tile order.
 typedef __attribute__((ext_vector_type(4))) float f4acc;
-constexpr int NB_GT_MAX = 1024;   // genes per split held in LDS (gene table)
+constexpr int NB_GSPL_MAX = 160;     // genes per split: their regressor weights (hi/lo) and gene table live in LDS
+constexpr int NB_WPITCH = 56;        // LDS row pitch of the weight slice in bf16 (112 B: conflict-free 16-B row reads)
+constexpr int NB_CELLS_PER_WG = 64;  // 4 waves x 1 tile of 16 cells
 
-template <bool TRAIN, typename GT, typename LT>
-__global__ __launch_bounds__(256, TRAIN ? 3 : 4) void dec_nb_kernel(DecParams p) {
-  __shared__ float4 s_gt[NB_GT_MAX];
+template <bool TRAIN, typename GT, typename LT, int CM>
+__global__ __launch_bounds__(256, 3) void dec_nb_kernel(DecParams p) {
+  __shared__ __attribute__((aligned(16))) bf16_t s_whi[NB_GSPL_MAX * NB_WPITCH], s_wlo[NB_GSPL_MAX * NB_WPITCH];
+  __shared__ float4 s_gt[NB_GSPL_MAX];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c16 = lane & 15, gq = lane >> 4;              // cell within the wave's 16, gene group within a chunk
-  const int tile16 = blockIdx.x * 4 + wave;               // 16-cell tile of this wave
-  const int cell = tile16 * 16 + c16;
-  const int cell_tile = tile16 >> 1, ch = tile16 & 1;     // 32-cell storage tile and which half of it
-  const bool cell_ok = cell < p.B;
   const int split = blockIdx.y;
-  const int gbeg = split * p.genes_per_split;
-  int gend = gbeg + p.genes_per_split;
+  const int gbeg = split * p.nb_genes_per_split;
+  int gend = gbeg + p.nb_genes_per_split;
   if (gend > p.Gp) gend = p.Gp;
   if (gend > ((p.G + 15) & ~15)) gend = (p.G + 15) & ~15;
-  for (int i = tid; i < gend - gbeg; i += 256) s_gt[i] = p.gene_tab[gbeg + i];
+  const int ng = gend - gbeg;
+  if (ng <= 0) {  // a split made of padding genes only: its partials are zeros
+    const int cell = blockIdx.x * NB_CELLS_PER_WG + tid;
+    if (cell < p.Bp) {
+      const long o = (long)split * p.Bp + cell;
+      p.rec_part[o] = 0.f;
+      if constexpr (TRAIN) { p.tp_part[o] = 0.f; p.ts_part[o] = 0.f; }
+    }
+    return;
+  }
+  // ---- stage this split's regressor weights [ng][48] (hi, lo) and gene table in LDS -------------------------
+  for (int i = tid; i < ng * 6; i += 256) {
+    const int row = i / 6, ch = i % 6;
+    *reinterpret_cast<u4v*>(s_whi + row * NB_WPITCH + 8 * ch) = *reinterpret_cast<const u4v*>(p.Wps_hi + (long)(gbeg + row) * DEC_KPS + 8 * ch);
+    *reinterpret_cast<u4v*>(s_wlo + row * NB_WPITCH + 8 * ch) = *reinterpret_cast<const u4v*>(p.Wps_lo + (long)(gbeg + row) * DEC_KPS + 8 * ch);
+  }
+  for (int i = tid; i < ng; i += 256) s_gt[i] = p.gene_tab[gbeg + i];
   __syncthreads();
+  const int nchunks = ng >> 4;
 
-  // resident cell-side fragments: B[k = 8 gq + i][col = cell]
-  const long aoff = (long)cell * DEC_KPS + 8 * gq;
-  s8v bp_hi = *reinterpret_cast<const s8v*>(p.Aps_hi + aoff), bp_lo = *reinterpret_cast<const s8v*>(p.Aps_lo + aoff);
-  if (gq >= 2) {  // the private regressor only has K = 16: its K = 32 MFMA sees zeros beyond
+  for (int t = 0; t < NB_CELLS_PER_WG / 64; ++t) {
+    const int tile16 = blockIdx.x * (NB_CELLS_PER_WG / 16) + 4 * t + wave;   // 16-cell tile of this wave
+    const int cell = tile16 * 16 + c16;
+    if (tile16 * 16 >= p.Bp) break;
+    const int cell_tile = tile16 >> 1, chh = tile16 & 1;   // 32-cell storage tile and which half of it
+    const bool cell_ok = cell < p.B;
+    // resident cell-side fragments: B[k = 8 gq + i][col = cell]
+    const long aoff = (long)cell * DEC_KPS + 8 * gq;
+    s8v bp_hi = *reinterpret_cast<const s8v*>(p.Aps_hi + aoff), bp_lo = *reinterpret_cast<const s8v*>(p.Aps_lo + aoff);
+    if (gq >= 2) {  // the private regressor only has K = 16: its K = 32 MFMA sees zeros beyond
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { bp_hi[i] = 0; bp_lo[i] = 0; }
-  }
-  const s8v bs_hi = *reinterpret_cast<const s8v*>(p.Aps_hi + aoff + DEC_KP), bs_lo = *reinterpret_cast<const s8v*>(p.Aps_lo + aoff + DEC_KP);
-  const float ap = p.a_p[cell], as_ = p.a_s[cell];
-  const float w = p.w_row[cell];
-  const long row_of_cell = cell_ok ? (p.rows ? (long)p.rows[cell] : (long)cell) : 0;
-  float rec = 0.f, tp_sum = 0.f, ts_sum = 0.f;
-  // storage offset of this lane inside a 32x32 tile for gene half gh: qq = 2 gh + (gq >> 1), h = gq & 1
-  const int lane_st = (16 * ch + c16 + 32 * (gq & 1)) * 4 + (gq >> 1) * 256;
-
-  float cnt4[4], ell4[4];
-  if (gbeg < gend) {
-    load_counts4(p, row_of_cell, gbeg + 4 * gq, cell_ok, cnt4);
-    load4<LT>(p.logits, ((long)cell_tile * p.n_gene_tiles + (gbeg >> 5)) * 1024 + ((gbeg >> 4) & 1) * 512 + lane_st, ell4);
-  }
-  for (int g0 = gbeg; g0 < gend; g0 += 16) {
-    const long toff = ((long)cell_tile * p.n_gene_tiles + (g0 >> 5)) * 1024 + ((g0 >> 4) & 1) * 512 + lane_st;
-    // ---- y_p, y_s for this chunk: A[row = gene g0 + (lane & 15)][k = 8 gq + i] ------------------------------
-    const long woff = (long)(g0 + c16) * DEC_KPS + 8 * gq;
-    const s8v wp_hi = *reinterpret_cast<const s8v*>(p.Wps_hi + woff), wp_lo = *reinterpret_cast<const s8v*>(p.Wps_lo + woff);
-    const s8v ws_hi = *reinterpret_cast<const s8v*>(p.Wps_hi + woff + DEC_KP), ws_lo = *reinterpret_cast<const s8v*>(p.Wps_lo + woff + DEC_KP);
-    f4acc yp = {0.f, 0.f, 0.f, 0.f}, ys = {0.f, 0.f, 0.f, 0.f};
-    yp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp_hi, bp_lo, yp, 0, 0, 0);
-    yp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp_lo, bp_hi, yp, 0, 0, 0);
-    yp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp_hi, bp_hi, yp, 0, 0, 0);
-    ys = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws_hi, bs_lo, ys, 0, 0, 0);
-    ys = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws_lo, bs_hi, ys, 0, 0, 0);
-    ys = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws_hi, bs_hi, ys, 0, 0, 0);
-    // ---- this chunk's inputs were fetched one trip ago; fetch the next chunk's now ------------------------------
-    float cnt[4], ell[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { cnt[j] = cnt4[j]; ell[j] = ell4[j]; }
-    if (g0 + 16 < gend) {
-      const int gn = g0 + 16;
-      load_counts4(p, row_of_cell, gn + 4 * gq, cell_ok, cnt4);
-      load4<LT>(p.logits, ((long)cell_tile * p.n_gene_tiles + (gn >> 5)) * 1024 + ((gn >> 4) & 1) * 512 + lane_st, ell4);
+      for (int i = 0; i < 8; ++i) { bp_hi[i] = 0; bp_lo[i] = 0; }
     }
-    const int gq0 = g0 + 4 * gq;  // first of this lane's 4 consecutive genes
-    float o_dl[4], o_tp[4], o_ts[4], dth4[4];
+    const s8v bs_hi = *reinterpret_cast<const s8v*>(p.Aps_hi + aoff + DEC_KP), bs_lo = *reinterpret_cast<const s8v*>(p.Aps_lo + aoff + DEC_KP);
+    const float ap = p.a_p[cell], as_ = p.a_s[cell];
+    const float w = p.w_row[cell];
+    const long row_of_cell = cell_ok ? (p.rows ? (long)p.rows[cell] : (long)cell) : 0;
+    float rec = 0.f, tp_sum = 0.f, ts_sum = 0.f;
+    // storage offset of this lane inside a 32x32 tile for gene half gh: qq = 2 gh + (gq >> 1), h = gq & 1
+    const int lane_st = (16 * chh + c16 + 32 * (gq & 1)) * 4 + (gq >> 1) * 256;
+    const long tile_row = (long)cell_tile * p.n_gene_tiles;
+    auto tile_off = [&](int g0) { return (tile_row + (g0 >> 5)) * 1024 + ((g0 >> 4) & 1) * 512 + lane_st; };
+    auto gather_tab = [&](const float (&c)[4], int g0, float2 (&tab)[4]) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int g = gq0 + j;
-      const bool ok = cell_ok && (g < p.G);
-      const float4 gt = s_gt[g - gbeg];
-      const float theta = gt.x, lt = gt.y, ith = gt.z;
-      const float c = cnt[j];
-      const float x = log1p_count(c);
-      const float2 tt = p.cnt_tab[(long)(int)fminf(c, (float)(NB_CMAX - 1)) * p.Gp + g];
-      const float F = tt.x, Psi = tt.y;
-      const float el_ = ell[j];
-      const float mu1 = fast_exp(yp[j] + ap), mu2 = fast_exp(ys[j] + as_);
-      const float S1 = theta + mu1 + SPV_EPS_NB, S2 = theta + mu2 + SPV_EPS_NB;
-      const float L1 = fast_log(S1), L2 = fast_log(S2);
-      const float e1 = mu1 + SPV_EPS_NB, e2 = mu2 + SPV_EPS_NB;
-      const float nb1 = theta * (lt - L1) + x * (fast_log(e1) - L1);
-      const float v2 = theta * (lt - L2) + x * (fast_log(e2) - L2) - el_;
-      const float d = nb1 - v2, M = fmaxf(nb1, v2);
-      const float ed = fast_exp(-fabsf(d)), el = fast_exp(-fabsf(el_));
-      const float iol = fast_rcp(1.0f + el);
-      const float logp = M - fmaxf(-el_, 0.f) + fast_log((1.0f + ed) * iol) + F;
-      rec -= ok ? logp : 0.f;
-      if constexpr (TRAIN) {
-        const float iod = fast_rcp(1.0f + ed);
-        const float r1 = (d >= 0.f) ? iod : ed * iod, r2 = 1.0f - r1;
-        const float sig = (el_ <= 0.f) ? iol : el * iol;  // sigmoid(-logit)
-        const float iS1 = fast_rcp(S1), iS2 = fast_rcp(S2);
-        const float g1 = x * mu1 * fast_rcp(e1) - (theta + x) * mu1 * iS1;
-        const float g2 = x * mu2 * fast_rcp(e2) - (theta + x) * mu2 * iS2;
-        const float t1 = r1 * g1, t2 = r2 * g2;
-        const float dn1 = (lt - L1) + theta * (ith - iS1) - x * iS1;
-        const float dn2 = (lt - L2) + theta * (ith - iS2) - x * iS2;
-        const float wk = ok ? -w : 0.f;  // loss = sum_b w_b * (-sum_g logp)
-        o_dl[j] = wk * (sig - r2);
-        o_tp[j] = wk * t1;
-        o_ts[j] = wk * t2;
-        tp_sum += o_tp[j];
-        ts_sum += o_ts[j];
-        dth4[j] = wk * (r1 * dn1 + r2 * dn2 + Psi);
+      for (int j = 0; j < 4; ++j) tab[j] = p.cnt_tab[(long)(int)fminf(c[j], (float)(NB_CMAX - 1)) * p.Gp + g0 + 4 * gq + j];
+    };
+
+    // software pipeline: counts two chunks ahead (undecoded), logits and (count, gene) table rows one chunk ahead;
+    // every load is issued before the stores of the chunk in flight, so its wait never drains those stores
+    RawCounts<CM> rawA = load_counts4_raw<CM>(p, row_of_cell, gbeg + 4 * gq, cell_ok), rawB = rawA, rawC = rawA;
+    float ellA[4];
+    float2 tabA[4];
+    load4<LT>(p.logits, tile_off(gbeg), ellA);
+    if (nchunks > 1) rawB = load_counts4_raw<CM>(p, row_of_cell, gbeg + 16 + 4 * gq, cell_ok);
+    {
+      float c0[4];
+      decode_counts4<CM>(p, rawA, row_of_cell, gbeg + 4 * gq, cell_ok, c0);
+      gather_tab(c0, gbeg, tabA);
+    }
+
+    for (int c = 0; c < nchunks; ++c) {
+      const int g0 = gbeg + 16 * c;
+      const long toff = tile_off(g0);
+      // ---- y_p, y_s for this chunk: A[row = gene][k = 8 gq + i] from the LDS slice ------------------------------
+      const int wrow = (16 * c + c16) * NB_WPITCH + 8 * gq;
+      const s8v wp_hi = *reinterpret_cast<const s8v*>(s_whi + wrow), wp_lo = *reinterpret_cast<const s8v*>(s_wlo + wrow);
+      const s8v ws_hi = *reinterpret_cast<const s8v*>(s_whi + wrow + DEC_KP), ws_lo = *reinterpret_cast<const s8v*>(s_wlo + wrow + DEC_KP);
+      f4acc yp = {0.f, 0.f, 0.f, 0.f}, ys = {0.f, 0.f, 0.f, 0.f};
+      yp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp_hi, bp_lo, yp, 0, 0, 0);
+      yp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp_lo, bp_hi, yp, 0, 0, 0);
+      yp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wp_hi, bp_hi, yp, 0, 0, 0);
+      ys = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws_hi, bs_lo, ys, 0, 0, 0);
+      ys = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws_lo, bs_hi, ys, 0, 0, 0);
+      ys = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ws_hi, bs_hi, ys, 0, 0, 0);
+      // ---- issue the loads of the following chunks (past the end: the last chunk again, unused) ------------------
+      const int g1 = gbeg + 16 * min(c + 1, nchunks - 1), g2 = gbeg + 16 * min(c + 2, nchunks - 1);
+      float ellB[4];
+      float2 tabB[4];
+      rawC = load_counts4_raw<CM>(p, row_of_cell, g2 + 4 * gq, cell_ok);
+      load4<LT>(p.logits, tile_off(g1), ellB);
+      {
+        float cB[4];
+        decode_counts4<CM>(p, rawB, row_of_cell, g1 + 4 * gq, cell_ok, cB);
+        gather_tab(cB, g1, tabB);
       }
-    }
-    if (__builtin_expect(__any(fmaxf(fmaxf(cnt[0], cnt[1]), fmaxf(cnt[2], cnt[3])) >= (float)NB_CMAX), 0)) {
-#pragma unroll 1
+      float cntA[4];
+      decode_counts4<CM>(p, rawA, row_of_cell, g0 + 4 * gq, cell_ok, cntA);
+      const int gq0 = g0 + 4 * gq;  // first of this lane's 4 consecutive genes
+      float o_dl[4], o_tp[4], o_ts[4], dth4[4];
+#pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float cj = (j == 0) ? cnt[0] : (j == 1) ? cnt[1] : (j == 2) ? cnt[2] : cnt[3];
-        if (cj >= (float)NB_CMAX && cell_ok && gq0 + j < p.G) {
-          const float2 fx = gamma_terms_fixup(p, gq0 + j, cj);
-          rec -= fx.x;
-          if constexpr (TRAIN) {
-            const float dv = -w * fx.y;
-            dth4[0] += (j == 0) ? dv : 0.f; dth4[1] += (j == 1) ? dv : 0.f;
-            dth4[2] += (j == 2) ? dv : 0.f; dth4[3] += (j == 3) ? dv : 0.f;
+        const int g = gq0 + j;
+        const bool ok = cell_ok && (g < p.G);
+        const float4 gt = s_gt[g - gbeg];
+        const float theta = gt.x, lt = gt.y, ith = gt.z;
+        const float cj = cntA[j];
+        const float x = log1p_count(cj);
+        const float F = tabA[j].x, Psi = tabA[j].y;
+        const float el_ = ellA[j];
+        const float mu1 = fast_exp(yp[j] + ap), mu2 = fast_exp(ys[j] + as_);
+        const float S1 = theta + mu1 + SPV_EPS_NB, S2 = theta + mu2 + SPV_EPS_NB;
+        const float L1 = fast_log(S1), L2 = fast_log(S2);
+        const float e1 = mu1 + SPV_EPS_NB, e2 = mu2 + SPV_EPS_NB;
+        const float nb1 = theta * (lt - L1) + x * (fast_log(e1) - L1);
+        const float v2 = theta * (lt - L2) + x * (fast_log(e2) - L2) - el_;
+        const float d = nb1 - v2, M = fmaxf(nb1, v2);
+        const float ed = fast_exp(-fabsf(d)), el = fast_exp(-fabsf(el_));
+        const float iol = fast_rcp(1.0f + el);
+        const float logp = M - fmaxf(-el_, 0.f) + fast_log((1.0f + ed) * iol) + F;
+        rec -= ok ? logp : 0.f;
+        if constexpr (TRAIN) {
+          const float iod = fast_rcp(1.0f + ed);
+          const float r1 = (d >= 0.f) ? iod : ed * iod, r2 = 1.0f - r1;
+          const float sig = (el_ <= 0.f) ? iol : el * iol;  // sigmoid(-logit)
+          const float iS1 = fast_rcp(S1), iS2 = fast_rcp(S2);
+          const float g1 = x * mu1 * fast_rcp(e1) - (theta + x) * mu1 * iS1;
+          const float g2 = x * mu2 * fast_rcp(e2) - (theta + x) * mu2 * iS2;
+          const float t1 = r1 * g1, t2 = r2 * g2;
+          const float dn1 = (lt - L1) + theta * (ith - iS1) - x * iS1;
+          const float dn2 = (lt - L2) + theta * (ith - iS2) - x * iS2;
+          const float wk = ok ? -w : 0.f;  // loss = sum_b w_b * (-sum_g logp)
+          o_dl[j] = wk * (sig - r2);
+          o_tp[j] = wk * t1;
+          o_ts[j] = wk * t2;
+          tp_sum += o_tp[j];
+          ts_sum += o_ts[j];
+          dth4[j] = wk * (r1 * dn1 + r2 * dn2 + Psi);
+        }
+      }
+      if (__builtin_expect(__any(fmaxf(fmaxf(cntA[0], cntA[1]), fmaxf(cntA[2], cntA[3])) >= (float)NB_CMAX), 0)) {
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) {
+          const float cj = (j == 0) ? cntA[0] : (j == 1) ? cntA[1] : (j == 2) ? cntA[2] : cntA[3];
+          if (cj >= (float)NB_CMAX && cell_ok && gq0 + j < p.G) {
+            const float2 fx = gamma_terms_fixup(p, gq0 + j, cj);
+            rec -= fx.x;
+            if constexpr (TRAIN) {
+              const float dv = -w * fx.y;
+              dth4[0] += (j == 0) ? dv : 0.f; dth4[1] += (j == 1) ? dv : 0.f;
+              dth4[2] += (j == 2) ? dv : 0.f; dth4[3] += (j == 3) ? dv : 0.f;
+            }
           }
         }
       }
+      if constexpr (TRAIN) {
+        store4<GT>(p.dL, toff, o_dl);
+        store4<GT>(p.tP, toff, o_tp);
+        store4<GT>(p.tS, toff, o_ts);
+        // per-gene sums over this wave's 16 cells (lanes sharing gq): 4 values x 16 lanes -> lane keeps gene 2*b3 + b2
+        const bool u3 = lane & 8, u2 = lane & 4;
+        const float a0 = (u3 ? dth4[2] : dth4[0]) + __shfl_xor(u3 ? dth4[0] : dth4[2], 8, 64);
+        const float a1 = (u3 ? dth4[3] : dth4[1]) + __shfl_xor(u3 ? dth4[1] : dth4[3], 8, 64);
+        float s = (u2 ? a1 : a0) + __shfl_xor(u2 ? a0 : a1, 4, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 1, 64);
+        if ((lane & 3) == 0) p.dtheta_part[(long)tile16 * p.Gp + gq0 + 2 * ((lane >> 3) & 1) + ((lane >> 2) & 1)] = s;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { ellA[j] = ellB[j]; tabA[j] = tabB[j]; }
+      rawA = rawB; rawB = rawC;
     }
+    // the four gene groups of a cell sit in lanes c16, c16+16, c16+32, c16+48
+    rec += __shfl_xor(rec, 16, 64); rec += __shfl_xor(rec, 32, 64);
     if constexpr (TRAIN) {
-      store4<GT>(p.dL, toff, o_dl);
-      store4<GT>(p.tP, toff, o_tp);
-      store4<GT>(p.tS, toff, o_ts);
-      // per-gene sums over this wave's 16 cells (lanes sharing gq): 4 values x 16 lanes -> lane keeps gene 2*b3 + b2
-      const bool u3 = lane & 8, u2 = lane & 4;
-      const float a0 = (u3 ? dth4[2] : dth4[0]) + __shfl_xor(u3 ? dth4[0] : dth4[2], 8, 64);
-      const float a1 = (u3 ? dth4[3] : dth4[1]) + __shfl_xor(u3 ? dth4[1] : dth4[3], 8, 64);
-      float s = (u2 ? a1 : a0) + __shfl_xor(u2 ? a0 : a1, 4, 64);
-      s += __shfl_xor(s, 2, 64);
-      s += __shfl_xor(s, 1, 64);
-      if ((lane & 3) == 0) p.dtheta_part[(long)tile16 * p.Gp + gq0 + 2 * ((lane >> 3) & 1) + ((lane >> 2) & 1)] = s;
+      tp_sum += __shfl_xor(tp_sum, 16, 64); tp_sum += __shfl_xor(tp_sum, 32, 64);
+      ts_sum += __shfl_xor(ts_sum, 16, 64); ts_sum += __shfl_xor(ts_sum, 32, 64);
     }
-  }
-  // the four gene groups of a cell sit in lanes c16, c16+16, c16+32, c16+48
-  rec += __shfl_xor(rec, 16, 64); rec += __shfl_xor(rec, 32, 64);
-  if constexpr (TRAIN) {
-    tp_sum += __shfl_xor(tp_sum, 16, 64); tp_sum += __shfl_xor(tp_sum, 32, 64);
-    ts_sum += __shfl_xor(ts_sum, 16, 64); ts_sum += __shfl_xor(ts_sum, 32, 64);
-  }
-  if (gq == 0) {
-    const long o = (long)split * p.Bp + cell;
-    p.rec_part[o] = rec;
-    if constexpr (TRAIN) { p.tp_part[o] = tp_sum; p.ts_part[o] = ts_sum; }
+    if (gq == 0) {
+      const long o = (long)split * p.Bp + cell;
+      p.rec_part[o] = rec;
+      if constexpr (TRAIN) { p.tp_part[o] = tp_sum; p.ts_part[o] = ts_sum; }
+    }
   }
 }
 

@@ -20,7 +20,7 @@ from . import _abi
 from ._abi import (DEC_CELLS_PER_WG, DEC_KP, DEC_KPS, DEC_KS, NB_CMAX, SpvBnBatch, SpvDecParams, SpvFoldBatch, SpvZsplitArgs, ptr,
                    round_up, stream_ptr)
 from .nn_ops import _add_lin, _fptr, _lin_batch, _wgrad, grad_out
-from .ops import N_HIDDEN_MIX, GroupCounts, Workspace, _bf16_image, _gemm, _gene_splits, _pack
+from .ops import N_HIDDEN_MIX, GroupCounts, Workspace, _bf16_image, _gemm, _gene_splits, _nb_splits, _pack
 
 N_DEC_PARAMS = 13  # Wp, gamma_p, beta_p, Ws, gamma_s, beta_s, Wa, ba, gamma_a, beta_a, Wm, bm, px_r
 KMP = 320
@@ -134,8 +134,10 @@ class DecoderFused(torch.autograd.Function):
             logits = wsg.get("dec_logits_" + ("f32" if mlo else "f16"), (Bp, Gp), torch.float32 if mlo else torch.float16)
             _abi.call("spv_dec_logits", ptr(Am_hi), ptr(Am_lo), ptr(Wm_hi), ptr(Wm_lo), KMP, Bp, Gp, nsplit, ptr(logits), int(mlo), stream_ptr())
             splits, per = _gene_splits(Bp, Gp)
+            nbs, nbper = _nb_splits(Gp)
             vec = lambda nme: wsg.get(nme, (Bp,), torch.float32)
             part = lambda nme: wsg.get(nme, (splits, Bp), torch.float32)
+            nbpart = lambda nme: wsg.get(nme, (nbs, Bp), torch.float32)
             if need_grad:
                 dL = wsg.get("dec_dL_" + gname, (Bp, Gp), gdt, zero=True)
                 tP = wsg.get("dec_tP_" + gname, (Bp, Gp), gdt, zero=True)
@@ -152,19 +154,19 @@ class DecoderFused(torch.autograd.Function):
                 gene_tab=ptr(gene_tab), cnt_tab=ptr(cnt_tab), a_p=ptr(a_p), a_s=ptr(a_s), lse_p=ptr(lse_p), lse_s=ptr(lse_s),
                 w_row=ptr(w_pad), gene_splits=splits, genes_per_split=per,
                 part_max_p=ptr(part("dec_pmp")), part_sum_p=ptr(part("dec_psp")), part_max_s=ptr(part("dec_pms")), part_sum_s=ptr(part("dec_pss")),
-                rec_part=ptr(part("dec_rec")), tp_part=ptr(part("dec_tp")), ts_part=ptr(part("dec_ts")),
-                dtheta_part=ptr(dth), dL=ptr(dL), tP=ptr(tP), tS=ptr(tS), grads_f32=int(grads_f32),
+                rec_part=ptr(nbpart("dec_rec")), tp_part=ptr(nbpart("dec_tp")), ts_part=ptr(nbpart("dec_ts")),
+                dtheta_part=ptr(dth), dL=ptr(dL), tP=ptr(tP), tS=ptr(tS), grads_f32=int(grads_f32), nb_splits=nbs, nb_genes_per_split=nbper,
             )
             _abi.call("spv_dec_lse", C.byref(p), ptr(cont(library[g].flatten())), stream_ptr())
             _abi.call("spv_dec_nb_fwd", C.byref(p), int(need_grad), stream_ptr())
-            r = part("dec_rec").sum(0)[:B]
+            r = nbpart("dec_rec").sum(0)[:B]
             rec.append(r)
             l = (r * w_row).sum()
             loss = l if loss is None else loss + l
             P.append(p)
             if need_grad:
                 saved_g.append(dict(Wm=(Wm_hi, Wm_lo), Am=(Am_hi, Am_lo), Aps=(Aps_hi, Aps_lo), dL=dL, tP=tP, tS=tS, dth=dth,
-                                    Tp=part("dec_tp").sum(0), Ts=part("dec_ts").sum(0)))
+                                    Tp=nbpart("dec_tp").sum(0), Ts=nbpart("dec_ts").sum(0)))
         if need_grad:
             ctx.P, ctx.saved_g, ctx.ws, ctx.decoders, ctx.training, ctx.nsplit = P, saved_g, ws, decoders, training, nsplit
             ctx.dims = (B, Bp, Gs, Gps, n_p, n_s, n_m, KM)

@@ -150,10 +150,18 @@ def _gene_splits(Bp: int, Gp: int) -> Tuple[int, int]:
     cell_blocks = Bp // DEC_CELLS_PER_WG
     want = max(1, -(-1024 // cell_blocks))  # ~4 workgroups per CU
     tiles = Gp // 32
-    splits = max(1, min(want, tiles), -(-tiles // 32))  # at most 1024 genes per split (the NB kernel keeps them in LDS)
-    per = round_up(-(-tiles // splits), 1) * 32
+    splits = max(1, min(want, tiles))
+    per = -(-tiles // splits) * 32
     splits = -(-Gp // per)
     return splits, per
+
+
+NB_GSPL_MAX = 160  # genes per likelihood split (their regressor weights sit in LDS)
+
+
+def _nb_splits(Gp: int) -> Tuple[int, int]:
+    per = min(NB_GSPL_MAX, Gp)
+    return -(-Gp // per), per
 
 
 def _gemm(a_kmajor: bool, A_hi, A_lo, lda, B_hi, B_lo, ldb, M, N, K, nsplit, splits, ws: Workspace, name: str,
@@ -202,8 +210,10 @@ class DecoderNBLoss(torch.autograd.Function):
         cnt_tab = ws.get("dec_cnt_tab", (NB_CMAX, Gp, 2), torch.float32)
         _abi.call("spv_dec_tables", ptr(f32(px_r)), G, Gp, ptr(gene_tab), ptr(cnt_tab), stream_ptr())
         splits, per = _gene_splits(Bp, Gp)
+        nbs, nbper = _nb_splits(Gp)
         vec = lambda n: ws.get(n, (Bp,), torch.float32)
         part = lambda n: ws.get(n, (splits, Bp), torch.float32)
+        nbpart = lambda n: ws.get(n, (nbs, Bp), torch.float32)
         w_pad = ws.get("dec_w_row", (Bp,), torch.float32, zero=True)
         w_pad[:B].copy_(w_row)
         grads_f32 = bool(train and nsplit == 3)
@@ -227,17 +237,17 @@ class DecoderNBLoss(torch.autograd.Function):
             gene_tab=ptr(gene_tab), cnt_tab=ptr(cnt_tab), a_p=ptr(a_p), a_s=ptr(a_s), lse_p=ptr(lse_p), lse_s=ptr(lse_s),
             w_row=ptr(w_pad), gene_splits=splits, genes_per_split=per,
             part_max_p=ptr(part("dec_pmp")), part_sum_p=ptr(part("dec_psp")), part_max_s=ptr(part("dec_pms")), part_sum_s=ptr(part("dec_pss")),
-            rec_part=ptr(part("dec_rec")), tp_part=ptr(part("dec_tp")), ts_part=ptr(part("dec_ts")),
-            dtheta_part=ptr(dth), dL=ptr(dL), tP=ptr(tP), tS=ptr(tS), grads_f32=int(grads_f32),
+            rec_part=ptr(nbpart("dec_rec")), tp_part=ptr(nbpart("dec_tp")), ts_part=ptr(nbpart("dec_ts")),
+            dtheta_part=ptr(dth), dL=ptr(dL), tP=ptr(tP), tS=ptr(tS), grads_f32=int(grads_f32), nb_splits=nbs, nb_genes_per_split=nbper,
         )
         _abi.call("spv_dec_lse", C.byref(P), ptr(f32(library)), stream_ptr())
         _abi.call("spv_dec_nb_fwd", C.byref(P), int(train), stream_ptr())
-        rec = part("dec_rec").sum(0)[:B]
+        rec = nbpart("dec_rec").sum(0)[:B]
         loss = (rec * w_row).sum()
         if train:
             ctx.P, ctx.ws, ctx.nsplit, ctx.dims = P, ws, nsplit, (B, G, Bp, Gp, n_p, n_s, KM, KMp, m.shape[1])
             ctx.keep = (Wm_hi, Wm_lo, Am_hi, Am_lo, Wps_hi, Wps_lo, Aps_hi, Aps_lo, dL, tP, tS, dth, lse_p, lse_s, gene_tab)
-            ctx.Tp, ctx.Ts = part("dec_tp").sum(0), part("dec_ts").sum(0)
+            ctx.Tp, ctx.Ts = nbpart("dec_tp").sum(0), nbpart("dec_ts").sum(0)
             ctx.grads_f32, ctx.done = grads_f32, False
             ctx.save_for_backward(px_r)
         ctx.mark_non_differentiable(rec)
