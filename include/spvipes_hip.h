@@ -133,7 +133,7 @@ int spv_dec_tables(const float* px_r, int32_t G, int32_t Gp, void* gene_tab, voi
  * (the cast away of const on those four pointers is deliberate: they are this call's outputs). */
 int spv_dec_lse(const spv_dec_params* p, const float* library, void* stream);
 
-/* rec_part/tp_part/ts_part [nb_splits][Bp], dtheta_part [Bp/16][Gp]; when train != 0 also the
+/* rec_part/tp_part/ts_part [nb_splits][Bp], dtheta_part [Bp/64][Gp]; when train != 0 also the
  * per-element gradients dL, tP, tS (accumulator-tile order; bf16, or fp32 when grads_f32). */
 int spv_dec_nb_fwd(const spv_dec_params* p, int32_t train, void* stream);
 
@@ -234,7 +234,7 @@ typedef struct spv_poe_args {
   const float* eps[2];                     /* [B][n] */
   float* loc[2]; float* logvar[2]; float* scale[2]; float* logz[2]; float* theta[2]; float* kl[2];
   const float* g_loc[2]; const float* g_logvar[2]; const float* g_scale[2]; const float* g_logz[2]; const float* g_kl[2];
-  float* d_stats[2];                       /* backward output, same layout as stats, ZERO-INITIALISED by the caller */
+  float* d_stats[2];                       /* backward output, same layout as stats (zeroed by the call itself) */
   int32_t B[2]; int32_t n;
 } spv_poe_args;
 int spv_poe_fuse_fwd(const spv_poe_args* a, void* stream);
@@ -269,6 +269,30 @@ typedef struct spv_fold_prob {
 typedef struct spv_fold_batch { spv_fold_prob p[SPV_MAXP]; int32_t nprob, B, training; float eps, momentum; } spv_fold_batch;
 int spv_bn_fold_fwd(const spv_fold_batch* a, void* stream);
 int spv_bn_fold_bwd(const spv_fold_batch* a, void* stream);   /* fold backward + the z-statistics backward */
+
+/* ---------------------------------------------------------------------------------------------
+ * Deterministic slab reduction (the tail of every split-K GEMM and of the per-wave partials):
+ *   dst[r][c] (+)= alpha * escale(c) * sum_s src[s * slab_stride + r * ld_src + col_off + c]
+ * slabs are added in index order inside four fixed interleaved groups.  alpha: optional device scalar
+ * (the upstream gradient of the loss); exp_scale: optional per-column log-scale, multiplies by
+ * exp(exp_scale[c]) (d px_r = exp(px_r) * d theta, module/spVIPESmodule.py:758).
+ * ------------------------------------------------------------------------------------------- */
+#define SPV_MAXR 16
+typedef struct spv_reduce_prob {
+  const float* src; int64_t slab_stride; int64_t ld_src; int32_t nslabs; int32_t col_off;
+  int32_t rows, cols;
+  float* dst; int64_t ld_dst; int32_t accumulate; int32_t pad_;
+  const float* alpha; const float* exp_scale;
+} spv_reduce_prob;
+typedef struct spv_reduce_batch { spv_reduce_prob p[SPV_MAXR]; int32_t nprob; } spv_reduce_batch;
+int spv_reduce_slabs(const spv_reduce_batch* b, void* stream);
+
+/* Loss assembly (module/spVIPESmodule.py:870-872): rec_sum = sum_g sum_b w[b] * rec[g][b] and
+ *   loss = rec_sum + (kl_weight / B) * sum_b sum_i kl[i][b]   (i < nkl <= 4 KL vectors of length B);
+ * also writes gkl[b] = kl_weight / B, the gradient of the loss w.r.t. every kl[i][b].
+ * kl_weight is read from device memory (one float) so a captured graph sees later updates. */
+int spv_loss_assemble(const float* rec0, const float* rec1, const float* w, const float* const* kl, int32_t nkl, int32_t B,
+                      const float* kl_weight, float* loss, float* rec_sum, float* gkl, void* stream);
 
 #ifdef __cplusplus
 }

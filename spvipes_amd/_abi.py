@@ -39,6 +39,19 @@ class SpvDecParams(C.Structure):
     ]
 
 
+class SpvReduceProb(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("slab_stride", C.c_int64), ("ld_src", C.c_int64), ("nslabs", C.c_int32), ("col_off", C.c_int32),
+                ("rows", C.c_int32), ("cols", C.c_int32), ("dst", C.c_void_p), ("ld_dst", C.c_int64), ("accumulate", C.c_int32),
+                ("pad_", C.c_int32), ("alpha", C.c_void_p), ("exp_scale", C.c_void_p)]
+
+
+SPV_MAXR = 16
+
+
+class SpvReduceBatch(C.Structure):
+    _fields_ = [("p", SpvReduceProb * SPV_MAXR), ("nprob", C.c_int32)]
+
+
 SPV_MAXP = 8
 BN_ROWS = 64  # rows per workgroup of the BatchNorm kernels (sizes their partial-sum workspace)
 
@@ -133,6 +146,9 @@ _SIGNATURES = {
     "spv_zsplit_bwd": (C.c_int, [C.POINTER(SpvZsplitArgs), C.c_void_p]),
     "spv_bn_fold_fwd": (C.c_int, [C.POINTER(SpvFoldBatch), C.c_void_p]),
     "spv_bn_fold_bwd": (C.c_int, [C.POINTER(SpvFoldBatch), C.c_void_p]),
+    "spv_reduce_slabs": (C.c_int, [C.POINTER(SpvReduceBatch), C.c_void_p]),
+    "spv_loss_assemble": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     "spv_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float,
                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
 }

@@ -507,6 +507,9 @@ extern "C" int spv_poe_fuse_bwd(const spv_poe_args* a, void* stream) {
   if (rc) return rc;
   for (int g = 0; g < 2; ++g) if (!a->d_stats[g]) return fail(SPV_ERR_ARG, "spv_poe_fuse_bwd: null output%s");
   const int Bm = a->B[0] > a->B[1] ? a->B[0] : a->B[1];
+  for (int g = 0; g < 2; ++g)  // the kernel accumulates (own expert + partner's): start from zero
+    if (hipMemsetAsync(a->d_stats[g], 0, (size_t)a->B[g] * a->ld[g] * sizeof(float), (hipStream_t)stream) != hipSuccess)
+      return fail(SPV_ERR_LAUNCH, "spv_poe_fuse_bwd: memset failed%s");
   hipLaunchKernelGGL(poe_fuse_bwd_kernel, dim3((Bm + 7) / 8, 2), dim3(256), 0, (hipStream_t)stream, *a);
   return launch_status("spv_poe_fuse_bwd");
 }
@@ -563,3 +566,30 @@ extern "C" int spv_bn_fold_bwd(const spv_fold_batch* a, void* stream) {
   if (a->training) hipLaunchKernelGGL(zstats_bwd_kernel, dim3((a->B + 255) / 256, a->nprob), dim3(256), 0, s, *a);
   return launch_status("spv_bn_fold_bwd");
 }
+
+extern "C" int spv_reduce_slabs(const spv_reduce_batch* b, void* stream) {
+  if (!b || b->nprob <= 0 || b->nprob > SPV_MAXR) return fail(SPV_ERR_ARG, "spv_reduce_slabs: bad batch%s");
+  long most = 0;
+  for (int i = 0; i < b->nprob; ++i) {
+    const spv_reduce_prob& q = b->p[i];
+    if (!q.src || !q.dst || q.nslabs <= 0 || q.rows <= 0 || q.cols <= 0 || q.ld_src < q.col_off + q.cols || q.ld_dst < q.cols || q.col_off < 0)
+      return fail(SPV_ERR_ARG, "spv_reduce_slabs: bad problem%s");
+    const long t = (long)q.rows * q.cols;
+    if (t > most) most = t;
+  }
+  long blocks = (most + 63) / 64;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks, b->nprob), dim3(256), 0, (hipStream_t)stream, *b);
+  return launch_status("spv_reduce_slabs");
+}
+
+extern "C" int spv_loss_assemble(const float* rec0, const float* rec1, const float* w, const float* const* kl, int32_t nkl, int32_t B,
+                                 const float* kl_weight, float* loss, float* rec_sum, float* gkl, void* stream) {
+  if (!rec0 || !w || !loss || B <= 0 || nkl < 0 || nkl > 4 || (nkl > 0 && !kl)) return fail(SPV_ERR_ARG, "spv_loss_assemble: bad arguments%s");
+  const float* k[4] = {nullptr, nullptr, nullptr, nullptr};
+  for (int i = 0; i < nkl; ++i) k[i] = kl[i];   // kl is a HOST array of device pointers
+  hipLaunchKernelGGL(loss_assemble_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, rec0, rec1, w, k[0], k[1], k[2], k[3], B, kl_weight,
+                     loss, rec_sum, gkl);
+  return launch_status("spv_loss_assemble");
+}
+

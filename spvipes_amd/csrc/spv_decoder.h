@@ -54,7 +54,7 @@ struct DecParams {
   int gene_splits; int genes_per_split;      // multiples of 32
   float* part_max_p; float* part_sum_p; float* part_max_s; float* part_sum_s;  // [splits][Bp]  (lse)
   float* rec_part; float* tp_part; float* ts_part;                             // [nb_splits][Bp]  (nb)
-  float* dtheta_part;           // [Bp/16][Gp]  one partial row per 16-cell wave tile
+  float* dtheta_part;           // [Bp/64][Gp]  one partial row per 64-cell workgroup
   void* dL; void* tP; void* tS; int grads_f32;                                 // tiled like logits; bf16 or f32
   int nb_splits; int nb_genes_per_split;     // gene splits of the likelihood kernel (multiple of 32, <= NB_GSPL_MAX)
 };
@@ -311,12 +311,13 @@ __device__ __forceinline__ float half_sum16(const float (&v)[16], int lane) {
 typedef __attribute__((ext_vector_type(4))) float f4acc;
 constexpr int NB_GSPL_MAX = 160;     // genes per split: their regressor weights (hi/lo) and gene table live in LDS
 constexpr int NB_WPITCH = 56;        // LDS row pitch of the weight slice in bf16 (112 B: conflict-free 16-B row reads)
-constexpr int NB_CELLS_PER_WG = 64;  // 4 waves x 1 tile of 16 cells
+constexpr int NB_CELLS_PER_WG = 64;  // 4 waves x one 16-cell tile
 
 template <bool TRAIN, typename GT, typename LT, int CM>
 __global__ __launch_bounds__(256, 3) void dec_nb_kernel(DecParams p) {
   __shared__ __attribute__((aligned(16))) bf16_t s_whi[NB_GSPL_MAX * NB_WPITCH], s_wlo[NB_GSPL_MAX * NB_WPITCH];
   __shared__ float4 s_gt[NB_GSPL_MAX];
+  __shared__ float s_dth[TRAIN ? 4 : 1][NB_GSPL_MAX];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c16 = lane & 15, gq = lane >> 4;              // cell within the wave's 16, gene group within a chunk
   const int split = blockIdx.y;
@@ -344,10 +345,9 @@ __global__ __launch_bounds__(256, 3) void dec_nb_kernel(DecParams p) {
   __syncthreads();
   const int nchunks = ng >> 4;
 
-  for (int t = 0; t < NB_CELLS_PER_WG / 64; ++t) {
-    const int tile16 = blockIdx.x * (NB_CELLS_PER_WG / 16) + 4 * t + wave;   // 16-cell tile of this wave
+  {
+    const int tile16 = blockIdx.x * (NB_CELLS_PER_WG / 16) + wave;   // 16-cell tile of this wave (Bp % 64 == 0: always inside)
     const int cell = tile16 * 16 + c16;
-    if (tile16 * 16 >= p.Bp) break;
     const int cell_tile = tile16 >> 1, chh = tile16 & 1;   // 32-cell storage tile and which half of it
     const bool cell_ok = cell < p.B;
     // resident cell-side fragments: B[k = 8 gq + i][col = cell]
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256, 3) void dec_nb_kernel(DecParams p) {
         float s = (u2 ? a1 : a0) + __shfl_xor(u2 ? a0 : a1, 4, 64);
         s += __shfl_xor(s, 2, 64);
         s += __shfl_xor(s, 1, 64);
-        if ((lane & 3) == 0) p.dtheta_part[(long)tile16 * p.Gp + gq0 + 2 * ((lane >> 3) & 1) + ((lane >> 2) & 1)] = s;
+        if ((lane & 3) == 0) s_dth[wave][16 * c + 4 * gq + 2 * ((lane >> 3) & 1) + ((lane >> 2) & 1)] = s;
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) { ellA[j] = ellB[j]; tabA[j] = tabB[j]; }
@@ -496,6 +496,11 @@ __global__ __launch_bounds__(256, 3) void dec_nb_kernel(DecParams p) {
       p.rec_part[o] = rec;
       if constexpr (TRAIN) { p.tp_part[o] = tp_sum; p.ts_part[o] = ts_sum; }
     }
+  }
+  if constexpr (TRAIN) {  // per-gene d theta over the workgroup's 64 cells: the four waves' partials in wave order
+    __syncthreads();
+    for (int i = tid; i < ng; i += 256)
+      p.dtheta_part[(long)blockIdx.x * p.Gp + gbeg + i] = ((s_dth[0][i] + s_dth[1][i]) + s_dth[2][i]) + s_dth[3][i];
   }
 }
 

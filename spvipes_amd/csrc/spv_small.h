@@ -521,7 +521,7 @@ __global__ __launch_bounds__(256) void poe_fuse_fwd_kernel(PoeArgs a) {
   if (b < a.B[g] && d == 0) a.kl[g][b] = kl;
 }
 
-// d_stats[g] (same [B][ld] layout as stats[g], ZERO-INITIALISED by the caller) receives the gradient of a
+// d_stats[g] (same [B][ld] layout as stats[g], zeroed by spv_poe_fuse_bwd before the launch) receives the gradient of a
 // cell's own expert and, through its partner, of the other group's cell: at most two adds per element.
 __global__ __launch_bounds__(256) void poe_fuse_bwd_kernel(PoeArgs a) {
   const int g = blockIdx.y, o = 1 - g;
@@ -714,6 +714,73 @@ __global__ __launch_bounds__(256) void zstats_bwd_kernel(FoldBatch a) {
     float v = s_dz[k];
     for (int l = 0; l < K; ++l) v += s_S[k * K + l] * (zrow[l] - s_zbar[l]);
     q.dz[(long)b * q.lddz + k] += v;
+  }
+}
+
+
+// ---- deterministic slab reduction ------------------------------------------------------------------
+// block = 64 elements x 4 slab groups; group y adds slabs y, y+4, ... in order, the four group sums are
+// then added in order.
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(spv_reduce_batch b) {
+  __shared__ float s_part[4][64];
+  const spv_reduce_prob& q = b.p[blockIdx.y];
+  const long total = (long)q.rows * q.cols;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const float alpha = q.alpha ? *q.alpha : 1.f;
+  for (long base = (long)blockIdx.x * 64; base < total; base += (long)gridDim.x * 64) {  // block-uniform trip count
+    const long i = base + tx;
+    const bool ok = i < total;
+    int r = 0, c = 0;
+    float acc = 0.f;
+    if (ok) {
+      r = (int)(i / q.cols); c = (int)(i - (long)r * q.cols);
+      const float* s = q.src + (long)r * q.ld_src + q.col_off + c;
+#pragma unroll 4
+      for (int k = ty; k < q.nslabs; k += 4) acc += s[(long)k * q.slab_stride];
+    }
+    s_part[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && ok) {
+      float v = ((s_part[0][tx] + s_part[1][tx]) + s_part[2][tx]) + s_part[3][tx];
+      v *= alpha;
+      if (q.exp_scale) v *= expf(q.exp_scale[c]);
+      float* d = q.dst + (long)r * q.ld_dst + c;
+      *d = q.accumulate ? *d + v : v;
+    }
+    __syncthreads();
+  }
+}
+
+// ---- loss assembly: one workgroup, fixed-order tree --------------------------------------------------------
+__global__ __launch_bounds__(1024) void loss_assemble_kernel(const float* rec0, const float* rec1, const float* w, const float* kl0,
+                                                             const float* kl1, const float* kl2, const float* kl3, int B,
+                                                             const float* kl_weight, float* loss, float* rec_sum, float* gkl) {
+  __shared__ float s_r[1024], s_k[1024];
+  const int t = threadIdx.x;
+  float ar = 0.f, ak = 0.f;
+  const float klw = kl_weight ? *kl_weight : 1.f;
+  const float gk = klw / (float)B;
+  for (int i = t; i < B; i += 1024) {
+    const float wi = w[i];
+    ar += wi * rec0[i];
+    if (rec1) ar += wi * rec1[i];
+    float k = 0.f;
+    if (kl0) k += kl0[i];
+    if (kl1) k += kl1[i];
+    if (kl2) k += kl2[i];
+    if (kl3) k += kl3[i];
+    ak += k;
+    if (gkl) gkl[i] = gk;
+  }
+  s_r[t] = ar; s_k[t] = ak;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (t < o) { s_r[t] += s_r[t + o]; s_k[t] += s_k[t + o]; }
+    __syncthreads();
+  }
+  if (t == 0) {
+    if (rec_sum) *rec_sum = s_r[0];
+    *loss = s_r[0] + gk * s_k[0];
   }
 }
 

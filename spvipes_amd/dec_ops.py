@@ -17,10 +17,10 @@ from typing import List, Sequence
 import torch
 
 from . import _abi
-from ._abi import (DEC_CELLS_PER_WG, DEC_KP, DEC_KPS, DEC_KS, NB_CMAX, SpvBnBatch, SpvDecParams, SpvFoldBatch, SpvZsplitArgs, ptr,
-                   round_up, stream_ptr)
+from ._abi import (DEC_CELLS_PER_WG, DEC_KP, DEC_KPS, DEC_KS, NB_CMAX, SpvBnBatch, SpvDecParams, SpvFoldBatch, SpvReduceBatch, SpvZsplitArgs,
+                   ptr, round_up, stream_ptr)
 from .nn_ops import _add_lin, _fptr, _lin_batch, _wgrad, grad_out
-from .ops import N_HIDDEN_MIX, GroupCounts, Workspace, _bf16_image, _gemm, _gene_splits, _nb_splits, _pack
+from .ops import N_HIDDEN_MIX, GroupCounts, Workspace, _bf16_image, _gemm_slabs, _gene_splits, _nb_splits, _pack
 
 N_DEC_PARAMS = 13  # Wp, gamma_p, beta_p, Ws, gamma_s, beta_s, Wa, ba, gamma_a, beta_a, Wm, bm, px_r
 KMP = 320
@@ -32,16 +32,38 @@ def decoder_params(dec, px_r) -> List[torch.Tensor]:
             tr.linear.weight, tr.linear.bias, tr.bn.weight, tr.bn.bias, mx.linear.weight, mx.linear.bias, px_r]
 
 
+def _add_red(b: SpvReduceBatch, src: torch.Tensor, nslabs: int, slab_stride: int, ld_src: int, rows: int, cols: int, dst: torch.Tensor,
+             ld_dst: int, *, col_off: int = 0, dst_col: int = 0, accumulate: bool = False, alpha=None, exp_scale=None) -> None:
+    """one problem of spv_reduce_slabs: dst[r][dst_col + c] (+)= alpha * exp(exp_scale[c]) * sum_s src[s][r][col_off + c]"""
+    q = b.p[b.nprob]
+    q.src, q.slab_stride, q.ld_src, q.nslabs, q.col_off, q.rows, q.cols = ptr(src), slab_stride, ld_src, nslabs, col_off, rows, cols
+    q.dst, q.ld_dst, q.accumulate = dst.data_ptr() + 4 * dst_col, ld_dst, int(accumulate)
+    q.alpha, q.exp_scale = ptr(alpha), ptr(exp_scale)
+    b.nprob += 1
+
+
+def _run_red(b: SpvReduceBatch) -> None:
+    if b.nprob:
+        _abi.call("spv_reduce_slabs", C.byref(b), stream_ptr())
+
+
 class DecoderFused(torch.autograd.Function):
-    """inputs : per group (private_log_z [B,n_p], poe_log_z [B,n_s]) then per group its 13 parameters
-    outputs: (sum_g sum_b w_b rec_gb, rec_0 [B], rec_1 [B])   -- rec_g detached"""
+    """inputs : per group (private_log_z [B,n_p], poe_log_z [B,n_s]), per group its 13 parameters, then n_kl KL
+             vectors [B] (module/spVIPESmodule.py:841-868) that the loss adds with weight kl_weight / B
+    outputs: (loss, sum_g sum_b w_b rec_gb, rec_0 [B], rec_1 [B])   -- all but loss detached
+    ``w_pad``: the per-cell weights of the reconstruction term, length >= Bp, zero beyond B.
+    ``klw``  : 0-dim fp32 device tensor (read at run time: a captured graph sees later updates)."""
 
     @staticmethod
-    def forward(ctx, counts: Sequence[GroupCounts], rows, B: int, decoders, library: Sequence[torch.Tensor], w_row: torch.Tensor,
-                training: bool, nsplit: int, ws: Sequence[Workspace], *tensors):
+    def forward(ctx, counts: Sequence[GroupCounts], rows, B: int, decoders, library: Sequence[torch.Tensor], w_pad: torch.Tensor,
+                training: bool, nsplit: int, ws: Sequence[Workspace], klw: torch.Tensor, n_kl: int, *tensors):
         NG = 2
+        ctx.set_materialize_grads(False)
         lat = [(tensors[2 * g], tensors[2 * g + 1]) for g in range(NG)]
         par = [tensors[2 * NG + g * N_DEC_PARAMS: 2 * NG + (g + 1) * N_DEC_PARAMS] for g in range(NG)]
+        kls = [t if (t.is_contiguous() and t.dtype == torch.float32) else t.contiguous().float() for t in tensors[2 * NG + NG * N_DEC_PARAMS:]]
+        if len(kls) != n_kl or n_kl > 4:
+            raise _abi.SpvError("DecoderFused: expected n_kl <= 4 KL vectors after the parameters")
         dev = lat[0][0].device
         n_p, n_s = lat[0][0].shape[1], lat[0][1].shape[1]
         nt = n_p + n_s
@@ -112,12 +134,13 @@ class DecoderFused(torch.autograd.Function):
             q.part = ptr(ws[g].get("trunk_bn_part", (nblk, n_m, 2), torch.float32))
         _abi.call("spv_bn_fwd", C.byref(bn), stream_ptr())
         # ---- 5. per group: operand images, tables, logits GEMM, softmax statistics, likelihood ------
-        w_pad = ws[0].get("dec_w_row", (Bp,), torch.float32, zero=True)
-        w_pad[:B].copy_(w_row)
+        if w_pad.numel() < Bp or w_pad.dtype != torch.float32 or not w_pad.is_contiguous():
+            raise _abi.SpvError("DecoderFused: w_pad must be contiguous fp32 of length >= round_up(B, 128)")
         grads_f32 = bool(need_grad and mlo)
         gdt, gname = (torch.float32, "f32") if grads_f32 else (torch.int16, "bf16")
         P, rec, saved_g = [], [], []
-        loss = None
+        red = SpvReduceBatch()
+        red.nprob = 0
         for g in range(NG):
             G, Gp, wsg = Gs[g], Gps[g], ws[g]
             Wm_hi, Wm_lo = _bf16_image(wsg, "dec_Wm", Gp, KMP, mlo)
@@ -142,9 +165,10 @@ class DecoderFused(torch.autograd.Function):
                 dL = wsg.get("dec_dL_" + gname, (Bp, Gp), gdt, zero=True)
                 tP = wsg.get("dec_tP_" + gname, (Bp, Gp), gdt, zero=True)
                 tS = wsg.get("dec_tS_" + gname, (Bp, Gp), gdt, zero=True)
-                dth = wsg.get("dec_dtheta", (Bp // 16, Gp), torch.float32, zero=True)
+                dth = wsg.get("dec_dtheta", (Bp // 64, Gp), torch.float32, zero=True)
+                Tp, Ts = wsg.get("dec_Tp", (Bp,), torch.float32), wsg.get("dec_Ts", (Bp,), torch.float32)
             else:
-                dL = tP = tS = dth = None
+                dL = tP = tS = dth = Tp = Ts = None
             lse_p, lse_s, a_p, a_s = vec("dec_lse_p"), vec("dec_lse_s"), vec("dec_a_p"), vec("dec_a_s")
             cst = counts[g].c_struct(rows[g])
             p = SpvDecParams(
@@ -159,24 +183,29 @@ class DecoderFused(torch.autograd.Function):
             )
             _abi.call("spv_dec_lse", C.byref(p), ptr(cont(library[g].flatten())), stream_ptr())
             _abi.call("spv_dec_nb_fwd", C.byref(p), int(need_grad), stream_ptr())
-            r = nbpart("dec_rec").sum(0)[:B]
+            r = new(B)
             rec.append(r)
-            l = (r * w_row).sum()
-            loss = l if loss is None else loss + l
+            _add_red(red, nbpart("dec_rec"), nbs, Bp, Bp, 1, B, r, B)
+            if need_grad:
+                _add_red(red, nbpart("dec_tp"), nbs, Bp, Bp, 1, Bp, Tp, Bp)
+                _add_red(red, nbpart("dec_ts"), nbs, Bp, Bp, 1, Bp, Ts, Bp)
             P.append(p)
             if need_grad:
-                saved_g.append(dict(Wm=(Wm_hi, Wm_lo), Am=(Am_hi, Am_lo), Aps=(Aps_hi, Aps_lo), dL=dL, tP=tP, tS=tS, dth=dth,
-                                    Tp=nbpart("dec_tp").sum(0), Ts=nbpart("dec_ts").sum(0)))
+                saved_g.append(dict(Wm=(Wm_hi, Wm_lo), Am=(Am_hi, Am_lo), Aps=(Aps_hi, Aps_lo), dL=dL, tP=tP, tS=tS, dth=dth, Tp=Tp, Ts=Ts))
+        _run_red(red)
+        loss, rec_sum, gkl = new(()), new(()), new(B)
+        klp = (C.c_void_p * 4)(*[ptr(k) for k in kls], *([None] * (4 - n_kl)))
+        _abi.call("spv_loss_assemble", ptr(rec[0]), ptr(rec[1]), ptr(w_pad), klp, n_kl, B, ptr(klw), ptr(loss), ptr(rec_sum), ptr(gkl), stream_ptr())
         if need_grad:
             ctx.P, ctx.saved_g, ctx.ws, ctx.decoders, ctx.training, ctx.nsplit = P, saved_g, ws, decoders, training, nsplit
             ctx.dims = (B, Bp, Gs, Gps, n_p, n_s, n_m, KM)
             ctx.grads_f32, ctx.done, ctx.keep = grads_f32, False, keep
             ctx.Wps, ctx.fb = Wps, fb
             ctx.small = (zcat, zsum, zz, fstat, pre_a, m, tstat)
-            ctx.save_for_backward(*tensors)
-        for r in rec:
-            ctx.mark_non_differentiable(r)
-        return (loss, *rec)
+            ctx.gkl, ctx.n_kl = gkl, n_kl
+            ctx.save_for_backward(*tensors[:2 * NG + NG * N_DEC_PARAMS])
+        ctx.mark_non_differentiable(rec_sum, *rec)
+        return (loss, rec_sum, *rec)
 
     @staticmethod
     def backward(ctx, g_loss, *_g_rec):
@@ -192,7 +221,13 @@ class DecoderFused(torch.autograd.Function):
         zcat, zsum, zz, fstat, pre_a, m, tstat = ctx.small
         dev = zcat[0].device
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        d_zcat, dWm, dWp, dWs, dAm, d_pxr = [], [], [], [], [], []
+        if g_loss is None:
+            raise _abi.SpvError("DecoderFused.backward: the loss output received no gradient")
+        g_loss = g_loss if (g_loss.dtype == torch.float32 and g_loss.is_contiguous()) else g_loss.float().contiguous()
+        pg = [[grad_out(par[g][j]) for j in range(N_DEC_PARAMS)] for g in range(NG)]  # (kernel target, autograd return) per parameter
+        d_zcat, dWp, dWs, dAm = [], [], [], []
+        red, red2 = SpvReduceBatch(), SpvReduceBatch()
+        red.nprob = red2.nprob = 0
         for g in range(NG):
             G, Gp, wsg, S, P = Gs[g], Gps[g], ws[g], ctx.saved_g[g], ctx.P[g]
             _abi.call("spv_dec_softmax_bwd", C.byref(P), ptr(S["Tp"]), ptr(S["Ts"]), stream_ptr())
@@ -205,28 +240,38 @@ class DecoderFused(torch.autograd.Function):
             else:
                 dL_hi, tP_hi, tS_hi, dL_lo, tP_lo, tS_lo = S["dL"], S["tP"], S["tS"], None, None, None
             T = Gp // 32
-            # K splits (fp32 slabs, summed in order) sized for >= ~2 workgroups per CU: these GEMMs stream a
-            # [B,G] array once and are latency-bound with fewer resident workgroups
+            # K splits (fp32 slabs, reduced in order by spv_reduce_slabs) sized for >= ~2 workgroups per CU: these
+            # GEMMs stream a [B,G] array once and are latency-bound with fewer resident workgroups
             bt = Bp // 32
             ksp_m, ksp_n = max(1, min(T // 8, -(-512 // max(Bp // 64, 1)))), max(1, min(T // 8, -(-512 // max(Bp // 128, 1))))
             csp_m, csp_n = max(1, min(bt // 8, -(-512 // max(Gp // 64, 1)))), max(1, min(bt // 8, -(-512 // max(Gp // 128, 1))))
             (Wm_hi, Wm_lo), (Am_hi, Am_lo), (Aps_hi, Aps_lo) = S["Wm"], S["Am"], S["Aps"]
-            a = _gemm(True, dL_hi, dL_lo, Gp, Am_hi, Am_lo, KMP, G, KMP, Bp, nsplit, csp_m, wsg, "dec_dWm", a_tiles=T)
-            b_ = _gemm(True, tP_hi, tP_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KP, Bp, nsplit, csp_n, wsg, "dec_dWp", a_tiles=T)
-            c = _gemm(True, tS_hi, tS_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KS, Bp, nsplit, csp_n, wsg, "dec_dWs", b_col_off=DEC_KP, a_tiles=T)
-            d = _gemm(False, dL_hi, dL_lo, Gp, Wm_hi, Wm_lo, KMP, B, KMP, G, nsplit, ksp_m, wsg, "dec_dAm", a_tiles=T)
-            e = _gemm(False, tP_hi, tP_lo, Gp, ctx.Wps[g][0], ctx.Wps[g][1], DEC_KPS, B, DEC_KP, G, nsplit, ksp_n, wsg, "dec_dAp", a_tiles=T)
-            f = _gemm(False, tS_hi, tS_lo, Gp, ctx.Wps[g][0], ctx.Wps[g][1], DEC_KPS, B, DEC_KS, G, nsplit, ksp_n, wsg, "dec_dAs", b_col_off=DEC_KP, a_tiles=T)
-            for t in (a, b_, c, d, e, f):
-                t.mul_(g_loss)
-            dWm.append(a); dWp.append(b_); dWs.append(c); dAm.append(d)
+            a = _gemm_slabs(True, dL_hi, dL_lo, Gp, Am_hi, Am_lo, KMP, G, KMP, Bp, nsplit, csp_m, wsg, "dec_dWm", a_tiles=T)
+            b_ = _gemm_slabs(True, tP_hi, tP_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KP, Bp, nsplit, csp_n, wsg, "dec_dWp", a_tiles=T)
+            c = _gemm_slabs(True, tS_hi, tS_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KS, Bp, nsplit, csp_n, wsg, "dec_dWs", b_col_off=DEC_KP, a_tiles=T)
+            d = _gemm_slabs(False, dL_hi, dL_lo, Gp, Wm_hi, Wm_lo, KMP, B, KMP, G, nsplit, ksp_m, wsg, "dec_dAm", a_tiles=T)
+            e = _gemm_slabs(False, tP_hi, tP_lo, Gp, ctx.Wps[g][0], ctx.Wps[g][1], DEC_KPS, B, DEC_KP, G, nsplit, ksp_n, wsg, "dec_dAp", a_tiles=T)
+            f = _gemm_slabs(False, tS_hi, tS_lo, Gp, ctx.Wps[g][0], ctx.Wps[g][1], DEC_KPS, B, DEC_KS, G, nsplit, ksp_n, wsg, "dec_dAs", b_col_off=DEC_KP, a_tiles=T)
+            # slab sums, scaled by the upstream gradient, straight into their consumers' buffers
+            al = g_loss
+            _add_red(red, a, csp_m, G * KMP, KMP, G, KM - 1, pg[g][10][0], KM - 1, alpha=al)                 # d W_m
+            _add_red(red, a, csp_m, G * KMP, KMP, G, 1, pg[g][11][0], 1, col_off=KM - 1, alpha=al)           # d b_m
+            dwp, dws_, dam, dz = new(G, DEC_KP), new(G, DEC_KS), new(B, n_m), new(B, nt)
+            _add_red(red, b_, csp_n, G * DEC_KP, DEC_KP, G, DEC_KP, dwp, DEC_KP, alpha=al)                    # d [W'_p | c_p]
+            _add_red(red, c, csp_n, G * DEC_KS, DEC_KS, G, DEC_KS, dws_, DEC_KS, alpha=al)                    # d [W'_s | c_s]
+            _add_red(red, d, ksp_m, B * KMP, KMP, B, n_m, dam, n_m, alpha=al)                                 # d m (trunk output)
             # gradient reaching zcat directly: through the logits GEMM (columns n_m..) and the two regressors
-            d_zcat.append((d[:, n_m:n_m + nt] + torch.cat([e[:, :n_p], f[:, :n_s]], dim=1)).contiguous())
-            d_pxr.append(torch.exp(par[g][12]) * S["dth"].sum(0)[:G] * g_loss)
+            _add_red(red, d, ksp_m, B * KMP, KMP, B, nt, dz, nt, col_off=n_m, alpha=al)
+            _add_red(red2, e, ksp_n, B * DEC_KP, DEC_KP, B, n_p, dz, nt, accumulate=True, alpha=al)
+            _add_red(red2, f, ksp_n, B * DEC_KS, DEC_KS, B, n_s, dz, nt, dst_col=n_p, accumulate=True, alpha=al)
+            # d px_r = exp(px_r) * d theta (theta = exp(px_r): module/spVIPESmodule.py:758)
+            _add_red(red, S["dth"], Bp // 64, Gp, Gp, 1, G, pg[g][12][0], G, alpha=al, exp_scale=par[g][12])
+            dWp.append(dwp); dWs.append(dws_); dAm.append(dam); d_zcat.append(dz)
+        _run_red(red)
+        _run_red(red2)
         # ---- trunk backward (BatchNorm + relu, Linear) ----------------------------------------------
         nblk = -(-B // _abi.BN_ROWS)
         d_pre = [new(B, n_m) for _ in range(NG)]
-        pg = [[grad_out(par[g][j]) for j in range(10)] for g in range(NG)]  # small-layer parameters: Wp..beta_a
         d_gam_a, d_bet_a = [pg[g][8][0] for g in range(NG)], [pg[g][9][0] for g in range(NG)]
         bn = SpvBnBatch()
         bn.nprob, bn.B, bn.training, bn.relu, bn.eps, bn.momentum = NG, B, int(training), 1, 1e-3, 0.01
@@ -236,7 +281,7 @@ class DecoderFused(torch.autograd.Function):
             q.X, q.ldx, q.Y, q.ldy, q.gamma, q.beta = ptr(pre_a[g]), n_m, ptr(m[g]), n_m, ptr(par[g][8]), ptr(par[g][9])
             q.running_mean, q.running_var, q.stats, q.N = ptr(tb.running_mean), ptr(tb.running_var), ptr(tstat[g]), n_m
             q.part = ptr(ws[g].get("trunk_bn_part", (nblk, n_m, 2), torch.float32))
-            q.dY, q.lddy, q.dX, q.lddx, q.dgamma, q.dbeta = ptr(dAm[g]), KMP, ptr(d_pre[g]), n_m, ptr(d_gam_a[g]), ptr(d_bet_a[g])
+            q.dY, q.lddy, q.dX, q.lddx, q.dgamma, q.dbeta = ptr(dAm[g]), n_m, ptr(d_pre[g]), n_m, ptr(d_gam_a[g]), ptr(d_bet_a[g])
         _abi.call("spv_bn_bwd", C.byref(bn), stream_ptr())
         dWa, dba = [pg[g][6][0] for g in range(NG)], [pg[g][7][0] for g in range(NG)]
         bw, bd = _lin_batch(B), _lin_batch(B, accumulate=True)
@@ -270,5 +315,8 @@ class DecoderFused(torch.autograd.Function):
         for g in range(NG):
             grads += [d_priv[g], d_poe[g]]
         for g in range(NG):
-            grads += [pg[g][j][1] for j in range(10)] + [dWm[g][:, :KM - 1], dWm[g][:, KM - 1], d_pxr[g]]
-        return (None,) * 9 + tuple(grads)
+            grads += [pg[g][j][1] for j in range(N_DEC_PARAMS)]
+        if ctx.n_kl:
+            gk = ctx.gkl * g_loss  # d loss / d kl_i[b] = kl_weight / B for every KL vector
+            grads += [gk] * ctx.n_kl
+        return (None,) * 11 + tuple(grads)

@@ -30,6 +30,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import _abi
+from ._abi import DEC_CELLS_PER_WG, round_up
 from .ops import N_HIDDEN_MIX, EncoderFC1, GroupCounts, Workspace
 
 X_KEY, BATCH_KEY = "X", "batch"  # scvi.REGISTRY_KEYS.X_KEY / BATCH_KEY
@@ -47,6 +48,33 @@ class LossOutput:
 
 
 # ---- parameter containers with the reference's state_dict layout ---------------------------------
+class _LazyMeans(dict):
+    """extra_metrics of LossOutput (spVIPESmodule.py:884-897): batch means, evaluated when first read so that a
+    training step that never logs them launches nothing for them."""
+
+    def __init__(self, vectors):
+        super().__init__()
+        self._vectors = dict(vectors)
+        for k in vectors:
+            dict.__setitem__(self, k, None)
+
+    def __getitem__(self, k):
+        v = dict.__getitem__(self, k)
+        if v is None and k in self._vectors:
+            v = self._vectors[k].detach().mean()
+            dict.__setitem__(self, k, v)
+        return v
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+
 class Encoder(nn.Module):
     """Parameters of nn/networks.py:47-83 (forward lives in spVIPESmodule.inference)."""
 
@@ -354,18 +382,28 @@ class spVIPESmodule(nn.Module):
         if B0 != B1:
             raise RuntimeError(f"The size of tensor a ({B0}) must match the size of tensor b ({B1}) at non-singleton dimension 0")
         dev = inference_outputs["library"][0].device
-        w = torch.full((B0,), 1.0 / B0, device=dev)
+        Bp = round_up(B0, DEC_CELLS_PER_WG)
+        cache = getattr(self, "_w_cache", None)
+        if cache is None or cache[0] != (B0, dev):
+            w_pad = torch.zeros(Bp, dtype=torch.float32, device=dev)
+            w_pad[:B0] = 1.0 / B0  # the batch mean of spVIPESmodule.py:870-872 as per-cell weights
+            self._w_cache = cache = ((B0, dev), w_pad)
+        w_pad = cache[1]
+        if isinstance(kl_weight, torch.Tensor):
+            klw = kl_weight if (kl_weight.dtype == torch.float32 and kl_weight.device == dev) else kl_weight.to(dev, torch.float32)
+        else:
+            klw = torch.full((), float(kl_weight), dtype=torch.float32, device=dev)
         px = [generative_outputs["private_poe"][str(g)]["px"] for g in (0, 1)]
         lat = [t for g in (0, 1) for t in (px[g].private_log_z, px[g].poe_log_z)]
         params = [t for g in (0, 1) for t in decoder_params(self.decoders[g], self.px_r[g])]
-        res = DecoderFused.apply([self._step_inputs[g][0] for g in (0, 1)], [self._step_inputs[g][1] for g in (0, 1)], B0,
-                                 [self.decoders[g] for g in (0, 1)], [px[g].library for g in (0, 1)], w, self.training, self.nsplit,
-                                 [self._workspace(g, dev) for g in (0, 1)], *lat, *params)
-        rec_total, rec = res[0], [res[1], res[2]]
         pr, po = inference_outputs["private_stats"], inference_outputs["poe_stats"]
         kl_p = [self._kl_private[g] if g in self._kl_private else kl_normal_std(pr[g]["logtheta_loc"], pr[g]["logtheta_scale"]) for g in (0, 1)]
         kl_q = [self._kl_poe[g] if g in self._kl_poe else kl_normal_std(po[g]["logtheta_loc"], po[g]["logtheta_qz"].scale) for g in (0, 1)]
-        loss = rec_total + torch.mean(kl_weight * kl_p[0] + kl_weight * kl_q[0] + kl_weight * kl_p[1] + kl_weight * kl_q[1])
+        # reconstruction + kl_weight * mean_b(sum of the four KL terms), assembled by one kernel (spv_loss_assemble)
+        res = DecoderFused.apply([self._step_inputs[g][0] for g in (0, 1)], [self._step_inputs[g][1] for g in (0, 1)], B0,
+                                 [self.decoders[g] for g in (0, 1)], [px[g].library for g in (0, 1)], w_pad, self.training, self.nsplit,
+                                 [self._workspace(g, dev) for g in (0, 1)], klw, 4, *lat, *params, kl_p[0], kl_q[0], kl_p[1], kl_q[1])
+        loss, rec = res[0], [res[2], res[3]]
         return LossOutput(
             loss=loss,
             reconstruction_loss={"reconst_loss_groups_1_poe": rec[0], "reconst_loss_groups_2_poe": rec[1]},
@@ -373,10 +411,10 @@ class spVIPESmodule(nn.Module):
                 "kl_divergence_groups_1_private": kl_p[0], "kl_divergence_groups_1_poe": kl_q[0],
                 "kl_divergence_groups_2_private": kl_p[1], "kl_divergence_groups_2_poe": kl_q[1],
             },
-            extra_metrics={
-                "kl_divergence_private_groups_1": kl_p[0].mean(), "kl_divergence_poe_groups_1": kl_q[0].mean(),
-                "kl_divergence_private_groups_2": kl_p[1].mean(), "kl_divergence_poe_groups_2": kl_q[1].mean(),
-            },
+            extra_metrics=_LazyMeans({
+                "kl_divergence_private_groups_1": kl_p[0], "kl_divergence_poe_groups_1": kl_q[0],
+                "kl_divergence_private_groups_2": kl_p[1], "kl_divergence_poe_groups_2": kl_q[1],
+            }),
         )
 
     def forward(self, tensors, inference_kwargs=None, generative_kwargs=None, loss_kwargs=None, compute_loss=True):

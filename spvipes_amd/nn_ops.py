@@ -92,6 +92,7 @@ class EncoderTails(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, specs: Sequence[EncoderSpec], eps: Sequence[torch.Tensor], training: bool, drop_p: float, seed: int, ws, *tensors):
+        ctx.set_materialize_grads(False)  # outputs nobody differentiates (scale, unused loc/logvar) arrive as None, not as zero fills
         n_groups = max(s.h1_group for s in specs) + 1
         h1 = tensors[:n_groups]
         par = [tensors[n_groups + i * N_ENC_PARAMS: n_groups + (i + 1) * N_ENC_PARAMS] for i in range(len(specs))]
@@ -213,7 +214,11 @@ class EncoderTails(torch.autograd.Function):
             _abi.call("spv_linear_dgrad", C.byref(b), stream_ptr())
         # 5./6. fc2 backward (relu + dropout mask recovered from the saved h2 > 0)
         dW2, db2 = [pg[i][0][0] for i in range(E)], [pg[i][1][0] for i in range(E)]
-        dh1 = [torch.zeros_like(t) for t in h1]
+        # every column block of h1 that an encoder reads gets written by the dgrad below; zero only what none covers
+        covered = [sorted((s.h1_col, s.h1_col + H) for s in specs if s.h1_group == k) for k in range(n_groups)]
+        full = [bool(c) and c[0][0] == 0 and c[-1][1] == h1[k].shape[1] and all(c[i][1] == c[i + 1][0] for i in range(len(c) - 1))
+                for k, c in enumerate(covered)]
+        dh1 = [torch.empty_like(t) if full[k] else torch.zeros_like(t) for k, t in enumerate(h1)]
         bw = _lin_batch(B, relu=True, drop_p=ctx.dp)
         bd = _lin_batch(B, relu=True, drop_p=ctx.dp)
         for i, s in enumerate(specs):
@@ -250,6 +255,7 @@ class PoELabel(torch.autograd.Function):
     @staticmethod
     def forward(ctx, labels: Sequence[torch.Tensor], eps: Sequence[torch.Tensor], ws, loc0, logvar0, loc1, logvar1):
         from ._abi import SpvPoeArgs
+        ctx.set_materialize_grads(False)
         dev = loc0.device
         n = loc0.shape[1]
         Bs = [loc0.shape[0], loc1.shape[0]]
@@ -293,7 +299,7 @@ class PoELabel(torch.autograd.Function):
         cont = lambda t: None if t is None else t.contiguous()
         a = SpvPoeArgs()
         a.n = n
-        d = [torch.zeros(Bs[k], 2 * n, dtype=torch.float32, device=dev) for k in range(2)]
+        d = [torch.empty(Bs[k], 2 * n, dtype=torch.float32, device=dev) for k in range(2)]  # zeroed by spv_poe_fuse_bwd
         keep = []
         for k in range(2):
             gl, gv, gs, gz, _gt, gk = (cont(t) for t in g[6 * k: 6 * k + 6])
@@ -305,7 +311,7 @@ class PoELabel(torch.autograd.Function):
         for k in range(2):
             ld = ctx.blocks[k][2]
             if ld != 2 * n:
-                d[k] = torch.zeros(Bs[k], ld, dtype=torch.float32, device=dev)
+                d[k] = torch.empty(Bs[k], ld, dtype=torch.float32, device=dev)
             a.d_stats[k] = ptr(d[k])
         _abi.call("spv_poe_fuse_bwd", C.byref(a), stream_ptr())
         return (None, None, None, d[0][:, :n], d[0][:, n:2 * n], d[1][:, :n], d[1][:, n:2 * n])

@@ -106,6 +106,7 @@ class EncoderFC1(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, counts: GroupCounts, rows, B: int, w_priv, b_priv, w_sh, b_sh, nsplit: int, ws: Workspace):
+        ctx.set_materialize_grads(False)
         H, G = w_priv.shape
         N1 = 2 * H
         bn = 32 if N1 <= 32 else (128 if N1 <= 128 else 256)
@@ -129,6 +130,8 @@ class EncoderFC1(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dh1, _dlib):
+        if dh1 is None:
+            return (None,) * 9
         (h1,) = ctx.saved_tensors
         B, H, G, ws, nsplit = ctx.B, ctx.H, ctx.G, ctx.ws, ctx.nsplit
         N1 = 2 * H
@@ -162,6 +165,16 @@ NB_GSPL_MAX = 160  # genes per likelihood split (their regressor weights sit in 
 def _nb_splits(Gp: int) -> Tuple[int, int]:
     per = min(NB_GSPL_MAX, Gp)
     return -(-Gp // per), per
+
+
+def _gemm_slabs(a_kmajor: bool, A_hi, A_lo, lda, B_hi, B_lo, ldb, M, N, K, nsplit, splits, ws: Workspace, name: str,
+                b_col_off: int = 0, a_tiles: int = 0) -> torch.Tensor:
+    """split-K GEMM leaving its ``splits`` fp32 partial slabs [splits][M][N] for spv_reduce_slabs"""
+    out = ws.get(name, (splits, M, N), torch.float32)
+    b_off = b_col_off * 2
+    _abi.call("spv_gemm_bf16", int(a_kmajor), ptr(A_hi), ptr(A_lo), lda, ptr(B_hi) + b_off, (ptr(B_lo) + b_off) if B_lo is not None else None,
+                            ldb, ptr(out), N, M, N, K, nsplit, splits, M * N, a_tiles, stream_ptr())
+    return out
 
 
 def _gemm(a_kmajor: bool, A_hi, A_lo, lda, B_hi, B_lo, ldb, M, N, K, nsplit, splits, ws: Workspace, name: str,
@@ -223,7 +236,7 @@ class DecoderNBLoss(torch.autograd.Function):
             dL = ws.get("dec_dL_" + gname, (Bp, Gp), gdt, zero=True)
             tP = ws.get("dec_tP_" + gname, (Bp, Gp), gdt, zero=True)
             tS = ws.get("dec_tS_" + gname, (Bp, Gp), gdt, zero=True)
-            dth = ws.get("dec_dtheta", (Bp // 16, Gp), torch.float32, zero=True)
+            dth = ws.get("dec_dtheta", (Bp // 64, Gp), torch.float32, zero=True)
         else:
             dL = tP = tS = dth = None
         lse_p, lse_s, a_p, a_s = vec("dec_lse_p"), vec("dec_lse_s"), vec("dec_a_p"), vec("dec_a_s")

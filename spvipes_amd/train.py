@@ -102,14 +102,16 @@ class Trainer:
     def minibatch(self, rows: Sequence[torch.Tensor]):
         """tensors_by_group in the resident layout for the given per-group row indices."""
         out = []
+        need_idx = bool(getattr(self.module, "use_transport_plan", False))
+        if self.labels is not None and getattr(self, "_labels_f32", None) is None:
+            self._labels_f32 = [l.flatten().to(torch.float32).contiguous() for l in self.labels]  # once: the PoE kernel reads fp32 codes
         for g, r in enumerate(rows):
-            d = {"counts": self.counts[g], "rows": r, "indices": r.to(torch.float32).unsqueeze(1),
-                 "groups": None, "batch": None}
-            rl = r.long()
+            d = {"counts": self.counts[g], "rows": r, "groups": None, "batch": None}
+            d["indices"] = r.to(torch.float32).unsqueeze(1) if need_idx else None
             if self.labels is not None:
-                d["labels"] = self.labels[g][rl].unsqueeze(1)
+                d["labels"] = self._labels_f32[g].index_select(0, r).unsqueeze(1)  # one gather launch per group
             if self.components is not None:
-                d["processed_transport_labels"] = self.components[g][rl].unsqueeze(1)
+                d["processed_transport_labels"] = self.components[g][r.long()].unsqueeze(1)
             out.append(d)
         return tuple(out)
 
