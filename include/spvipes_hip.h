@@ -67,18 +67,29 @@ int spv_pack_bf16(const float* src, int64_t ld_src, int32_t R, int32_t C,
  * nn/networks.py:119):  h1 = relu(log1p(X[rows]) @ W1^T + b1) for the concatenated
  * [private ; shared] fc1 (N1 = 2 * n_hidden output columns), library = log(sum_g log1p(x)).
  *   W1_hi/lo : bf16 [N1p][ldw] (rows = output units, K = genes contiguous, ldw % 32 == 0)
+ *   bias     : fp32 [N1], or the two encoders' biases in place: bias [n_first] and bias2 [N1 - n_first]
+ *              (bias2 == NULL: one vector)
  *   slabs    : fp32 workspace [splits][B][N1];  rowsum_ws: fp32 [splits][B]
  *   h1       : fp32 [B][N1];  library: fp32 [B] */
 int spv_enc_fc1_fwd(const spv_counts* x, int32_t B, int32_t G,
                     const uint16_t* W1_hi, const uint16_t* W1_lo, int64_t ldw, int32_t N1,
-                    const float* bias, int32_t nsplit, int32_t splits,
+                    const float* bias, const float* bias2, int32_t n_first, int32_t nsplit, int32_t splits,
                     float* slabs, float* rowsum_ws, float* h1, float* library, void* stream);
 
 /* fc1 weight gradient (autograd of nn/networks.py:119):  dW1[N1][G] = dh^T @ log1p(X[rows]).
- *   dh_hi/lo : bf16 [round_up(B,64)][ld_dh] (ld_dh >= round_up(N1,128), zero padded)  */
+ *   dh_hi/lo : bf16 [round_up(B,64)][ld_dh] (ld_dh >= round_up(N1,128), zero padded)
+ *   dW2      : optional second destination: rows >= rows_first go to dW2[row - rows_first] (the shared
+ *              encoder's weight gradient, stored apart from the private encoder's)  */
 int spv_enc_fc1_wgrad(const spv_counts* x, int32_t B, int32_t G,
                       const uint16_t* dh_hi, const uint16_t* dh_lo, int64_t ld_dh, int32_t N1,
-                      int32_t nsplit, float* dW, int64_t ldc, void* stream);
+                      int32_t nsplit, float* dW, float* dW2, int32_t rows_first, int64_t ldc, void* stream);
+
+/* Backward of fc1's ReLU + bias (nn/networks.py:119): dpre = dh1 * (h1 > 0) packed as the bf16 image
+ * spv_enc_fc1_wgrad consumes ([Bp][ld_img], zero padded; img_lo optional), and the bias gradients
+ * db[col] = sum_b dpre[b][col] (cols >= n_first to db2[col - n_first] when db2 != NULL).
+ *   part : fp32 workspace [Bp / 64][N1] */
+int spv_enc_fc1_bwd_prep(const float* dh1, const float* h1, int32_t B, int32_t N1, uint16_t* img_hi, uint16_t* img_lo,
+                         int64_t ld_img, int32_t Bp, float* part, float* db, float* db2, int32_t n_first, void* stream);
 
 /* "Accumulator-tile" order of the [cells][genes] arrays exchanged between the decoder kernels
  * (mixing logits, dL, tP, tS):  T[cell/32][gene/32][qq][lane][j], lane = cell%32 + 32 h,
@@ -209,6 +220,7 @@ typedef struct spv_sample_prob {
   float* scale; float* logz; float* theta; float* kl;
   const float* g_loc; const float* g_logvar; const float* g_scale; const float* g_logz; const float* g_kl;
   float* d_post;
+  int64_t g_ld;   /* row pitch of g_loc / g_logvar (0 = n): they may be column blocks of a wider matrix */
 } spv_sample_prob;
 typedef struct spv_sample_batch { spv_sample_prob p[SPV_MAXP]; int32_t nprob, B; } spv_sample_batch;
 int spv_enc_sample_fwd(const spv_sample_batch* a, void* stream);

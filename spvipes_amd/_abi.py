@@ -82,7 +82,7 @@ class SpvBnBatch(C.Structure):
 class SpvSampleProb(C.Structure):
     _fields_ = [("post", C.c_void_p), ("n", C.c_int32), ("eps", C.c_void_p), ("scale", C.c_void_p), ("logz", C.c_void_p), ("theta", C.c_void_p),
                 ("kl", C.c_void_p), ("g_loc", C.c_void_p), ("g_logvar", C.c_void_p), ("g_scale", C.c_void_p), ("g_logz", C.c_void_p),
-                ("g_kl", C.c_void_p), ("d_post", C.c_void_p)]
+                ("g_kl", C.c_void_p), ("d_post", C.c_void_p), ("g_ld", C.c_int64)]
 
 
 class SpvSampleBatch(C.Structure):
@@ -120,9 +120,12 @@ _SIGNATURES = {
     "spv_pack_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                 C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "spv_enc_fc1_fwd": (C.c_int, [C.POINTER(SpvCounts), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
-                                  C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                  C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]),
     "spv_enc_fc1_wgrad": (C.c_int, [C.POINTER(SpvCounts), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
-                                    C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+                                    C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]),
+    "spv_enc_fc1_bwd_prep": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "spv_gemm_bf16": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                 C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
     "spv_dec_tables": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),

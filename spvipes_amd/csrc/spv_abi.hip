@@ -96,11 +96,12 @@ extern "C" int spv_pack_bf16(const float* src, int64_t ld_src, int32_t R, int32_
 // encoder fc1
 // ---------------------------------------------------------------------------------------------
 __global__ void fc1_epilogue_kernel(const float* slabs, const float* rowsum_ws, int splits, int B, int N1, const float* bias,
-                                    float* h1, float* library) {
+                                    const float* bias2, int n_first, float* h1, float* library) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)B * N1;
   if (idx < total) {
-    float v = bias[idx % N1];
+    const int col = (int)(idx % N1);
+    float v = (bias2 != nullptr && col >= n_first) ? bias2[col - n_first] : bias[col];
     for (int s = 0; s < splits; ++s) v += slabs[(long)s * total + idx];
     h1[idx] = fmaxf(v, 0.f);  // relu(fc1(x)), nn/networks.py:119
   }
@@ -111,18 +112,24 @@ __global__ void fc1_epilogue_kernel(const float* slabs, const float* rowsum_ws, 
   }
 }
 
+// every 8-gene chunk of a row is one aligned 16-byte load when base, row pitch and column offset are
+static int counts_aligned(const spv_counts* x) {
+  const long esz = (x->dtype == SPV_COUNT_U16) ? 2 : 4;
+  return ((reinterpret_cast<uintptr_t>(x->X) & 15) == 0) && ((x->ld * esz) % 16 == 0) && ((x->col_off * esz) % 16 == 0);
+}
+
 template <typename CT, int NSPLIT>
 static int fc1_fwd_dispatch(const GemmParams& p, int N1, int splits, hipStream_t s) {
-  if (N1 <= 32) return launch_gemm<GemmCfg<128, 32, 4, 1, false, false, SRC_COUNTS, SRC_PLAIN, CT, NSPLIT>>(p, splits, s);
-  if (N1 <= 128) return launch_gemm<GemmCfg<64, 128, 2, 2, false, false, SRC_COUNTS, SRC_PLAIN, CT, NSPLIT>>(p, splits, s);
-  return launch_gemm<GemmCfg<64, 256, 1, 4, false, false, SRC_COUNTS, SRC_PLAIN, CT, NSPLIT>>(p, splits, s);
+  if (N1 <= 32) return launch_gemm<GemmCfg<128, 32, 4, 1, false, false, SRC_COUNTS, SRC_PLAIN, CT, NSPLIT, 32, 4>>(p, splits, s);
+  if (N1 <= 128) return launch_gemm<GemmCfg<64, 128, 2, 2, false, false, SRC_COUNTS, SRC_PLAIN, CT, NSPLIT, 32, 4>>(p, splits, s);
+  return launch_gemm<GemmCfg<64, 256, 1, 4, false, false, SRC_COUNTS, SRC_PLAIN, CT, NSPLIT, 32, 4>>(p, splits, s);
 }
 
 static int fc1_bn(int N1) { return N1 <= 32 ? 32 : (N1 <= 128 ? 128 : 256); }
 
 extern "C" int spv_enc_fc1_fwd(const spv_counts* x, int32_t B, int32_t G, const uint16_t* W1_hi, const uint16_t* W1_lo,
-                               int64_t ldw, int32_t N1, const float* bias, int32_t nsplit, int32_t splits, float* slabs,
-                               float* rowsum_ws, float* h1, float* library, void* stream) {
+                               int64_t ldw, int32_t N1, const float* bias, const float* bias2, int32_t n_first, int32_t nsplit,
+                               int32_t splits, float* slabs, float* rowsum_ws, float* h1, float* library, void* stream) {
   if (!x || !x->X || !W1_hi || !bias || !slabs || !rowsum_ws || !h1 || !library) return fail(SPV_ERR_ARG, "spv_enc_fc1_fwd: null pointer%s");
   if (B <= 0 || G <= 0 || N1 <= 0 || splits <= 0 || (ldw % 32) != 0 || ldw < ((G + 31) & ~31)) return fail(SPV_ERR_ARG, "spv_enc_fc1_fwd: bad shape%s");
   if (nsplit != 1 && nsplit != 3) return fail(SPV_ERR_ARG, "spv_enc_fc1_fwd: nsplit must be 1 or 3%s");
@@ -130,7 +137,7 @@ extern "C" int spv_enc_fc1_fwd(const spv_counts* x, int32_t B, int32_t G, const 
   GemmParams p{};
   p.A = x->X; p.A_lo = nullptr; p.lda = x->ld;
   p.B = W1_hi; p.B_lo = W1_lo; p.ldb = ldw;
-  p.rows = x->rows; p.col_off = x->col_off; p.n_cells = B; p.n_genes = G;
+  p.rows = x->rows; p.counts_aligned = counts_aligned(x); p.col_off = x->col_off; p.n_cells = B; p.n_genes = G;
   p.rowsum = rowsum_ws;
   p.C = slabs; p.ldc = N1; p.slab_stride = (long)B * N1;
   p.M = B; p.N = N1; p.K = G;
@@ -144,12 +151,13 @@ extern "C" int spv_enc_fc1_fwd(const spv_counts* x, int32_t B, int32_t G, const 
   else return fail(SPV_ERR_ARG, "spv_enc_fc1_fwd: unknown count dtype%s");
   if (rc != SPV_OK) return launch_status("spv_enc_fc1_fwd gemm");
   const long total = (long)B * N1;
-  hipLaunchKernelGGL(fc1_epilogue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, slabs, rowsum_ws, splits, B, N1, bias, h1, library);
+  hipLaunchKernelGGL(fc1_epilogue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, slabs, rowsum_ws, splits, B, N1, bias, bias2, n_first, h1, library);
   return launch_status("spv_enc_fc1_fwd epilogue");
 }
 
 extern "C" int spv_enc_fc1_wgrad(const spv_counts* x, int32_t B, int32_t G, const uint16_t* dh_hi, const uint16_t* dh_lo,
-                                 int64_t ld_dh, int32_t N1, int32_t nsplit, float* dW, int64_t ldc, void* stream) {
+                                 int64_t ld_dh, int32_t N1, int32_t nsplit, float* dW, float* dW2, int32_t rows_first, int64_t ldc,
+                                 void* stream) {
   if (!x || !x->X || !dh_hi || !dW) return fail(SPV_ERR_ARG, "spv_enc_fc1_wgrad: null pointer%s");
   if (B <= 0 || G <= 0 || N1 <= 0 || ld_dh < ((N1 + 127) & ~127) || (ld_dh % 8) != 0 || ldc < G) return fail(SPV_ERR_ARG, "spv_enc_fc1_wgrad: bad shape%s");
   if (nsplit != 1 && nsplit != 3) return fail(SPV_ERR_ARG, "spv_enc_fc1_wgrad: nsplit must be 1 or 3%s");
@@ -157,32 +165,32 @@ extern "C" int spv_enc_fc1_wgrad(const spv_counts* x, int32_t B, int32_t G, cons
   GemmParams p{};
   p.A = dh_hi; p.A_lo = dh_lo; p.lda = ld_dh;
   p.B = x->X; p.B_lo = nullptr; p.ldb = x->ld;
-  p.rows = x->rows; p.col_off = x->col_off; p.n_cells = B; p.n_genes = G;
+  p.rows = x->rows; p.counts_aligned = counts_aligned(x); p.col_off = x->col_off; p.n_cells = B; p.n_genes = G;
   p.rowsum = nullptr;
   p.C = dW; p.ldc = ldc; p.slab_stride = 0;
+  p.C2 = dW2; p.c_split_row = rows_first;
   p.M = N1; p.N = G; p.K = B;
   p.k_per_split = (B + 63) & ~63;
   p.epi = EPI_STORE;
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if (x->dtype == SPV_COUNT_U16) {
-    rc = (nsplit == 3) ? launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_COUNTS, unsigned short, 3, 64>>(p, 1, s)
-                       : launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_COUNTS, unsigned short, 1, 64>>(p, 1, s);
+    rc = (nsplit == 3) ? launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_COUNTS, unsigned short, 3, 64, 4>>(p, 1, s)
+                       : launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_COUNTS, unsigned short, 1, 64, 4>>(p, 1, s);
   } else if (x->dtype == SPV_COUNT_F32) {
-    rc = (nsplit == 3) ? launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_COUNTS, float, 3, 64>>(p, 1, s)
-                       : launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_COUNTS, float, 1, 64>>(p, 1, s);
+    rc = (nsplit == 3) ? launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_COUNTS, float, 3, 64, 4>>(p, 1, s)
+                       : launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_COUNTS, float, 1, 64, 4>>(p, 1, s);
   } else return fail(SPV_ERR_ARG, "spv_enc_fc1_wgrad: unknown count dtype%s");
   (void)rc;
   return launch_status("spv_enc_fc1_wgrad");
 }
 
-// ---------------------------------------------------------------------------------------------
-// plain GEMM
+
 // ---------------------------------------------------------------------------------------------
 template <bool A_KMAJ, int NSPLIT, int A_SRC>
 static int gemm_dispatch(const GemmParams& p, int splits, hipStream_t s) {
-  if (p.N <= 32) return launch_gemm<GemmCfg<128, 32, 4, 1, A_KMAJ, true, A_SRC, SRC_PLAIN, unsigned short, NSPLIT, 64>>(p, splits, s);
-  return launch_gemm<GemmCfg<64, 320, 2, 2, A_KMAJ, true, A_SRC, SRC_PLAIN, unsigned short, NSPLIT, 64>>(p, splits, s);
+  if (p.N <= 32) return launch_gemm<GemmCfg<128, 32, 4, 1, A_KMAJ, true, A_SRC, SRC_PLAIN, unsigned short, NSPLIT, 64, 4>>(p, splits, s);
+  return launch_gemm<GemmCfg<64, 320, 2, 2, A_KMAJ, true, A_SRC, SRC_PLAIN, unsigned short, NSPLIT, 64, 1>>(p, splits, s);
 }
 
 extern "C" int spv_gemm_bf16(int32_t a_kmajor, const uint16_t* A_hi, const uint16_t* A_lo, int64_t lda, const uint16_t* B_hi,
@@ -253,7 +261,7 @@ extern "C" int spv_dec_lse(const spv_dec_params* q, const float* library, void* 
     return fail(SPV_ERR_ARG, "spv_dec_lse: null pointer%s");
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(dec_lse_kernel, dim3(p.Bp / DEC_CELLS_PER_WG, p.gene_splits), dim3(256), 0, s, p);
-  hipLaunchKernelGGL(dec_lse_combine_kernel, dim3((p.Bp + 255) / 256), dim3(256), 0, s, p.part_max_p, p.part_sum_p,
+  hipLaunchKernelGGL(dec_lse_combine_kernel, dim3((p.Bp + 63) / 64), dim3(256), 0, s, p.part_max_p, p.part_sum_p,
                      p.part_max_s, p.part_sum_s, p.gene_splits, p.Bp, p.B, library, (float*)p.lse_p, (float*)p.lse_s,
                      (float*)p.a_p, (float*)p.a_s);
   return launch_status("spv_dec_lse");
@@ -310,8 +318,8 @@ extern "C" int spv_dec_logits(const uint16_t* Am_hi, const uint16_t* Am_lo, cons
   p.epi = out_f32 ? EPI_TILED_F32 : EPI_TILED_F16;
   p.tiles_inner = Gp / 32;
   hipStream_t s = (hipStream_t)stream;
-  if (nsplit == 3) launch_gemm<GemmCfg<128, 128, 2, 2, false, false, SRC_PLAIN, SRC_PLAIN, unsigned short, 3>>(p, 1, s);
-  else launch_gemm<GemmCfg<128, 128, 2, 2, false, false, SRC_PLAIN, SRC_PLAIN, unsigned short, 1>>(p, 1, s);
+  if (nsplit == 3) launch_gemm<GemmCfg<128, 128, 2, 2, false, false, SRC_PLAIN, SRC_PLAIN, unsigned short, 3, 32, 4>>(p, 1, s);
+  else launch_gemm<GemmCfg<128, 128, 2, 2, false, false, SRC_PLAIN, SRC_PLAIN, unsigned short, 1, 32, 4>>(p, 1, s);
   return launch_status("spv_dec_logits");
 }
 
@@ -577,8 +585,8 @@ extern "C" int spv_reduce_slabs(const spv_reduce_batch* b, void* stream) {
     const long t = (long)q.rows * q.cols;
     if (t > most) most = t;
   }
-  long blocks = (most + 63) / 64;
-  if (blocks > 4096) blocks = 4096;
+  long blocks = (most + 255) / 256;   // problems with many slabs take 64 elements per block and loop
+  if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks, b->nprob), dim3(256), 0, (hipStream_t)stream, *b);
   return launch_status("spv_reduce_slabs");
 }
@@ -591,5 +599,46 @@ extern "C" int spv_loss_assemble(const float* rec0, const float* rec1, const flo
   hipLaunchKernelGGL(loss_assemble_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, rec0, rec1, w, k[0], k[1], k[2], k[3], B, kl_weight,
                      loss, rec_sum, gkl);
   return launch_status("spv_loss_assemble");
+}
+
+// relu mask + bf16 (hi/lo) packing of the fc1 output gradient and its column sums (the bias gradients):
+// one workgroup per 64 rows, one thread per column; partial sums reduced in block order by the second kernel.
+__global__ __launch_bounds__(256) void fc1_bwd_prep_kernel(const float* dh1, const float* h1, int B, int N1, bf16_t* img_hi, bf16_t* img_lo,
+                                                           long ld_img, float* part) {
+  const int r0 = blockIdx.x * 64;
+  for (int col = threadIdx.x; col < (int)ld_img; col += 256) {
+    float sum = 0.f;
+    for (int r = r0; r < r0 + 64; ++r) {
+      float v = 0.f;
+      if (r < B && col < N1) {
+        const long i = (long)r * N1 + col;
+        v = (h1[i] > 0.f) ? dh1[i] : 0.f;
+      }
+      bf16_t hi, lo;
+      split_bf16(v, hi, lo);
+      img_hi[(long)r * ld_img + col] = hi;
+      if (img_lo) img_lo[(long)r * ld_img + col] = lo;
+      sum += v;
+    }
+    if (col < N1) part[(long)blockIdx.x * N1 + col] = sum;
+  }
+}
+__global__ void fc1_bwd_bias_kernel(const float* part, int nblk, int N1, float* db, float* db2, int n_first) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= N1) return;
+  float v = 0.f;
+  for (int k = 0; k < nblk; ++k) v += part[(long)k * N1 + col];
+  if (db2 != nullptr && col >= n_first) db2[col - n_first] = v;
+  else db[col] = v;
+}
+
+extern "C" int spv_enc_fc1_bwd_prep(const float* dh1, const float* h1, int32_t B, int32_t N1, uint16_t* img_hi, uint16_t* img_lo,
+                                    int64_t ld_img, int32_t Bp, float* part, float* db, float* db2, int32_t n_first, void* stream) {
+  if (!dh1 || !h1 || !img_hi || !part || !db) return fail(SPV_ERR_ARG, "spv_enc_fc1_bwd_prep: null pointer%s");
+  if (B <= 0 || N1 <= 0 || Bp < B || (Bp % 64) || ld_img < N1) return fail(SPV_ERR_ARG, "spv_enc_fc1_bwd_prep: bad shape (Bp a multiple of 64)%s");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(fc1_bwd_prep_kernel, dim3(Bp / 64), dim3(256), 0, s, dh1, h1, B, N1, img_hi, img_lo, (long)ld_img, part);
+  hipLaunchKernelGGL(fc1_bwd_bias_kernel, dim3((N1 + 255) / 256), dim3(256), 0, s, part, Bp / 64, N1, db, db2, n_first);
+  return launch_status("spv_enc_fc1_bwd_prep");
 }
 

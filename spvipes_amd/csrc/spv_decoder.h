@@ -203,22 +203,40 @@ __global__ __launch_bounds__(256) void dec_lse_kernel(DecParams p) {
 }
 
 // lse_k[b] = log sum_splits ...;  a_k[b] = library[b] - lse_k[b]   (log of exp(library) * softmax)
-__global__ void dec_lse_combine_kernel(const float* pmp, const float* psp, const float* pms, const float* pss, int splits,
-                                       int Bp, int B, const float* library, float* lse_p, float* lse_s, float* a_p, float* a_s) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= Bp) return;
-  float mp = -INFINITY, ms = -INFINITY;
-  for (int s = 0; s < splits; ++s) { mp = fmaxf(mp, pmp[(long)s * Bp + b]); ms = fmaxf(ms, pms[(long)s * Bp + b]); }
-  float sp = 0.f, ss = 0.f;
-  for (int s = 0; s < splits; ++s) {
-    const float m1 = pmp[(long)s * Bp + b], m2 = pms[(long)s * Bp + b];
-    if (m1 != -INFINITY) sp += psp[(long)s * Bp + b] * __expf(m1 - mp);
-    if (m2 != -INFINITY) ss += pss[(long)s * Bp + b] * __expf(m2 - ms);
+// block = 64 cells x 4 split groups: group y merges splits y, y+4, ... in order (online log-sum-exp), the four group
+// results are merged in order
+__device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2) {
+  if (m2 == -INFINITY) return;
+  if (m2 > m) { s = s * __expf(m - m2) + s2; m = m2; }
+  else s += s2 * __expf(m2 - m);
+}
+__global__ __launch_bounds__(256) void dec_lse_combine_kernel(const float* pmp, const float* psp, const float* pms, const float* pss, int splits,
+                                                              int Bp, int B, const float* library, float* lse_p, float* lse_s, float* a_p,
+                                                              float* a_s) {
+  __shared__ float s_m[2][4][64], s_s[2][4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int b = blockIdx.x * 64 + tx;
+  float mp = -INFINITY, ms = -INFINITY, sp = 0.f, ss = 0.f;
+  if (b < Bp) {
+#pragma unroll 4
+    for (int k = ty; k < splits; k += 4) {
+      const long o = (long)k * Bp + b;
+      lse_merge(mp, sp, pmp[o], psp[o]);
+      lse_merge(ms, ss, pms[o], pss[o]);
+    }
   }
-  const float lp = mp + __logf(sp), ls = ms + __logf(ss);
-  const float lib = (b < B) ? library[b] : 0.f;
-  lse_p[b] = lp; lse_s[b] = ls;
-  a_p[b] = lib - lp; a_s[b] = lib - ls;
+  s_m[0][ty][tx] = mp; s_s[0][ty][tx] = sp; s_m[1][ty][tx] = ms; s_s[1][ty][tx] = ss;
+  __syncthreads();
+  if (ty == 0 && b < Bp) {
+    for (int y = 1; y < 4; ++y) {
+      lse_merge(mp, sp, s_m[0][y][tx], s_s[0][y][tx]);
+      lse_merge(ms, ss, s_m[1][y][tx], s_s[1][y][tx]);
+    }
+    const float lp = mp + __logf(sp), ls = ms + __logf(ss);
+    const float lib = (b < B) ? library[b] : 0.f;
+    lse_p[b] = lp; lse_s[b] = ls;
+    a_p[b] = lib - lp; a_s[b] = lib - ls;
+  }
 }
 
 // Counts >= NB_CMAX fall outside the (count, gene) table: the hot loop looks them up clamped to the

@@ -40,10 +40,12 @@ struct GemmParams {
   int n_genes;       // logical number of genes (K for natural-A counts, N for k-major-B counts)
   float* rowsum;     // [splits][M] partial sums of log1p(x) (natural-A counts), nullable
   float* C; long ldc; long slab_stride;
+  float* C2; int c_split_row;   // optional: rows >= c_split_row of an EPI_STORE output go to C2 (row - c_split_row), same ldc
   int M, N, K;
   int k_per_split;   // multiple of 32
   int epi;
   int tiles_inner;   // gene tiles per cell tile of a SRC_TILED operand / EPI_TILED_* output (= Gp / 32)
+  int counts_aligned;  // count matrix base, row pitch and col_off all multiples of 16 bytes: every 8-gene chunk is one 16-B load
 };
 
 __host__ __device__ constexpr int kmajor_pitch(int cols) {
@@ -55,9 +57,12 @@ __host__ __device__ constexpr int kmajor_pitch(int cols) {
 }
 __host__ __device__ constexpr int nat_pitch(int bk) { return bk + 8; }  // BK k + 8 pad (16-B aligned rows, conflict-free 16-B reads)
 
-template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ_, bool B_KMAJ_, int A_SRC_, int B_SRC_, typename CT_, int NSPLIT_, int BK_ = 32>
+// PF_: operand tiles each thread keeps in flight in registers (HBM latency is ~10 MFMA phases of a tile: one tile
+// ahead leaves the kernel latency-bound at ~1 workgroup per CU).  With PF_ > 1 the LDS image is double buffered
+// when it fits, which also drops one of the two barriers per tile.
+template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ_, bool B_KMAJ_, int A_SRC_, int B_SRC_, typename CT_, int NSPLIT_, int BK_ = 32, int PF_ = 1>
 struct GemmCfg {
-  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BK = BK_;
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BK = BK_, PF = PF_;
   static constexpr int NAT_PITCH = nat_pitch(BK_);
   static constexpr bool A_KMAJ = A_KMAJ_, B_KMAJ = B_KMAJ_;
   static constexpr int A_SRC = A_SRC_, B_SRC = B_SRC_, NSPLIT = NSPLIT_;
@@ -68,7 +73,9 @@ struct GemmCfg {
   static constexpr int A_ELEMS = A_KMAJ ? BK * A_PITCH : BM * NAT_PITCH;
   static constexpr int B_ELEMS = B_KMAJ ? BK * B_PITCH : BN * NAT_PITCH;
   static constexpr int NIMG = (NSPLIT == 3) ? 2 : 1;
-  static constexpr int LDS_BYTES = (A_ELEMS + B_ELEMS) * NIMG * 2;
+  static constexpr int STAGE_ELEMS = (A_ELEMS + B_ELEMS) * NIMG;
+  static constexpr int NBUF = (PF_ > 1 && STAGE_ELEMS * 4 <= 96 * 1024) ? 2 : 1;
+  static constexpr int LDS_BYTES = STAGE_ELEMS * 2 * NBUF;
   // 16-byte chunks each thread moves per tile
   static constexpr int A_CHUNKS = (BM * BK / 8 + 255) / 256;
   static constexpr int B_CHUNKS = (BN * BK / 8 + 255) / 256;
@@ -88,6 +95,8 @@ struct Stager {
   // per-chunk register payload
   u4v hi[NCH], lo[NCH];
   float csum[NCH];
+  int ridx[NCH];    // SRC_COUNTS: row of the count matrix this thread's chunk i reads next (prefetched: see prep_rows)
+  bool valid[NCH];  // SRC_COUNTS: chunk holds real counts (else it decodes as zeros)
 
   // slow/fast coordinates of chunk i for this thread
   __device__ __forceinline__ static void coord(int i, int tid, int& s, int& f, bool& ok) {
@@ -111,6 +120,7 @@ struct Stager {
       hi[i] = u4v{0u, 0u, 0u, 0u};
       lo[i] = u4v{0u, 0u, 0u, 0u};
       csum[i] = 0.f;
+      valid[i] = false;
       if (!ok) continue;
       if constexpr (SRC == SRC_TILED) {
         // k-major (k = cell, ext = gene): tile (k0/32, ext0/32 + s); natural (ext = cell, k = gene): (ext0/32 + s, k0/32)
@@ -126,20 +136,26 @@ struct Stager {
         if constexpr (Cfg::NSPLIT == 3) lo[i] = *reinterpret_cast<const u4v*>(reinterpret_cast<const bf16_t*>(ptr_lo) + off);
       } else {
         // counts: slow index = cell, fast index = gene.  Only the RAW words are fetched here (u16: 8 counts in
-        // hi[i]; f32: 4 + 4 floats in hi[i], lo[i]); log1p / bf16 split happen in store(), after the MFMAs of
-        // the current tile, so the gather's latency hides under them.  Out-of-range -> 0 -> log1p(0) = 0.
+        // hi[i]; f32: 4 + 4 floats in hi[i], lo[i]); log1p / bf16 split happen in store(), PF tiles later, so the
+        // gather's latency hides under the MFMAs in between.  Branch-free on the fast path (a divergent branch
+        // around a load makes the compiler wait for it inside the branch, which drains every prefetch in flight);
+        // lanes with nothing to read fetch the first element of the matrix and store() zeroes them.
+        typedef typename Cfg::CT CT;
         const int cell = KMAJ ? k0 + s : ext0 + s;
         const int gene = KMAJ ? ext0 + 8 * f : k0 + 8 * f;
-        if (cell < p.n_cells && gene < p.n_genes) {
-          const long row = p.rows ? (long)p.rows[cell] : (long)cell;
-          const typename Cfg::CT* src = reinterpret_cast<const typename Cfg::CT*>(ptr) + row * ld + p.col_off + gene;
-          const bool full = gene + 8 <= p.n_genes;
-          const bool aligned = ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
-          if (full && aligned) {
-            hi[i] = *reinterpret_cast<const u4v*>(src);
-            if constexpr (sizeof(typename Cfg::CT) == 4) lo[i] = *reinterpret_cast<const u4v*>(src + 4);
-          } else {
-            if constexpr (sizeof(typename Cfg::CT) == 2) {
+        const bool inb = cell < p.n_cells && gene < p.n_genes;
+        const bool full = gene + 8 <= p.n_genes;
+        const CT* src = reinterpret_cast<const CT*>(ptr) + (long)ridx[i] * ld + p.col_off + gene;
+        valid[i] = inb;
+        if (p.counts_aligned) {  // uniform
+          const CT* s2 = (inb && full) ? src : reinterpret_cast<const CT*>(ptr);
+          hi[i] = *reinterpret_cast<const u4v*>(s2);
+          if constexpr (sizeof(CT) == 4) lo[i] = *reinterpret_cast<const u4v*>(s2 + 4);
+        }
+        const bool slow = inb && !(p.counts_aligned && full);  // the group's last, partial chunk -- or an unaligned matrix
+        if (__builtin_expect(__any(slow), 0)) {
+          if (slow) {
+            if constexpr (sizeof(CT) == 2) {
               unsigned w[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
               for (int j = 0; j < 8; ++j)
@@ -155,6 +171,22 @@ struct Stager {
             }
           }
         }
+      }
+    }
+    if constexpr (SRC == SRC_COUNTS && KMAJ) prep_rows(p, ext0, k0 + Cfg::PF * Cfg::BK, tid);  // this stage's next tile
+  }
+
+  // row indices of the count chunks of tile (ext0, k0): fetched one use ahead so that load() never waits on them
+  __device__ __forceinline__ void prep_rows(const GemmParams& p, int ext0, int k0, int tid) {
+    if constexpr (SRC == SRC_COUNTS) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        int s, f; bool ok;
+        coord(i, tid, s, f, ok);
+        const int cell = KMAJ ? k0 + s : ext0 + s;
+        const int c2 = (ok && cell < p.n_cells) ? cell : 0;  // clamped: the load below is unconditional (no wait at issue)
+        if (p.rows) ridx[i] = p.rows[c2];
+        else ridx[i] = c2;
       }
     }
   }
@@ -207,7 +239,8 @@ struct Stager {
       }
       if constexpr (SRC == SRC_COUNTS) {
         u4v o_hi, o_lo;
-        decode_counts(hi[i], lo[i], o_hi, o_lo, csum[i]);
+        const u4v zero = u4v{0u, 0u, 0u, 0u};
+        decode_counts(valid[i] ? hi[i] : zero, valid[i] ? lo[i] : zero, o_hi, o_lo, csum[i]);
         *reinterpret_cast<u4v*>(img_hi + s * PITCH + 8 * f) = o_hi;
         if constexpr (Cfg::NSPLIT == 3) *reinterpret_cast<u4v*>(img_lo + s * PITCH + 8 * f) = o_lo;
         continue;
@@ -243,56 +276,75 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-  Stager<Cfg, Cfg::A_KMAJ, Cfg::A_SRC, Cfg::BM> stA;
-  Stager<Cfg, Cfg::B_KMAJ, Cfg::B_SRC, Cfg::BN> stB;
-  float rowsum_acc[Stager<Cfg, Cfg::A_KMAJ, Cfg::A_SRC, Cfg::BM>::NCH];
+  typedef Stager<Cfg, Cfg::A_KMAJ, Cfg::A_SRC, Cfg::BM> StA;
+  typedef Stager<Cfg, Cfg::B_KMAJ, Cfg::B_SRC, Cfg::BN> StB;
+  StA stA[Cfg::PF];
+  StB stB[Cfg::PF];
+  float rowsum_acc[StA::NCH];
 #pragma unroll
-  for (int i = 0; i < stA.NCH; ++i) rowsum_acc[i] = 0.f;
+  for (int i = 0; i < StA::NCH; ++i) rowsum_acc[i] = 0.f;
 
-  if (kbeg < kend) {
-    stA.load(p, p.A, p.A_lo, p.lda, m0, kbeg, tid);
-    stB.load(p, p.B, p.B_lo, p.ldb, n0, kbeg, tid);
-  }
-  for (int k0 = kbeg; k0 < kend; k0 += Cfg::BK) {
-    __syncthreads();  // previous tile's fragment reads are done
-    stA.store(sA, sA_lo, tid);
-    stB.store(sB, sB_lo, tid);
-    if constexpr (Cfg::A_SRC == SRC_COUNTS && !Cfg::A_KMAJ) {
 #pragma unroll
-      for (int i = 0; i < stA.NCH; ++i) rowsum_acc[i] += stA.csum[i];
+  for (int s = 0; s < Cfg::PF; ++s)
+    if (kbeg + s * Cfg::BK < kend) {
+      stA[s].prep_rows(p, m0, kbeg + s * Cfg::BK, tid);
+      stB[s].prep_rows(p, n0, kbeg + s * Cfg::BK, tid);
+      stA[s].load(p, p.A, p.A_lo, p.lda, m0, kbeg + s * Cfg::BK, tid);
+      stB[s].load(p, p.B, p.B_lo, p.ldb, n0, kbeg + s * Cfg::BK, tid);
     }
-    __syncthreads();
-    if (k0 + Cfg::BK < kend) {  // prefetch the next tile into registers; lands under the MFMAs
-      stA.load(p, p.A, p.A_lo, p.lda, m0, k0 + Cfg::BK, tid);
-      stB.load(p, p.B, p.B_lo, p.ldb, n0, k0 + Cfg::BK, tid);
-    }
+  int buf = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += Cfg::PF * Cfg::BK) {
 #pragma unroll
-    for (int ks = 0; ks < Cfg::BK; ks += 16) {
-      s8v a_hi[Cfg::TM], a_lo[Cfg::TM];
+    for (int s = 0; s < Cfg::PF; ++s) {
+      const int k = k0 + s * Cfg::BK;
+      if (k < kend) {  // uniform
+        const int bo = buf * Cfg::STAGE_ELEMS;
+        bf16_t* const a_hi_img = sA + bo; bf16_t* const a_lo_img = sA_lo + bo;
+        bf16_t* const b_hi_img = sB + bo; bf16_t* const b_lo_img = sB_lo + bo;
+        // single buffer: wait until the previous tile's fragment reads are done.  Double buffer: this image was last
+        // read two tiles ago and every wave has passed the previous tile's barrier since.
+        if constexpr (Cfg::NBUF == 1) __syncthreads();
+        stA[s].store(a_hi_img, a_lo_img, tid);
+        stB[s].store(b_hi_img, b_lo_img, tid);
+        if constexpr (Cfg::A_SRC == SRC_COUNTS && !Cfg::A_KMAJ) {
 #pragma unroll
-      for (int i = 0; i < Cfg::TM; ++i) {
-        const int r0 = wm * (Cfg::BM / Cfg::WM) + 32 * i;
-        if constexpr (Cfg::A_KMAJ) {
-          a_hi[i] = frag_kmajor(sA, Cfg::A_PITCH, r0, ks, lane);
-          if constexpr (Cfg::NSPLIT == 3) a_lo[i] = frag_kmajor(sA_lo, Cfg::A_PITCH, r0, ks, lane);
-        } else {
-          a_hi[i] = frag_natural(sA, Cfg::A_PITCH, r0, ks, lane);
-          if constexpr (Cfg::NSPLIT == 3) a_lo[i] = frag_natural(sA_lo, Cfg::A_PITCH, r0, ks, lane);
+          for (int i = 0; i < StA::NCH; ++i) rowsum_acc[i] += stA[s].csum[i];
         }
-      }
-#pragma unroll
-      for (int j = 0; j < Cfg::TN; ++j) {
-        const int c0 = wn * (Cfg::BN / Cfg::WN) + 32 * j;
-        s8v b_hi, b_lo;
-        if constexpr (Cfg::B_KMAJ) {
-          b_hi = frag_kmajor(sB, Cfg::B_PITCH, c0, ks, lane);
-          if constexpr (Cfg::NSPLIT == 3) b_lo = frag_kmajor(sB_lo, Cfg::B_PITCH, c0, ks, lane);
-        } else {
-          b_hi = frag_natural(sB, Cfg::B_PITCH, c0, ks, lane);
-          if constexpr (Cfg::NSPLIT == 3) b_lo = frag_natural(sB_lo, Cfg::B_PITCH, c0, ks, lane);
+        __syncthreads();
+        if (k + Cfg::PF * Cfg::BK < kend) {  // refill this register stage; lands under the MFMAs of the next PF tiles
+          stA[s].load(p, p.A, p.A_lo, p.lda, m0, k + Cfg::PF * Cfg::BK, tid);
+          stB[s].load(p, p.B, p.B_lo, p.ldb, n0, k + Cfg::PF * Cfg::BK, tid);
         }
 #pragma unroll
-        for (int i = 0; i < Cfg::TM; ++i) acc[i][j] = mfma32_split<Cfg::NSPLIT>(a_hi[i], a_lo[i], b_hi, b_lo, acc[i][j]);
+        for (int ks = 0; ks < Cfg::BK; ks += 16) {
+          s8v a_hi[Cfg::TM], a_lo[Cfg::TM];
+#pragma unroll
+          for (int i = 0; i < Cfg::TM; ++i) {
+            const int r0 = wm * (Cfg::BM / Cfg::WM) + 32 * i;
+            if constexpr (Cfg::A_KMAJ) {
+              a_hi[i] = frag_kmajor(a_hi_img, Cfg::A_PITCH, r0, ks, lane);
+              if constexpr (Cfg::NSPLIT == 3) a_lo[i] = frag_kmajor(a_lo_img, Cfg::A_PITCH, r0, ks, lane);
+            } else {
+              a_hi[i] = frag_natural(a_hi_img, Cfg::A_PITCH, r0, ks, lane);
+              if constexpr (Cfg::NSPLIT == 3) a_lo[i] = frag_natural(a_lo_img, Cfg::A_PITCH, r0, ks, lane);
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < Cfg::TN; ++j) {
+            const int c0 = wn * (Cfg::BN / Cfg::WN) + 32 * j;
+            s8v b_hi, b_lo;
+            if constexpr (Cfg::B_KMAJ) {
+              b_hi = frag_kmajor(b_hi_img, Cfg::B_PITCH, c0, ks, lane);
+              if constexpr (Cfg::NSPLIT == 3) b_lo = frag_kmajor(b_lo_img, Cfg::B_PITCH, c0, ks, lane);
+            } else {
+              b_hi = frag_natural(b_hi_img, Cfg::B_PITCH, c0, ks, lane);
+              if constexpr (Cfg::NSPLIT == 3) b_lo = frag_natural(b_lo_img, Cfg::B_PITCH, c0, ks, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i) acc[i][j] = mfma32_split<Cfg::NSPLIT>(a_hi[i], a_lo[i], b_hi, b_lo, acc[i][j]);
+          }
+        }
+        if constexpr (Cfg::NBUF == 2) buf ^= 1;
       }
     }
   }
@@ -331,7 +383,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
       for (int q = 0; q < 16; ++q) {
         const int row = m0 + wm * (Cfg::BM / Cfg::WM) + 32 * i + crow(q, h);
         if (row < p.M && col < p.N) {
-          float* dst = C + (long)row * p.ldc + col;
+          float* dst = (p.C2 != nullptr && row >= p.c_split_row) ? p.C2 + (long)(row - p.c_split_row) * p.ldc + col : C + (long)row * p.ldc + col;
           if (p.epi == EPI_ATOMIC) atomicAdd(dst, acc[i][j][q]);
           else *dst = acc[i][j][q];
         }
@@ -341,12 +393,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     // per-cell sum of log1p(x): the 4 threads of a row hold disjoint 8-gene chunks
     if (p.rowsum != nullptr && blockIdx.y == 0) {
 #pragma unroll
-      for (int i = 0; i < stA.NCH; ++i) {
+      for (int i = 0; i < StA::NCH; ++i) {
         float v = rowsum_acc[i];
         v += __shfl_xor(v, 1, 64);
         v += __shfl_xor(v, 2, 64);
         int s, f; bool ok;
-        stA.coord(i, tid, s, f, ok);
+        StA::coord(i, tid, s, f, ok);
         if (ok && f == 0 && m0 + s < p.M) p.rowsum[(long)split * p.M + m0 + s] = v;
       }
     }

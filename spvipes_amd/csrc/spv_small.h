@@ -385,9 +385,10 @@ __global__ __launch_bounds__(256) void enc_sample_bwd_kernel(SampleBatch a) {
   const float gk = q.g_kl ? q.g_kl[b] : 0.f;
   const float loc = q.post[(long)b * 2 * n + d], sc = q.scale[i];
   const float gz = q.g_logz ? q.g_logz[i] : 0.f;
-  const float gl = (q.g_loc ? q.g_loc[i] : 0.f) + gz + gk * loc;
+  const long ig = q.g_ld ? (long)b * q.g_ld + d : i;
+  const float gl = (q.g_loc ? q.g_loc[ig] : 0.f) + gz + gk * loc;
   const float gs = (q.g_scale ? q.g_scale[i] : 0.f) + gz * q.eps[i] + gk * sc;
-  const float gv = (q.g_logvar ? q.g_logvar[i] : 0.f) + 0.5f * sc * gs - 0.5f * gk;
+  const float gv = (q.g_logvar ? q.g_logvar[ig] : 0.f) + 0.5f * sc * gs - 0.5f * gk;
   q.d_post[(long)b * 2 * n + d] = gl;
   q.d_post[(long)b * 2 * n + n + d] = gv;
 }
@@ -719,14 +720,34 @@ __global__ __launch_bounds__(256) void zstats_bwd_kernel(FoldBatch a) {
 
 
 // ---- deterministic slab reduction ------------------------------------------------------------------
-// block = 64 elements x 4 slab groups; group y adds slabs y, y+4, ... in order, the four group sums are
-// then added in order.
+// few slabs (<= 8): one thread per element adds them in order.  Many slabs: block = 64 elements x 4 slab groups;
+// group y adds slabs y, y+4, ... in order and the four group sums are then added in order.
+__device__ __forceinline__ void reduce_finish(const spv_reduce_prob& q, int r, int c, float v, float alpha) {
+  v *= alpha;
+  if (q.exp_scale) v *= expf(q.exp_scale[c]);
+  float* d = q.dst + (long)r * q.ld_dst + c;
+  *d = q.accumulate ? *d + v : v;
+}
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(spv_reduce_batch b) {
   __shared__ float s_part[4][64];
   const spv_reduce_prob& q = b.p[blockIdx.y];
   const long total = (long)q.rows * q.cols;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const float alpha = q.alpha ? *q.alpha : 1.f;
+  if (q.nslabs <= 8) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+      const int r = (int)(i / q.cols), c = (int)(i - (long)r * q.cols);
+      const float* s = q.src + (long)r * q.ld_src + q.col_off + c;
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = (k < q.nslabs) ? s[(long)k * q.slab_stride] : 0.f;  // independent loads, then an ordered sum
+      float acc = v[0];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) acc += v[k];
+      reduce_finish(q, r, c, acc, alpha);
+    }
+    return;
+  }
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (long base = (long)blockIdx.x * 64; base < total; base += (long)gridDim.x * 64) {  // block-uniform trip count
     const long i = base + tx;
     const bool ok = i < total;
@@ -740,13 +761,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(spv_reduce_batch b) {
     }
     s_part[ty][tx] = acc;
     __syncthreads();
-    if (ty == 0 && ok) {
-      float v = ((s_part[0][tx] + s_part[1][tx]) + s_part[2][tx]) + s_part[3][tx];
-      v *= alpha;
-      if (q.exp_scale) v *= expf(q.exp_scale[c]);
-      float* d = q.dst + (long)r * q.ld_dst + c;
-      *d = q.accumulate ? *d + v : v;
-    }
+    if (ty == 0 && ok) reduce_finish(q, r, c, ((s_part[0][tx] + s_part[1][tx]) + s_part[2][tx]) + s_part[3][tx], alpha);
     __syncthreads();
   }
 }

@@ -172,11 +172,19 @@ class EncoderTails(torch.autograd.Function):
         sb.nprob, sb.B = E, B
         keep = []
         for i, s in enumerate(specs):
-            gl, gv, gs, gz, _gt, gk = (cont(t) for t in g[6 * i: 6 * i + 6])
+            gl, gv, gs, gz, _gt, gk = g[6 * i: 6 * i + 6]
+            # g_loc / g_logvar usually arrive as the two column halves of one [B][2n] buffer (PoELabel.backward): read them in place
+            g_ld = 0
+            strided = [t for t in (gl, gv) if t is not None and not t.is_contiguous()]
+            if strided and all(t is None or (t.dtype == torch.float32 and t.stride(1) == 1 and t.stride(0) == strided[0].stride(0)) for t in (gl, gv)):
+                g_ld = strided[0].stride(0)
+            else:
+                gl, gv = cont(gl), cont(gv)
+            gs, gz, gk = cont(gs), cont(gz), cont(gk)
             keep += [gl, gv, gs, gz, gk]
             q = sb.p[i]
             q.post, q.n, q.eps, q.scale = ptr(post[i]), s.n, ptr(ctx.eps[i]), ptr(scale[i])
-            q.g_loc, q.g_logvar, q.g_scale, q.g_logz, q.g_kl, q.d_post = ptr(gl), ptr(gv), ptr(gs), ptr(gz), ptr(gk), ptr(d_post[i])
+            q.g_loc, q.g_logvar, q.g_scale, q.g_logz, q.g_kl, q.d_post, q.g_ld = ptr(gl), ptr(gv), ptr(gs), ptr(gz), ptr(gk), ptr(d_post[i]), g_ld
         _abi.call("spv_enc_sample_bwd", C.byref(sb), stream_ptr())
         # 2. BatchNorm backward -> d_pre, d gamma / beta
         d_pre = [new(B, 2 * s.n) for s in specs]

@@ -114,36 +114,40 @@ class EncoderFC1(torch.autograd.Function):
         W_hi, W_lo = _bf16_image(ws, "fc1_W", N1p, Gp, nsplit == 3)
         _pack(w_priv, W_hi, W_lo, dst_row_off=0, rows_cover=H)
         _pack(w_sh, W_hi, W_lo, dst_row_off=H, rows_cover=N1p - H)
-        bias = torch.cat([b_priv, b_sh]).contiguous()
+        f32c = lambda t: t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+        b_priv, b_sh = f32c(b_priv), f32c(b_sh)
         splits = _fc1_splits(B, G, N1)
         slabs = ws.get("fc1_slabs", (splits, B, N1), torch.float32)
         rowsum = ws.get("fc1_rowsum", (splits, B), torch.float32)
         h1 = torch.empty((B, N1), dtype=torch.float32, device=w_priv.device)
         library = torch.empty((B,), dtype=torch.float32, device=w_priv.device)
         cs = counts.c_struct(rows)
-        _abi.call("spv_enc_fc1_fwd", C.byref(cs), B, G, ptr(W_hi), ptr(W_lo), Gp, N1, ptr(bias), nsplit, splits, ptr(slabs),
+        _abi.call("spv_enc_fc1_fwd", C.byref(cs), B, G, ptr(W_hi), ptr(W_lo), Gp, N1, ptr(b_priv), ptr(b_sh), H, nsplit, splits, ptr(slabs),
                                   ptr(rowsum), ptr(h1), ptr(library), stream_ptr())
         ctx.counts, ctx.rows, ctx.B, ctx.nsplit, ctx.ws, ctx.H, ctx.G = counts, rows, B, nsplit, ws, H, G
-        ctx.save_for_backward(h1)
+        ctx.save_for_backward(h1, w_priv, b_priv, w_sh, b_sh)
         ctx.mark_non_differentiable(library)
         return h1, library
 
     @staticmethod
     def backward(ctx, dh1, _dlib):
+        from .nn_ops import grad_out
+
         if dh1 is None:
             return (None,) * 9
-        (h1,) = ctx.saved_tensors
+        h1, w_priv, b_priv, w_sh, b_sh = ctx.saved_tensors
         B, H, G, ws, nsplit = ctx.B, ctx.H, ctx.G, ctx.ws, ctx.nsplit
         N1 = 2 * H
-        dpre = (dh1 * (h1 > 0)).contiguous()
         Bp, N1p = round_up(B, 64), round_up(N1, 128)
+        dh1 = dh1 if (dh1.dtype == torch.float32 and dh1.is_contiguous()) else dh1.float().contiguous()
         dh_hi, dh_lo = _bf16_image(ws, "fc1_dh", Bp, N1p, nsplit == 3)
-        _pack(dpre, dh_hi, dh_lo)
-        dW = torch.empty((N1, G), dtype=torch.float32, device=dh1.device)
+        part = ws.get("fc1_db_part", (Bp // 64, N1), torch.float32)
+        # (kernel target, autograd return): with the trainer's gradient sink the kernels write straight into .grad
+        (dWp, rWp), (dbp, rbp), (dWs, rWs), (dbs, rbs) = grad_out(w_priv), grad_out(b_priv), grad_out(w_sh), grad_out(b_sh)
+        _abi.call("spv_enc_fc1_bwd_prep", ptr(dh1), ptr(h1), B, N1, ptr(dh_hi), ptr(dh_lo), N1p, Bp, ptr(part), ptr(dbp), ptr(dbs), H, stream_ptr())
         cs = ctx.counts.c_struct(ctx.rows)
-        _abi.call("spv_enc_fc1_wgrad", C.byref(cs), B, G, ptr(dh_hi), ptr(dh_lo), N1p, N1, nsplit, ptr(dW), G, stream_ptr())
-        db = dpre.sum(0)
-        return None, None, None, dW[:H], db[:H], dW[H:], db[H:], None, None
+        _abi.call("spv_enc_fc1_wgrad", C.byref(cs), B, G, ptr(dh_hi), ptr(dh_lo), N1p, N1, nsplit, ptr(dWp), ptr(dWs), H, G, stream_ptr())
+        return None, None, None, rWp, rbp, rWs, rbs, None, None
 
 
 # ------------------------------------------------------------------------------------------------
