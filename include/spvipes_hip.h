@@ -87,7 +87,7 @@ int spv_enc_fc1_wgrad(const spv_counts* x, int32_t B, int32_t G,
 /* Backward of fc1's ReLU + bias (nn/networks.py:119): dpre = dh1 * (h1 > 0) packed as the bf16 image
  * spv_enc_fc1_wgrad consumes ([Bp][ld_img], zero padded; img_lo optional), and the bias gradients
  * db[col] = sum_b dpre[b][col] (cols >= n_first to db2[col - n_first] when db2 != NULL).
- *   part : fp32 workspace [Bp / 64][N1] */
+ *   part : fp32 workspace [Bp / 16][N1] */
 int spv_enc_fc1_bwd_prep(const float* dh1, const float* h1, int32_t B, int32_t N1, uint16_t* img_hi, uint16_t* img_lo,
                          int64_t ld_img, int32_t Bp, float* part, float* db, float* db2, int32_t n_first, void* stream);
 
@@ -274,7 +274,7 @@ typedef struct spv_fold_prob {
   uint16_t* img_hi; uint16_t* img_lo; int64_t ld_img; int32_t col_off; int32_t slot;   /* packed [Gp][ld_img] */
   const float* dWeff; int64_t ld_dw;                       /* backward in: [G][ld_dw], col K = d c */
   float* dW; float* dgamma; float* dbeta;                  /* backward out                */
-  float* red_part;                                         /* [ceil(G/256)][K + K*K]      */
+  float* red_part;                                         /* [ceil(G/256) + 1][K + K*K]  */
   float* dz; int64_t lddz;                                 /* backward out (+=): [B][lddz] */
   int32_t G, Gp, K;
 } spv_fold_prob;

@@ -53,7 +53,7 @@ class SpvReduceBatch(C.Structure):
 
 
 SPV_MAXP = 8
-BN_ROWS = 64  # rows per workgroup of the BatchNorm kernels (sizes their partial-sum workspace)
+BN_ROWS = 32  # rows per workgroup of the BatchNorm kernels (sizes their partial-sum workspace)
 
 
 class SpvLinearProb(C.Structure):

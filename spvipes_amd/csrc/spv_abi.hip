@@ -443,7 +443,10 @@ extern "C" int spv_bn_fwd(const spv_bn_batch* a, void* stream) {
   for (int i = 0; i < a->nprob; ++i) if (!a->p[i].Y) return fail(SPV_ERR_ARG, "spv_bn_fwd: null output%s");
   dim3 grid((a->B + BN_ROWS - 1) / BN_ROWS, a->nprob);
   hipStream_t s = (hipStream_t)stream;
+  int nmax = 0;
+  for (int i = 0; i < a->nprob; ++i) nmax = a->p[i].N > nmax ? a->p[i].N : nmax;
   if (a->training) hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(256), 0, s, *a);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((nmax + 63) / 64, a->nprob), dim3(256), 0, s, *a);
   hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(256), 0, s, *a);
   return launch_status("spv_bn_fwd");
 }
@@ -454,7 +457,10 @@ extern "C" int spv_bn_bwd(const spv_bn_batch* a, void* stream) {
     if (!a->p[i].dY || !a->p[i].dX || !a->p[i].dgamma || !a->p[i].dbeta || (a->relu && !a->p[i].Y)) return fail(SPV_ERR_ARG, "spv_bn_bwd: null pointer%s");
   dim3 grid((a->B + BN_ROWS - 1) / BN_ROWS, a->nprob);
   hipStream_t s = (hipStream_t)stream;
+  int nmax = 0;
+  for (int i = 0; i < a->nprob; ++i) nmax = a->p[i].N > nmax ? a->p[i].N : nmax;
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, s, *a);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((nmax + 63) / 64, a->nprob), dim3(256), 0, s, *a);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, s, *a);
   return launch_status("spv_bn_bwd");
 }
@@ -571,7 +577,10 @@ extern "C" int spv_bn_fold_bwd(const spv_fold_batch* a, void* stream) {
   }
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_fold_bwd_kernel, dim3((gmax + 255) / 256, a->nprob), dim3(256), 0, s, *a);
-  if (a->training) hipLaunchKernelGGL(zstats_bwd_kernel, dim3((a->B + 255) / 256, a->nprob), dim3(256), 0, s, *a);
+  if (a->training) {
+    hipLaunchKernelGGL(fold_red_finalize_kernel, dim3((FOLD_KMAX + FOLD_KMAX * FOLD_KMAX + 63) / 64, a->nprob), dim3(256), 0, s, *a);
+    hipLaunchKernelGGL(zstats_bwd_kernel, dim3((a->B + 63) / 64, a->nprob), dim3(256), 0, s, *a);
+  }
   return launch_status("spv_bn_fold_bwd");
 }
 
@@ -605,10 +614,11 @@ extern "C" int spv_loss_assemble(const float* rec0, const float* rec1, const flo
 // one workgroup per 64 rows, one thread per column; partial sums reduced in block order by the second kernel.
 __global__ __launch_bounds__(256) void fc1_bwd_prep_kernel(const float* dh1, const float* h1, int B, int N1, bf16_t* img_hi, bf16_t* img_lo,
                                                            long ld_img, float* part) {
-  const int r0 = blockIdx.x * 64;
+  const int r0 = blockIdx.x * 16;
   for (int col = threadIdx.x; col < (int)ld_img; col += 256) {
     float sum = 0.f;
-    for (int r = r0; r < r0 + 64; ++r) {
+#pragma unroll 4
+    for (int r = r0; r < r0 + 16; ++r) {
       float v = 0.f;
       if (r < B && col < N1) {
         const long i = (long)r * N1 + col;
@@ -623,11 +633,17 @@ __global__ __launch_bounds__(256) void fc1_bwd_prep_kernel(const float* dh1, con
     if (col < N1) part[(long)blockIdx.x * N1 + col] = sum;
   }
 }
-__global__ void fc1_bwd_bias_kernel(const float* part, int nblk, int N1, float* db, float* db2, int n_first) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= N1) return;
+__global__ __launch_bounds__(256) void fc1_bwd_bias_kernel(const float* part, int nblk, int N1, float* db, float* db2, int n_first) {
+  __shared__ float s_p[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + tx;
   float v = 0.f;
-  for (int k = 0; k < nblk; ++k) v += part[(long)k * N1 + col];
+  if (col < N1)
+    for (int k = ty; k < nblk; k += 4) v += part[(long)k * N1 + col];
+  s_p[ty][tx] = v;
+  __syncthreads();
+  if (ty != 0 || col >= N1) return;
+  v = ((s_p[0][tx] + s_p[1][tx]) + s_p[2][tx]) + s_p[3][tx];
   if (db2 != nullptr && col >= n_first) db2[col - n_first] = v;
   else db[col] = v;
 }
@@ -637,8 +653,8 @@ extern "C" int spv_enc_fc1_bwd_prep(const float* dh1, const float* h1, int32_t B
   if (!dh1 || !h1 || !img_hi || !part || !db) return fail(SPV_ERR_ARG, "spv_enc_fc1_bwd_prep: null pointer%s");
   if (B <= 0 || N1 <= 0 || Bp < B || (Bp % 64) || ld_img < N1) return fail(SPV_ERR_ARG, "spv_enc_fc1_bwd_prep: bad shape (Bp a multiple of 64)%s");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(fc1_bwd_prep_kernel, dim3(Bp / 64), dim3(256), 0, s, dh1, h1, B, N1, img_hi, img_lo, (long)ld_img, part);
-  hipLaunchKernelGGL(fc1_bwd_bias_kernel, dim3((N1 + 255) / 256), dim3(256), 0, s, part, Bp / 64, N1, db, db2, n_first);
+  hipLaunchKernelGGL(fc1_bwd_prep_kernel, dim3(Bp / 16), dim3(256), 0, s, dh1, h1, B, N1, img_hi, img_lo, (long)ld_img, part);
+  hipLaunchKernelGGL(fc1_bwd_bias_kernel, dim3((N1 + 63) / 64), dim3(256), 0, s, part, Bp / 16, N1, db, db2, n_first);
   return launch_status("spv_enc_fc1_bwd_prep");
 }
 

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(LinearBatch a,
 // ---------------------------------------------------------------------------------------------
 typedef spv_bn_prob BnProb;
 typedef spv_bn_batch BnBatch;
-constexpr int BN_ROWS = 64;   // rows per workgroup (B = 4096 -> 64 workgroups per problem)
+constexpr int BN_ROWS = 32;   // rows per workgroup (B = 4096 -> 128 workgroups per problem)
 
 // column c = tid % NC, row slot = tid / NC (NC = N rounded up to a power of two): every thread strides over the
 // block's rows; the per-slot partials are then summed in slot order (deterministic)
@@ -228,41 +228,52 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(BnBatch a) {
   }
 }
 
-__global__ __launch_bounds__(256) void bn_apply_kernel(BnBatch a) {
+// per column: combine the per-block (mean, M2) partials (Chan's parallel formula, two passes over the partials),
+// update the running statistics (torch: UNBIASED variance) and leave (mean, 1/sqrt(var + eps)) in stats.
+// block = 64 columns x 4 partial groups; group y takes blocks y, y+4, ... in order, groups are added in order.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(BnBatch a) {
   const BnProb& q = a.p[blockIdx.y];
-  __shared__ float s_mean[256], s_inv[256];
-  const int j = threadIdx.x;
+  __shared__ float s_p[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + tx;
+  const bool ok = j < q.N;
   const int nblk = (a.B + BN_ROWS - 1) / BN_ROWS;
-  if (j < q.N) {
-    float mean, var;
-    if (a.training) {  // Chan's parallel combination of the per-block (count, mean, M2)
-      float tot = 0.f;
-      for (int k = 0; k < nblk; ++k) tot += q.part[((long)k * q.N + j) * 2] * (float)(min((k + 1) * BN_ROWS, a.B) - k * BN_ROWS);
-      mean = tot / (float)a.B;
-      float m2 = 0.f;
-      for (int k = 0; k < nblk; ++k) {
+  float mean = 0.f, var = 1.f;
+  if (a.training) {
+    float tot = 0.f;
+    if (ok)
+      for (int k = ty; k < nblk; k += 4) tot += q.part[((long)k * q.N + j) * 2] * (float)(min((k + 1) * BN_ROWS, a.B) - k * BN_ROWS);
+    s_p[ty][tx] = tot;
+    __syncthreads();
+    mean = (((s_p[0][tx] + s_p[1][tx]) + s_p[2][tx]) + s_p[3][tx]) / (float)a.B;
+    __syncthreads();
+    float m2 = 0.f;
+    if (ok)
+      for (int k = ty; k < nblk; k += 4) {
         const float cnt = (float)(min((k + 1) * BN_ROWS, a.B) - k * BN_ROWS), d = q.part[((long)k * q.N + j) * 2] - mean;
         m2 += q.part[((long)k * q.N + j) * 2 + 1] + cnt * d * d;
       }
-      var = m2 / (float)a.B;
-      if (blockIdx.x == 0) {  // torch: running stats take the UNBIASED variance
-        q.running_mean[j] = (1.f - a.momentum) * q.running_mean[j] + a.momentum * mean;
-        q.running_var[j] = (1.f - a.momentum) * q.running_var[j] + a.momentum * var * ((float)a.B / fmaxf((float)a.B - 1.f, 1.f));
-      }
-    } else {
-      mean = q.running_mean[j];
-      var = q.running_var[j];
+    s_p[ty][tx] = m2;
+    __syncthreads();
+    var = (((s_p[0][tx] + s_p[1][tx]) + s_p[2][tx]) + s_p[3][tx]) / (float)a.B;
+    if (ok && ty == 0) {
+      q.running_mean[j] = (1.f - a.momentum) * q.running_mean[j] + a.momentum * mean;
+      q.running_var[j] = (1.f - a.momentum) * q.running_var[j] + a.momentum * var * ((float)a.B / fmaxf((float)a.B - 1.f, 1.f));
     }
-    const float inv = rsqrtf(var + a.eps);
-    s_mean[j] = mean; s_inv[j] = inv;
-    if (blockIdx.x == 0) { q.stats[2 * j] = mean; q.stats[2 * j + 1] = inv; }
+  } else if (ok) {
+    mean = q.running_mean[j];
+    var = q.running_var[j];
   }
-  __syncthreads();
+  if (ok && ty == 0) { q.stats[2 * j] = mean; q.stats[2 * j + 1] = rsqrtf(var + a.eps); }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(BnBatch a) {
+  const BnProb& q = a.p[blockIdx.y];
   const int b0 = blockIdx.x * BN_ROWS, b1 = min(b0 + BN_ROWS, a.B);
   const int NC = pow2_at_least(q.N), RS = 256 / NC;
   const int c = threadIdx.x % NC, slot = threadIdx.x / NC;
   if (c >= q.N) return;
-  const float mean = s_mean[c], sc = s_inv[c] * q.gamma[c], be = q.beta[c];
+  const float mean = q.stats[2 * c], sc = q.stats[2 * c + 1] * q.gamma[c], be = q.beta[c];
 #pragma unroll 4
   for (int b = b0 + slot; b < b1; b += RS) {
     float v = (q.X[(long)b * q.ldx + c] - mean) * sc + be;
@@ -302,25 +313,33 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBatch a) {
   }
 }
 
+// d gamma = sum_b g * xhat, d beta = sum_b g: the per-block partials added in block order within four interleaved groups
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBatch a) {
+  const BnProb& q = a.p[blockIdx.y];
+  __shared__ float s_g[4][64], s_gx[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + tx;
+  const int nblk = (a.B + BN_ROWS - 1) / BN_ROWS;
+  float sg = 0.f, sgx = 0.f;
+  if (j < q.N)
+    for (int k = ty; k < nblk; k += 4) { sg += q.part[((long)k * q.N + j) * 2]; sgx += q.part[((long)k * q.N + j) * 2 + 1]; }
+  s_g[ty][tx] = sg; s_gx[ty][tx] = sgx;
+  __syncthreads();
+  if (ty == 0 && j < q.N) {
+    q.dbeta[j] = ((s_g[0][tx] + s_g[1][tx]) + s_g[2][tx]) + s_g[3][tx];
+    q.dgamma[j] = ((s_gx[0][tx] + s_gx[1][tx]) + s_gx[2][tx]) + s_gx[3][tx];
+  }
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBatch a) {
   const BnProb& q = a.p[blockIdx.y];
-  __shared__ float s_sg[256], s_sgx[256];
-  const int j = threadIdx.x;
-  const int nblk = (a.B + BN_ROWS - 1) / BN_ROWS;
-  if (j < q.N) {
-    float sg = 0.f, sgx = 0.f;
-    for (int k = 0; k < nblk; ++k) { sg += q.part[((long)k * q.N + j) * 2]; sgx += q.part[((long)k * q.N + j) * 2 + 1]; }
-    s_sg[j] = sg; s_sgx[j] = sgx;
-    if (blockIdx.x == 0) { q.dgamma[j] = sgx; q.dbeta[j] = sg; }
-  }
-  __syncthreads();
   const int b0 = blockIdx.x * BN_ROWS, b1 = min(b0 + BN_ROWS, a.B);
   const float invB = 1.0f / (float)a.B;
   const int NC = pow2_at_least(q.N), RS = 256 / NC;
   const int c = threadIdx.x % NC, slot = threadIdx.x / NC;
   if (c >= q.N) return;
   const float mean = q.stats[2 * c], inv = q.stats[2 * c + 1], gi = q.gamma[c] * inv;
-  const float msg = s_sg[c] * invB, msgx = s_sgx[c] * invB;
+  const float msg = q.dbeta[c] * invB, msgx = q.dgamma[c] * invB;  // written by bn_bwd_finalize_kernel
 #pragma unroll 4
   for (int b = b0 + slot; b < b1; b += RS) {
     const float g = bn_masked_dy(a, q, b, c);
@@ -643,6 +662,7 @@ __global__ __launch_bounds__(256) void bn_fold_bwd_kernel(FoldBatch a) {
   __shared__ float s_zbar[FOLD_KMAX], s_C[FOLD_KMAX * FOLD_KMAX], s_w[256 * FOLD_KMAX], s_dm[256], s_dv[256];
   const int K = q.K;
   const int nred = K + K * K;
+  if (blockIdx.x * 256 >= q.G) return;  // (the grid is sized for the largest problem)
   if (a.training) {
     const float invB = 1.0f / (float)a.B;
     for (int i = threadIdx.x; i < K; i += 256) s_zbar[i] = q.zsum[i] * invB;
@@ -691,27 +711,40 @@ __global__ __launch_bounds__(256) void bn_fold_bwd_kernel(FoldBatch a) {
   }
 }
 
-// d z[b][k] (+)= d zbar[k] / B + (1/B) sum_l (dC + dC^T)[k][l] (z[b][l] - zbar[l]);   red = sum over blocks of red_part
+// red = sum over gene blocks of red_part, in block order within four interleaved groups; stored in row nblk of red_part
+__global__ __launch_bounds__(256) void fold_red_finalize_kernel(FoldBatch a) {
+  const FoldProb& q = a.p[blockIdx.y];
+  __shared__ float s_p[4][64];
+  const int K = q.K, nred = K + K * K;
+  const int nblk = (q.G + 255) / 256;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + tx;
+  float s = 0.f;
+  if (i < nred)
+    for (int k = ty; k < nblk; k += 4) s += q.red_part[(long)k * nred + i];
+  s_p[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && i < nred) q.red_part[(long)nblk * nred + i] = ((s_p[0][tx] + s_p[1][tx]) + s_p[2][tx]) + s_p[3][tx];
+}
+
+// d z[b][k] (+)= d zbar[k] / B + (1/B) sum_l (dC + dC^T)[k][l] (z[b][l] - zbar[l]);   red = row nblk of red_part
 __global__ __launch_bounds__(256) void zstats_bwd_kernel(FoldBatch a) {
   const FoldProb& q = a.p[blockIdx.y];
   __shared__ float s_zbar[FOLD_KMAX], s_dz[FOLD_KMAX], s_S[FOLD_KMAX * FOLD_KMAX], s_red[FOLD_KMAX + FOLD_KMAX * FOLD_KMAX];
   const int K = q.K, nred = K + K * K;
   const int nblk = (q.G + 255) / 256;
   const float invB = 1.0f / (float)a.B;
-  for (int i = threadIdx.x; i < nred; i += 256) {
-    float s = 0.f;
-    for (int k = 0; k < nblk; ++k) s += q.red_part[(long)k * nred + i];
-    s_red[i] = s;
-  }
+  for (int i = threadIdx.x; i < nred; i += 256) s_red[i] = q.red_part[(long)nblk * nred + i];
   for (int i = threadIdx.x; i < K; i += 256) s_zbar[i] = q.zsum[i] * invB;
   __syncthreads();
   for (int i = threadIdx.x; i < K; i += 256) s_dz[i] = s_red[i] * invB;
   for (int i = threadIdx.x; i < K * K; i += 256) s_S[i] = (s_red[K + i] + s_red[K + (i % K) * K + i / K]) * invB;
   __syncthreads();
-  const int b = blockIdx.x * 256 + threadIdx.x;
+  // 4 threads per cell, each a quarter of the K outputs
+  const int b = blockIdx.x * 64 + (threadIdx.x >> 2), part = threadIdx.x & 3;
   if (b >= a.B) return;
   const float* zrow = q.z + (long)b * q.ldz;
-  for (int k = 0; k < K; ++k) {
+  for (int k = part; k < K; k += 4) {
     float v = s_dz[k];
     for (int l = 0; l < K; ++l) v += s_S[k * K + l] * (zrow[l] - s_zbar[l]);
     q.dz[(long)b * q.lddz + k] += v;

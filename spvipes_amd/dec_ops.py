@@ -300,7 +300,7 @@ class DecoderFused(torch.autograd.Function):
             for k, (dweff, ld, n, zoff) in enumerate(((dWp[g], DEC_KP, n_p, 0), (dWs[g], DEC_KS, n_s, n_p))):
                 q = fb.p[i]
                 q.dWeff, q.ld_dw, q.dW, q.dgamma, q.dbeta = ptr(dweff), ld, ptr(dWraw[g][k]), ptr(dgam[g][k]), ptr(dbet[g][k])
-                q.red_part = ptr(ws[g].get(f"fold_red_{k}", (-(-Gs[g] // 256), n + n * n), torch.float32))
+                q.red_part = ptr(ws[g].get(f"fold_red_{k}", (-(-Gs[g] // 256) + 1, n + n * n), torch.float32))
                 q.dz, q.lddz = _fptr(d_zcat[g], zoff), nt
                 i += 1
         _abi.call("spv_bn_fold_bwd", C.byref(fb), stream_ptr())

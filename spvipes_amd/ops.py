@@ -141,7 +141,7 @@ class EncoderFC1(torch.autograd.Function):
         Bp, N1p = round_up(B, 64), round_up(N1, 128)
         dh1 = dh1 if (dh1.dtype == torch.float32 and dh1.is_contiguous()) else dh1.float().contiguous()
         dh_hi, dh_lo = _bf16_image(ws, "fc1_dh", Bp, N1p, nsplit == 3)
-        part = ws.get("fc1_db_part", (Bp // 64, N1), torch.float32)
+        part = ws.get("fc1_db_part", (Bp // 16, N1), torch.float32)
         # (kernel target, autograd return): with the trainer's gradient sink the kernels write straight into .grad
         (dWp, rWp), (dbp, rbp), (dWs, rWs), (dbs, rbs) = grad_out(w_priv), grad_out(b_priv), grad_out(w_sh), grad_out(b_sh)
         _abi.call("spv_enc_fc1_bwd_prep", ptr(dh1), ptr(h1), B, N1, ptr(dh_hi), ptr(dh_lo), N1p, Bp, ptr(part), ptr(dbp), ptr(dbs), H, stream_ptr())
