@@ -639,6 +639,7 @@ __global__ __launch_bounds__(256) void fc1_bwd_bias_kernel(const float* part, in
   const int col = blockIdx.x * 64 + tx;
   float v = 0.f;
   if (col < N1)
+#pragma unroll 8
     for (int k = ty; k < nblk; k += 4) v += part[(long)k * N1 + col];
   s_p[ty][tx] = v;
   __syncthreads();

@@ -126,7 +126,7 @@ __device__ __forceinline__ void decode_counts4(const DecParams& p, const RawCoun
 }
 
 // y_p / y_s tiles (32 genes x 32 cells) with split-bf16 operands straight from L2 (K = 16 / 32):
-// A fragment = W' rows (natural [g][k]), B fragment = the wave's resident z fragments.
+// A fragment = W' rows (natural [g][k], PsW below), B fragment = the wave's resident z fragments.
 struct PsFrags { s8v hi[3], lo[3]; };
 __device__ __forceinline__ void load_ps_cell_frags(const DecParams& p, int cell0, int lane, PsFrags& f) {
   const long off = (long)(cell0 + (lane & 31)) * DEC_KPS + 8 * (lane >> 5);
@@ -136,17 +136,13 @@ __device__ __forceinline__ void load_ps_cell_frags(const DecParams& p, int cell0
     f.lo[s] = *reinterpret_cast<const s8v*>(p.Aps_lo + off + 16 * s);
   }
 }
-__device__ __forceinline__ void ps_tiles(const DecParams& p, int g0, int lane, const PsFrags& cf, f16v& yp, f16v& ys) {
+struct PsW { s8v hi[3], lo[3]; };  // gene-side fragments of one 32-gene tile (K slices 0: private, 1..2: shared)
+__device__ __forceinline__ void load_ps_w(const DecParams& p, int g0, int lane, PsW& w) {
   const long off = (long)(g0 + (lane & 31)) * DEC_KPS + 8 * (lane >> 5);
 #pragma unroll
-  for (int q = 0; q < 16; ++q) { yp[q] = 0.f; ys[q] = 0.f; }
-  s8v a_hi = *reinterpret_cast<const s8v*>(p.Wps_hi + off), a_lo = *reinterpret_cast<const s8v*>(p.Wps_lo + off);
-  yp = mfma32_split<3>(a_hi, a_lo, cf.hi[0], cf.lo[0], yp);
-#pragma unroll
-  for (int s = 1; s < 3; ++s) {
-    a_hi = *reinterpret_cast<const s8v*>(p.Wps_hi + off + 16 * s);
-    a_lo = *reinterpret_cast<const s8v*>(p.Wps_lo + off + 16 * s);
-    ys = mfma32_split<3>(a_hi, a_lo, cf.hi[s], cf.lo[s], ys);
+  for (int s = 0; s < 3; ++s) {
+    w.hi[s] = *reinterpret_cast<const s8v*>(p.Wps_hi + off + 16 * s);
+    w.lo[s] = *reinterpret_cast<const s8v*>(p.Wps_lo + off + 16 * s);
   }
 }
 
@@ -161,10 +157,20 @@ __global__ __launch_bounds__(256) void dec_lse_kernel(DecParams p) {
   const int gbeg = split * p.genes_per_split;
   int gend = gbeg + p.genes_per_split;
   if (gend > p.Gp) gend = p.Gp;
-  for (int g0 = gbeg; g0 < gend; g0 += 32) {
-    if (g0 >= p.G) break;
+  if (gend > ((p.G + 31) & ~31)) gend = (p.G + 31) & ~31;
+  const int ntile = (gend - gbeg) >> 5;
+  PsW wA;
+  if (ntile > 0) load_ps_w(p, gbeg, lane, wA);
+  for (int t = 0; t < ntile; ++t) {
+    const int g0 = gbeg + 32 * t;
     f16v yp, ys;
-    ps_tiles(p, g0, lane, cf, yp, ys);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { yp[q] = 0.f; ys[q] = 0.f; }
+    yp = mfma32_split<3>(wA.hi[0], wA.lo[0], cf.hi[0], cf.lo[0], yp);
+    ys = mfma32_split<3>(wA.hi[1], wA.lo[1], cf.hi[1], cf.lo[1], ys);
+    ys = mfma32_split<3>(wA.hi[2], wA.lo[2], cf.hi[2], cf.lo[2], ys);
+    PsW wB;
+    load_ps_w(p, gbeg + 32 * min(t + 1, ntile - 1), lane, wB);  // next tile's fragments fly under this tile's exps
     float tmp = -INFINITY, tms = -INFINITY;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -185,6 +191,7 @@ __global__ __launch_bounds__(256) void dec_lse_kernel(DecParams p) {
       ss += fast_exp(ys[q] - sms);
     }
     mp = nmp; ms = nms;
+    wA = wB;
   }
   // merge the two lane halves (same cell, different genes)
   {
@@ -526,8 +533,26 @@ __global__ __launch_bounds__(256, 3) void dec_nb_kernel(DecParams p) {
 //   d/dy_k[b,g] = t_k[b,g] - softmax_k[b,g] * T_k[b],   T_k[b] = sum_g t_k[b,g]
 // (t_k came out of dec_nb_kernel with a_k = library - lse_k held fixed; the second term is the
 // derivative through lse_k).  Re-evaluates y_k with the K = 16/32 split MFMAs and one exp each.
+template <typename GT> struct Raw4;
+template <> struct Raw4<bf16_t> { typedef u2v type; };
+template <> struct Raw4<float> { typedef f4v type; };
+template <typename GT>
+__device__ __forceinline__ typename Raw4<GT>::type load4_raw(const void* base, long off) {
+  return *reinterpret_cast<const typename Raw4<GT>::type*>(reinterpret_cast<const GT*>(base) + off);
+}
+__device__ __forceinline__ void decode4(const u2v& x, float (&v)[4]) {
+  v[0] = bf2f(x[0] & 0xFFFF); v[1] = bf2f(x[0] >> 16); v[2] = bf2f(x[1] & 0xFFFF); v[3] = bf2f(x[1] >> 16);
+}
+__device__ __forceinline__ void decode4(const f4v& x, float (&v)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = x[j];
+}
+
+// Software pipelined over 32-gene tiles: the next tile's fragments and gradient words are requested before the
+// current tile's stores are issued, so waiting for them never has to drain those stores (vmcnt is in order).
 template <typename GT>
 __global__ __launch_bounds__(256) void dec_softmax_bwd_kernel(DecParams p, const float* Tp, const float* Ts) {
+  typedef typename Raw4<GT>::type raw_t;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
   const int cell_tile = blockIdx.x * (DEC_CELLS_PER_WG / 32) + wave;
   const int cell0 = cell_tile * 32;
@@ -540,17 +565,38 @@ __global__ __launch_bounds__(256) void dec_softmax_bwd_kernel(DecParams p, const
   const int gbeg = split * p.genes_per_split;
   int gend = gbeg + p.genes_per_split;
   if (gend > p.Gp) gend = p.Gp;
-  for (int g0 = gbeg; g0 < gend; g0 += 32) {
-    if (g0 >= p.G) break;
+  if (gend > ((p.G + 31) & ~31)) gend = (p.G + 31) & ~31;
+  const int ntile = (gend - gbeg) >> 5;
+  if (ntile <= 0) return;
+  const long trow = (long)cell_tile * p.n_gene_tiles;
+  PsW wA;
+  raw_t rpA[4], rsA[4];
+  load_ps_w(p, gbeg, lane, wA);
+  {
+    const long tb = (trow + (gbeg >> 5)) * 1024 + lane * 4;
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) { rpA[qq] = load4_raw<GT>(p.tP, tb + 256 * qq); rsA[qq] = load4_raw<GT>(p.tS, tb + 256 * qq); }
+  }
+  for (int t = 0; t < ntile; ++t) {
+    const int g0 = gbeg + 32 * t, gn = gbeg + 32 * min(t + 1, ntile - 1);
     f16v yp, ys;
-    ps_tiles(p, g0, lane, cf, yp, ys);
-    const long tbase = ((long)cell_tile * p.n_gene_tiles + (g0 >> 5)) * 1024 + lane * 4;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { yp[q] = 0.f; ys[q] = 0.f; }
+    yp = mfma32_split<3>(wA.hi[0], wA.lo[0], cf.hi[0], cf.lo[0], yp);
+    ys = mfma32_split<3>(wA.hi[1], wA.lo[1], cf.hi[1], cf.lo[1], ys);
+    ys = mfma32_split<3>(wA.hi[2], wA.lo[2], cf.hi[2], cf.lo[2], ys);
+    PsW wB;
+    raw_t rpB[4], rsB[4];
+    load_ps_w(p, gn, lane, wB);
+    const long tbase = (trow + (g0 >> 5)) * 1024 + lane * 4, tnext = (trow + (gn >> 5)) * 1024 + lane * 4;
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) { rpB[qq] = load4_raw<GT>(p.tP, tnext + 256 * qq); rsB[qq] = load4_raw<GT>(p.tS, tnext + 256 * qq); }
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
       const int g = g0 + 8 * qq + 4 * h;
       float vp[4], vs[4];
-      load4<GT>(p.tP, tbase + 256 * qq, vp);
-      load4<GT>(p.tS, tbase + 256 * qq, vs);
+      decode4(rpA[qq], vp);
+      decode4(rsA[qq], vs);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int q = 4 * qq + j;
@@ -561,6 +607,9 @@ __global__ __launch_bounds__(256) void dec_softmax_bwd_kernel(DecParams p, const
       store4<GT>(p.tP, tbase + 256 * qq, vp);
       store4<GT>(p.tS, tbase + 256 * qq, vs);
     }
+    wA = wB;
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) { rpA[qq] = rpB[qq]; rsA[qq] = rsB[qq]; }
   }
 }
 

@@ -242,6 +242,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(BnBatch a) {
   if (a.training) {
     float tot = 0.f;
     if (ok)
+#pragma unroll 8
       for (int k = ty; k < nblk; k += 4) tot += q.part[((long)k * q.N + j) * 2] * (float)(min((k + 1) * BN_ROWS, a.B) - k * BN_ROWS);
     s_p[ty][tx] = tot;
     __syncthreads();
@@ -249,6 +250,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(BnBatch a) {
     __syncthreads();
     float m2 = 0.f;
     if (ok)
+#pragma unroll 8
       for (int k = ty; k < nblk; k += 4) {
         const float cnt = (float)(min((k + 1) * BN_ROWS, a.B) - k * BN_ROWS), d = q.part[((long)k * q.N + j) * 2] - mean;
         m2 += q.part[((long)k * q.N + j) * 2 + 1] + cnt * d * d;
@@ -322,6 +324,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBatch a) {
   const int nblk = (a.B + BN_ROWS - 1) / BN_ROWS;
   float sg = 0.f, sgx = 0.f;
   if (j < q.N)
+#pragma unroll 8
     for (int k = ty; k < nblk; k += 4) { sg += q.part[((long)k * q.N + j) * 2]; sgx += q.part[((long)k * q.N + j) * 2 + 1]; }
   s_g[ty][tx] = sg; s_gx[ty][tx] = sgx;
   __syncthreads();
@@ -721,6 +724,7 @@ __global__ __launch_bounds__(256) void fold_red_finalize_kernel(FoldBatch a) {
   const int i = blockIdx.x * 64 + tx;
   float s = 0.f;
   if (i < nred)
+#pragma unroll 8
     for (int k = ty; k < nblk; k += 4) s += q.red_part[(long)k * nred + i];
   s_p[ty][tx] = s;
   __syncthreads();
@@ -789,7 +793,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(spv_reduce_batch b) {
     if (ok) {
       r = (int)(i / q.cols); c = (int)(i - (long)r * q.cols);
       const float* s = q.src + (long)r * q.ld_src + q.col_off + c;
-#pragma unroll 4
+#pragma unroll 8
       for (int k = ty; k < q.nslabs; k += 4) acc += s[(long)k * q.slab_stride];
     }
     s_part[ty][tx] = acc;
