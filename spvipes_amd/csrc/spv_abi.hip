@@ -190,7 +190,7 @@ extern "C" int spv_enc_fc1_wgrad(const spv_counts* x, int32_t B, int32_t G, cons
 template <bool A_KMAJ, int NSPLIT, int A_SRC>
 static int gemm_dispatch(const GemmParams& p, int splits, hipStream_t s) {
   if (p.N <= 32) return launch_gemm<GemmCfg<128, 32, 4, 1, A_KMAJ, true, A_SRC, SRC_PLAIN, unsigned short, NSPLIT, 64, 4>>(p, splits, s);
-  return launch_gemm<GemmCfg<64, 320, 2, 2, A_KMAJ, true, A_SRC, SRC_PLAIN, unsigned short, NSPLIT, 64, 1>>(p, splits, s);
+  return launch_gemm<GemmCfg<64, 320, 2, 2, A_KMAJ, true, A_SRC, SRC_PLAIN, unsigned short, NSPLIT, 64, 1, (NSPLIT == 1 ? 2 : 1)>>(p, splits, s);
 }
 
 extern "C" int spv_gemm_bf16(int32_t a_kmajor, const uint16_t* A_hi, const uint16_t* A_lo, int64_t lda, const uint16_t* B_hi,
@@ -401,7 +401,7 @@ extern "C" int spv_linear_fwd(const spv_linear_batch* a, void* stream) {
   if (rc) return rc;
   for (int i = 0; i < a->nprob; ++i) if (!a->p[i].X || !a->p[i].Y) return fail(SPV_ERR_ARG, "spv_linear_fwd: null pointer%s");
   int nmax, kmax; linear_extents(a, nmax, kmax);
-  hipLaunchKernelGGL(linear_fwd_kernel, dim3((a->B + 31) / 32, (nmax + 31) / 32, a->nprob), dim3(256), 0, (hipStream_t)stream, *a);
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3((a->B + 63) / 64, (nmax + 63) / 64, a->nprob), dim3(256), 0, (hipStream_t)stream, *a);
   return launch_status("spv_linear_fwd");
 }
 extern "C" int spv_linear_dgrad(const spv_linear_batch* a, void* stream) {
@@ -410,7 +410,7 @@ extern "C" int spv_linear_dgrad(const spv_linear_batch* a, void* stream) {
   for (int i = 0; i < a->nprob; ++i)
     if (!a->p[i].dY || !a->p[i].dX || ((a->relu || a->drop_p > 0.f) && !a->p[i].Y)) return fail(SPV_ERR_ARG, "spv_linear_dgrad: null pointer%s");
   int nmax, kmax; linear_extents(a, nmax, kmax);
-  hipLaunchKernelGGL(linear_dgrad_kernel, dim3((a->B + 31) / 32, (kmax + 31) / 32, a->nprob), dim3(256), 0, (hipStream_t)stream, *a);
+  hipLaunchKernelGGL(linear_dgrad_kernel, dim3((a->B + 63) / 64, (kmax + 63) / 64, a->nprob), dim3(256), 0, (hipStream_t)stream, *a);
   return launch_status("spv_linear_dgrad");
 }
 extern "C" int spv_linear_wgrad(const spv_linear_batch* a, float* wpart, int64_t wpart_elems, void* stream) {

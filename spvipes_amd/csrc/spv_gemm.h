@@ -60,9 +60,9 @@ __host__ __device__ constexpr int nat_pitch(int bk) { return bk + 8; }  // BK k 
 // PF_: operand tiles each thread keeps in flight in registers (HBM latency is ~10 MFMA phases of a tile: one tile
 // ahead leaves the kernel latency-bound at ~1 workgroup per CU).  With PF_ > 1 the LDS image is double buffered
 // when it fits, which also drops one of the two barriers per tile.
-template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ_, bool B_KMAJ_, int A_SRC_, int B_SRC_, typename CT_, int NSPLIT_, int BK_ = 32, int PF_ = 1>
+template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ_, bool B_KMAJ_, int A_SRC_, int B_SRC_, typename CT_, int NSPLIT_, int BK_ = 32, int PF_ = 1, int OCC_ = 1>
 struct GemmCfg {
-  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BK = BK_, PF = PF_;
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BK = BK_, PF = PF_, OCC = OCC_;  // OCC: waves per SIMD to fit (register budget)
   static constexpr int NAT_PITCH = nat_pitch(BK_);
   static constexpr bool A_KMAJ = A_KMAJ_, B_KMAJ = B_KMAJ_;
   static constexpr int A_SRC = A_SRC_, B_SRC = B_SRC_, NSPLIT = NSPLIT_;
@@ -89,7 +89,7 @@ template <typename Cfg, bool KMAJ, int SRC, int EXT /*BM or BN*/>
 struct Stager {
   static constexpr int FAST8 = KMAJ ? EXT / 8 : Cfg::BK / 8;   // chunks along the contiguous dim
   static constexpr int SLOW = KMAJ ? Cfg::BK : EXT;            // rows of the LDS image
-  static constexpr int NCHUNKS = (SRC == SRC_TILED) ? (EXT / 32) * (Cfg::BK / 32) * 128 : SLOW * FAST8;
+  static constexpr int NCHUNKS = SLOW * FAST8;
   static constexpr int NCH = (NCHUNKS + 255) / 256;
   static constexpr int PITCH = KMAJ ? kmajor_pitch(EXT) : Cfg::NAT_PITCH;
   // per-chunk register payload
@@ -102,13 +102,8 @@ struct Stager {
   __device__ __forceinline__ static void coord(int i, int tid, int& s, int& f, bool& ok) {
     const int c = tid + 256 * i;
     ok = c < NCHUNKS;
-    if constexpr (SRC == SRC_TILED) {
-      s = c >> 7;    // 32x32 tile: (tile along EXT) * (BK/32) + (tile along K)
-      f = c & 127;   // (qq << 5) | lane pair
-    } else {
-      s = c / FAST8;
-      f = c % FAST8;
-    }
+    s = c / FAST8;   // row of the LDS image
+    f = c % FAST8;   // 16-byte chunk within the row: consecutive lanes fill a row contiguously (conflict-free stores)
   }
 
   // tile origin: `ext0` along the M/N dimension, `k0` along K
@@ -123,12 +118,20 @@ struct Stager {
       valid[i] = false;
       if (!ok) continue;
       if constexpr (SRC == SRC_TILED) {
-        // k-major (k = cell, ext = gene): tile (k0/32, ext0/32 + s); natural (ext = cell, k = gene): (ext0/32 + s, k0/32)
-        const int et = s / (Cfg::BK / 32), kt = s % (Cfg::BK / 32);
-        const long ct = KMAJ ? k0 / 32 + kt : ext0 / 32 + et, gt = KMAJ ? ext0 / 32 + et : k0 / 32 + kt;
-        const long off = (ct * p.tiles_inner + gt) * 1024 + 8 * f;  // 16 B = registers 4qq..4qq+3 of lanes 2lp, 2lp+1
-        hi[i] = *reinterpret_cast<const u4v*>(reinterpret_cast<const bf16_t*>(ptr) + off);
-        if constexpr (Cfg::NSPLIT == 3) lo[i] = *reinterpret_cast<const u4v*>(reinterpret_cast<const bf16_t*>(ptr_lo) + off);
+        // The source is stored in 32x32 accumulator tiles T[cell/32][gene/32][qq][lane = cell%32 + 32h][j], gene%32 = 8qq+4h+j.
+        // A chunk = 8 consecutive genes (8qq .. 8qq+7) of one cell = the 8-byte words of storage lanes r and r + 32.
+        // k-major (k = cell, ext = gene): image row s = cell, f = gene chunk; natural (ext = cell, k = gene): row s = cell too.
+        const int r = s & 31, st = s >> 5, ft = f >> 2, qq = f & 3;   // cell within its tile / cell tile / gene tile / gene chunk
+        const long ct = KMAJ ? k0 / 32 + st : ext0 / 32 + st, gt = KMAJ ? ext0 / 32 + ft : k0 / 32 + ft;
+        const long off = (ct * p.tiles_inner + gt) * 1024 + qq * 256 + r * 4;
+        const u2v a = *reinterpret_cast<const u2v*>(reinterpret_cast<const bf16_t*>(ptr) + off);
+        const u2v b = *reinterpret_cast<const u2v*>(reinterpret_cast<const bf16_t*>(ptr) + off + 128);
+        hi[i] = u4v{a[0], a[1], b[0], b[1]};
+        if constexpr (Cfg::NSPLIT == 3) {
+          const u2v c2 = *reinterpret_cast<const u2v*>(reinterpret_cast<const bf16_t*>(ptr_lo) + off);
+          const u2v d2 = *reinterpret_cast<const u2v*>(reinterpret_cast<const bf16_t*>(ptr_lo) + off + 128);
+          lo[i] = u4v{c2[0], c2[1], d2[0], d2[1]};
+        }
       } else if constexpr (SRC == SRC_PLAIN) {
         // natural: mem[ext0 + s][k0 + 8f]; k-major: mem[k0 + s][ext0 + 8f]; producer-padded
         const long off = KMAJ ? (long)(k0 + s) * ld + ext0 + 8 * f : (long)(ext0 + s) * ld + k0 + 8 * f;
@@ -223,20 +226,6 @@ struct Stager {
       int s, f; bool ok;
       coord(i, tid, s, f, ok);
       if (!ok) continue;
-      if constexpr (SRC == SRC_TILED) {
-        // genes 8qq + 4h + {0..3} of the two cells r, r+1 held by lanes 2lp and 2lp+1
-        const int qq = f >> 5, lane = (f & 31) * 2, r = lane & 31, h = lane >> 5;
-        const int g = 8 * qq + 4 * h;
-        const int et = s / (Cfg::BK / 32), kt = s % (Cfg::BK / 32);
-        const int o = KMAJ ? (32 * kt + r) * PITCH + 32 * et + g : (32 * et + r) * PITCH + 32 * kt + g;
-        *reinterpret_cast<u2v*>(img_hi + o) = u2v{hi[i][0], hi[i][1]};
-        *reinterpret_cast<u2v*>(img_hi + o + PITCH) = u2v{hi[i][2], hi[i][3]};
-        if constexpr (Cfg::NSPLIT == 3) {
-          *reinterpret_cast<u2v*>(img_lo + o) = u2v{lo[i][0], lo[i][1]};
-          *reinterpret_cast<u2v*>(img_lo + o + PITCH) = u2v{lo[i][2], lo[i][3]};
-        }
-        continue;
-      }
       if constexpr (SRC == SRC_COUNTS) {
         u4v o_hi, o_lo;
         const u4v zero = u4v{0u, 0u, 0u, 0u};
@@ -252,7 +241,7 @@ struct Stager {
 };
 
 template <typename Cfg>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+__global__ __launch_bounds__(256, Cfg::OCC) void gemm_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* sA = reinterpret_cast<bf16_t*>(smem_raw);
   bf16_t* sA_lo = sA + Cfg::A_ELEMS * (Cfg::NIMG - 1);

@@ -12,8 +12,6 @@
 
 namespace spv {
 
-constexpr int SM_T = 32;        // tile edge
-constexpr int SM_PITCH = 36;    // LDS row pitch in floats (144 B: 16-B aligned, breaks the 128-B bank period)
 
 typedef spv_linear_prob LinearProb;    // field meanings: include/spvipes_hip.h
 typedef spv_linear_batch LinearBatch;
@@ -28,51 +26,70 @@ __device__ __forceinline__ bool dropout_keep(unsigned long long seed, int prob, 
   return (float)(u >> 8) * (1.0f / 16777216.0f) >= p;
 }
 
-// Y = act(X W^T + b): tile 32 rows x 32 cols per workgroup, 4 outputs per thread
+// ---- small dense layers on the fp32 matrix pipe ------------------------------------------------------
+// v_mfma_f32_32x32x2_f32 (exact fp32 products and sums) with both operands read straight from global/L2 into
+// registers: no LDS staging, no barriers.  One wave owns a 32 x 32 output tile; lane l supplies row/col l % 32
+// and the contraction indices c0 + 8 (l / 32) + j, j < 8, of a 16-deep step (any bijection of the 16 indices
+// onto the 8 x 2 MFMA k-slots is valid as long as A and B agree).
+__device__ __forceinline__ f16v mfma_f32(float x, float w, const f16v& c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(x, w, c, 0, 0, 0); }
+
+// v[j] = p[j] for j < lim, else 0 (lim may be <= 0).  vec: p is 16-byte aligned and lim is >= 8 or <= 0.
+// Branch-free: out-of-range elements are read from `safe` (any valid aligned address) and zeroed afterwards.
+__device__ __forceinline__ void load8(const float* p, const float* safe, int lim, bool vec, float (&v)[8]) {
+  if (vec) {
+    const float* s = (lim >= 8) ? p : safe;
+    const f4v a = *reinterpret_cast<const f4v*>(s), b = *reinterpret_cast<const f4v*>(s + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = (lim >= 8) ? a[j] : 0.f; v[4 + j] = (lim >= 8) ? b[j] : 0.f; }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float t = *((j < lim) ? p + j : safe); v[j] = (j < lim) ? t : 0.f; }
+  }
+}
+// v[j] = p[(c0 + j) * ld] for c0 + j < lim, else 0: a column walk (coalesced across the lanes of a wave)
+__device__ __forceinline__ void load8_strided(const float* p, long ld, int c0, int lim, float (&v)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { const bool ok = c0 + j < lim; const float t = p[ok ? (long)(c0 + j) * ld : 0]; v[j] = ok ? t : 0.f; }
+}
+__device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// Y = act(X W^T + b): workgroup = 2 x 2 waves = 64 rows x 64 columns
 __global__ __launch_bounds__(256) void linear_fwd_kernel(LinearBatch a) {
   const LinearProb& q = a.p[blockIdx.z];
-  const int n0 = blockIdx.y * SM_T, b0 = blockIdx.x * SM_T;
-  if (n0 >= q.N) return;
-  __shared__ __attribute__((aligned(16))) float sX[SM_T * SM_PITCH], sW[SM_T * SM_PITCH];
-  const int tid = threadIdx.x, r = tid >> 3, cg = (tid & 7) * 4;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < q.K; k0 += SM_T) {
-    {  // stage 32x32 of X and of W (rows n0.., cols k0..): one float4 per thread per matrix
-      const int rr = tid >> 3, kk = (tid & 7) * 4;
-      f4v vx = {0.f, 0.f, 0.f, 0.f}, vw = {0.f, 0.f, 0.f, 0.f};
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
+  const int b0 = blockIdx.x * 64 + 32 * (wave >> 1), n0 = blockIdx.y * 64 + 32 * (wave & 1);
+  if (n0 >= q.N || b0 >= a.B) return;  // wave-uniform
+  const int row = b0 + r, col = n0 + r;
+  const float* xr = q.X + (long)min(row, a.B - 1) * q.ldx;   // rows / columns beyond the problem only feed outputs never stored
+  const float* wr = q.W + (long)min(col, q.N - 1) * q.K;
+  const bool vx = ((q.ldx & 3) == 0) && aligned16(q.X) && ((q.K & 7) == 0);
+  const bool vw = aligned16(q.W) && ((q.K & 7) == 0);
+  f16v acc;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int k = k0 + kk + j;
-        if (k < q.K) {
-          if (b0 + rr < a.B) vx[j] = q.X[(long)(b0 + rr) * q.ldx + k];
-          if (n0 + rr < q.N) vw[j] = q.W[(long)(n0 + rr) * q.K + k];
-        }
-      }
-      *reinterpret_cast<f4v*>(&sX[rr * SM_PITCH + kk]) = vx;
-      *reinterpret_cast<f4v*>(&sW[rr * SM_PITCH + kk]) = vw;
-    }
-    __syncthreads();
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float xa[8], wb[8];
+  load8(xr + 8 * h, xr, q.K - 8 * h, vx, xa);
+  load8(wr + 8 * h, wr, q.K - 8 * h, vw, wb);
+  for (int k0 = 0; k0 < q.K; k0 += 16) {
+    float xn[8], wn[8];
+    const int kn = k0 + 16 + 8 * h;   // next step's elements fly under this step's eight MFMAs
+    load8(xr + kn, xr, q.K - kn, vx, xn);
+    load8(wr + kn, wr, q.K - kn, vw, wn);
 #pragma unroll
-    for (int kk = 0; kk < SM_T; kk += 4) {
-      const f4v x = *reinterpret_cast<const f4v*>(&sX[r * SM_PITCH + kk]);
+    for (int j = 0; j < 8; ++j) acc = mfma_f32(xa[j], wb[j], acc);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const f4v w = *reinterpret_cast<const f4v*>(&sW[(cg + i) * SM_PITCH + kk]);
-        acc[i] += x[0] * w[0] + x[1] * w[1] + x[2] * w[2] + x[3] * w[3];
-      }
-    }
-    __syncthreads();
+    for (int j = 0; j < 8; ++j) { xa[j] = xn[j]; wb[j] = wn[j]; }
   }
-  const int b = b0 + r;
-  if (b >= a.B) return;
+  if (col >= q.N) return;
+  const float bias = q.bias ? q.bias[col] : 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int n = n0 + cg + i;
-    if (n >= q.N) continue;
-    float v = acc[i] + (q.bias ? q.bias[n] : 0.f);
+  for (int i = 0; i < 16; ++i) {
+    const int b = b0 + crow(i, h);
+    if (b >= a.B) continue;
+    float v = acc[i] + bias;
     if (a.relu) v = fmaxf(v, 0.f);
-    if (a.drop_p > 0.f) v = dropout_keep(a.seed + (a.seed_ptr ? *a.seed_ptr : 0ull), blockIdx.z, (long)b * q.N + n, a.drop_p) ? v * (1.0f / (1.0f - a.drop_p)) : 0.f;
-    q.Y[(long)b * q.ldy + n] = v;
+    if (a.drop_p > 0.f) v = dropout_keep(a.seed + (a.seed_ptr ? *a.seed_ptr : 0ull), blockIdx.z, (long)b * q.N + col, a.drop_p) ? v * (1.0f / (1.0f - a.drop_p)) : 0.f;
+    q.Y[(long)b * q.ldy + col] = v;
   }
 }
 
@@ -81,91 +98,111 @@ __device__ __forceinline__ float masked_dy(const LinearBatch& a, const LinearPro
   if (a.relu || a.drop_p > 0.f) g = (q.Y[(long)b * q.ldy + n] > 0.f) ? g * (a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f) : 0.f;
   return g;
 }
+// mask (relu / dropout) of 8 loaded gradient values given the 8 matching forward outputs
+__device__ __forceinline__ void apply_mask8(const LinearBatch& a, float (&g)[8], const float (&y)[8]) {
+  const float sc = (a.drop_p > 0.f) ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) g[j] = (y[j] > 0.f) ? g[j] * sc : 0.f;
+}
 
-// dX = mask(dY) W : tile 32 rows x 32 k-cols
+// dX (+)= mask(dY) W : rows = cells, columns = k, contraction over the N outputs of the layer
 __global__ __launch_bounds__(256) void linear_dgrad_kernel(LinearBatch a) {
   const LinearProb& q = a.p[blockIdx.z];
-  const int k0 = blockIdx.y * SM_T, b0 = blockIdx.x * SM_T;
-  if (k0 >= q.K) return;
-  __shared__ __attribute__((aligned(16))) float sG[SM_T * SM_PITCH], sW[SM_T * SM_PITCH];
-  const int tid = threadIdx.x, r = tid >> 3, cg = (tid & 7) * 4;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int n0 = 0; n0 < q.N; n0 += SM_T) {
-    {
-      const int rr = tid >> 3, cc = (tid & 7) * 4;
-      f4v vg = {0.f, 0.f, 0.f, 0.f}, vw = {0.f, 0.f, 0.f, 0.f};
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
+  const int b0 = blockIdx.x * 64 + 32 * (wave >> 1), k0 = blockIdx.y * 64 + 32 * (wave & 1);
+  if (k0 >= q.K || b0 >= a.B) return;
+  const int row = b0 + r, col = k0 + r;
+  const bool masked = a.relu || a.drop_p > 0.f;
+  const float* gr = q.dY + (long)min(row, a.B - 1) * q.lddy;
+  const float* yr = masked ? q.Y + (long)min(row, a.B - 1) * q.ldy : gr;
+  const float* wc = q.W + min(col, q.K - 1);
+  const bool vg = ((q.lddy & 3) == 0) && aligned16(q.dY) && ((q.N & 7) == 0);
+  const bool vy = masked && ((q.ldy & 3) == 0) && aligned16(q.Y) && ((q.N & 7) == 0);
+  f16v acc;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (b0 + rr < a.B && n0 + cc + j < q.N) vg[j] = masked_dy(a, q, b0 + rr, n0 + cc + j);   // sG[b][n]
-        if (n0 + rr < q.N && k0 + cc + j < q.K) vw[j] = q.W[(long)(n0 + rr) * q.K + k0 + cc + j];  // sW[n][k]
-      }
-      *reinterpret_cast<f4v*>(&sG[rr * SM_PITCH + cc]) = vg;
-      *reinterpret_cast<f4v*>(&sW[rr * SM_PITCH + cc]) = vw;
-    }
-    __syncthreads();
-#pragma unroll 8
-    for (int n = 0; n < SM_T; ++n) {
-      const float g = sG[r * SM_PITCH + n];
-      const f4v w = *reinterpret_cast<const f4v*>(&sW[n * SM_PITCH + cg]);
-      acc[0] += g * w[0]; acc[1] += g * w[1]; acc[2] += g * w[2]; acc[3] += g * w[3];
-    }
-    __syncthreads();
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float ga[8], wb[8];
+  auto fetch = [&](int n, float (&g)[8], float (&w)[8]) {
+    load8(gr + n, gr, q.N - n, vg, g);
+    if (masked) { float y[8]; load8(yr + n, yr, q.N - n, vy, y); apply_mask8(a, g, y); }
+    load8_strided(wc, q.K, n, q.N, w);
+  };
+  fetch(8 * h, ga, wb);
+  for (int n0 = 0; n0 < q.N; n0 += 16) {
+    float gn[8], wn[8];
+    fetch(n0 + 16 + 8 * h, gn, wn);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = mfma_f32(ga[j], wb[j], acc);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ga[j] = gn[j]; wb[j] = wn[j]; }
   }
-  const int b = b0 + r;
-  if (b >= a.B) return;
+  if (col >= q.K) return;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int k = k0 + cg + i;
-    if (k >= q.K) continue;
-    float* dst = q.dX + (long)b * q.lddx + k;
+  for (int i = 0; i < 16; ++i) {
+    const int b = b0 + crow(i, h);
+    if (b >= a.B) continue;
+    float* dst = q.dX + (long)b * q.lddx + col;
     *dst = a.accumulate ? *dst + acc[i] : acc[i];
   }
 }
 
-// dW = mask(dY)^T X, db = colsum(mask(dY)): tile 32 n x 32 k; the batch is cut into WG_SLICES slices (one
-// workgroup each, partial tiles into `wpart`), summed in slice order by linear_wgrad_reduce_kernel
+// dW = mask(dY)^T X, db = colsum(mask(dY)): rows = n, columns = k, contraction over the batch.  The batch is cut into
+// WG_SLICES slices (one workgroup each; its four waves take a quarter each and are added in wave order); partial
+// tiles go to `wpart` and are summed in slice order by linear_wgrad_reduce_kernel.
 constexpr int WG_SLICES = 16;
 
 __global__ __launch_bounds__(256) void linear_wgrad_kernel(LinearBatch a, float* wpart, long prob_stride) {
   const int prob = blockIdx.z / WG_SLICES, slice = blockIdx.z % WG_SLICES;
   const LinearProb& q = a.p[prob];
-  const int n0 = blockIdx.x * SM_T, k0 = blockIdx.y * SM_T;
-  if (n0 >= q.N || k0 >= q.K) return;
-  __shared__ __attribute__((aligned(16))) float sG[SM_T * SM_PITCH], sX[SM_T * SM_PITCH];
-  const int tid = threadIdx.x, nn = tid >> 3, cg = (tid & 7) * 4;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f}, bsum = 0.f;
-  const int per = ((a.B + WG_SLICES * SM_T - 1) / (WG_SLICES * SM_T)) * SM_T;
-  const int bbeg = slice * per, bend = min(bbeg + per, a.B);
-  for (int b0 = bbeg; b0 < bend; b0 += SM_T) {
-    {
-      const int rr = tid >> 3, cc = (tid & 7) * 4;
-      f4v vg = {0.f, 0.f, 0.f, 0.f}, vx = {0.f, 0.f, 0.f, 0.f};
+  const int n0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+  if (n0 >= q.N || k0 >= q.K) return;  // block-uniform
+  __shared__ float s_acc[3][16][64], s_b[3][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
+  const bool masked = a.relu || a.drop_p > 0.f;
+  const int per = ((a.B + WG_SLICES * 64 - 1) / (WG_SLICES * 64)) * 64;   // rows per slice, a multiple of 64 (16 per wave and step)
+  const int bbeg = slice * per + wave * (per / 4), bend = min(bbeg + per / 4, a.B);
+  const float* gc = q.dY + min(n0 + r, q.N - 1);
+  const float* yc = masked ? q.Y + min(n0 + r, q.N - 1) : gc;
+  const float* xc = q.X + min(k0 + r, q.K - 1);
+  f16v acc;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (b0 + rr < bend && n0 + cc + j < q.N) vg[j] = masked_dy(a, q, b0 + rr, n0 + cc + j);        // sG[b][n]
-        if (b0 + rr < bend && k0 + cc + j < q.K) vx[j] = q.X[(long)(b0 + rr) * q.ldx + k0 + cc + j];   // sX[b][k]
-      }
-      *reinterpret_cast<f4v*>(&sG[rr * SM_PITCH + cc]) = vg;
-      *reinterpret_cast<f4v*>(&sX[rr * SM_PITCH + cc]) = vx;
-    }
-    __syncthreads();
-#pragma unroll 8
-    for (int b = 0; b < SM_T; ++b) {
-      const float g = sG[b * SM_PITCH + nn];
-      const f4v x = *reinterpret_cast<const f4v*>(&sX[b * SM_PITCH + cg]);
-      acc[0] += g * x[0]; acc[1] += g * x[1]; acc[2] += g * x[2]; acc[3] += g * x[3];
-      bsum += g;
-    }
-    __syncthreads();
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float bsum = 0.f;
+  float ga[8], xb[8];
+  auto fetch = [&](int b, float (&g)[8], float (&x)[8]) {
+    load8_strided(gc, q.lddy, b, bend, g);
+    if (masked) { float y[8]; load8_strided(yc, q.ldy, b, bend, y); apply_mask8(a, g, y); }
+    load8_strided(xc, q.ldx, b, bend, x);
+  };
+  fetch(bbeg + 8 * h, ga, xb);
+  for (int b0 = bbeg; b0 < bend; b0 += 16) {
+    float gn[8], xn[8];
+    fetch(b0 + 16 + 8 * h, gn, xn);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { acc = mfma_f32(ga[j], xb[j], acc); bsum += ga[j]; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ga[j] = gn[j]; xb[j] = xn[j]; }
   }
-  const int n = n0 + nn;
-  if (n >= q.N) return;
-  // partial layout per problem: [slice][N][K + 1] (last column = bias partial)
-  float* dst = wpart + prob * prob_stride + ((long)slice * q.N + n) * (q.K + 1);
+  bsum += __shfl_xor(bsum, 32, 64);
+  if (wave > 0) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-    if (k0 + cg + i < q.K) dst[k0 + cg + i] = acc[i];
-  if (blockIdx.y == 0 && cg == 0) dst[q.K] = bsum;
+    for (int i = 0; i < 16; ++i) s_acc[wave - 1][i][lane] = acc[i];
+    if (h == 0) s_b[wave - 1][r] = bsum;
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = ((acc[i] + s_acc[0][i][lane]) + s_acc[1][i][lane]) + s_acc[2][i][lane];
+  bsum = ((bsum + s_b[0][r]) + s_b[1][r]) + s_b[2][r];
+  // partial layout per problem: [slice][N][K + 1] (last column = bias partial)
+  float* base = wpart + prob * prob_stride + (long)slice * q.N * (q.K + 1);
+  const int k = k0 + r;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int n = n0 + crow(i, h);
+    if (n < q.N && k < q.K) base[(long)n * (q.K + 1) + k] = acc[i];
+  }
+  if (blockIdx.y == 0 && h == 0 && n0 + r < q.N) base[(long)(n0 + r) * (q.K + 1) + q.K] = bsum;
 }
 
 __global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(LinearBatch a, const float* wpart, long prob_stride) {

@@ -282,14 +282,28 @@ class spVIPESmodule(nn.Module):
             ep, es = self.encoders[g]["private"], self.encoders[g]["shared"]
             ws = self._workspace(g, counts.X.device)
             h1, lib = EncoderFC1.apply(counts, rows, B, ep.fc1.weight, ep.fc1.bias, es.fc1.weight, es.fc1.bias, self.nsplit, ws)
-            dev = h1.device
-            e_p = noise.get(f"enc_{g}_private")
-            e_s = noise.get(f"enc_{g}_shared")
-            eps_enc[g] = (torch.randn(B, self.n_dimensions_private, device=dev) if e_p is None else e_p,
-                          torch.randn(B, self.n_dimensions_shared, device=dev) if e_s is None else e_s)
             h1s[g] = h1
             library[g] = lib.unsqueeze(1)
         groups_ = sorted(x.keys())
+        # every standard-normal draw of the step (encoder heads + PoE) comes out of ONE generator launch
+        n_p_, n_s_ = self.n_dimensions_private, self.n_dimensions_shared
+        want = {}
+        for g in groups_:
+            Bg = self._step_inputs[g][2]
+            want[f"enc_{g}_private"], want[f"enc_{g}_shared"], want[f"poe_{g}"] = (Bg, n_p_), (Bg, n_s_), (Bg, n_s_)
+        missing = [k for k in want if noise.get(k) is None]
+        draws = {}
+        if missing:
+            dev = h1s[groups_[0]].device
+            flat = torch.randn(sum(want[k][0] * want[k][1] for k in missing), device=dev)
+            off = 0
+            for k in missing:
+                n = want[k][0] * want[k][1]
+                draws[k] = flat[off:off + n].view(want[k])
+                off += n
+        draw = lambda k: noise[k] if noise.get(k) is not None else draws[k]
+        for g in groups_:
+            eps_enc[g] = (draw(f"enc_{g}_private"), draw(f"enc_{g}_shared"))
         same_B = len({self._step_inputs[g][2] for g in groups_}) == 1
         if dropout_masks is None and same_B:
             # all four encoder tails (fc2, dropout, heads, BatchNorm, draw, KL) as a few batched HIP launches
@@ -328,8 +342,7 @@ class spVIPESmodule(nn.Module):
         if self.use_labels and labels is not None:
             # label-based PoE (priority as spVIPESmodule.py:492-493): pairing + fusion + draw + KL in HIP
             dev = shared_stats[0]["logtheta_loc"].device
-            e = [noise.get(f"poe_{g}") for g in (0, 1)]
-            e = [torch.randn_like(shared_stats[g]["logtheta_loc"]) if e[g] is None else e[g] for g in (0, 1)]
+            e = [draw(f"poe_{g}") for g in (0, 1)]
             o = PoELabel.apply([labels[0], labels[1]], e, self._workspace(0, dev), shared_stats[0]["logtheta_loc"], shared_stats[0]["logtheta_logvar"],
                                shared_stats[1]["logtheta_loc"], shared_stats[1]["logtheta_logvar"])
             poe_stats = {}
