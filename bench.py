@@ -94,6 +94,24 @@ def cpu_baseline(groups, args, n_threads):
             "sample": f"{args.cpu_steps} steps of 2 x {B} cells x {Gs[0]} genes (same synthetic data, fwd+loss+bwd+Adam), {sec:.2f} s/step"}
 
 
+
+def _pmc_traffic():
+    """HBM bytes per launch of the dominant kernel = FETCH_SIZE + WRITE_SIZE (KiB) of the newest committed rocprofv3 --pmc
+    passes under profiles/ (separate passes of this same command; bench.py itself cannot run under the profiler).  The
+    kernel's reads are 8 B / lane: outside the access widths the gfx950 FETCH_SIZE correction is calibrated for, so the
+    raw counter is reported."""
+    import glob, re
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_dec_nb_kernel.txt")))
+    if not files:
+        return None, None
+    txt = open(files[-1]).read()
+    f = re.search(r"FETCH_SIZE\s+n=\s*\d+\s+avg=\s*([0-9.]+)", txt)
+    w = re.search(r"WRITE_SIZE\s+n=\s*\d+\s+avg=\s*([0-9.]+)", txt)
+    if not (f and w):
+        return None, None
+    return (float(f.group(1)) + float(w.group(1))) * 1024.0, "profiles/" + os.path.basename(files[-1]) + " (raw FETCH_SIZE + WRITE_SIZE, KiB -> bytes)"
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -186,8 +204,10 @@ def main():
         nb_bytes = B * G * sx + G * (KM + 2 * (n_s + n_p + 2)) * 2 + B * KM * 2
         nb_flops = 2.0 * B * G * (KM + n_s + n_p + 2)
         per_kernel = {k: {"calls_per_step": len(v) / prof_steps, "avg_ms": float(np.mean(v))} for k, v in prof.items() if v}
+        traffic, traffic_src = _pmc_traffic()
         roof = {"kernel": "dec_nb_kernel (spv_dec_nb_fwd)", "bound": "hbm", "achieved": nb_bytes / (nb_avg * 1e-3) / 1e9,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nb_bytes / (nb_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nb_bytes / (nb_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": traffic_src,
                 "avg_launch_ms": nb_avg, "algorithmic_bytes_per_launch": nb_bytes,
                 "mfma_view": {"achieved_TFLOPs": nb_flops / (nb_avg * 1e-3) / 1e12, "peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS,
                               "frac": nb_flops / (nb_avg * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS},
