@@ -70,19 +70,25 @@ int spv_pack_bf16(const float* src, int64_t ld_src, int32_t R, int32_t C,
  *   bias     : fp32 [N1], or the two encoders' biases in place: bias [n_first] and bias2 [N1 - n_first]
  *              (bias2 == NULL: one vector)
  *   slabs    : fp32 workspace [splits][B][N1];  rowsum_ws: fp32 [splits][B]
- *   h1       : fp32 [B][N1];  library: fp32 [B] */
+ *   h1       : fp32 [B][N1];  library: fp32 [B]
+ *   xb_out   : optional by-product (nsplit 1 only): bf16(log1p(x)) of the minibatch, [B][ld_xb], ld_xb >= round_up(G, 32);
+ *              spv_enc_fc1_wgrad reads it instead of decoding the counts again */
 int spv_enc_fc1_fwd(const spv_counts* x, int32_t B, int32_t G,
                     const uint16_t* W1_hi, const uint16_t* W1_lo, int64_t ldw, int32_t N1,
                     const float* bias, const float* bias2, int32_t n_first, int32_t nsplit, int32_t splits,
-                    float* slabs, float* rowsum_ws, float* h1, float* library, void* stream);
+                    float* slabs, float* rowsum_ws, float* h1, float* library,
+                    uint16_t* xb_out, int64_t ld_xb, void* stream);
 
 /* fc1 weight gradient (autograd of nn/networks.py:119):  dW1[N1][G] = dh^T @ log1p(X[rows]).
  *   dh_hi/lo : bf16 [round_up(B,64)][ld_dh] (ld_dh >= round_up(N1,128), zero padded)
+ *   xb       : optional bf16 log1p image written by spv_enc_fc1_fwd ([round_up(B,64)][ld_xb], rows >= B and columns
+ *              >= G zero, ld_xb >= round_up(G, 64)); NULL = decode the counts here
  *   dW2      : optional second destination: rows >= rows_first go to dW2[row - rows_first] (the shared
  *              encoder's weight gradient, stored apart from the private encoder's)  */
 int spv_enc_fc1_wgrad(const spv_counts* x, int32_t B, int32_t G,
                       const uint16_t* dh_hi, const uint16_t* dh_lo, int64_t ld_dh, int32_t N1,
-                      int32_t nsplit, float* dW, float* dW2, int32_t rows_first, int64_t ldc, void* stream);
+                      int32_t nsplit, float* dW, float* dW2, int32_t rows_first, int64_t ldc,
+                      const uint16_t* xb, int64_t ld_xb, void* stream);
 
 /* Backward of fc1's ReLU + bias (nn/networks.py:119): dpre = dh1 * (h1 > 0) packed as the bf16 image
  * spv_enc_fc1_wgrad consumes ([Bp][ld_img], zero padded; img_lo optional), and the bias gradients

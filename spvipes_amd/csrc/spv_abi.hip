@@ -129,7 +129,8 @@ static int fc1_bn(int N1) { return N1 <= 32 ? 32 : (N1 <= 128 ? 128 : 256); }
 
 extern "C" int spv_enc_fc1_fwd(const spv_counts* x, int32_t B, int32_t G, const uint16_t* W1_hi, const uint16_t* W1_lo,
                                int64_t ldw, int32_t N1, const float* bias, const float* bias2, int32_t n_first, int32_t nsplit,
-                               int32_t splits, float* slabs, float* rowsum_ws, float* h1, float* library, void* stream) {
+                               int32_t splits, float* slabs, float* rowsum_ws, float* h1, float* library, uint16_t* xb_out,
+                               int64_t ld_xb, void* stream) {
   if (!x || !x->X || !W1_hi || !bias || !slabs || !rowsum_ws || !h1 || !library) return fail(SPV_ERR_ARG, "spv_enc_fc1_fwd: null pointer%s");
   if (B <= 0 || G <= 0 || N1 <= 0 || splits <= 0 || (ldw % 32) != 0 || ldw < ((G + 31) & ~31)) return fail(SPV_ERR_ARG, "spv_enc_fc1_fwd: bad shape%s");
   if (nsplit != 1 && nsplit != 3) return fail(SPV_ERR_ARG, "spv_enc_fc1_fwd: nsplit must be 1 or 3%s");
@@ -139,6 +140,10 @@ extern "C" int spv_enc_fc1_fwd(const spv_counts* x, int32_t B, int32_t G, const 
   p.B = W1_hi; p.B_lo = W1_lo; p.ldb = ldw;
   p.rows = x->rows; p.counts_aligned = counts_aligned(x); p.col_off = x->col_off; p.n_cells = B; p.n_genes = G;
   p.rowsum = rowsum_ws;
+  if (xb_out != nullptr) {
+    if (nsplit != 1 || ld_xb < ((G + 31) & ~31) || (ld_xb % 8)) return fail(SPV_ERR_ARG, "spv_enc_fc1_fwd: the bf16 log1p by-product needs nsplit 1 and ld_xb >= round_up(G, 32)%s");
+    p.xb_out = xb_out; p.ld_xb = ld_xb;
+  }
   p.C = slabs; p.ldc = N1; p.slab_stride = (long)B * N1;
   p.M = B; p.N = N1; p.K = G;
   const int ktiles = (G + 31) / 32;
@@ -157,7 +162,7 @@ extern "C" int spv_enc_fc1_fwd(const spv_counts* x, int32_t B, int32_t G, const 
 
 extern "C" int spv_enc_fc1_wgrad(const spv_counts* x, int32_t B, int32_t G, const uint16_t* dh_hi, const uint16_t* dh_lo,
                                  int64_t ld_dh, int32_t N1, int32_t nsplit, float* dW, float* dW2, int32_t rows_first, int64_t ldc,
-                                 void* stream) {
+                                 const uint16_t* xb, int64_t ld_xb, void* stream) {
   if (!x || !x->X || !dh_hi || !dW) return fail(SPV_ERR_ARG, "spv_enc_fc1_wgrad: null pointer%s");
   if (B <= 0 || G <= 0 || N1 <= 0 || ld_dh < ((N1 + 127) & ~127) || (ld_dh % 8) != 0 || ldc < G) return fail(SPV_ERR_ARG, "spv_enc_fc1_wgrad: bad shape%s");
   if (nsplit != 1 && nsplit != 3) return fail(SPV_ERR_ARG, "spv_enc_fc1_wgrad: nsplit must be 1 or 3%s");
@@ -174,7 +179,11 @@ extern "C" int spv_enc_fc1_wgrad(const spv_counts* x, int32_t B, int32_t G, cons
   p.epi = EPI_STORE;
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  if (x->dtype == SPV_COUNT_U16) {
+  if (xb != nullptr) {  // log1p(x) of this minibatch already sits in HBM as bf16 (by-product of spv_enc_fc1_fwd): plain k-major GEMM
+    if (nsplit != 1 || ld_xb < ((G + 63) & ~63) || (ld_xb % 8)) return fail(SPV_ERR_ARG, "spv_enc_fc1_wgrad: xb needs nsplit 1 and ld_xb >= round_up(G, 64)%s");
+    p.B = xb; p.ldb = ld_xb; p.rows = nullptr; p.col_off = 0;
+    rc = launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_PLAIN, unsigned short, 1, 64, 4>>(p, 1, s);
+  } else if (x->dtype == SPV_COUNT_U16) {
     rc = (nsplit == 3) ? launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_COUNTS, unsigned short, 3, 64, 4>>(p, 1, s)
                        : launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_COUNTS, unsigned short, 1, 64, 4>>(p, 1, s);
   } else if (x->dtype == SPV_COUNT_F32) {

@@ -45,6 +45,7 @@ struct GemmParams {
   int k_per_split;   // multiple of 32
   int epi;
   int tiles_inner;   // gene tiles per cell tile of a SRC_TILED operand / EPI_TILED_* output (= Gp / 32)
+  bf16_t* xb_out; long ld_xb;  // optional (natural-A counts, NSPLIT 1): bf16 log1p(x) image [cells][ld_xb] written as a by-product
   int counts_aligned;  // count matrix base, row pitch and col_off all multiples of 16 bytes: every 8-gene chunk is one 16-B load
 };
 
@@ -220,7 +221,8 @@ struct Stager {
     o_lo = u4v{lw[0], lw[1], lw[2], lw[3]};
   }
 
-  __device__ __forceinline__ void store(bf16_t* img_hi, bf16_t* img_lo, int tid) {
+  // (ext0, k0): origin of the tile being stored (only used by the log1p by-product)
+  __device__ __forceinline__ void store(bf16_t* img_hi, bf16_t* img_lo, int tid, const GemmParams& p, int ext0, int k0) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       int s, f; bool ok;
@@ -232,6 +234,9 @@ struct Stager {
         decode_counts(valid[i] ? hi[i] : zero, valid[i] ? lo[i] : zero, o_hi, o_lo, csum[i]);
         *reinterpret_cast<u4v*>(img_hi + s * PITCH + 8 * f) = o_hi;
         if constexpr (Cfg::NSPLIT == 3) *reinterpret_cast<u4v*>(img_lo + s * PITCH + 8 * f) = o_lo;
+        if constexpr (!KMAJ && Cfg::NSPLIT == 1) {  // the weight-gradient GEMM re-reads log1p(x) as plain bf16 instead of decoding the counts again
+          if (p.xb_out != nullptr && blockIdx.y == 0 && ext0 + s < p.n_cells) *reinterpret_cast<u4v*>(p.xb_out + (long)(ext0 + s) * p.ld_xb + k0 + 8 * f) = o_hi;
+        }
         continue;
       }
       *reinterpret_cast<u4v*>(img_hi + s * PITCH + 8 * f) = hi[i];
@@ -293,8 +298,8 @@ __global__ __launch_bounds__(256, Cfg::OCC) void gemm_kernel(GemmParams p) {
         // single buffer: wait until the previous tile's fragment reads are done.  Double buffer: this image was last
         // read two tiles ago and every wave has passed the previous tile's barrier since.
         if constexpr (Cfg::NBUF == 1) __syncthreads();
-        stA[s].store(a_hi_img, a_lo_img, tid);
-        stB[s].store(b_hi_img, b_lo_img, tid);
+        stA[s].store(a_hi_img, a_lo_img, tid, p, m0, k);
+        stB[s].store(b_hi_img, b_lo_img, tid, p, n0, k);
         if constexpr (Cfg::A_SRC == SRC_COUNTS && !Cfg::A_KMAJ) {
 #pragma unroll
           for (int i = 0; i < StA::NCH; ++i) rowsum_acc[i] += stA[s].csum[i];

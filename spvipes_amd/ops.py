@@ -122,9 +122,16 @@ class EncoderFC1(torch.autograd.Function):
         h1 = torch.empty((B, N1), dtype=torch.float32, device=w_priv.device)
         library = torch.empty((B,), dtype=torch.float32, device=w_priv.device)
         cs = counts.c_struct(rows)
+        # bf16 mode, training: the GEMM also leaves bf16(log1p(x)) of the minibatch in HBM so that the weight-gradient
+        # GEMM streams it as a plain operand instead of gathering + decoding the counts a second time
+        xb, ld_xb = None, 0
+        if nsplit == 1 and any(ctx.needs_input_grad):
+            ld_xb = round_up(G, 128)
+            xb = ws.get(f"fc1_xb_{B}", (round_up(B, 64), ld_xb), torch.int16, zero=True)  # rows >= B / columns >= G stay zero
         _abi.call("spv_enc_fc1_fwd", C.byref(cs), B, G, ptr(W_hi), ptr(W_lo), Gp, N1, ptr(b_priv), ptr(b_sh), H, nsplit, splits, ptr(slabs),
-                                  ptr(rowsum), ptr(h1), ptr(library), stream_ptr())
+                                  ptr(rowsum), ptr(h1), ptr(library), ptr(xb), ld_xb, stream_ptr())
         ctx.counts, ctx.rows, ctx.B, ctx.nsplit, ctx.ws, ctx.H, ctx.G = counts, rows, B, nsplit, ws, H, G
+        ctx.xb, ctx.ld_xb = xb, ld_xb
         ctx.save_for_backward(h1, w_priv, b_priv, w_sh, b_sh)
         ctx.mark_non_differentiable(library)
         return h1, library
@@ -146,7 +153,8 @@ class EncoderFC1(torch.autograd.Function):
         (dWp, rWp), (dbp, rbp), (dWs, rWs), (dbs, rbs) = grad_out(w_priv), grad_out(b_priv), grad_out(w_sh), grad_out(b_sh)
         _abi.call("spv_enc_fc1_bwd_prep", ptr(dh1), ptr(h1), B, N1, ptr(dh_hi), ptr(dh_lo), N1p, Bp, ptr(part), ptr(dbp), ptr(dbs), H, stream_ptr())
         cs = ctx.counts.c_struct(ctx.rows)
-        _abi.call("spv_enc_fc1_wgrad", C.byref(cs), B, G, ptr(dh_hi), ptr(dh_lo), N1p, N1, nsplit, ptr(dWp), ptr(dWs), H, G, stream_ptr())
+        _abi.call("spv_enc_fc1_wgrad", C.byref(cs), B, G, ptr(dh_hi), ptr(dh_lo), N1p, N1, nsplit, ptr(dWp), ptr(dWs), H, G,
+                  ptr(ctx.xb), ctx.ld_xb, stream_ptr())
         return None, None, None, rWp, rbp, rWs, rbs, None, None
 
 
