@@ -20,7 +20,7 @@ from . import _abi
 from ._abi import (DEC_CELLS_PER_WG, DEC_KP, DEC_KPS, DEC_KS, NB_CMAX, SpvBnBatch, SpvDecParams, SpvFoldBatch, SpvReduceBatch, SpvZsplitArgs,
                    ptr, round_up, stream_ptr)
 from .nn_ops import _add_lin, _fptr, _lin_batch, _wgrad, grad_out
-from .ops import N_HIDDEN_MIX, GroupCounts, Workspace, _bf16_image, _gemm_slabs, _gene_splits, _nb_splits, _pack
+from .ops import N_HIDDEN_MIX, GroupCounts, Workspace, _bf16_image, _gemm_slabs, _gene_splits, _nb_splits, _pack, fork, group_streams, join
 
 N_DEC_PARAMS = 13  # Wp, gamma_p, beta_p, Ws, gamma_s, beta_s, Wa, ba, gamma_a, beta_a, Wm, bm, px_r
 KMP = 320
@@ -138,60 +138,64 @@ class DecoderFused(torch.autograd.Function):
             raise _abi.SpvError("DecoderFused: w_pad must be contiguous fp32 of length >= round_up(B, 128)")
         grads_f32 = bool(need_grad and mlo)
         gdt, gname = (torch.float32, "f32") if grads_f32 else (torch.int16, "bf16")
-        P, rec, saved_g = [], [], []
+        P, saved_g = [], []
+        rec = [new(B) for _ in range(NG)]  # (allocated before the fork: every temporary belongs to the main stream)
         red = SpvReduceBatch()
         red.nprob = 0
+        streams = group_streams(dev, NG)
+        fork(streams)
         for g in range(NG):
-            G, Gp, wsg = Gs[g], Gps[g], ws[g]
-            Wm_hi, Wm_lo = _bf16_image(wsg, "dec_Wm", Gp, KMP, mlo)
-            _pack(cont(par[g][10]), Wm_hi, Wm_lo, extra_col=cont(par[g][11]))
-            Am_hi, Am_lo = _bf16_image(wsg, "dec_Am", Bp, KMP, mlo)
-            _pack(m[g], Am_hi, Am_lo, dst_col_off=0, cslot=n_m)
-            _pack(zcat[g], Am_hi, Am_lo, extra_one=True, dst_col_off=n_m, cslot=KMP - n_m)
-            Aps_hi, Aps_lo = _bf16_image(wsg, "dec_Aps", Bp, DEC_KPS, True)
-            _pack(zcat[g][:, :n_p], Aps_hi, Aps_lo, extra_one=True, dst_col_off=0, cslot=DEC_KP)
-            _pack(zcat[g][:, n_p:], Aps_hi, Aps_lo, extra_one=True, dst_col_off=DEC_KP, cslot=DEC_KS)
-            gene_tab = wsg.get("dec_gene_tab", (Gp, 4), torch.float32)
-            cnt_tab = wsg.get("dec_cnt_tab", (NB_CMAX, Gp, 2), torch.float32)
-            _abi.call("spv_dec_tables", ptr(cont(par[g][12])), G, Gp, ptr(gene_tab), ptr(cnt_tab), stream_ptr())
-            logits = wsg.get("dec_logits_" + ("f32" if mlo else "f16"), (Bp, Gp), torch.float32 if mlo else torch.float16)
-            _abi.call("spv_dec_logits", ptr(Am_hi), ptr(Am_lo), ptr(Wm_hi), ptr(Wm_lo), KMP, Bp, Gp, nsplit, ptr(logits), int(mlo), stream_ptr())
-            splits, per = _gene_splits(Bp, Gp)
-            nbs, nbper = _nb_splits(Gp)
-            vec = lambda nme: wsg.get(nme, (Bp,), torch.float32)
-            part = lambda nme: wsg.get(nme, (splits, Bp), torch.float32)
-            nbpart = lambda nme: wsg.get(nme, (nbs, Bp), torch.float32)
-            if need_grad:
-                dL = wsg.get("dec_dL_" + gname, (Bp, Gp), gdt, zero=True)
-                tP = wsg.get("dec_tP_" + gname, (Bp, Gp), gdt, zero=True)
-                tS = wsg.get("dec_tS_" + gname, (Bp, Gp), gdt, zero=True)
-                dth = wsg.get("dec_dtheta", (Bp // 64, Gp), torch.float32, zero=True)
-                Tp, Ts = wsg.get("dec_Tp", (Bp,), torch.float32), wsg.get("dec_Ts", (Bp,), torch.float32)
-            else:
-                dL = tP = tS = dth = Tp = Ts = None
-            lse_p, lse_s, a_p, a_s = vec("dec_lse_p"), vec("dec_lse_s"), vec("dec_a_p"), vec("dec_a_s")
-            cst = counts[g].c_struct(rows[g])
-            p = SpvDecParams(
-                X=cst.X, ldx=cst.ld, rows=cst.rows, col_off=cst.col_off, count_is_u16=int(cst.dtype == _abi.SPV_COUNT_U16),
-                B=B, G=G, Bp=Bp, Gp=Gp, logits=ptr(logits), n_gene_tiles=Gp // 32, logits_f32=int(mlo),
-                Wps_hi=ptr(Wps[g][0]), Wps_lo=ptr(Wps[g][1]), Aps_hi=ptr(Aps_hi), Aps_lo=ptr(Aps_lo),
-                gene_tab=ptr(gene_tab), cnt_tab=ptr(cnt_tab), a_p=ptr(a_p), a_s=ptr(a_s), lse_p=ptr(lse_p), lse_s=ptr(lse_s),
-                w_row=ptr(w_pad), gene_splits=splits, genes_per_split=per,
-                part_max_p=ptr(part("dec_pmp")), part_sum_p=ptr(part("dec_psp")), part_max_s=ptr(part("dec_pms")), part_sum_s=ptr(part("dec_pss")),
-                rec_part=ptr(nbpart("dec_rec")), tp_part=ptr(nbpart("dec_tp")), ts_part=ptr(nbpart("dec_ts")),
-                dtheta_part=ptr(dth), dL=ptr(dL), tP=ptr(tP), tS=ptr(tS), grads_f32=int(grads_f32), nb_splits=nbs, nb_genes_per_split=nbper,
-            )
-            _abi.call("spv_dec_lse", C.byref(p), ptr(cont(library[g].flatten())), stream_ptr())
-            _abi.call("spv_dec_nb_fwd", C.byref(p), int(need_grad), stream_ptr())
-            r = new(B)
-            rec.append(r)
-            _add_red(red, nbpart("dec_rec"), nbs, Bp, Bp, 1, B, r, B)
-            if need_grad:
-                _add_red(red, nbpart("dec_tp"), nbs, Bp, Bp, 1, Bp, Tp, Bp)
-                _add_red(red, nbpart("dec_ts"), nbs, Bp, Bp, 1, Bp, Ts, Bp)
-            P.append(p)
-            if need_grad:
-                saved_g.append(dict(Wm=(Wm_hi, Wm_lo), Am=(Am_hi, Am_lo), Aps=(Aps_hi, Aps_lo), dL=dL, tP=tP, tS=tS, dth=dth, Tp=Tp, Ts=Ts))
+          with torch.cuda.stream(streams[g]):
+              G, Gp, wsg = Gs[g], Gps[g], ws[g]
+              Wm_hi, Wm_lo = _bf16_image(wsg, "dec_Wm", Gp, KMP, mlo)
+              _pack(cont(par[g][10]), Wm_hi, Wm_lo, extra_col=cont(par[g][11]))
+              Am_hi, Am_lo = _bf16_image(wsg, "dec_Am", Bp, KMP, mlo)
+              _pack(m[g], Am_hi, Am_lo, dst_col_off=0, cslot=n_m)
+              _pack(zcat[g], Am_hi, Am_lo, extra_one=True, dst_col_off=n_m, cslot=KMP - n_m)
+              Aps_hi, Aps_lo = _bf16_image(wsg, "dec_Aps", Bp, DEC_KPS, True)
+              _pack(zcat[g][:, :n_p], Aps_hi, Aps_lo, extra_one=True, dst_col_off=0, cslot=DEC_KP)
+              _pack(zcat[g][:, n_p:], Aps_hi, Aps_lo, extra_one=True, dst_col_off=DEC_KP, cslot=DEC_KS)
+              gene_tab = wsg.get("dec_gene_tab", (Gp, 4), torch.float32)
+              cnt_tab = wsg.get("dec_cnt_tab", (NB_CMAX, Gp, 2), torch.float32)
+              _abi.call("spv_dec_tables", ptr(cont(par[g][12])), G, Gp, ptr(gene_tab), ptr(cnt_tab), stream_ptr())
+              logits = wsg.get("dec_logits_" + ("f32" if mlo else "f16"), (Bp, Gp), torch.float32 if mlo else torch.float16)
+              _abi.call("spv_dec_logits", ptr(Am_hi), ptr(Am_lo), ptr(Wm_hi), ptr(Wm_lo), KMP, Bp, Gp, nsplit, ptr(logits), int(mlo), stream_ptr())
+              splits, per = _gene_splits(Bp, Gp)
+              nbs, nbper = _nb_splits(Gp)
+              vec = lambda nme: wsg.get(nme, (Bp,), torch.float32)
+              part = lambda nme: wsg.get(nme, (splits, Bp), torch.float32)
+              nbpart = lambda nme: wsg.get(nme, (nbs, Bp), torch.float32)
+              if need_grad:
+                  dL = wsg.get("dec_dL_" + gname, (Bp, Gp), gdt, zero=True)
+                  tP = wsg.get("dec_tP_" + gname, (Bp, Gp), gdt, zero=True)
+                  tS = wsg.get("dec_tS_" + gname, (Bp, Gp), gdt, zero=True)
+                  dth = wsg.get("dec_dtheta", (Bp // 64, Gp), torch.float32, zero=True)
+                  Tp, Ts = wsg.get("dec_Tp", (Bp,), torch.float32), wsg.get("dec_Ts", (Bp,), torch.float32)
+              else:
+                  dL = tP = tS = dth = Tp = Ts = None
+              lse_p, lse_s, a_p, a_s = vec("dec_lse_p"), vec("dec_lse_s"), vec("dec_a_p"), vec("dec_a_s")
+              cst = counts[g].c_struct(rows[g])
+              p = SpvDecParams(
+                  X=cst.X, ldx=cst.ld, rows=cst.rows, col_off=cst.col_off, count_is_u16=int(cst.dtype == _abi.SPV_COUNT_U16),
+                  B=B, G=G, Bp=Bp, Gp=Gp, logits=ptr(logits), n_gene_tiles=Gp // 32, logits_f32=int(mlo),
+                  Wps_hi=ptr(Wps[g][0]), Wps_lo=ptr(Wps[g][1]), Aps_hi=ptr(Aps_hi), Aps_lo=ptr(Aps_lo),
+                  gene_tab=ptr(gene_tab), cnt_tab=ptr(cnt_tab), a_p=ptr(a_p), a_s=ptr(a_s), lse_p=ptr(lse_p), lse_s=ptr(lse_s),
+                  w_row=ptr(w_pad), gene_splits=splits, genes_per_split=per,
+                  part_max_p=ptr(part("dec_pmp")), part_sum_p=ptr(part("dec_psp")), part_max_s=ptr(part("dec_pms")), part_sum_s=ptr(part("dec_pss")),
+                  rec_part=ptr(nbpart("dec_rec")), tp_part=ptr(nbpart("dec_tp")), ts_part=ptr(nbpart("dec_ts")),
+                  dtheta_part=ptr(dth), dL=ptr(dL), tP=ptr(tP), tS=ptr(tS), grads_f32=int(grads_f32), nb_splits=nbs, nb_genes_per_split=nbper,
+              )
+              _abi.call("spv_dec_lse", C.byref(p), ptr(cont(library[g].flatten())), stream_ptr())
+              _abi.call("spv_dec_nb_fwd", C.byref(p), int(need_grad), stream_ptr())
+              r = rec[g]
+              _add_red(red, nbpart("dec_rec"), nbs, Bp, Bp, 1, B, r, B)
+              if need_grad:
+                  _add_red(red, nbpart("dec_tp"), nbs, Bp, Bp, 1, Bp, Tp, Bp)
+                  _add_red(red, nbpart("dec_ts"), nbs, Bp, Bp, 1, Bp, Ts, Bp)
+              P.append(p)
+              if need_grad:
+                  saved_g.append(dict(Wm=(Wm_hi, Wm_lo), Am=(Am_hi, Am_lo), Aps=(Aps_hi, Aps_lo), dL=dL, tP=tP, tS=tS, dth=dth, Tp=Tp, Ts=Ts))
+        join(streams)
         _run_red(red)
         loss, rec_sum, gkl = new(()), new(()), new(B)
         klp = (C.c_void_p * 4)(*[ptr(k) for k in kls], *([None] * (4 - n_kl)))
@@ -225,48 +229,52 @@ class DecoderFused(torch.autograd.Function):
             raise _abi.SpvError("DecoderFused.backward: the loss output received no gradient")
         g_loss = g_loss if (g_loss.dtype == torch.float32 and g_loss.is_contiguous()) else g_loss.float().contiguous()
         pg = [[grad_out(par[g][j]) for j in range(N_DEC_PARAMS)] for g in range(NG)]  # (kernel target, autograd return) per parameter
-        d_zcat, dWp, dWs, dAm = [], [], [], []
         red, red2 = SpvReduceBatch(), SpvReduceBatch()
         red.nprob = red2.nprob = 0
+        dWp, dWs = [new(Gs[g], DEC_KP) for g in range(NG)], [new(Gs[g], DEC_KS) for g in range(NG)]
+        dAm, d_zcat = [new(B, n_m) for _ in range(NG)], [new(B, nt) for _ in range(NG)]
+        streams = group_streams(dev, NG)  # (measured: also forking the dL GEMMs onto their own streams is slower)
+        fork(streams)
         for g in range(NG):
-            G, Gp, wsg, S, P = Gs[g], Gps[g], ws[g], ctx.saved_g[g], ctx.P[g]
-            _abi.call("spv_dec_softmax_bwd", C.byref(P), ptr(S["Tp"]), ptr(S["Ts"]), stream_ptr())
-            if ctx.grads_f32:
-                def split(t, name):
-                    hi, lo = _bf16_image(wsg, name, Bp, Gp, True)
-                    _pack(t, hi, lo)
-                    return hi, lo
-                (dL_hi, dL_lo), (tP_hi, tP_lo), (tS_hi, tS_lo) = split(S["dL"], "dec_dL_split"), split(S["tP"], "dec_tP_split"), split(S["tS"], "dec_tS_split")
-            else:
-                dL_hi, tP_hi, tS_hi, dL_lo, tP_lo, tS_lo = S["dL"], S["tP"], S["tS"], None, None, None
-            T = Gp // 32
-            # K splits (fp32 slabs, reduced in order by spv_reduce_slabs) sized for >= ~2 workgroups per CU: these
-            # GEMMs stream a [B,G] array once and are latency-bound with fewer resident workgroups
-            bt = Bp // 32
-            ksp_m, ksp_n = max(1, min(T // 8, -(-512 // max(Bp // 64, 1)))), max(1, min(T // 8, -(-512 // max(Bp // 128, 1))))
-            csp_m, csp_n = max(1, min(bt // 8, -(-512 // max(Gp // 64, 1)))), max(1, min(bt // 8, -(-512 // max(Gp // 128, 1))))
-            (Wm_hi, Wm_lo), (Am_hi, Am_lo), (Aps_hi, Aps_lo) = S["Wm"], S["Am"], S["Aps"]
-            a = _gemm_slabs(True, dL_hi, dL_lo, Gp, Am_hi, Am_lo, KMP, G, KMP, Bp, nsplit, csp_m, wsg, "dec_dWm", a_tiles=T)
-            b_ = _gemm_slabs(True, tP_hi, tP_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KP, Bp, nsplit, csp_n, wsg, "dec_dWp", a_tiles=T)
-            c = _gemm_slabs(True, tS_hi, tS_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KS, Bp, nsplit, csp_n, wsg, "dec_dWs", b_col_off=DEC_KP, a_tiles=T)
-            d = _gemm_slabs(False, dL_hi, dL_lo, Gp, Wm_hi, Wm_lo, KMP, B, KMP, G, nsplit, ksp_m, wsg, "dec_dAm", a_tiles=T)
-            e = _gemm_slabs(False, tP_hi, tP_lo, Gp, ctx.Wps[g][0], ctx.Wps[g][1], DEC_KPS, B, DEC_KP, G, nsplit, ksp_n, wsg, "dec_dAp", a_tiles=T)
-            f = _gemm_slabs(False, tS_hi, tS_lo, Gp, ctx.Wps[g][0], ctx.Wps[g][1], DEC_KPS, B, DEC_KS, G, nsplit, ksp_n, wsg, "dec_dAs", b_col_off=DEC_KP, a_tiles=T)
-            # slab sums, scaled by the upstream gradient, straight into their consumers' buffers
-            al = g_loss
-            _add_red(red, a, csp_m, G * KMP, KMP, G, KM - 1, pg[g][10][0], KM - 1, alpha=al)                 # d W_m
-            _add_red(red, a, csp_m, G * KMP, KMP, G, 1, pg[g][11][0], 1, col_off=KM - 1, alpha=al)           # d b_m
-            dwp, dws_, dam, dz = new(G, DEC_KP), new(G, DEC_KS), new(B, n_m), new(B, nt)
-            _add_red(red, b_, csp_n, G * DEC_KP, DEC_KP, G, DEC_KP, dwp, DEC_KP, alpha=al)                    # d [W'_p | c_p]
-            _add_red(red, c, csp_n, G * DEC_KS, DEC_KS, G, DEC_KS, dws_, DEC_KS, alpha=al)                    # d [W'_s | c_s]
-            _add_red(red, d, ksp_m, B * KMP, KMP, B, n_m, dam, n_m, alpha=al)                                 # d m (trunk output)
-            # gradient reaching zcat directly: through the logits GEMM (columns n_m..) and the two regressors
-            _add_red(red, d, ksp_m, B * KMP, KMP, B, nt, dz, nt, col_off=n_m, alpha=al)
-            _add_red(red2, e, ksp_n, B * DEC_KP, DEC_KP, B, n_p, dz, nt, accumulate=True, alpha=al)
-            _add_red(red2, f, ksp_n, B * DEC_KS, DEC_KS, B, n_s, dz, nt, dst_col=n_p, accumulate=True, alpha=al)
-            # d px_r = exp(px_r) * d theta (theta = exp(px_r): module/spVIPESmodule.py:758)
-            _add_red(red, S["dth"], Bp // 64, Gp, Gp, 1, G, pg[g][12][0], G, alpha=al, exp_scale=par[g][12])
-            dWp.append(dwp); dWs.append(dws_); dAm.append(dam); d_zcat.append(dz)
+          with torch.cuda.stream(streams[g]):
+              G, Gp, wsg, S, P = Gs[g], Gps[g], ws[g], ctx.saved_g[g], ctx.P[g]
+              _abi.call("spv_dec_softmax_bwd", C.byref(P), ptr(S["Tp"]), ptr(S["Ts"]), stream_ptr())
+              if ctx.grads_f32:
+                  def split(t, name):
+                      hi, lo = _bf16_image(wsg, name, Bp, Gp, True)
+                      _pack(t, hi, lo)
+                      return hi, lo
+                  (dL_hi, dL_lo), (tP_hi, tP_lo), (tS_hi, tS_lo) = split(S["dL"], "dec_dL_split"), split(S["tP"], "dec_tP_split"), split(S["tS"], "dec_tS_split")
+              else:
+                  dL_hi, tP_hi, tS_hi, dL_lo, tP_lo, tS_lo = S["dL"], S["tP"], S["tS"], None, None, None
+              T = Gp // 32
+              # K splits (fp32 slabs, reduced in order by spv_reduce_slabs) sized for >= ~2 workgroups per CU: these
+              # GEMMs stream a [B,G] array once and are latency-bound with fewer resident workgroups
+              bt = Bp // 32
+              ksp_m, ksp_n = max(1, min(T // 8, -(-512 // max(Bp // 64, 1)))), max(1, min(T // 8, -(-512 // max(Bp // 128, 1))))
+              csp_m, csp_n = max(1, min(bt // 8, -(-512 // max(Gp // 64, 1)))), max(1, min(bt // 8, -(-512 // max(Gp // 128, 1))))
+              (Wm_hi, Wm_lo), (Am_hi, Am_lo), (Aps_hi, Aps_lo) = S["Wm"], S["Am"], S["Aps"]
+              a = _gemm_slabs(True, dL_hi, dL_lo, Gp, Am_hi, Am_lo, KMP, G, KMP, Bp, nsplit, csp_m, wsg, "dec_dWm", a_tiles=T)
+              d = _gemm_slabs(False, dL_hi, dL_lo, Gp, Wm_hi, Wm_lo, KMP, B, KMP, G, nsplit, ksp_m, wsg, "dec_dAm", a_tiles=T)
+              b_ = _gemm_slabs(True, tP_hi, tP_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KP, Bp, nsplit, csp_n, wsg, "dec_dWp", a_tiles=T)
+              c = _gemm_slabs(True, tS_hi, tS_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KS, Bp, nsplit, csp_n, wsg, "dec_dWs", b_col_off=DEC_KP, a_tiles=T)
+              e = _gemm_slabs(False, tP_hi, tP_lo, Gp, ctx.Wps[g][0], ctx.Wps[g][1], DEC_KPS, B, DEC_KP, G, nsplit, ksp_n, wsg, "dec_dAp", a_tiles=T)
+              f = _gemm_slabs(False, tS_hi, tS_lo, Gp, ctx.Wps[g][0], ctx.Wps[g][1], DEC_KPS, B, DEC_KS, G, nsplit, ksp_n, wsg, "dec_dAs", b_col_off=DEC_KP, a_tiles=T)
+              # slab sums, scaled by the upstream gradient, straight into their consumers' buffers
+              al = g_loss
+              _add_red(red, a, csp_m, G * KMP, KMP, G, KM - 1, pg[g][10][0], KM - 1, alpha=al)                 # d W_m
+              _add_red(red, a, csp_m, G * KMP, KMP, G, 1, pg[g][11][0], 1, col_off=KM - 1, alpha=al)           # d b_m
+              dwp, dws_, dam, dz = dWp[g], dWs[g], dAm[g], d_zcat[g]
+              _add_red(red, b_, csp_n, G * DEC_KP, DEC_KP, G, DEC_KP, dwp, DEC_KP, alpha=al)                    # d [W'_p | c_p]
+              _add_red(red, c, csp_n, G * DEC_KS, DEC_KS, G, DEC_KS, dws_, DEC_KS, alpha=al)                    # d [W'_s | c_s]
+              _add_red(red, d, ksp_m, B * KMP, KMP, B, n_m, dam, n_m, alpha=al)                                 # d m (trunk output)
+              # gradient reaching zcat directly: through the logits GEMM (columns n_m..) and the two regressors
+              _add_red(red, d, ksp_m, B * KMP, KMP, B, nt, dz, nt, col_off=n_m, alpha=al)
+              _add_red(red2, e, ksp_n, B * DEC_KP, DEC_KP, B, n_p, dz, nt, accumulate=True, alpha=al)
+              _add_red(red2, f, ksp_n, B * DEC_KS, DEC_KS, B, n_s, dz, nt, dst_col=n_p, accumulate=True, alpha=al)
+              # d px_r = exp(px_r) * d theta (theta = exp(px_r): module/spVIPESmodule.py:758)
+              _add_red(red, S["dth"], Bp // 64, Gp, Gp, 1, G, pg[g][12][0], G, alpha=al, exp_scale=par[g][12])
+        join(streams)
         _run_red(red)
         _run_red(red2)
         # ---- trunk backward (BatchNorm + relu, Linear) ----------------------------------------------

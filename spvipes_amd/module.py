@@ -31,7 +31,7 @@ from torch import nn
 
 from . import _abi
 from ._abi import DEC_CELLS_PER_WG, round_up
-from .ops import N_HIDDEN_MIX, EncoderFC1, GroupCounts, Workspace
+from .ops import N_HIDDEN_MIX, EncoderFC1, GroupCounts, Workspace, fork, group_streams, join
 
 X_KEY, BATCH_KEY = "X", "batch"  # scvi.REGISTRY_KEYS.X_KEY / BATCH_KEY
 
@@ -276,14 +276,21 @@ class spVIPESmodule(nn.Module):
         self._step_inputs, self._kl_private, self._kl_poe = {}, {}, {}
         h1s, eps_enc = {}, {}
         H = self.n_hidden
+        streams = None
         for g, group in x.items():
             counts, rows, B = self._counts_of(g, group)
             self._step_inputs[g] = (counts, rows, B)
             ep, es = self.encoders[g]["private"], self.encoders[g]["shared"]
             ws = self._workspace(g, counts.X.device)
-            h1, lib = EncoderFC1.apply(counts, rows, B, ep.fc1.weight, ep.fc1.bias, es.fc1.weight, es.fc1.bias, self.nsplit, ws)
+            if streams is None:  # the groups' fc1 GEMMs are independent: group g > 0 runs on a side stream (autograd replays
+                streams = group_streams(counts.X.device, len(x))  # each node's backward on its forward stream as well)
+                fork(streams)
+            with torch.cuda.stream(streams[g % len(streams)]):
+                h1, lib = EncoderFC1.apply(counts, rows, B, ep.fc1.weight, ep.fc1.bias, es.fc1.weight, es.fc1.bias, self.nsplit, ws)
             h1s[g] = h1
             library[g] = lib.unsqueeze(1)
+        if streams is not None:
+            join(streams)
         groups_ = sorted(x.keys())
         # every standard-normal draw of the step (encoder heads + PoE) comes out of ONE generator launch
         n_p_, n_s_ = self.n_dimensions_private, self.n_dimensions_shared

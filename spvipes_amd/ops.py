@@ -70,6 +70,34 @@ class Workspace:
         return t
 
 
+_SIDE_STREAMS: Dict[Tuple, "torch.cuda.Stream"] = {}
+
+
+def group_streams(device, n: int = 2):
+    """[current stream, side stream, ...]: the two groups' launch chains are independent for long stretches of the step
+    (fc1, operand packing, logits / lse / likelihood, the backward GEMMs) and most of those kernels leave CUs idle on
+    their own, so group 1 runs on a side stream: fork with ``fork(streams)``, join with ``join(streams)``.  Under
+    hipGraph capture the fork/join become parallel branches of the graph."""
+    dev = torch.device(device)
+    out = [torch.cuda.current_stream(dev)]
+    for i in range(1, n):
+        key = (dev.index, i)
+        if key not in _SIDE_STREAMS:
+            _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+        out.append(_SIDE_STREAMS[key])
+    return out
+
+
+def fork(streams) -> None:
+    for st in streams[1:]:
+        st.wait_stream(streams[0])
+
+
+def join(streams) -> None:
+    for st in streams[1:]:
+        streams[0].wait_stream(st)
+
+
 def _pack(src: torch.Tensor, dst_hi: torch.Tensor, dst_lo: Optional[torch.Tensor], *, extra_col: Optional[torch.Tensor] = None,
           extra_one: bool = False, dst_row_off: int = 0, dst_col_off: int = 0, rows_cover: Optional[int] = None,
           cslot: Optional[int] = None) -> None:
