@@ -254,9 +254,29 @@ typedef struct spv_poe_args {
   const float* g_loc[2]; const float* g_logvar[2]; const float* g_scale[2]; const float* g_logz[2]; const float* g_kl[2];
   float* d_stats[2];                       /* backward output, same layout as stats (zeroed by the call itself) */
   int32_t B[2]; int32_t n;
+  int32_t clamp_scale;                     /* paired / cluster PoE: the draw and the KL use scale.clamp(min = 1e-6)  */
+  int32_t lone_passthrough;                /* cluster PoE: mode 2 keeps the cell's own encoder statistics           */
+  const float* expert[2]; int64_t ld_expert[2];  /* cluster PoE: plan-weighted experts [B][ld] (loc | logvar) fused in
+                                                    place of the encoder statistics; NULL = label / paired PoE      */
+  float* d_expert[2];                      /* backward output for expert (zeroed by the call itself)                */
 } spv_poe_args;
 int spv_poe_fuse_fwd(const spv_poe_args* a, void* stream);
 int spv_poe_fuse_bwd(const spv_poe_args* a, void* stream);
+
+/* Sparse transport plan: CSR of the plan (rows = dataset cells of group 0, int32 indptr / column
+ * indices, fp32 values >= 0) and CSR of its transpose (rows = dataset cells of group 1).  Replaces the dense
+ * plan[idx_0][:, idx_1] gather of module/spVIPESmodule.py:474-482.                                                    */
+typedef struct spv_plan {
+  const int32_t* ptr0; const int32_t* ind0; const float* val0; int32_t n0;   /* plan   : n0 rows */
+  const int32_t* ptr1; const int32_t* ind1; const float* val1; int32_t n1;   /* plan^T : n1 rows */
+} spv_plan;
+/* inv0[c] / inv1[c] = position of dataset cell c in the minibatch (idx0 [B0] / idx1 [B1], unique), -1 if absent */
+int spv_plan_invmap(const int32_t* idx0, int32_t B0, const int32_t* idx1, int32_t B1, int32_t* inv0, int32_t n0, int32_t* inv1,
+                    int32_t n1, void* stream);
+/* paired PoE partners (module/spVIPESmodule.py:520-523): partner0[i] = argmax_j block[i][j], partner1[j] = argmax_i
+ * block[i][j] of the minibatch block of the plan; first maximum, 0 for an all-zero row / column                       */
+int spv_plan_argmax(const spv_plan* plan, const int32_t* idx0, const int32_t* idx1, const int32_t* inv0, const int32_t* inv1,
+                    int32_t B0, int32_t B1, int32_t* partner0, int32_t* partner1, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Decoder preparation: latent slicing (spVIPESmodule.py:733-754) and BatchNorm folding of the two

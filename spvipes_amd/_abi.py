@@ -93,7 +93,14 @@ class SpvPoeArgs(C.Structure):
     _fields_ = [("stats", C.c_void_p * 2), ("ld", C.c_int64 * 2), ("partner", C.c_void_p * 2), ("mode", C.c_void_p * 2), ("eps", C.c_void_p * 2),
                 ("loc", C.c_void_p * 2), ("logvar", C.c_void_p * 2), ("scale", C.c_void_p * 2), ("logz", C.c_void_p * 2), ("theta", C.c_void_p * 2),
                 ("kl", C.c_void_p * 2), ("g_loc", C.c_void_p * 2), ("g_logvar", C.c_void_p * 2), ("g_scale", C.c_void_p * 2),
-                ("g_logz", C.c_void_p * 2), ("g_kl", C.c_void_p * 2), ("d_stats", C.c_void_p * 2), ("B", C.c_int32 * 2), ("n", C.c_int32)]
+                ("g_logz", C.c_void_p * 2), ("g_kl", C.c_void_p * 2), ("d_stats", C.c_void_p * 2), ("B", C.c_int32 * 2), ("n", C.c_int32),
+                ("clamp_scale", C.c_int32), ("lone_passthrough", C.c_int32), ("expert", C.c_void_p * 2), ("ld_expert", C.c_int64 * 2),
+                ("d_expert", C.c_void_p * 2)]
+
+
+class SpvPlan(C.Structure):
+    _fields_ = [("ptr0", C.c_void_p), ("ind0", C.c_void_p), ("val0", C.c_void_p), ("n0", C.c_int32),
+                ("ptr1", C.c_void_p), ("ind1", C.c_void_p), ("val1", C.c_void_p), ("n1", C.c_int32)]
 
 
 class SpvZsplitArgs(C.Structure):
@@ -145,6 +152,9 @@ _SIGNATURES = {
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "spv_poe_fuse_fwd": (C.c_int, [C.POINTER(SpvPoeArgs), C.c_void_p]),
     "spv_poe_fuse_bwd": (C.c_int, [C.POINTER(SpvPoeArgs), C.c_void_p]),
+    "spv_plan_invmap": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "spv_plan_argmax": (C.c_int, [C.POINTER(SpvPlan), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]),
     "spv_zsplit_fwd": (C.c_int, [C.POINTER(SpvZsplitArgs), C.c_void_p]),
     "spv_zsplit_bwd": (C.c_int, [C.POINTER(SpvZsplitArgs), C.c_void_p]),
     "spv_bn_fold_fwd": (C.c_int, [C.POINTER(SpvFoldBatch), C.c_void_p]),

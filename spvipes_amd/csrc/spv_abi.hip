@@ -513,7 +513,8 @@ extern "C" int spv_poe_partner(const float* labels0, const float* labels1, int32
 static int check_poe(const spv_poe_args* a, const char* who) {
   if (!a || a->n <= 0 || a->n > 32 || a->B[0] <= 0 || a->B[1] <= 0) return fail(SPV_ERR_ARG, "%s: bad shape (latent dimension <= 32)", who);
   for (int g = 0; g < 2; ++g)
-    if (!a->stats[g] || !a->partner[g] || !a->mode[g] || !a->eps[g] || !a->loc[g] || !a->scale[g] || a->ld[g] < 2 * a->n)
+    if (!a->stats[g] || !a->partner[g] || !a->mode[g] || !a->eps[g] || !a->loc[g] || !a->scale[g] || a->ld[g] < 2 * a->n ||
+        (a->expert[g] && a->ld_expert[g] < 2 * a->n))
       return fail(SPV_ERR_ARG, "%s: null pointer / bad pitch", who);
   return SPV_OK;
 }
@@ -530,9 +531,15 @@ extern "C" int spv_poe_fuse_bwd(const spv_poe_args* a, void* stream) {
   if (rc) return rc;
   for (int g = 0; g < 2; ++g) if (!a->d_stats[g]) return fail(SPV_ERR_ARG, "spv_poe_fuse_bwd: null output%s");
   const int Bm = a->B[0] > a->B[1] ? a->B[0] : a->B[1];
-  for (int g = 0; g < 2; ++g)  // the kernel accumulates (own expert + partner's): start from zero
+  for (int g = 0; g < 2; ++g) {  // the kernel accumulates (own expert + partner's): start from zero
     if (hipMemsetAsync(a->d_stats[g], 0, (size_t)a->B[g] * a->ld[g] * sizeof(float), (hipStream_t)stream) != hipSuccess)
       return fail(SPV_ERR_LAUNCH, "spv_poe_fuse_bwd: memset failed%s");
+    if (a->expert[g]) {
+      if (!a->d_expert[g]) return fail(SPV_ERR_ARG, "spv_poe_fuse_bwd: d_expert missing%s");
+      if (hipMemsetAsync(a->d_expert[g], 0, (size_t)a->B[g] * a->ld_expert[g] * sizeof(float), (hipStream_t)stream) != hipSuccess)
+        return fail(SPV_ERR_LAUNCH, "spv_poe_fuse_bwd: memset failed%s");
+    }
+  }
   hipLaunchKernelGGL(poe_fuse_bwd_kernel, dim3((Bm + 7) / 8, 2), dim3(256), 0, (hipStream_t)stream, *a);
   return launch_status("spv_poe_fuse_bwd");
 }
@@ -666,5 +673,32 @@ extern "C" int spv_enc_fc1_bwd_prep(const float* dh1, const float* h1, int32_t B
   hipLaunchKernelGGL(fc1_bwd_prep_kernel, dim3(Bp / 16), dim3(256), 0, s, dh1, h1, B, N1, img_hi, img_lo, (long)ld_img, part);
   hipLaunchKernelGGL(fc1_bwd_bias_kernel, dim3((N1 + 63) / 64), dim3(256), 0, s, part, Bp / 16, N1, db, db2, n_first);
   return launch_status("spv_enc_fc1_bwd_prep");
+}
+
+extern "C" int spv_plan_invmap(const int32_t* idx0, int32_t B0, const int32_t* idx1, int32_t B1, int32_t* inv0, int32_t n0, int32_t* inv1,
+                               int32_t n1, void* stream) {
+  if (!idx0 || !idx1 || !inv0 || !inv1 || B0 <= 0 || B1 <= 0 || n0 <= 0 || n1 <= 0) return fail(SPV_ERR_ARG, "spv_plan_invmap: bad arguments%s");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(inv0, 0xFF, (size_t)n0 * sizeof(int32_t), s) != hipSuccess || hipMemsetAsync(inv1, 0xFF, (size_t)n1 * sizeof(int32_t), s) != hipSuccess)
+    return fail(SPV_ERR_LAUNCH, "spv_plan_invmap: memset failed%s");
+  const int Bm = B0 > B1 ? B0 : B1;
+  hipLaunchKernelGGL(plan_invmap_kernel, dim3((Bm + 255) / 256, 2), dim3(256), 0, s, idx0, B0, idx1, B1, inv0, n0, inv1, n1);
+  return launch_status("spv_plan_invmap");
+}
+
+static int check_plan(const spv_plan* p, const char* who) {
+  if (!p || !p->ptr0 || !p->ind0 || !p->val0 || !p->ptr1 || !p->ind1 || !p->val1 || p->n0 <= 0 || p->n1 <= 0) return fail(SPV_ERR_ARG, "%s: incomplete plan", who);
+  return SPV_OK;
+}
+
+extern "C" int spv_plan_argmax(const spv_plan* plan, const int32_t* idx0, const int32_t* idx1, const int32_t* inv0, const int32_t* inv1,
+                               int32_t B0, int32_t B1, int32_t* partner0, int32_t* partner1, void* stream) {
+  int rc = check_plan(plan, "spv_plan_argmax");
+  if (rc) return rc;
+  if (!idx0 || !idx1 || !inv0 || !inv1 || !partner0 || !partner1 || B0 <= 0 || B1 <= 0) return fail(SPV_ERR_ARG, "spv_plan_argmax: bad arguments%s");
+  const int Bm = B0 > B1 ? B0 : B1;
+  hipLaunchKernelGGL(plan_argmax_kernel, dim3((Bm + 255) / 256, 2), dim3(256), 0, (hipStream_t)stream, plan->ptr0, plan->ind0, plan->val0,
+                     plan->ptr1, plan->ind1, plan->val1, idx0, idx1, inv0, inv1, B0, B1, plan->n0, plan->n1, partner0, partner1);
+  return launch_status("spv_plan_argmax");
 }
 

@@ -554,6 +554,13 @@ __global__ __launch_bounds__(256) void poe_lookup_kernel(const float* lab0, cons
 
 typedef spv_poe_args PoeArgs;
 
+// One fusion kernel serves the three pairings of the reference:
+//   label PoE   (:583-718): self expert = the cell's own encoder statistics, partner / mode from poe_lookup_kernel
+//   paired PoE  (:511-571): same, every cell has a partner (mode 0) = arg max of its transport-plan row / column;
+//                           clamp_scale: the Normal the draw and the KL use has scale.clamp(min = 1e-6)
+//   cluster PoE (:184-280): self / partner experts = plan-weighted averages (expert[g], see plan_expert_*), the
+//                           _poe2 padding for mode 1, and with lone_passthrough a component absent from the other
+//                           minibatch (mode 2) keeps its own encoder statistics
 __global__ __launch_bounds__(256) void poe_fuse_fwd_kernel(PoeArgs a) {
   const int g = blockIdx.y, o = 1 - g;
   const int b = blockIdx.x * 8 + (threadIdx.x >> 5), d = threadIdx.x & 31;
@@ -564,15 +571,21 @@ __global__ __launch_bounds__(256) void poe_fuse_fwd_kernel(PoeArgs a) {
   if (ok) {
     const int m = a.mode[g][b], pr = a.partner[g][b];
     const float* own = a.stats[g] + (long)b * a.ld[g];           // (loc | logvar) rows of the shared encoder
-    const float* oth = a.stats[o] + (long)(pr < 0 ? 0 : pr) * a.ld[o];
-    const float loc = own[d], inv = expf(-own[n + d]);
-    float t, u;
-    if (m == 0) { t = expf(-oth[n + d]); u = oth[d] * t; }
-    else { t = (m == 1) ? 1.0f : 0.36787944117144233f; u = 0.f; }
-    const float J = 1.0f / (1.0f + (inv + t));
-    jl = (loc * inv + u) * J; jv = logf(J); sc = sqrtf(expf(jv));
-    z = jl + sc * a.eps[g][i];
-    klt = 0.5f * (sc * sc + jl * jl - 1.0f - logf(sc * sc));
+    const float* self = a.expert[g] ? a.expert[g] + (long)b * a.ld_expert[g] : own;
+    const float* oth = a.expert[o] ? a.expert[o] + (long)(pr < 0 ? 0 : pr) * a.ld_expert[o] : a.stats[o] + (long)(pr < 0 ? 0 : pr) * a.ld[o];
+    if (m == 2 && a.lone_passthrough) {
+      jl = own[d]; jv = own[n + d]; sc = expf(0.5f * jv);
+    } else {
+      const float loc = self[d], inv = expf(-self[n + d]);
+      float t, u;
+      if (m == 0) { t = expf(-oth[n + d]); u = oth[d] * t; }
+      else { t = (m == 1) ? 1.0f : 0.36787944117144233f; u = 0.f; }
+      const float J = 1.0f / (1.0f + (inv + t));
+      jl = (loc * inv + u) * J; jv = logf(J); sc = sqrtf(expf(jv));
+    }
+    const float sq = a.clamp_scale ? fmaxf(sc, 1e-6f) : sc;
+    z = jl + sq * a.eps[g][i];
+    klt = 0.5f * (sq * sq + jl * jl - 1.0f - logf(sq * sq));
   }
   const float mx = max32(z);
   const float e = ok ? expf(z - mx) : 0.f;
@@ -581,36 +594,88 @@ __global__ __launch_bounds__(256) void poe_fuse_fwd_kernel(PoeArgs a) {
   if (b < a.B[g] && d == 0) a.kl[g][b] = kl;
 }
 
-// d_stats[g] (same [B][ld] layout as stats[g], zeroed by spv_poe_fuse_bwd before the launch) receives the gradient of a
-// cell's own expert and, through its partner, of the other group's cell: at most two adds per element.
+// d_stats[g] / d_expert[g] (same layouts as stats / expert, zeroed by spv_poe_fuse_bwd before the launch) receive the
+// gradient of a cell's self expert and, through its partner, of the other group's expert.  Label PoE: at most two adds
+// per element (order-independent); paired PoE: a cell can be the arg max of several rows, so its adds commute only up
+// to fp32 rounding (the same holds for the index_add of the reference's autograd).
 __global__ __launch_bounds__(256) void poe_fuse_bwd_kernel(PoeArgs a) {
   const int g = blockIdx.y, o = 1 - g;
   const int b = blockIdx.x * 8 + (threadIdx.x >> 5), d = threadIdx.x & 31;
   const int n = a.n;
   if (b >= a.B[g] || d >= n) return;
   const int m = a.mode[g][b], pr = a.partner[g][b];
+  const long prc = pr < 0 ? 0 : pr;
   const float* own = a.stats[g] + (long)b * a.ld[g];
-  const float* oth = a.stats[o] + (long)(pr < 0 ? 0 : pr) * a.ld[o];
+  const float* self = a.expert[g] ? a.expert[g] + (long)b * a.ld_expert[g] : own;
+  const float* oth = a.expert[o] ? a.expert[o] + prc * a.ld_expert[o] : a.stats[o] + prc * a.ld[o];
   float* d_own = a.d_stats[g] + (long)b * a.ld[g];
-  float* d_oth = a.d_stats[o] + (long)(pr < 0 ? 0 : pr) * a.ld[o];
+  float* d_self = a.expert[g] ? a.d_expert[g] + (long)b * a.ld_expert[g] : d_own;
+  float* d_oth = a.expert[o] ? a.d_expert[o] + prc * a.ld_expert[o] : a.d_stats[o] + prc * a.ld[o];
   const float gk = a.g_kl[g] ? a.g_kl[g][b] : 0.f;
   const long i = (long)b * n + d;
-  const float loc = own[d], inv = expf(-own[n + d]);
+  const float jl = a.loc[g][i], sc = a.scale[g][i];
+  const bool live = !a.clamp_scale || sc >= 1e-6f;   // below the clamp the draw and the KL do not depend on the scale
+  const float sq = a.clamp_scale ? fmaxf(sc, 1e-6f) : sc;
+  const float gz = a.g_logz[g] ? a.g_logz[g][i] : 0.f;
+  const float Gl = (a.g_loc[g] ? a.g_loc[g][i] : 0.f) + gz + gk * jl;
+  const float Gs = (a.g_scale[g] ? a.g_scale[g][i] : 0.f) + (live ? gz * a.eps[g][i] + gk * (sq - 1.0f / sq) : 0.f);
+  const float Gv = (a.g_logvar[g] ? a.g_logvar[g][i] : 0.f) + 0.5f * sc * Gs;
+  if (m == 2 && a.lone_passthrough) {  // loc* = loc, logvar* = logvar, scale* = exp(logvar / 2)
+    atomicAdd(&d_own[d], Gl);
+    atomicAdd(&d_own[n + d], Gv);
+    return;
+  }
+  const float loc = self[d], inv = expf(-self[n + d]);
   float t = (m == 1) ? 1.0f : 0.36787944117144233f, lo = 0.f;
   if (m == 0) { lo = oth[d]; t = expf(-oth[n + d]); }
   const float J = 1.0f / (1.0f + (inv + t));
-  const float jl = a.loc[g][i], sc = a.scale[g][i];
-  const float gz = a.g_logz[g] ? a.g_logz[g][i] : 0.f;
-  const float Gl = (a.g_loc[g] ? a.g_loc[g][i] : 0.f) + gz + gk * jl;
-  const float Gs = (a.g_scale[g] ? a.g_scale[g][i] : 0.f) + gz * a.eps[g][i] + gk * (sc - 1.0f / sc);
-  const float Gv = (a.g_logvar[g] ? a.g_logvar[g][i] : 0.f) + 0.5f * sc * Gs;
   const float dN = Gl * J, dP = -J * (Gl * jl + Gv);
-  atomicAdd(&d_own[d], dN * inv);
-  atomicAdd(&d_own[n + d], -inv * (dN * loc + dP));
+  atomicAdd(&d_self[d], dN * inv);
+  atomicAdd(&d_self[n + d], -inv * (dN * loc + dP));
   if (m == 0) {
     atomicAdd(&d_oth[d], dN * t);
     atomicAdd(&d_oth[n + d], -t * (dP + dN * lo));
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Transport plans kept sparse on device.  The reference stores the plan dense, gathers the
+// [B0, B1] block of a minibatch pair (module/spVIPESmodule.py:474-482) and takes arg max over its rows and columns
+// (:520-523) or masked row-normalised products with it (:213-229).  Here the plan is CSR (rows = cells of group 0)
+// plus its transpose (CSR of the plan^T: rows = cells of group 1); a step touches only the stored entries of the
+// minibatch's rows.  inv*[c] = position of dataset cell c in the current minibatch, -1 if absent.
+// Plan values are transport masses (>= 0); positions that are not stored count as 0.
+// ---------------------------------------------------------------------------------------------
+__global__ void plan_invmap_kernel(const int* idx0, int B0, const int* idx1, int B1, int* inv0, int n0, int* inv1, int n1) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = blockIdx.y;
+  const int* idx = g ? idx1 : idx0;
+  int* inv = g ? inv1 : inv0;
+  const int B = g ? B1 : B0, nn = g ? n1 : n0;
+  if (i < B) { const int c = idx[i]; if (c >= 0 && c < nn) inv[c] = i; }
+}
+
+// partner[i] = arg max_j block[i][j] with block[i][j] = plan[idx_self[i]][idx_other[j]]: first maximum, like torch.argmax
+// (an all-zero row gives 0).  One thread per cell; a row holds ~10 stored entries.
+__global__ void plan_argmax_kernel(const int* ptr0, const int* ind0, const float* val0, const int* ptr1, const int* ind1, const float* val1,
+                                   const int* idx0, const int* idx1, const int* inv0, const int* inv1, int B0, int B1, int n0, int n1,
+                                   int* partner0, int* partner1) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = blockIdx.y;
+  if (i >= (g ? B1 : B0)) return;
+  const int* ptr = g ? ptr1 : ptr0; const int* ind = g ? ind1 : ind0; const float* val = g ? val1 : val0;
+  const int* inv_o = g ? inv0 : inv1;
+  const int r = (g ? idx1 : idx0)[i];
+  float best = 0.f; int bj = 0; bool any = false;
+  if (r >= 0 && r < (g ? n1 : n0)) {
+    for (int k = ptr[r]; k < ptr[r + 1]; ++k) {
+      const int j = inv_o[ind[k]];
+      if (j < 0) continue;
+      const float v = val[k];
+      if (v > 0.f && (!any || v > best || (v == best && j < bj))) { best = v; bj = j; any = true; }
+    }
+  }
+  (g ? partner1 : partner0)[i] = any ? bj : 0;
 }
 
 // ---------------------------------------------------------------------------------------------

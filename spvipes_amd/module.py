@@ -368,13 +368,44 @@ class spVIPESmodule(nn.Module):
         if self.use_labels and labels is not None:
             return P.label_based_poe(shared_stats, labels, noise)
         elif self.use_transport_plan:
-            plan_block = P.batch_transport_plan(self.transport_plan, global_indices)
             if self.pair_data:
-                return P.paired_poe(shared_stats, plan_block, noise)
+                return self._paired_poe_hip(shared_stats, global_indices, noise)
+            plan_block = P.batch_transport_plan(self.transport_plan, global_indices)
             if processed_labels is None:
                 raise ValueError("Processed labels are required when using transport plan.")
             return P.cluster_based_poe(shared_stats, plan_block, processed_labels, noise)
         raise ValueError("Either transport plan or labels must be provided for supervised POE.")
+
+    def sparse_plan(self, device):
+        """The transport plan as CSR + CSR of the transpose on ``device`` (built once from whatever the constructor got:
+        the reference's dense tensor, a scipy.sparse matrix or a ready SparsePlan)."""
+        from .plan import SparsePlan
+
+        sp = getattr(self, "_sparse_plan", None)
+        if sp is None or sp.device != torch.device(device):
+            sp = self._sparse_plan = SparsePlan.from_any(self.transport_plan, device)
+        return sp
+
+    def _paired_poe_hip(self, shared_stats, global_indices, noise):
+        """spVIPESmodule.py:511-571 on the sparse plan: arg max partners + fusion + draw + KL in HIP."""
+        from .nn_ops import PoEPaired
+
+        if global_indices is None or global_indices[0] is None:
+            raise ValueError("paired PoE needs the cells' dataset indices ('indices') to look up the transport plan")
+        dev = shared_stats[0]["logtheta_loc"].device
+        e = [noise.get(f"poe_{g}") for g in (0, 1)]
+        e = [torch.randn_like(shared_stats[g]["logtheta_loc"]) if e[g] is None else e[g] for g in (0, 1)]
+        o = PoEPaired.apply(self.sparse_plan(dev), [global_indices[0], global_indices[1]], e, self._workspace(0, dev),
+                            shared_stats[0]["logtheta_loc"], shared_stats[0]["logtheta_logvar"],
+                            shared_stats[1]["logtheta_loc"], shared_stats[1]["logtheta_logvar"])
+        out = {}
+        for g in (0, 1):
+            loc, logvar, scale, log_z, theta, kl, qscale = o[7 * g: 7 * g + 7]
+            out[g] = OrderedDict([("logtheta_loc", loc), ("logtheta_logvar", logvar), ("logtheta_scale", scale),
+                                  ("logtheta_qz", torch.distributions.Normal(loc, qscale, validate_args=False)),
+                                  ("logtheta_log_z", log_z), ("logtheta_theta", theta)])
+            self._kl_poe[g] = kl
+        return out
 
     def generative(self, private_stats, shared_stats, poe_stats, library, groups, batch_index):
         """spVIPESmodule.py:720-771: latent concatenation + slicing quirk; the decoder itself is

@@ -323,3 +323,69 @@ class PoELabel(torch.autograd.Function):
             a.d_stats[k] = ptr(d[k])
         _abi.call("spv_poe_fuse_bwd", C.byref(a), stream_ptr())
         return (None, None, None, d[0][:, :n], d[0][:, n:2 * n], d[1][:, :n], d[1][:, n:2 * n])
+
+
+class PoEPaired(torch.autograd.Function):
+    """Paired PoE (module/spVIPESmodule.py:511-571) on a sparse transport plan: every cell is fused with the arg max of its
+    plan row (group 0) / column (group 1) inside the minibatch pair.  2 + 1 forward launches, 1 backward launch.
+    inputs : loc0, logvar0, loc1, logvar1; outputs per group (loc*, logvar*, scale*, log_z, theta, kl, qscale)
+    -- theta and qscale (= scale*.clamp(min = 1e-6), the scale of the reference's Normal) are not differentiable."""
+
+    @staticmethod
+    def forward(ctx, plan, idx: Sequence[torch.Tensor], eps: Sequence[torch.Tensor], ws, loc0, logvar0, loc1, logvar1):
+        from ._abi import SpvPoeArgs
+        ctx.set_materialize_grads(False)
+        dev = loc0.device
+        n = loc0.shape[1]
+        Bs = [loc0.shape[0], loc1.shape[0]]
+        if Bs[0] != Bs[1]:
+            raise AssertionError("Paired PoE requires equal number of cells from both groups")
+        idx = [i.flatten().to(torch.int32).contiguous() for i in idx]
+        plan.bind_minibatch(idx[0], idx[1])
+        partner = [torch.empty(Bs[g], dtype=torch.int32, device=dev) for g in range(2)]
+        mode = [ws.get(f"poe_mode0_{g}", (Bs[g],), torch.int32, zero=True) for g in range(2)]  # every cell has a partner
+        ps = plan.c_struct()
+        _abi.call("spv_plan_argmax", C.byref(ps), ptr(idx[0]), ptr(idx[1]), ptr(plan.inv0), ptr(plan.inv1), Bs[0], Bs[1], ptr(partner[0]),
+                  ptr(partner[1]), stream_ptr())
+        blocks = [_loc_logvar_block(loc0, logvar0), _loc_logvar_block(loc1, logvar1)]
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        out = {k: [new(Bs[g], n) for g in range(2)] for k in ("loc", "logvar", "scale", "logz", "theta")}
+        kl = [new(Bs[g]) for g in range(2)]
+        eps = [e.contiguous() for e in eps]
+        a = SpvPoeArgs()
+        a.n, a.clamp_scale, a.lone_passthrough = n, 1, 0
+        for g in range(2):
+            a.stats[g], a.ld[g], a.partner[g], a.mode[g], a.eps[g], a.B[g] = blocks[g][1], blocks[g][2], ptr(partner[g]), ptr(mode[g]), ptr(eps[g]), Bs[g]
+            a.loc[g], a.logvar[g], a.scale[g], a.logz[g], a.theta[g] = (ptr(out[k][g]) for k in ("loc", "logvar", "scale", "logz", "theta"))
+            a.kl[g] = ptr(kl[g])
+        _abi.call("spv_poe_fuse_fwd", C.byref(a), stream_ptr())
+        ctx.blocks, ctx.eps, ctx.partner, ctx.mode, ctx.n, ctx.Bs = blocks, eps, partner, mode, n, Bs
+        ctx.save_for_backward(out["loc"][0], out["loc"][1], out["scale"][0], out["scale"][1])
+        res = []
+        for g in range(2):
+            qscale = out["scale"][g].clamp(min=1e-6)
+            res += [out["loc"][g], out["logvar"][g], out["scale"][g], out["logz"][g], out["theta"][g], kl[g], qscale]
+            ctx.mark_non_differentiable(out["theta"][g], qscale)
+        return tuple(res)
+
+    @staticmethod
+    def backward(ctx, *g):
+        from ._abi import SpvPoeArgs
+        loc, scale = ctx.saved_tensors[0:2], ctx.saved_tensors[2:4]
+        n, Bs = ctx.n, ctx.Bs
+        dev = loc[0].device
+        cont = lambda t: None if t is None else t.contiguous()
+        a = SpvPoeArgs()
+        a.n, a.clamp_scale, a.lone_passthrough = n, 1, 0
+        keep, d = [], []
+        for k in range(2):
+            gl, gv, gs, gz, _gt, gk, _gq = (cont(t) for t in g[7 * k: 7 * k + 7])
+            keep += [gl, gv, gs, gz, gk]
+            a.stats[k], a.ld[k], a.partner[k], a.mode[k], a.eps[k], a.B[k] = ctx.blocks[k][1], ctx.blocks[k][2], ptr(ctx.partner[k]), ptr(ctx.mode[k]), ptr(ctx.eps[k]), Bs[k]
+            a.loc[k], a.scale[k] = ptr(loc[k]), ptr(scale[k])
+            a.g_loc[k], a.g_logvar[k], a.g_scale[k], a.g_logz[k], a.g_kl[k] = ptr(gl), ptr(gv), ptr(gs), ptr(gz), ptr(gk)
+            d.append(torch.empty(Bs[k], ctx.blocks[k][2], dtype=torch.float32, device=dev))  # zeroed by spv_poe_fuse_bwd
+            a.d_stats[k] = ptr(d[k])
+        _abi.call("spv_poe_fuse_bwd", C.byref(a), stream_ptr())
+        return (None, None, None, None, d[0][:, :n], d[0][:, n:2 * n], d[1][:, :n], d[1][:, n:2 * n])
+
