@@ -275,6 +275,21 @@ int spv_plan_invmap(const int32_t* idx0, int32_t B0, const int32_t* idx1, int32_
                     int32_t n1, void* stream);
 /* paired PoE partners (module/spVIPESmodule.py:520-523): partner0[i] = argmax_j block[i][j], partner1[j] = argmax_i
  * block[i][j] of the minibatch block of the plan; first maximum, 0 for an all-zero row / column                       */
+/* Cluster PoE experts (module/spVIPESmodule.py:213-229) from the stored plan entries of the minibatch:
+ *   expert[g][i] = sum_j w'_ij * stats[g][j]   (loc | logvar),  j = positions of the other minibatch in i's component,
+ *   w' = row-normalised plan weights (row sums clamped at 1e-10, kept in rowsum[g] for the backward).
+ * comp[g]: component codes as fp32 [B]; both minibatches have B cells.  The backward ADDS into d_stats[g].            */
+typedef struct spv_plan_expert_args {
+  spv_plan plan;
+  const int32_t* idx[2]; const int32_t* inv[2]; const float* comp[2];
+  const float* stats[2]; int64_t ld[2];
+  float* expert[2]; int64_t ld_expert[2];
+  float* rowsum[2];
+  const float* d_expert[2]; float* d_stats[2];
+  int32_t B, n;
+} spv_plan_expert_args;
+int spv_plan_expert_fwd(const spv_plan_expert_args* a, void* stream);
+int spv_plan_expert_bwd(const spv_plan_expert_args* a, void* stream);
 int spv_plan_argmax(const spv_plan* plan, const int32_t* idx0, const int32_t* idx1, const int32_t* inv0, const int32_t* inv1,
                     int32_t B0, int32_t B1, int32_t* partner0, int32_t* partner1, void* stream);
 

@@ -103,6 +103,12 @@ class SpvPlan(C.Structure):
                 ("ptr1", C.c_void_p), ("ind1", C.c_void_p), ("val1", C.c_void_p), ("n1", C.c_int32)]
 
 
+class SpvPlanExpertArgs(C.Structure):
+    _fields_ = [("plan", SpvPlan), ("idx", C.c_void_p * 2), ("inv", C.c_void_p * 2), ("comp", C.c_void_p * 2), ("stats", C.c_void_p * 2),
+                ("ld", C.c_int64 * 2), ("expert", C.c_void_p * 2), ("ld_expert", C.c_int64 * 2), ("rowsum", C.c_void_p * 2),
+                ("d_expert", C.c_void_p * 2), ("d_stats", C.c_void_p * 2), ("B", C.c_int32), ("n", C.c_int32)]
+
+
 class SpvZsplitArgs(C.Structure):
     _fields_ = [("priv", C.c_void_p * 2), ("poe", C.c_void_p * 2), ("zcat", C.c_void_p * 2), ("d_zcat", C.c_void_p * 2),
                 ("d_priv", C.c_void_p * 2), ("d_poe", C.c_void_p * 2), ("B", C.c_int32), ("n_p", C.c_int32), ("n_s", C.c_int32), ("ngroups", C.c_int32)]
@@ -155,6 +161,8 @@ _SIGNATURES = {
     "spv_plan_invmap": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "spv_plan_argmax": (C.c_int, [C.POINTER(SpvPlan), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
+    "spv_plan_expert_fwd": (C.c_int, [C.POINTER(SpvPlanExpertArgs), C.c_void_p]),
+    "spv_plan_expert_bwd": (C.c_int, [C.POINTER(SpvPlanExpertArgs), C.c_void_p]),
     "spv_zsplit_fwd": (C.c_int, [C.POINTER(SpvZsplitArgs), C.c_void_p]),
     "spv_zsplit_bwd": (C.c_int, [C.POINTER(SpvZsplitArgs), C.c_void_p]),
     "spv_bn_fold_fwd": (C.c_int, [C.POINTER(SpvFoldBatch), C.c_void_p]),

@@ -702,3 +702,28 @@ extern "C" int spv_plan_argmax(const spv_plan* plan, const int32_t* idx0, const 
   return launch_status("spv_plan_argmax");
 }
 
+static int check_expert(const spv_plan_expert_args* a, const char* who) {
+  if (!a) return fail(SPV_ERR_ARG, "%s: null arguments", who);
+  int rc = check_plan(&a->plan, who);
+  if (rc) return rc;
+  if (a->B <= 0 || a->n <= 0 || a->n > 32) return fail(SPV_ERR_ARG, "%s: bad shape (latent dimension <= 32)", who);
+  for (int g = 0; g < 2; ++g)
+    if (!a->idx[g] || !a->inv[g] || !a->comp[g] || !a->stats[g] || !a->rowsum[g] || a->ld[g] < 2 * a->n || a->ld_expert[g] < 2 * a->n)
+      return fail(SPV_ERR_ARG, "%s: null pointer / bad pitch", who);
+  return SPV_OK;
+}
+extern "C" int spv_plan_expert_fwd(const spv_plan_expert_args* a, void* stream) {
+  int rc = check_expert(a, "spv_plan_expert_fwd");
+  if (rc) return rc;
+  for (int g = 0; g < 2; ++g) if (!a->expert[g]) return fail(SPV_ERR_ARG, "spv_plan_expert_fwd: null output%s");
+  hipLaunchKernelGGL(plan_expert_fwd_kernel, dim3((a->B + 7) / 8, 2), dim3(256), 0, (hipStream_t)stream, *a);
+  return launch_status("spv_plan_expert_fwd");
+}
+extern "C" int spv_plan_expert_bwd(const spv_plan_expert_args* a, void* stream) {
+  int rc = check_expert(a, "spv_plan_expert_bwd");
+  if (rc) return rc;
+  for (int g = 0; g < 2; ++g) if (!a->d_expert[g] || !a->d_stats[g]) return fail(SPV_ERR_ARG, "spv_plan_expert_bwd: null pointer%s");
+  hipLaunchKernelGGL(plan_expert_bwd_kernel, dim3((a->B + 7) / 8, 2), dim3(256), 0, (hipStream_t)stream, *a);
+  return launch_status("spv_plan_expert_bwd");
+}
+

@@ -678,6 +678,62 @@ __global__ void plan_argmax_kernel(const int* ptr0, const int* ind0, const float
   (g ? partner1 : partner0)[i] = any ? bj : 0;
 }
 
+// Cluster PoE experts (module/spVIPESmodule.py:213-229): for cell i of group g in component c,
+//   E_g[i] = sum_j w'_ij * stats_g[j],  j over the other minibatch's positions in component c,  w'_ij = w_ij / max(sum_j w_ij, 1e-10)
+// with w_ij the plan entry between the two cells -- the reference multiplies group g's OWN statistics by weights indexed with
+// the other group's positions (both minibatches have B rows), and so does this.  32 lanes per cell (one per latent
+// dimension, loc and logvar together), a serial walk over the row's stored entries.
+typedef spv_plan_expert_args ExpertArgs;
+
+__global__ __launch_bounds__(256) void plan_expert_fwd_kernel(ExpertArgs a) {
+  const int g = blockIdx.y, o = 1 - g;
+  const int i = blockIdx.x * 8 + (threadIdx.x >> 5), d = threadIdx.x & 31;
+  if (i >= a.B) return;
+  const int* ptr = g ? a.plan.ptr1 : a.plan.ptr0; const int* ind = g ? a.plan.ind1 : a.plan.ind0; const float* val = g ? a.plan.val1 : a.plan.val0;
+  const int nrows = g ? a.plan.n1 : a.plan.n0;
+  const int r = a.idx[g][i];
+  const float ci = a.comp[g][i];
+  const bool on = d < a.n;
+  float al = 0.f, av = 0.f, rs = 0.f;
+  if (r >= 0 && r < nrows) {
+    for (int k = ptr[r]; k < ptr[r + 1]; ++k) {
+      const int j = a.inv[o][ind[k]];
+      if (j < 0 || a.comp[o][j] != ci) continue;
+      const float w = val[k];
+      rs += w;
+      if (on) { const float* sj = a.stats[g] + (long)j * a.ld[g]; al += w * sj[d]; av += w * sj[a.n + d]; }
+    }
+  }
+  const float rc = fmaxf(rs, 1e-10f);
+  if (on) { float* e = a.expert[g] + (long)i * a.ld_expert[g]; e[d] = al / rc; e[a.n + d] = av / rc; }
+  if (d == 0) a.rowsum[g][i] = rc;
+}
+
+// d stats_g[t] += sum_i w'_it * dE_g[i]: a gather over the transposed structure (the stored entries of the OTHER group's
+// dataset cell at position t), so every element is written by one lane and the sum order is fixed.
+__global__ __launch_bounds__(256) void plan_expert_bwd_kernel(ExpertArgs a) {
+  const int g = blockIdx.y, o = 1 - g;
+  const int t = blockIdx.x * 8 + (threadIdx.x >> 5), d = threadIdx.x & 31;
+  if (t >= a.B || d >= a.n) return;
+  // rows of the transposed-for-g structure are the other group's cells: g = 0 walks plan^T, g = 1 walks the plan
+  const int* ptr = g ? a.plan.ptr0 : a.plan.ptr1; const int* ind = g ? a.plan.ind0 : a.plan.ind1; const float* val = g ? a.plan.val0 : a.plan.val1;
+  const int nrows = g ? a.plan.n0 : a.plan.n1;
+  const int r = a.idx[o][t];
+  const float ct = a.comp[o][t];
+  float gl = 0.f, gv = 0.f;
+  if (r >= 0 && r < nrows) {
+    for (int k = ptr[r]; k < ptr[r + 1]; ++k) {
+      const int i = a.inv[g][ind[k]];
+      if (i < 0 || a.comp[g][i] != ct) continue;
+      const float w = val[k] / a.rowsum[g][i];
+      const float* de = a.d_expert[g] + (long)i * a.ld_expert[g];
+      gl += w * de[d]; gv += w * de[a.n + d];
+    }
+  }
+  float* ds = a.d_stats[g] + (long)t * a.ld[g];
+  ds[d] += gl; ds[a.n + d] += gv;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Decoder preparation (module/spVIPESmodule.py:733-754 + the BatchNorm of the two factor regressors,
 // nn/networks.py:314,318 with scvi FCLayers' BatchNorm1d(eps 1e-3, momentum 0.01)).

@@ -364,16 +364,14 @@ class spVIPESmodule(nn.Module):
         return {"private_stats": private_stats, "shared_stats": shared_stats, "poe_stats": poe_stats, "library": library}
 
     def _supervised_poe(self, shared_stats, global_indices, processed_labels, labels, noise, P):
-        """Dispatch of spVIPESmodule.py:484-509 (same priorities and errors)."""
-        if self.use_labels and labels is not None:
-            return P.label_based_poe(shared_stats, labels, noise)
-        elif self.use_transport_plan:
+        """Dispatch of spVIPESmodule.py:484-509 (same priorities and errors); label-based PoE, first in that order, has
+        already been taken by ``inference``."""
+        if self.use_transport_plan:
             if self.pair_data:
                 return self._paired_poe_hip(shared_stats, global_indices, noise)
-            plan_block = P.batch_transport_plan(self.transport_plan, global_indices)
             if processed_labels is None:
                 raise ValueError("Processed labels are required when using transport plan.")
-            return P.cluster_based_poe(shared_stats, plan_block, processed_labels, noise)
+            return self._cluster_poe_hip(shared_stats, global_indices, processed_labels, noise)
         raise ValueError("Either transport plan or labels must be provided for supervised POE.")
 
     def sparse_plan(self, device):
@@ -398,6 +396,27 @@ class spVIPESmodule(nn.Module):
         o = PoEPaired.apply(self.sparse_plan(dev), [global_indices[0], global_indices[1]], e, self._workspace(0, dev),
                             shared_stats[0]["logtheta_loc"], shared_stats[0]["logtheta_logvar"],
                             shared_stats[1]["logtheta_loc"], shared_stats[1]["logtheta_logvar"])
+        out = {}
+        for g in (0, 1):
+            loc, logvar, scale, log_z, theta, kl, qscale = o[7 * g: 7 * g + 7]
+            out[g] = OrderedDict([("logtheta_loc", loc), ("logtheta_logvar", logvar), ("logtheta_scale", scale),
+                                  ("logtheta_qz", torch.distributions.Normal(loc, qscale, validate_args=False)),
+                                  ("logtheta_log_z", log_z), ("logtheta_theta", theta)])
+            self._kl_poe[g] = kl
+        return out
+
+    def _cluster_poe_hip(self, shared_stats, global_indices, processed_labels, noise):
+        """spVIPESmodule.py:184-280 on the sparse plan: plan-weighted component experts + _poe2 fusion in HIP."""
+        from .nn_ops import PoECluster
+
+        if global_indices is None or global_indices[0] is None:
+            raise ValueError("cluster-based PoE needs the cells' dataset indices ('indices') to look up the transport plan")
+        dev = shared_stats[0]["logtheta_loc"].device
+        e = [noise.get(f"poe_{g}") for g in (0, 1)]
+        e = [torch.randn_like(shared_stats[g]["logtheta_loc"]) if e[g] is None else e[g] for g in (0, 1)]
+        o = PoECluster.apply(self.sparse_plan(dev), [global_indices[0], global_indices[1]], [processed_labels[0], processed_labels[1]], e,
+                             self._workspace(0, dev), shared_stats[0]["logtheta_loc"], shared_stats[0]["logtheta_logvar"],
+                             shared_stats[1]["logtheta_loc"], shared_stats[1]["logtheta_logvar"])
         out = {}
         for g in (0, 1):
             loc, logvar, scale, log_z, theta, kl, qscale = o[7 * g: 7 * g + 7]

@@ -389,3 +389,96 @@ class PoEPaired(torch.autograd.Function):
         _abi.call("spv_poe_fuse_bwd", C.byref(a), stream_ptr())
         return (None, None, None, None, d[0][:, :n], d[0][:, n:2 * n], d[1][:, :n], d[1][:, n:2 * n])
 
+
+class PoECluster(torch.autograd.Function):
+    """Cluster-matched PoE (module/spVIPESmodule.py:184-280) on a sparse transport plan: plan-weighted experts inside
+    each component (spv_plan_expert_fwd), rank-within-component pairing (spv_poe_partner on the component codes) and the
+    _poe2 fusion with its padding rule; a component present in one minibatch only keeps its encoder statistics.
+    inputs : loc0, logvar0, loc1, logvar1; outputs per group (loc*, logvar*, scale*, log_z, theta, kl, qscale)."""
+
+    @staticmethod
+    def forward(ctx, plan, idx: Sequence[torch.Tensor], comps: Sequence[torch.Tensor], eps: Sequence[torch.Tensor], ws, loc0, logvar0, loc1, logvar1):
+        from ._abi import SpvPlanExpertArgs, SpvPoeArgs
+        ctx.set_materialize_grads(False)
+        dev = loc0.device
+        n = loc0.shape[1]
+        Bs = [loc0.shape[0], loc1.shape[0]]
+        if Bs[0] != Bs[1]:
+            raise RuntimeError("cluster-based PoE needs equally sized minibatches (the reference indexes one group's statistics with the other's mask)")
+        B = Bs[0]
+        idx = [i.flatten().to(torch.int32).contiguous() for i in idx]
+        comp = [c.flatten().contiguous().float() for c in comps]
+        plan.bind_minibatch(idx[0], idx[1])
+        i32 = lambda name, k: ws.get(name, (k,), torch.int32)
+        order = [i32(f"poe_order{g}", B) for g in range(2)]
+        rank = [i32(f"poe_rank{g}", B) for g in range(2)]
+        partner = [torch.empty(B, dtype=torch.int32, device=dev) for g in range(2)]
+        mode = [torch.empty(B, dtype=torch.int32, device=dev) for g in range(2)]
+        err = ws.get("poe_err", (1,), torch.int32, zero=True)
+        tables = ws.get("poe_tables", (2, 2, 1024), torch.int32)
+        _abi.call("spv_poe_partner", ptr(comp[0]), ptr(comp[1]), B, B, ptr(order[0]), ptr(order[1]), ptr(rank[0]), ptr(rank[1]),
+                  ptr(tables), ptr(partner[0]), ptr(mode[0]), ptr(partner[1]), ptr(mode[1]), ptr(err), stream_ptr())
+        blocks = [_loc_logvar_block(loc0, logvar0), _loc_logvar_block(loc1, logvar1)]
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        expert = [new(B, 2 * n) for _ in range(2)]
+        rowsum = [new(B) for _ in range(2)]
+        ea = SpvPlanExpertArgs()
+        ea.plan, ea.B, ea.n = plan.c_struct(), B, n
+        inv = [plan.inv0, plan.inv1]
+        for g in range(2):
+            ea.idx[g], ea.inv[g], ea.comp[g], ea.stats[g], ea.ld[g] = ptr(idx[g]), ptr(inv[g]), ptr(comp[g]), blocks[g][1], blocks[g][2]
+            ea.expert[g], ea.ld_expert[g], ea.rowsum[g] = ptr(expert[g]), 2 * n, ptr(rowsum[g])
+        _abi.call("spv_plan_expert_fwd", C.byref(ea), stream_ptr())
+        out = {k: [new(B, n) for g in range(2)] for k in ("loc", "logvar", "scale", "logz", "theta")}
+        kl = [new(B) for g in range(2)]
+        eps = [e.contiguous() for e in eps]
+        a = SpvPoeArgs()
+        a.n, a.clamp_scale, a.lone_passthrough = n, 1, 1
+        for g in range(2):
+            a.stats[g], a.ld[g], a.partner[g], a.mode[g], a.eps[g], a.B[g] = blocks[g][1], blocks[g][2], ptr(partner[g]), ptr(mode[g]), ptr(eps[g]), B
+            a.expert[g], a.ld_expert[g] = ptr(expert[g]), 2 * n
+            a.loc[g], a.logvar[g], a.scale[g], a.logz[g], a.theta[g] = (ptr(out[k][g]) for k in ("loc", "logvar", "scale", "logz", "theta"))
+            a.kl[g] = ptr(kl[g])
+        _abi.call("spv_poe_fuse_fwd", C.byref(a), stream_ptr())
+        # the inverse maps of the plan are rebuilt by the next minibatch: keep what the backward needs of them
+        ctx.plan, ctx.idx, ctx.comp, ctx.inv = plan, idx, comp, [plan.inv0.clone(), plan.inv1.clone()]
+        ctx.blocks, ctx.eps, ctx.partner, ctx.mode, ctx.n, ctx.B = blocks, eps, partner, mode, n, B
+        ctx.expert, ctx.rowsum = expert, rowsum
+        ctx.save_for_backward(out["loc"][0], out["loc"][1], out["scale"][0], out["scale"][1])
+        res = []
+        for g in range(2):
+            qscale = out["scale"][g].clamp(min=1e-6)
+            res += [out["loc"][g], out["logvar"][g], out["scale"][g], out["logz"][g], out["theta"][g], kl[g], qscale]
+            ctx.mark_non_differentiable(out["theta"][g], qscale)
+        return tuple(res)
+
+    @staticmethod
+    def backward(ctx, *g):
+        from ._abi import SpvPlanExpertArgs, SpvPoeArgs
+        loc, scale = ctx.saved_tensors[0:2], ctx.saved_tensors[2:4]
+        n, B = ctx.n, ctx.B
+        dev = loc[0].device
+        cont = lambda t: None if t is None else t.contiguous()
+        a = SpvPoeArgs()
+        a.n, a.clamp_scale, a.lone_passthrough = n, 1, 1
+        keep, d, de = [], [], []
+        for k in range(2):
+            gl, gv, gs, gz, _gt, gk, _gq = (cont(t) for t in g[7 * k: 7 * k + 7])
+            keep += [gl, gv, gs, gz, gk]
+            a.stats[k], a.ld[k], a.partner[k], a.mode[k], a.eps[k], a.B[k] = ctx.blocks[k][1], ctx.blocks[k][2], ptr(ctx.partner[k]), ptr(ctx.mode[k]), ptr(ctx.eps[k]), B
+            a.expert[k], a.ld_expert[k] = ptr(ctx.expert[k]), 2 * n
+            a.loc[k], a.scale[k] = ptr(loc[k]), ptr(scale[k])
+            a.g_loc[k], a.g_logvar[k], a.g_scale[k], a.g_logz[k], a.g_kl[k] = ptr(gl), ptr(gv), ptr(gs), ptr(gz), ptr(gk)
+            d.append(torch.empty(B, ctx.blocks[k][2], dtype=torch.float32, device=dev))   # both zeroed by spv_poe_fuse_bwd
+            de.append(torch.empty(B, 2 * n, dtype=torch.float32, device=dev))
+            a.d_stats[k], a.d_expert[k] = ptr(d[k]), ptr(de[k])
+        _abi.call("spv_poe_fuse_bwd", C.byref(a), stream_ptr())
+        ea = SpvPlanExpertArgs()
+        ea.plan, ea.B, ea.n = ctx.plan.c_struct(), B, n
+        for k in range(2):
+            ea.idx[k], ea.inv[k], ea.comp[k], ea.stats[k], ea.ld[k] = ptr(ctx.idx[k]), ptr(ctx.inv[k]), ptr(ctx.comp[k]), ctx.blocks[k][1], ctx.blocks[k][2]
+            ea.expert[k], ea.ld_expert[k], ea.rowsum[k] = ptr(ctx.expert[k]), 2 * n, ptr(ctx.rowsum[k])
+            ea.d_expert[k], ea.d_stats[k] = ptr(de[k]), ptr(d[k])
+        _abi.call("spv_plan_expert_bwd", C.byref(ea), stream_ptr())
+        return (None, None, None, None, None, d[0][:, :n], d[0][:, n:2 * n], d[1][:, :n], d[1][:, n:2 * n])
+
