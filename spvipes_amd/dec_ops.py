@@ -20,6 +20,7 @@ from . import _abi
 from ._abi import (DEC_CELLS_PER_WG, DEC_KP, DEC_KPS, DEC_KS, NB_CMAX, SpvBnBatch, SpvDecParams, SpvFoldBatch, SpvReduceBatch, SpvZsplitArgs,
                    ptr, round_up, stream_ptr)
 from .nn_ops import _add_lin, _fptr, _lin_batch, _wgrad, grad_out
+from . import ops as _ops
 from .ops import N_HIDDEN_MIX, GroupCounts, Workspace, _bf16_image, _gemm_slabs, _gene_splits, _nb_splits, _pack, fork, group_streams, join
 
 N_DEC_PARAMS = 13  # Wp, gamma_p, beta_p, Ws, gamma_s, beta_s, Wa, ba, gamma_a, beta_a, Wm, bm, px_r
@@ -235,6 +236,7 @@ class DecoderFused(torch.autograd.Function):
         dAm, d_zcat = [new(B, n_m) for _ in range(NG)], [new(B, nt) for _ in range(NG)]
         streams = group_streams(dev, NG)  # (measured: also forking the dL GEMMs onto their own streams is slower)
         fork(streams)
+        late = []
         for g in range(NG):
           with torch.cuda.stream(streams[g]):
               G, Gp, wsg, S, P = Gs[g], Gps[g], ws[g], ctx.saved_g[g], ctx.P[g]
@@ -254,7 +256,7 @@ class DecoderFused(torch.autograd.Function):
               ksp_m, ksp_n = max(1, min(T // 8, -(-512 // max(Bp // 64, 1)))), max(1, min(T // 8, -(-512 // max(Bp // 128, 1))))
               csp_m, csp_n = max(1, min(bt // 8, -(-512 // max(Gp // 64, 1)))), max(1, min(bt // 8, -(-512 // max(Gp // 128, 1))))
               (Wm_hi, Wm_lo), (Am_hi, Am_lo), (Aps_hi, Aps_lo) = S["Wm"], S["Am"], S["Aps"]
-              a = _gemm_slabs(True, dL_hi, dL_lo, Gp, Am_hi, Am_lo, KMP, G, KMP, Bp, nsplit, csp_m, wsg, "dec_dWm", a_tiles=T)
+              late.append((g, dL_hi, dL_lo, Am_hi, Am_lo, csp_m, T))  # d W_m: nothing downstream needs it -> see below
               d = _gemm_slabs(False, dL_hi, dL_lo, Gp, Wm_hi, Wm_lo, KMP, B, KMP, G, nsplit, ksp_m, wsg, "dec_dAm", a_tiles=T)
               b_ = _gemm_slabs(True, tP_hi, tP_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KP, Bp, nsplit, csp_n, wsg, "dec_dWp", a_tiles=T)
               c = _gemm_slabs(True, tS_hi, tS_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KS, Bp, nsplit, csp_n, wsg, "dec_dWs", b_col_off=DEC_KP, a_tiles=T)
@@ -262,8 +264,6 @@ class DecoderFused(torch.autograd.Function):
               f = _gemm_slabs(False, tS_hi, tS_lo, Gp, ctx.Wps[g][0], ctx.Wps[g][1], DEC_KPS, B, DEC_KS, G, nsplit, ksp_n, wsg, "dec_dAs", b_col_off=DEC_KP, a_tiles=T)
               # slab sums, scaled by the upstream gradient, straight into their consumers' buffers
               al = g_loss
-              _add_red(red, a, csp_m, G * KMP, KMP, G, KM - 1, pg[g][10][0], KM - 1, alpha=al)                 # d W_m
-              _add_red(red, a, csp_m, G * KMP, KMP, G, 1, pg[g][11][0], 1, col_off=KM - 1, alpha=al)           # d b_m
               dwp, dws_, dam, dz = dWp[g], dWs[g], dAm[g], d_zcat[g]
               _add_red(red, b_, csp_n, G * DEC_KP, DEC_KP, G, DEC_KP, dwp, DEC_KP, alpha=al)                    # d [W'_p | c_p]
               _add_red(red, c, csp_n, G * DEC_KS, DEC_KS, G, DEC_KS, dws_, DEC_KS, alpha=al)                    # d [W'_s | c_s]
@@ -277,6 +277,24 @@ class DecoderFused(torch.autograd.Function):
         join(streams)
         _run_red(red)
         _run_red(red2)
+        # The mixture-weight gradients (2 x [G, K_M] from dL^T A_m, the largest GEMMs of the backward) feed nothing but the
+        # optimiser: they go to a side stream that starts here, i.e. runs beside the ~30 tiny kernels of the trunk / PoE /
+        # encoder-tail backward that follow and leave the GPU almost empty, and is joined at the end of the backward pass.
+        side = group_streams(dev, 3)[2]
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            red3 = SpvReduceBatch()
+            red3.nprob = 0
+            for (g, dL_hi, dL_lo, Am_hi, Am_lo, csp_m, T) in late:
+                G, Gp = Gs[g], Gps[g]
+                a = _gemm_slabs(True, dL_hi, dL_lo, Gp, Am_hi, Am_lo, KMP, G, KMP, Bp, nsplit, csp_m, ws[g], "dec_dWm", a_tiles=T)
+                _add_red(red3, a, csp_m, G * KMP, KMP, G, KM - 1, pg[g][10][0], KM - 1, alpha=g_loss)                 # d W_m
+                _add_red(red3, a, csp_m, G * KMP, KMP, G, 1, pg[g][11][0], 1, col_off=KM - 1, alpha=g_loss)           # d b_m
+            _run_red(red3)
+        if _ops.DEFER_JOIN:
+            _ops.defer(side, [g_loss])
+        else:
+            torch.cuda.current_stream(dev).wait_stream(side)
         # ---- trunk backward (BatchNorm + relu, Linear) ----------------------------------------------
         nblk = -(-B // _abi.BN_ROWS)
         d_pre = [new(B, n_m) for _ in range(NG)]

@@ -54,7 +54,9 @@ def grad_out(param: torch.Tensor):
 
 
 def _wgrad(b: SpvLinearBatch, ws) -> None:
-    """spv_linear_wgrad with its slice-partial workspace (16 batch slices, summed in fixed order)."""
+    """spv_linear_wgrad with its slice-partial workspace (16 batch slices, summed in fixed order).
+    (Measured: moving these parameter-gradient launches to the side stream of the mixture-weight GEMMs makes the step
+    slower -- they are too small to be worth the cross-stream edges.)"""
     nmax = max(b.p[i].N for i in range(b.nprob))
     kmax = max(b.p[i].K for i in range(b.nprob))
     n = b.nprob * 16 * nmax * (kmax + 1)

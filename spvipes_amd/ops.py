@@ -98,6 +98,29 @@ def join(streams) -> None:
         streams[0].wait_stream(st)
 
 
+# Work that nothing later in the backward pass depends on (the mixture-weight gradient GEMMs) is queued on a side stream
+# that starts when the GPU is about to run the long chain of tiny encoder / PoE backward kernels, and is joined as late as
+# possible.  With DEFER_JOIN False the join happens before DecoderFused.backward returns (any caller may then read .grad);
+# train.Trainer sets it True around its backward pass and joins with ``join_pending`` right after it.
+DEFER_JOIN = False
+_PENDING: list = []
+_PENDING_KEEP: list = []
+
+
+def defer(stream, keep=()) -> None:
+    """register side-stream work (and the tensors it reads) to be joined by ``join_pending``"""
+    if stream not in _PENDING:
+        _PENDING.append(stream)
+    _PENDING_KEEP.extend(keep)
+
+
+def join_pending(device=None) -> None:
+    while _PENDING:
+        st = _PENDING.pop()
+        torch.cuda.current_stream(st.device if device is None else device).wait_stream(st)
+    _PENDING_KEEP.clear()
+
+
 def _pack(src: torch.Tensor, dst_hi: torch.Tensor, dst_lo: Optional[torch.Tensor], *, extra_col: Optional[torch.Tensor] = None,
           extra_one: bool = False, dst_row_off: int = 0, dst_col_off: int = 0, rows_cover: Optional[int] = None,
           cslot: Optional[int] = None) -> None:

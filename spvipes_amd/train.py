@@ -120,11 +120,16 @@ class Trainer:
 
         self.fp.grad.zero_()
         _, _, lo = self.module(self.minibatch(rows), loss_kwargs={"kl_weight": kl_weight})
+        from . import ops
+
         nn_ops.GRAD_SINK = True  # small-layer gradients land directly in the flat buffer (see nn_ops.grad_out)
+        ops.DEFER_JOIN = True    # side-stream gradient GEMMs are joined here, after the whole backward pass
         try:
             lo.loss.backward()
         finally:
             nn_ops.GRAD_SINK = False
+            ops.DEFER_JOIN = False
+            ops.join_pending()
         return lo
 
     def capture(self, rows: Sequence[torch.Tensor], warmup: int = 3) -> None:
