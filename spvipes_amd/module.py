@@ -276,7 +276,7 @@ class spVIPESmodule(nn.Module):
         self._step_inputs, self._kl_private, self._kl_poe = {}, {}, {}
         h1s, eps_enc = {}, {}
         H = self.n_hidden
-        streams = None
+        streams, label_pre = None, None
         for g, group in x.items():
             counts, rows, B = self._counts_of(g, group)
             self._step_inputs[g] = (counts, rows, B)
@@ -284,7 +284,7 @@ class spVIPESmodule(nn.Module):
             ws = self._workspace(g, counts.X.device)
             if streams is None:  # the groups' fc1 GEMMs are independent: group g > 0 runs on a side stream (autograd replays
                 streams = group_streams(counts.X.device, len(x))  # each node's backward on its forward stream as well)
-                fork(streams)
+                fork(streams)  # (measured: also hoisting the label pairing onto a third stream here makes the step slower)
             with torch.cuda.stream(streams[g % len(streams)]):
                 h1, lib = EncoderFC1.apply(counts, rows, B, ep.fc1.weight, ep.fc1.bias, es.fc1.weight, es.fc1.bias, self.nsplit, ws)
             h1s[g] = h1
@@ -350,7 +350,7 @@ class spVIPESmodule(nn.Module):
             # label-based PoE (priority as spVIPESmodule.py:492-493): pairing + fusion + draw + KL in HIP
             dev = shared_stats[0]["logtheta_loc"].device
             e = [draw(f"poe_{g}") for g in (0, 1)]
-            o = PoELabel.apply([labels[0], labels[1]], e, self._workspace(0, dev), shared_stats[0]["logtheta_loc"], shared_stats[0]["logtheta_logvar"],
+            o = PoELabel.apply([labels[0], labels[1]], e, self._workspace(0, dev), label_pre, shared_stats[0]["logtheta_loc"], shared_stats[0]["logtheta_logvar"],
                                shared_stats[1]["logtheta_loc"], shared_stats[1]["logtheta_logvar"])
             poe_stats = {}
             for g in (0, 1):

@@ -257,28 +257,38 @@ def _loc_logvar_block(loc: torch.Tensor, logvar: torch.Tensor):
     return blk, blk.data_ptr(), 2 * n
 
 
+def label_partners(labels: Sequence[torch.Tensor], ws):
+    """(partner, mode) of every cell of both minibatches from the label codes alone (spv_poe_partner): no dependence on
+    the encoders, so ``module.inference`` launches it on a side stream while the fc1 GEMMs run."""
+    dev = labels[0].device
+    lab = [l.flatten().contiguous().float() for l in labels]
+    Bs = [lab[0].numel(), lab[1].numel()]
+    i32 = lambda name, k: ws.get(name, (k,), torch.int32)
+    order = [i32(f"poe_order{g}", Bs[g]) for g in range(2)]
+    rank = [i32(f"poe_rank{g}", Bs[g]) for g in range(2)]
+    partner = [torch.empty(Bs[g], dtype=torch.int32, device=dev) for g in range(2)]
+    mode = [torch.empty(Bs[g], dtype=torch.int32, device=dev) for g in range(2)]
+    err = ws.get("poe_err", (1,), torch.int32, zero=True)
+    tables = ws.get("poe_tables", (2, 2, 1024), torch.int32)
+    _abi.call("spv_poe_partner", ptr(lab[0]), ptr(lab[1]), Bs[0], Bs[1], ptr(order[0]), ptr(order[1]), ptr(rank[0]), ptr(rank[1]),
+              ptr(tables), ptr(partner[0]), ptr(mode[0]), ptr(partner[1]), ptr(mode[1]), ptr(err), stream_ptr())
+    return partner, mode, lab
+
+
 class PoELabel(torch.autograd.Function):
     """Both groups' label-based PoE in 2 forward launches (pairing + fusion/draw/KL) and 1 backward launch.
     inputs : loc0, logvar0, loc1, logvar1 (shared-encoder statistics); outputs per group
-    (loc*, logvar*, scale*, log_z, theta, kl) -- theta not differentiable."""
+    (loc*, logvar*, scale*, log_z, theta, kl) -- theta not differentiable.  ``pre``: the result of ``label_partners`` when
+    the caller has already launched the pairing."""
 
     @staticmethod
-    def forward(ctx, labels: Sequence[torch.Tensor], eps: Sequence[torch.Tensor], ws, loc0, logvar0, loc1, logvar1):
+    def forward(ctx, labels: Sequence[torch.Tensor], eps: Sequence[torch.Tensor], ws, pre, loc0, logvar0, loc1, logvar1):
         from ._abi import SpvPoeArgs
         ctx.set_materialize_grads(False)
         dev = loc0.device
         n = loc0.shape[1]
         Bs = [loc0.shape[0], loc1.shape[0]]
-        i32 = lambda name, k: ws.get(name, (k,), torch.int32)
-        lab = [l.flatten().contiguous().float() for l in labels]
-        order = [i32(f"poe_order{g}", Bs[g]) for g in range(2)]
-        partner = [torch.empty(Bs[g], dtype=torch.int32, device=dev) for g in range(2)]
-        mode = [torch.empty(Bs[g], dtype=torch.int32, device=dev) for g in range(2)]
-        err = ws.get("poe_err", (1,), torch.int32, zero=True)
-        rank = [i32(f"poe_rank{g}", Bs[g]) for g in range(2)]
-        tables = ws.get("poe_tables", (2, 2, 1024), torch.int32)
-        _abi.call("spv_poe_partner", ptr(lab[0]), ptr(lab[1]), Bs[0], Bs[1], ptr(order[0]), ptr(order[1]), ptr(rank[0]), ptr(rank[1]),
-                  ptr(tables), ptr(partner[0]), ptr(mode[0]), ptr(partner[1]), ptr(mode[1]), ptr(err), stream_ptr())
+        partner, mode, _lab = pre if pre is not None else label_partners(labels, ws)
         blocks = [_loc_logvar_block(loc0, logvar0), _loc_logvar_block(loc1, logvar1)]
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         out = {k: [new(Bs[g], n) for g in range(2)] for k in ("loc", "logvar", "scale", "logz", "theta")}
@@ -291,7 +301,7 @@ class PoELabel(torch.autograd.Function):
             a.loc[g], a.logvar[g], a.scale[g], a.logz[g], a.theta[g] = (ptr(out[k][g]) for k in ("loc", "logvar", "scale", "logz", "theta"))
             a.kl[g] = ptr(kl[g])
         _abi.call("spv_poe_fuse_fwd", C.byref(a), stream_ptr())
-        ctx.blocks, ctx.eps, ctx.partner, ctx.mode, ctx.n, ctx.Bs, ctx.err = blocks, eps, partner, mode, n, Bs, err
+        ctx.blocks, ctx.eps, ctx.partner, ctx.mode, ctx.n, ctx.Bs = blocks, eps, partner, mode, n, Bs
         ctx.save_for_backward(out["loc"][0], out["loc"][1], out["scale"][0], out["scale"][1])
         res = []
         for g in range(2):
@@ -324,7 +334,7 @@ class PoELabel(torch.autograd.Function):
                 d[k] = torch.empty(Bs[k], ld, dtype=torch.float32, device=dev)
             a.d_stats[k] = ptr(d[k])
         _abi.call("spv_poe_fuse_bwd", C.byref(a), stream_ptr())
-        return (None, None, None, d[0][:, :n], d[0][:, n:2 * n], d[1][:, :n], d[1][:, n:2 * n])
+        return (None, None, None, None, d[0][:, :n], d[0][:, n:2 * n], d[1][:, :n], d[1][:, n:2 * n])
 
 
 class PoEPaired(torch.autograd.Function):
