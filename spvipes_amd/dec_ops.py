@@ -77,7 +77,7 @@ class DecoderFused(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad)  # (grad mode is off inside Function.forward)
         Bp = round_up(B, DEC_CELLS_PER_WG)
         Gs = [c.G for c in counts]
-        Gps = [round_up(G, 128) for G in Gs]
+        Gps = [round_up(G, 256) for G in Gs]  # 256: the logits GEMM runs 256-gene workgroup tiles
         mlo = nsplit == 3
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         cont = lambda t: t if (t.is_contiguous() and t.dtype == torch.float32) else t.contiguous().float()

@@ -266,7 +266,7 @@ class DecoderNBLoss(torch.autograd.Function):
         KMp = 320  # one 320-wide N tile of the backward GEMMs; K steps beyond `ksteps` are never issued
         if KM > KMp:
             raise _abi.SpvError("mixture input wider than 320 columns is not supported")
-        Bp, Gp = round_up(B, DEC_CELLS_PER_WG), round_up(G, 128)
+        Bp, Gp = round_up(B, DEC_CELLS_PER_WG), round_up(G, 256)
         lo = True  # the small regressor operands always travel as hi/lo pairs
         mlo = nsplit == 3
         f32 = lambda t: t.contiguous().float()
