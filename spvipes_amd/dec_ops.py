@@ -115,7 +115,22 @@ class DecoderFused(torch.autograd.Function):
                 q.img_hi, q.img_lo, q.ld_img, q.col_off, q.slot = ptr(Wps[g][0]), ptr(Wps[g][1]), DEC_KPS, off, slot
                 q.G, q.Gp, q.K = Gs[g], Gps[g], n
                 fb.nprob += 1
-        _abi.call("spv_bn_fold_fwd", C.byref(fb), stream_ptr())
+        # The fold, the mixture-weight images and the (count, gene) tables depend on nothing the trunk (step 4) computes:
+        # they run beside it on a side stream and are joined before the per-group section.
+        side = group_streams(dev, 3)[2] if _ops.OVERLAP_SMALL else torch.cuda.current_stream(dev)
+        if _ops.OVERLAP_SMALL:
+            side.wait_stream(torch.cuda.current_stream(dev))
+        Wm_img, tabs = [], []
+        with torch.cuda.stream(side):
+            _abi.call("spv_bn_fold_fwd", C.byref(fb), stream_ptr())
+            for g in range(NG):
+                Wm_hi, Wm_lo = _bf16_image(ws[g], "dec_Wm", Gps[g], KMP, mlo)
+                _pack(cont(par[g][10]), Wm_hi, Wm_lo, extra_col=cont(par[g][11]))
+                gene_tab = ws[g].get("dec_gene_tab", (Gps[g], 4), torch.float32)
+                cnt_tab = ws[g].get("dec_cnt_tab", (NB_CMAX, Gps[g], 2), torch.float32)
+                _abi.call("spv_dec_tables", ptr(cont(par[g][12])), Gs[g], Gps[g], ptr(gene_tab), ptr(cnt_tab), stream_ptr())
+                Wm_img.append((Wm_hi, Wm_lo))
+                tabs.append((gene_tab, cnt_tab))
         # ---- 4. mixing trunk: m = relu(BN(zcat Wa^T + ba)) -------------------------------------------
         pre_a = [new(B, n_m) for _ in range(NG)]
         m = [new(B, n_m) for _ in range(NG)]
@@ -143,22 +158,20 @@ class DecoderFused(torch.autograd.Function):
         rec = [new(B) for _ in range(NG)]  # (allocated before the fork: every temporary belongs to the main stream)
         red = SpvReduceBatch()
         red.nprob = 0
+        if _ops.OVERLAP_SMALL:
+            torch.cuda.current_stream(dev).wait_stream(side)
         streams = group_streams(dev, NG)
         fork(streams)
         for g in range(NG):
           with torch.cuda.stream(streams[g]):
               G, Gp, wsg = Gs[g], Gps[g], ws[g]
-              Wm_hi, Wm_lo = _bf16_image(wsg, "dec_Wm", Gp, KMP, mlo)
-              _pack(cont(par[g][10]), Wm_hi, Wm_lo, extra_col=cont(par[g][11]))
+              (Wm_hi, Wm_lo), (gene_tab, cnt_tab) = Wm_img[g], tabs[g]
               Am_hi, Am_lo = _bf16_image(wsg, "dec_Am", Bp, KMP, mlo)
               _pack(m[g], Am_hi, Am_lo, dst_col_off=0, cslot=n_m)
               _pack(zcat[g], Am_hi, Am_lo, extra_one=True, dst_col_off=n_m, cslot=KMP - n_m)
               Aps_hi, Aps_lo = _bf16_image(wsg, "dec_Aps", Bp, DEC_KPS, True)
               _pack(zcat[g][:, :n_p], Aps_hi, Aps_lo, extra_one=True, dst_col_off=0, cslot=DEC_KP)
               _pack(zcat[g][:, n_p:], Aps_hi, Aps_lo, extra_one=True, dst_col_off=DEC_KP, cslot=DEC_KS)
-              gene_tab = wsg.get("dec_gene_tab", (Gp, 4), torch.float32)
-              cnt_tab = wsg.get("dec_cnt_tab", (NB_CMAX, Gp, 2), torch.float32)
-              _abi.call("spv_dec_tables", ptr(cont(par[g][12])), G, Gp, ptr(gene_tab), ptr(cnt_tab), stream_ptr())
               logits = wsg.get("dec_logits_" + ("f32" if mlo else "f16"), (Bp, Gp), torch.float32 if mlo else torch.float16)
               _abi.call("spv_dec_logits", ptr(Am_hi), ptr(Am_lo), ptr(Wm_hi), ptr(Wm_lo), KMP, Bp, Gp, nsplit, ptr(logits), int(mlo), stream_ptr())
               splits, per = _gene_splits(Bp, Gp)

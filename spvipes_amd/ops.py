@@ -11,6 +11,7 @@ Reference arithmetic replaced (file:line into /root/reference/src/spVIPES):
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
@@ -103,6 +104,7 @@ def join(streams) -> None:
 # possible.  With DEFER_JOIN False the join happens before DecoderFused.backward returns (any caller may then read .grad);
 # train.Trainer sets it True around its backward pass and joins with ``join_pending`` right after it.
 DEFER_JOIN = False
+OVERLAP_SMALL = os.environ.get("SPV_OVERLAP_SMALL", "1") != "0"  # side-stream overlap of independent small-kernel groups
 _PENDING: list = []
 _PENDING_KEEP: list = []
 
