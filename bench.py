@@ -157,6 +157,13 @@ def main():
         # A captured hipGraph cannot carry per-call events, so the per-kernel durations for the roofline line are
         # taken with HIP events on the launch stream in an eager pass of the same steps, immediately before the
         # graph is captured and timed (same kernels, same shapes, same data; rocprofv3 averages agree: profiles/).
+        # In the timed (captured) step the two groups' chains run on two HIP streams and overlap; a kernel's own
+        # duration is only defined when it runs alone, so this event pass keeps every launch on one stream
+        # (ops.SERIAL_STREAMS).  `SPV_SERIAL_STREAMS=1 python bench.py ...` runs the whole benchmark that way: that is
+        # the command of the rocprofv3 summary whose per-kernel averages these numbers agree with (profiles/README.md).
+        from spvipes_amd import ops as _ops
+        serial_before = _ops.SERIAL_STREAMS
+        _ops.SERIAL_STREAMS = True
         for _ in range(2):
             trainer.step(next(it), kl_weight=1.0)
         torch.cuda.synchronize()
@@ -164,6 +171,7 @@ def main():
         for _ in range(max(3, min(args.steps, 10))):
             trainer.step(next(it), kl_weight=1.0)
         prof = _abi.profile_stop()
+        _ops.SERIAL_STREAMS = serial_before
         trainer.capture(next(it))
     for _ in range(args.warmup):
         trainer.step(next(it), kl_weight=1.0)
@@ -218,7 +226,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32(split-bf16)", "data": "synthetic",
             "config": {"workload": f"2 groups x {args.cells} cells x {G} genes per GPU, label-based PoE, n_shared={n_s} n_private={n_p} "
                                    f"n_hidden={H}, batch {B} cells/group/step/GPU, counts resident as {args.count_dtype} (BASELINE configs[1])",
-                       "parallelism": f"dp{world}", "precision": args.precision, "launch": "hipGraph replay" if use_graph else "eager"},
+                       "parallelism": f"dp{world}", "precision": args.precision, "launch": "hipGraph replay, 2 streams" if use_graph else "eager"},
             "final_loss": loss,
             "roofline": roof,
         }

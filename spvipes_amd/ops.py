@@ -72,6 +72,7 @@ class Workspace:
 
 
 _SIDE_STREAMS: Dict[Tuple, "torch.cuda.Stream"] = {}
+SERIAL_STREAMS = os.environ.get("SPV_SERIAL_STREAMS", "0") == "1"
 
 
 def group_streams(device, n: int = 2):
@@ -81,6 +82,8 @@ def group_streams(device, n: int = 2):
     hipGraph capture the fork/join become parallel branches of the graph."""
     dev = torch.device(device)
     out = [torch.cuda.current_stream(dev)]
+    if SERIAL_STREAMS:  # every chain on the caller's stream: kernels run one at a time (per-kernel timing, debugging)
+        return out * n
     for i in range(1, n):
         key = (dev.index, i)
         if key not in _SIDE_STREAMS:
