@@ -1,0 +1,130 @@
+"""Direct checks of the auxiliary C-ABI entry points against plain torch on the same inputs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from spvipes_amd import _abi
+    _abi.load()  # raises if libspvipes_hip.so is missing: no fallback
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("nslabs", [1, 4, 8, 9, 64])
+def test_reduce_slabs_matches_torch(dev, nslabs):
+    from spvipes_amd import _abi
+    from spvipes_amd._abi import SpvReduceBatch, stream_ptr
+    from spvipes_amd.dec_ops import _add_red
+    g = torch.Generator(device=dev).manual_seed(nslabs)
+    rows, ld, cols, off = 37, 50, 21, 7
+    src = torch.randn(nslabs, rows, ld, generator=g, device=dev)
+    alpha = torch.tensor(0.75, device=dev)
+    es = torch.randn(cols, generator=g, device=dev) * 0.3
+    dst0 = torch.randn(rows, 30, generator=g, device=dev)
+    dst = dst0.clone()
+    plain = torch.empty(rows, cols, device=dev)
+    b = SpvReduceBatch()
+    b.nprob = 0
+    _add_red(b, src, nslabs, rows * ld, ld, rows, cols, plain, cols, col_off=off)
+    _add_red(b, src, nslabs, rows * ld, ld, rows, cols, dst, 30, col_off=off, dst_col=4, accumulate=True, alpha=alpha, exp_scale=es)
+    _abi.call("spv_reduce_slabs", C.byref(b), stream_ptr())
+    want = src[:, :, off:off + cols].double().sum(0)
+    torch.testing.assert_close(plain.double(), want, rtol=1e-6, atol=1e-5)
+    want2 = dst0.double().clone()
+    want2[:, 4:4 + cols] += 0.75 * torch.exp(es.double()) * want
+    torch.testing.assert_close(dst.double(), want2, rtol=1e-5, atol=1e-5)
+    # deterministic: a second run gives the same bits
+    plain2 = torch.empty_like(plain)
+    b2 = SpvReduceBatch()
+    b2.nprob = 0
+    _add_red(b2, src, nslabs, rows * ld, ld, rows, cols, plain2, cols, col_off=off)
+    _abi.call("spv_reduce_slabs", C.byref(b2), stream_ptr())
+    assert torch.equal(plain, plain2)
+
+
+@pytest.mark.parametrize("B,nkl", [(7, 0), (300, 4), (4096, 2)])
+def test_loss_assemble_matches_torch(dev, B, nkl):
+    from spvipes_amd import _abi
+    from spvipes_amd._abi import ptr, stream_ptr
+    g = torch.Generator(device=dev).manual_seed(B)
+    rec = [torch.randn(B, generator=g, device=dev) * 50 + 900 for _ in range(2)]
+    w = torch.full((B,), 1.0 / B, device=dev)
+    kls = [torch.rand(B, generator=g, device=dev) * 3 for _ in range(nkl)]
+    klw = torch.tensor(0.37, device=dev)
+    loss, rs, gkl = torch.empty((), device=dev), torch.empty((), device=dev), torch.empty(B, device=dev)
+    klp = (C.c_void_p * 4)(*[ptr(k) for k in kls], *([None] * (4 - nkl)))
+    _abi.call("spv_loss_assemble", ptr(rec[0]), ptr(rec[1]), ptr(w), klp, nkl, B, ptr(klw), ptr(loss), ptr(rs), ptr(gkl), stream_ptr())
+    want_rs = (w.double() * (rec[0].double() + rec[1].double())).sum()
+    want = want_rs + 0.37 * sum(k.double() for k in kls).mean() if nkl else want_rs
+    assert abs(float(rs) - float(want_rs)) < 1e-5 * abs(float(want_rs))
+    assert abs(float(loss) - float(want)) < 1e-5 * abs(float(want))
+    torch.testing.assert_close(gkl, torch.full((B,), 0.37 / B, device=dev), rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("B,H", [(50, 8), (4096, 128)])
+def test_fc1_bwd_prep_matches_torch(dev, B, H):
+    from spvipes_amd import _abi
+    from spvipes_amd._abi import ptr, round_up, stream_ptr
+    g = torch.Generator(device=dev).manual_seed(H)
+    N1 = 2 * H
+    dh1 = torch.randn(B, N1, generator=g, device=dev)
+    h1 = torch.relu(torch.randn(B, N1, generator=g, device=dev))
+    Bp, ld = round_up(B, 64), round_up(N1, 128)
+    hi = torch.full((Bp, ld), 77, dtype=torch.int16, device=dev)
+    lo = torch.full((Bp, ld), 77, dtype=torch.int16, device=dev)
+    part = torch.empty(Bp // 16, N1, device=dev)
+    db, db2 = torch.empty(H, device=dev), torch.empty(H, device=dev)
+    _abi.call("spv_enc_fc1_bwd_prep", ptr(dh1), ptr(h1), B, N1, ptr(hi), ptr(lo), ld, Bp, ptr(part), ptr(db), ptr(db2), H, stream_ptr())
+    dpre = dh1 * (h1 > 0)
+    hi_f = (hi.to(torch.int32) << 16).view(torch.float32)
+    lo_f = (lo.to(torch.int32) << 16).view(torch.float32)
+    torch.testing.assert_close(hi_f[:B, :N1], dpre.to(torch.bfloat16).float(), rtol=0, atol=0)
+    torch.testing.assert_close((hi_f + lo_f)[:B, :N1], dpre, rtol=2e-5, atol=1e-6)      # hi + lo carries ~16 mantissa bits
+    assert float(hi_f[B:].abs().max() if Bp > B else 0) == 0 and float(hi_f[:, N1:].abs().max() if ld > N1 else 0) == 0
+    want = dpre.double().sum(0)
+    torch.testing.assert_close(torch.cat([db, db2]).double(), want, rtol=1e-5, atol=1e-4)
+
+
+def test_plan_experts_match_dense_autograd(dev):
+    """spv_plan_expert_fwd / _bwd against the masked, row-normalised dense products of the reference's cluster PoE."""
+    import scipy.sparse as sp
+    from spvipes_amd import _abi
+    from spvipes_amd._abi import SpvPlanExpertArgs, ptr, stream_ptr
+    from spvipes_amd.plan import SparsePlan
+    rng = np.random.default_rng(0)
+    n0, n1, B, n = 400, 350, 96, 7
+    m = sp.random(n0, n1, density=0.06, random_state=3, format="csr", dtype=np.float32)
+    m.data = m.data + 0.05
+    plan = SparsePlan.from_scipy(m, dev)
+    idx = [torch.tensor(rng.permutation(nn)[:B].astype(np.int32), device=dev) for nn in (n0, n1)]
+    comp = [torch.tensor(rng.integers(0, 4, size=B).astype(np.float32), device=dev) for _ in (0, 1)]
+    stats = [torch.randn(B, 2 * n, device=dev, dtype=torch.float32) for _ in (0, 1)]
+    plan.bind_minibatch(idx[0], idx[1])
+    inv = [plan.inv0, plan.inv1]
+    expert = [torch.empty(B, 2 * n, device=dev) for _ in (0, 1)]
+    rowsum = [torch.empty(B, device=dev) for _ in (0, 1)]
+    d_exp = [torch.randn(B, 2 * n, device=dev) for _ in (0, 1)]
+    d_stats = [torch.zeros(B, 2 * n, device=dev) for _ in (0, 1)]
+    a = SpvPlanExpertArgs()
+    a.plan, a.B, a.n = plan.c_struct(), B, n
+    for g in (0, 1):
+        a.idx[g], a.inv[g], a.comp[g], a.stats[g], a.ld[g] = ptr(idx[g]), ptr(inv[g]), ptr(comp[g]), ptr(stats[g]), 2 * n
+        a.expert[g], a.ld_expert[g], a.rowsum[g], a.d_expert[g], a.d_stats[g] = ptr(expert[g]), 2 * n, ptr(rowsum[g]), ptr(d_exp[g]), ptr(d_stats[g])
+    _abi.call("spv_plan_expert_fwd", C.byref(a), stream_ptr())
+    _abi.call("spv_plan_expert_bwd", C.byref(a), stream_ptr())
+    block = torch.tensor(m.toarray(), device=dev)[idx[0].long()][:, idx[1].long()].double()
+    same = comp[0].unsqueeze(1) == comp[1].unsqueeze(0)
+    for g, T, sm in ((0, block, same), (1, block.t(), same.t())):
+        W = torch.where(sm, T, torch.zeros_like(T))
+        W = torch.where(W > 0, W / W.sum(1, keepdim=True).clamp(min=1e-10), W)
+        s = stats[g].double().requires_grad_(True)
+        E = W @ s
+        torch.testing.assert_close(expert[g].double(), E.detach(), rtol=1e-5, atol=1e-6)
+        E.backward(d_exp[g].double())
+        torch.testing.assert_close(d_stats[g].double(), s.grad, rtol=1e-5, atol=1e-6)
