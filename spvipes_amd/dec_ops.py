@@ -293,8 +293,9 @@ class DecoderFused(torch.autograd.Function):
         # The mixture-weight gradients (2 x [G, K_M] from dL^T A_m, the largest GEMMs of the backward) feed nothing but the
         # optimiser: they go to a side stream that starts here, i.e. runs beside the ~30 tiny kernels of the trunk / PoE /
         # encoder-tail backward that follow and leave the GPU almost empty, and is joined at the end of the backward pass.
-        side = group_streams(dev, 3)[2]
-        side.wait_stream(torch.cuda.current_stream(dev))
+        side = group_streams(dev, 3)[2] if _ops.DEFER_WM else torch.cuda.current_stream(dev)
+        if _ops.DEFER_WM:
+            side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             red3 = SpvReduceBatch()
             red3.nprob = 0
@@ -304,7 +305,9 @@ class DecoderFused(torch.autograd.Function):
                 _add_red(red3, a, csp_m, G * KMP, KMP, G, KM - 1, pg[g][10][0], KM - 1, alpha=g_loss)                 # d W_m
                 _add_red(red3, a, csp_m, G * KMP, KMP, G, 1, pg[g][11][0], 1, col_off=KM - 1, alpha=g_loss)           # d b_m
             _run_red(red3)
-        if _ops.DEFER_JOIN:
+        if not _ops.DEFER_WM:
+            pass
+        elif _ops.DEFER_JOIN:
             _ops.defer(side, [g_loss])
         else:
             torch.cuda.current_stream(dev).wait_stream(side)
