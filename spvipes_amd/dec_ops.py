@@ -173,7 +173,9 @@ class DecoderFused(torch.autograd.Function):
               _pack(zcat[g][:, :n_p], Aps_hi, Aps_lo, extra_one=True, dst_col_off=0, cslot=DEC_KP)
               _pack(zcat[g][:, n_p:], Aps_hi, Aps_lo, extra_one=True, dst_col_off=DEC_KP, cslot=DEC_KS)
               logits = wsg.get("dec_logits_" + ("f32" if mlo else "f16"), (Bp, Gp), torch.float32 if mlo else torch.float16)
-              _abi.call("spv_dec_logits", ptr(Am_hi), ptr(Am_lo), ptr(Wm_hi), ptr(Wm_lo), KMP, Bp, Gp, nsplit, ptr(logits), int(mlo), stream_ptr())
+              lse_first = bool(_ops.STAGGER and g % 2 == 1)  # group 1 runs its (VALU-bound) softmax statistics beside group 0's logits GEMM
+              if not lse_first:
+                  _abi.call("spv_dec_logits", ptr(Am_hi), ptr(Am_lo), ptr(Wm_hi), ptr(Wm_lo), KMP, Bp, Gp, nsplit, ptr(logits), int(mlo), stream_ptr())
               splits, per = _gene_splits(Bp, Gp)
               nbs, nbper = _nb_splits(Gp)
               vec = lambda nme: wsg.get(nme, (Bp,), torch.float32)
@@ -200,6 +202,8 @@ class DecoderFused(torch.autograd.Function):
                   dtheta_part=ptr(dth), dL=ptr(dL), tP=ptr(tP), tS=ptr(tS), grads_f32=int(grads_f32), nb_splits=nbs, nb_genes_per_split=nbper,
               )
               _abi.call("spv_dec_lse", C.byref(p), ptr(cont(library[g].flatten())), stream_ptr())
+              if lse_first:
+                  _abi.call("spv_dec_logits", ptr(Am_hi), ptr(Am_lo), ptr(Wm_hi), ptr(Wm_lo), KMP, Bp, Gp, nsplit, ptr(logits), int(mlo), stream_ptr())
               _abi.call("spv_dec_nb_fwd", C.byref(p), int(need_grad), stream_ptr())
               r = rec[g]
               _add_red(red, nbpart("dec_rec"), nbs, Bp, Bp, 1, B, r, B)

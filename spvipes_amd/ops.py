@@ -108,6 +108,7 @@ def join(streams) -> None:
 # train.Trainer sets it True around its backward pass and joins with ``join_pending`` right after it.
 DEFER_JOIN = False
 OVERLAP_SMALL = os.environ.get("SPV_OVERLAP_SMALL", "1") != "0"  # side-stream overlap of independent small-kernel groups
+STAGGER = os.environ.get("SPV_STAGGER", "1") != "0"  # group 1 orders its independent kernels differently from group 0
 DEFER_WM = os.environ.get("SPV_DEFER_WM", "1") != "0"  # mixture-weight gradient GEMMs on the late side stream
 _PENDING: list = []
 _PENDING_KEEP: list = []
