@@ -154,8 +154,11 @@ int spv_dec_lse(const spv_dec_params* p, const float* library, void* stream);
  * per-element gradients dL, tP, tS (accumulator-tile order; bf16, or fp32 when grads_f32). */
 int spv_dec_nb_fwd(const spv_dec_params* p, int32_t train, void* stream);
 
-/* in place: tP <- tP - softmax_p * Tp[b],  tS <- tS - softmax_s * Ts[b]  */
-int spv_dec_softmax_bwd(const spv_dec_params* p, const float* Tp, const float* Ts, void* stream);
+/* in place: tP <- tP - softmax_p * Tp[b],  tS <- tS - softmax_s * Ts[b].
+ * dz_part (optional, bf16 gradient arrays only): fp32 [gene_splits][Bp][48]; per gene split the gradient reaching the latents
+ * through the two rate heads, columns 0..15 = sum_g tP[b][g] * W'_p[g][.], columns 16..47 = sum_g tS[b][g] * W'_s[g][.]
+ * (sum the slabs with spv_reduce_slabs): replaces the two [B,G] x [G,K] GEMMs over tP and tS. */
+int spv_dec_softmax_bwd(const spv_dec_params* p, const float* Tp, const float* Ts, float* dz_part, void* stream);
 
 /* One Adam step (torch.optim.Adam semantics, L2 weight decay folded into the gradient) over a
  * flat fp32 parameter buffer; grad_scale multiplies g first (1/world for data-parallel means).

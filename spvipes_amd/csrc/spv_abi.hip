@@ -334,16 +334,18 @@ extern "C" int spv_dec_logits(const uint16_t* Am_hi, const uint16_t* Am_lo, cons
   return launch_status("spv_dec_logits");
 }
 
-extern "C" int spv_dec_softmax_bwd(const spv_dec_params* q, const float* Tp, const float* Ts, void* stream) {
+extern "C" int spv_dec_softmax_bwd(const spv_dec_params* q, const float* Tp, const float* Ts, float* dz_part, void* stream) {
   DecParams p;
   int rc = to_dec(q, p);
   if (rc != SPV_OK) return rc;
   if (!Tp || !Ts || !p.tP || !p.tS || !p.lse_p || !p.lse_s) return fail(SPV_ERR_ARG, "spv_dec_softmax_bwd: null pointer%s");
   if (p.n_gene_tiles != p.Gp / 32) return fail(SPV_ERR_ARG, "spv_dec_softmax_bwd: n_gene_tiles must be Gp / 32%s");
+  if (dz_part && p.grads_f32) return fail(SPV_ERR_ARG, "spv_dec_softmax_bwd: the fused latent gradient needs bf16 gradient arrays%s");
   dim3 grid(p.Bp / DEC_CELLS_PER_WG, p.gene_splits);
   hipStream_t s = (hipStream_t)stream;
-  if (p.grads_f32) hipLaunchKernelGGL(dec_softmax_bwd_kernel<float>, grid, dim3(256), 0, s, p, Tp, Ts);
-  else hipLaunchKernelGGL(dec_softmax_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, p, Tp, Ts);
+  if (p.grads_f32) hipLaunchKernelGGL((dec_softmax_bwd_kernel<float, false>), grid, dim3(256), 0, s, p, Tp, Ts, (float*)nullptr);
+  else if (dz_part) hipLaunchKernelGGL((dec_softmax_bwd_kernel<bf16_t, true>), grid, dim3(256), 0, s, p, Tp, Ts, dz_part);
+  else hipLaunchKernelGGL((dec_softmax_bwd_kernel<bf16_t, false>), grid, dim3(256), 0, s, p, Tp, Ts, (float*)nullptr);
   return launch_status("spv_dec_softmax_bwd");
 }
 

@@ -550,9 +550,20 @@ __device__ __forceinline__ void decode4(const f4v& x, float (&v)[4]) {
 
 // Software pipelined over 32-gene tiles: the next tile's fragments and gradient words are requested before the
 // current tile's stores are issued, so waiting for them never has to drain those stores (vmcnt is in order).
-template <typename GT>
-__global__ __launch_bounds__(256) void dec_softmax_bwd_kernel(DecParams p, const float* Tp, const float* Ts) {
+//
+// FUSE (bf16 gradients only): the corrected tile sits in registers in MFMA accumulator layout [gene][cell]; read as the
+// B operand of two more 32x32x16 MFMAs per head (k-slots = the lane's 2 x 4 consecutive genes, the A operand = the
+// transposed regressor slice W'^T[k][gene] staged in LDS with the same slot order) it yields the gradient reaching the
+// latents through the two rate heads,  dz_p[cell][k] = sum_gene t'_P[gene][cell] W'_p[gene][k]  (and dz_s), accumulated
+// over the split's genes and written as one partial slab per split -- the two [B,G] x [G,16|32] GEMMs of the backward
+// pass and their re-read of t'_P / t'_S disappear.
+constexpr int SMB_SUB = 320;            // genes of the transposed slice resident in LDS at a time
+constexpr int SMB_PITCH = SMB_SUB + 8;  // bf16 per row: 656 B = 164 dwords, rows 16 / 32 lanes apart fall on different banks
+
+template <typename GT, bool FUSE>
+__global__ __launch_bounds__(256) void dec_softmax_bwd_kernel(DecParams p, const float* Tp, const float* Ts, float* dz_part) {
   typedef typename Raw4<GT>::type raw_t;
+  __shared__ __attribute__((aligned(16))) bf16_t s_wT[FUSE ? DEC_KPS * SMB_PITCH : 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
   const int cell_tile = blockIdx.x * (DEC_CELLS_PER_WG / 32) + wave;
   const int cell0 = cell_tile * 32;
@@ -567,49 +578,96 @@ __global__ __launch_bounds__(256) void dec_softmax_bwd_kernel(DecParams p, const
   if (gend > p.Gp) gend = p.Gp;
   if (gend > ((p.G + 31) & ~31)) gend = (p.G + 31) & ~31;
   const int ntile = (gend - gbeg) >> 5;
-  if (ntile <= 0) return;
-  const long trow = (long)cell_tile * p.n_gene_tiles;
-  PsW wA;
-  raw_t rpA[4], rsA[4];
-  load_ps_w(p, gbeg, lane, wA);
-  {
-    const long tb = (trow + (gbeg >> 5)) * 1024 + lane * 4;
+  f16v accP, accS;
 #pragma unroll
-    for (int qq = 0; qq < 4; ++qq) { rpA[qq] = load4_raw<GT>(p.tP, tb + 256 * qq); rsA[qq] = load4_raw<GT>(p.tS, tb + 256 * qq); }
-  }
-  for (int t = 0; t < ntile; ++t) {
-    const int g0 = gbeg + 32 * t, gn = gbeg + 32 * min(t + 1, ntile - 1);
-    f16v yp, ys;
+  for (int q = 0; q < 16; ++q) { accP[q] = 0.f; accS[q] = 0.f; }
+  if (ntile > 0) {   // (block-uniform)
+    const long trow = (long)cell_tile * p.n_gene_tiles;
+    PsW wA;
+    raw_t rpA[4], rsA[4];
+    load_ps_w(p, gbeg, lane, wA);
+    {
+      const long tb = (trow + (gbeg >> 5)) * 1024 + lane * 4;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) { yp[q] = 0.f; ys[q] = 0.f; }
-    yp = mfma32_split<3>(wA.hi[0], wA.lo[0], cf.hi[0], cf.lo[0], yp);
-    ys = mfma32_split<3>(wA.hi[1], wA.lo[1], cf.hi[1], cf.lo[1], ys);
-    ys = mfma32_split<3>(wA.hi[2], wA.lo[2], cf.hi[2], cf.lo[2], ys);
-    PsW wB;
-    raw_t rpB[4], rsB[4];
-    load_ps_w(p, gn, lane, wB);
-    const long tbase = (trow + (g0 >> 5)) * 1024 + lane * 4, tnext = (trow + (gn >> 5)) * 1024 + lane * 4;
-#pragma unroll
-    for (int qq = 0; qq < 4; ++qq) { rpB[qq] = load4_raw<GT>(p.tP, tnext + 256 * qq); rsB[qq] = load4_raw<GT>(p.tS, tnext + 256 * qq); }
-#pragma unroll
-    for (int qq = 0; qq < 4; ++qq) {
-      const int g = g0 + 8 * qq + 4 * h;
-      float vp[4], vs[4];
-      decode4(rpA[qq], vp);
-      decode4(rsA[qq], vs);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int q = 4 * qq + j;
-        const bool ok = (g + j < p.G) && (cell < p.B);
-        vp[j] = ok ? vp[j] - fast_exp(yp[q] - lp) * tpb : 0.f;
-        vs[j] = ok ? vs[j] - fast_exp(ys[q] - ls) * tsb : 0.f;
-      }
-      store4<GT>(p.tP, tbase + 256 * qq, vp);
-      store4<GT>(p.tS, tbase + 256 * qq, vs);
+      for (int qq = 0; qq < 4; ++qq) { rpA[qq] = load4_raw<GT>(p.tP, tb + 256 * qq); rsA[qq] = load4_raw<GT>(p.tS, tb + 256 * qq); }
     }
-    wA = wB;
+    for (int t = 0; t < ntile; ++t) {
+      const int g0 = gbeg + 32 * t, gn = gbeg + 32 * min(t + 1, ntile - 1);
+      if constexpr (FUSE) {
+        if (t % (SMB_SUB / 32) == 0) {  // (re)stage W'^T for the next SMB_SUB genes: s_wT[k][gene - g0]
+          __syncthreads();
+          const int ng = min(SMB_SUB, gend - g0);
+          for (int i = threadIdx.x; i < ng * (DEC_KPS / 8); i += 256) {
+            const int gl = i / (DEC_KPS / 8), c8 = (i % (DEC_KPS / 8)) * 8;
+            const s8v w = *reinterpret_cast<const s8v*>(p.Wps_hi + (long)(g0 + gl) * DEC_KPS + c8);
 #pragma unroll
-    for (int qq = 0; qq < 4; ++qq) { rpA[qq] = rpB[qq]; rsA[qq] = rsB[qq]; }
+            for (int j = 0; j < 8; ++j) s_wT[(c8 + j) * SMB_PITCH + gl] = (bf16_t)w[j];
+          }
+          __syncthreads();
+        }
+      }
+      f16v yp, ys;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { yp[q] = 0.f; ys[q] = 0.f; }
+      yp = mfma32_split<3>(wA.hi[0], wA.lo[0], cf.hi[0], cf.lo[0], yp);
+      ys = mfma32_split<3>(wA.hi[1], wA.lo[1], cf.hi[1], cf.lo[1], ys);
+      ys = mfma32_split<3>(wA.hi[2], wA.lo[2], cf.hi[2], cf.lo[2], ys);
+      PsW wB;
+      raw_t rpB[4], rsB[4];
+      load_ps_w(p, gn, lane, wB);
+      const long tbase = (trow + (g0 >> 5)) * 1024 + lane * 4, tnext = (trow + (gn >> 5)) * 1024 + lane * 4;
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) { rpB[qq] = load4_raw<GT>(p.tP, tnext + 256 * qq); rsB[qq] = load4_raw<GT>(p.tS, tnext + 256 * qq); }
+      float cp[16], cs[16];
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const int g = g0 + 8 * qq + 4 * h;
+        float vp[4], vs[4];
+        decode4(rpA[qq], vp);
+        decode4(rsA[qq], vs);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int q = 4 * qq + j;
+          const bool ok = (g + j < p.G) && (cell < p.B);
+          vp[j] = ok ? vp[j] - fast_exp(yp[q] - lp) * tpb : 0.f;
+          vs[j] = ok ? vs[j] - fast_exp(ys[q] - ls) * tsb : 0.f;
+          cp[q] = vp[j]; cs[q] = vs[j];
+        }
+        store4<GT>(p.tP, tbase + 256 * qq, vp);
+        store4<GT>(p.tS, tbase + 256 * qq, vs);
+      }
+      if constexpr (FUSE) {
+        const int gl = (g0 - gbeg) % SMB_SUB;   // offset of this tile inside the staged slice
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          // B operand: this lane's genes 16m + 4h + {0..3} and 16m + 8 + 4h + {0..3} (registers 8m .. 8m + 7), as stored (bf16)
+          s8v bP, bS;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { bP[i] = (short)f2bf(cp[8 * m + i]); bS[i] = (short)f2bf(cs[8 * m + i]); }
+          // A operand: row k = lane & 31 of W'^T at the same genes
+          const bf16_t* wr = s_wT + gl + 16 * m + 4 * h;
+          const u2v p0 = *reinterpret_cast<const u2v*>(wr + (r & 15) * SMB_PITCH), p1 = *reinterpret_cast<const u2v*>(wr + (r & 15) * SMB_PITCH + 8);
+          const u2v s0 = *reinterpret_cast<const u2v*>(wr + (DEC_KP + r) * SMB_PITCH), s1 = *reinterpret_cast<const u2v*>(wr + (DEC_KP + r) * SMB_PITCH + 8);
+          u4v ap = u4v{p0[0], p0[1], p1[0], p1[1]};
+          if (r >= DEC_KP) ap = u4v{0u, 0u, 0u, 0u};   // the private head has 16 rows
+          const u4v as4 = u4v{s0[0], s0[1], s1[0], s1[1]};
+          accP = mfma32(*reinterpret_cast<const s8v*>(&ap), bP, accP);
+          accS = mfma32(*reinterpret_cast<const s8v*>(&as4), bS, accS);
+        }
+      }
+      wA = wB;
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) { rpA[qq] = rpB[qq]; rsA[qq] = rsB[qq]; }
+    }
+  }
+  if constexpr (FUSE) {   // acc[q]: row = crow(q, h) = k, column = lane & 31 = cell; one slab per split, zeros for empty splits
+    float* out = dz_part + ((long)split * p.Bp + cell) * DEC_KPS;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int k = crow(q, h);
+      if (k < DEC_KP) out[k] = accP[q];
+      out[DEC_KP + k] = accS[q];
+    }
   }
 }
 

@@ -257,7 +257,11 @@ class DecoderFused(torch.autograd.Function):
         for g in range(NG):
           with torch.cuda.stream(streams[g]):
               G, Gp, wsg, S, P = Gs[g], Gps[g], ws[g], ctx.saved_g[g], ctx.P[g]
-              _abi.call("spv_dec_softmax_bwd", C.byref(P), ptr(S["Tp"]), ptr(S["Ts"]), stream_ptr())
+              # bf16 gradients: the softmax fix also produces the latent gradient through the two rate heads (one slab per
+              # gene split), which replaces the two GEMMs over tP / tS further down
+              fused_dz = bool(_ops.FUSED_DZ and not ctx.grads_f32)
+              dz_part = wsg.get("dec_dz_part", (P.gene_splits, Bp, DEC_KPS), torch.float32) if fused_dz else None
+              _abi.call("spv_dec_softmax_bwd", C.byref(P), ptr(S["Tp"]), ptr(S["Ts"]), ptr(dz_part), stream_ptr())
               if ctx.grads_f32:
                   def split(t, name):
                       hi, lo = _bf16_image(wsg, name, Bp, Gp, True)
@@ -277,8 +281,9 @@ class DecoderFused(torch.autograd.Function):
               d = _gemm_slabs(False, dL_hi, dL_lo, Gp, Wm_hi, Wm_lo, KMP, B, KMP, G, nsplit, ksp_m, wsg, "dec_dAm", a_tiles=T)
               b_ = _gemm_slabs(True, tP_hi, tP_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KP, Bp, nsplit, csp_n, wsg, "dec_dWp", a_tiles=T)
               c = _gemm_slabs(True, tS_hi, tS_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KS, Bp, nsplit, csp_n, wsg, "dec_dWs", b_col_off=DEC_KP, a_tiles=T)
-              e = _gemm_slabs(False, tP_hi, tP_lo, Gp, ctx.Wps[g][0], ctx.Wps[g][1], DEC_KPS, B, DEC_KP, G, nsplit, ksp_n, wsg, "dec_dAp", a_tiles=T)
-              f = _gemm_slabs(False, tS_hi, tS_lo, Gp, ctx.Wps[g][0], ctx.Wps[g][1], DEC_KPS, B, DEC_KS, G, nsplit, ksp_n, wsg, "dec_dAs", b_col_off=DEC_KP, a_tiles=T)
+              if not fused_dz:
+                  e = _gemm_slabs(False, tP_hi, tP_lo, Gp, ctx.Wps[g][0], ctx.Wps[g][1], DEC_KPS, B, DEC_KP, G, nsplit, ksp_n, wsg, "dec_dAp", a_tiles=T)
+                  f = _gemm_slabs(False, tS_hi, tS_lo, Gp, ctx.Wps[g][0], ctx.Wps[g][1], DEC_KPS, B, DEC_KS, G, nsplit, ksp_n, wsg, "dec_dAs", b_col_off=DEC_KP, a_tiles=T)
               # slab sums, scaled by the upstream gradient, straight into their consumers' buffers
               al = g_loss
               dwp, dws_, dam, dz = dWp[g], dWs[g], dAm[g], d_zcat[g]
@@ -287,8 +292,12 @@ class DecoderFused(torch.autograd.Function):
               _add_red(red, d, ksp_m, B * KMP, KMP, B, n_m, dam, n_m, alpha=al)                                 # d m (trunk output)
               # gradient reaching zcat directly: through the logits GEMM (columns n_m..) and the two regressors
               _add_red(red, d, ksp_m, B * KMP, KMP, B, nt, dz, nt, col_off=n_m, alpha=al)
-              _add_red(red2, e, ksp_n, B * DEC_KP, DEC_KP, B, n_p, dz, nt, accumulate=True, alpha=al)
-              _add_red(red2, f, ksp_n, B * DEC_KS, DEC_KS, B, n_s, dz, nt, dst_col=n_p, accumulate=True, alpha=al)
+              if fused_dz:
+                  _add_red(red2, dz_part, P.gene_splits, Bp * DEC_KPS, DEC_KPS, B, n_p, dz, nt, accumulate=True, alpha=al)
+                  _add_red(red2, dz_part, P.gene_splits, Bp * DEC_KPS, DEC_KPS, B, n_s, dz, nt, col_off=DEC_KP, dst_col=n_p, accumulate=True, alpha=al)
+              else:
+                  _add_red(red2, e, ksp_n, B * DEC_KP, DEC_KP, B, n_p, dz, nt, accumulate=True, alpha=al)
+                  _add_red(red2, f, ksp_n, B * DEC_KS, DEC_KS, B, n_s, dz, nt, dst_col=n_p, accumulate=True, alpha=al)
               # d px_r = exp(px_r) * d theta (theta = exp(px_r): module/spVIPESmodule.py:758)
               _add_red(red, S["dth"], Bp // 64, Gp, Gp, 1, G, pg[g][12][0], G, alpha=al, exp_scale=par[g][12])
         join(streams)

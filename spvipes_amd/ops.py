@@ -109,6 +109,7 @@ def join(streams) -> None:
 DEFER_JOIN = False
 OVERLAP_SMALL = os.environ.get("SPV_OVERLAP_SMALL", "1") != "0"  # side-stream overlap of independent small-kernel groups
 STAGGER = os.environ.get("SPV_STAGGER", "1") != "0"  # group 1 orders its independent kernels differently from group 0
+FUSED_DZ = os.environ.get("SPV_FUSED_DZ", "1") != "0"  # softmax fix also produces the latent gradient of the rate heads
 DEFER_WM = os.environ.get("SPV_DEFER_WM", "1") != "0"  # mixture-weight gradient GEMMs on the late side stream
 _PENDING: list = []
 _PENDING_KEEP: list = []
@@ -345,7 +346,7 @@ class DecoderNBLoss(torch.autograd.Function):
         B, G, Bp, Gp, n_p, n_s, KM, KMp, n_m = ctx.dims
         ws, nsplit, P = ctx.ws, ctx.nsplit, ctx.P
         Wm_hi, Wm_lo, Am_hi, Am_lo, Wps_hi, Wps_lo, Aps_hi, Aps_lo, dL, tP, tS, dth, lse_p, lse_s, gene_tab = ctx.keep
-        _abi.call("spv_dec_softmax_bwd", C.byref(P), ptr(ctx.Tp), ptr(ctx.Ts), stream_ptr())
+        _abi.call("spv_dec_softmax_bwd", C.byref(P), ptr(ctx.Tp), ptr(ctx.Ts), None, stream_ptr())
         if ctx.grads_f32:  # fp32 mode: split the stored fp32 gradients into hi/lo images for the MFMA GEMMs
             def split(t, name):
                 hi, lo = _bf16_image(ws, name, Bp, Gp, True)

@@ -128,3 +128,34 @@ def test_plan_experts_match_dense_autograd(dev):
         torch.testing.assert_close(expert[g].double(), E.detach(), rtol=1e-5, atol=1e-6)
         E.backward(d_exp[g].double())
         torch.testing.assert_close(d_stats[g].double(), s.grad, rtol=1e-5, atol=1e-6)
+
+
+def test_fused_latent_gradient_matches_gemm_path(dev):
+    """bf16 mode: the latent gradient produced inside the softmax fix (spv_dec_softmax_bwd dz_part) against the two
+    [B,G] x [G,K] GEMMs it replaces -- every parameter gradient of a step, both ways."""
+    from spvipes_amd import ops
+    from spvipes_amd.data import make_synthetic_group
+    from spvipes_amd.module import spVIPESmodule
+    from spvipes_amd.train import Trainer
+    n, G, B = 1500, 1100, 384
+    groups = [make_synthetic_group(g, n, G, dev) for g in (0, 1)]
+    res = []
+    before = ops.FUSED_DZ
+    try:
+        for fused in (True, False):
+            ops.FUSED_DZ = fused
+            torch.manual_seed(0)
+            m = spVIPESmodule({0: G, 1: G}, use_labels=True, n_hidden=64, n_dimensions_shared=12, n_dimensions_private=6, dropout_rate=0.0,
+                              precision="bf16").to(dev)
+            tr = Trainer(m, [g.counts for g in groups], labels=[g.labels for g in groups])
+            m.train()
+            rows = [torch.arange(B, dtype=torch.int32, device=dev) for _ in (0, 1)]
+            torch.manual_seed(5)
+            lo = tr._forward_backward(rows, 1.0)
+            torch.cuda.synchronize()
+            res.append((float(lo.loss.detach()), tr.fp.grad.clone()))
+    finally:
+        ops.FUSED_DZ = before
+    assert res[0][0] == res[1][0]
+    diff, scale = float((res[0][1] - res[1][1]).abs().max()), float(res[1][1].abs().max())
+    assert diff < 1e-3 * scale, (diff, scale)   # same bf16 operands, different fp32 summation order

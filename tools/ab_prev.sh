@@ -1,15 +1,10 @@
 #!/bin/bash
-# A/B on one box: working tree vs the committed package under _prev/ (dev tool)
+# A/B on one box: working tree vs the committed package copied + built under _prev/ (dev tool).
+# bench.py imports the package that sits next to it, so the "prev" leg runs a copy of bench.py placed in _prev/.
+cp bench.py _prev/bench.py
+mkdir -p _prev/profiles
 for v in cur prev cur prev cur prev; do
   echo -n "$v  "
-  if [ $v = prev ]; then P=_prev; else P=.; fi
-  PYTHONPATH=$P python -c "
-import sys, runpy, io, json, contextlib
-sys.path.insert(0, '$P')
-sys.argv = ['bench.py', '--no-cpu-baseline', '--steps', '60']
-buf = io.StringIO()
-with contextlib.redirect_stdout(buf):
-    runpy.run_path('bench.py', run_name='__main__')
-print(json.loads(buf.getvalue().strip().splitlines()[-1])['ms_per_step'])
-" 2>/dev/null
+  if [ $v = prev ]; then f=_prev/bench.py; else f=bench.py; fi
+  python $f --no-cpu-baseline --steps 60 2>/dev/null | python -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])"
 done
