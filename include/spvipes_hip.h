@@ -211,6 +211,9 @@ typedef struct spv_bn_prob {
   float* dX; int64_t lddx;
   float* dgamma; float* dbeta;
   int32_t N;
+  /* optional forward by-product: Y also as a packed bf16 operand image (hi, and lo = bf16(Y - hi) when img_lo != NULL)
+   * img[b][c], b < img_rows (rows >= B are written as zeros), c < N, row pitch ld_img                              */
+  uint16_t* img_hi; uint16_t* img_lo; int64_t ld_img; int32_t img_rows;
 } spv_bn_prob;
 typedef struct spv_bn_batch {
   spv_bn_prob p[SPV_MAXP];
@@ -305,6 +308,11 @@ typedef struct spv_zsplit_args {
   float* zcat[2];                               /* [B][n_p + n_s] = [z_private | z_shared]    */
   const float* d_zcat[2]; float* d_priv[2]; float* d_poe[2];
   int32_t B, n_p, n_s, ngroups;
+  /* optional forward by-products (all rows < Bp, zero beyond B): the decoder's packed bf16 operand images
+   *   am  [Bp][ld_am]  columns am_col .. am_col + am_cols - 1  <-  [ zcat | 1 | 0 .. ]   (mixture-logit operand tail)
+   *   aps [Bp][48]     <-  [ z_private | 1 | 0 ..(16) | z_shared | 1 | 0 ..(32) ]        (rate-regressor operand)     */
+  uint16_t* am_hi[2]; uint16_t* am_lo[2]; int64_t ld_am; int32_t am_col; int32_t am_cols;
+  uint16_t* aps_hi[2]; uint16_t* aps_lo[2]; int32_t Bp;
 } spv_zsplit_args;
 int spv_zsplit_fwd(const spv_zsplit_args* a, void* stream);
 int spv_zsplit_bwd(const spv_zsplit_args* a, void* stream);

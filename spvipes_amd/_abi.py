@@ -71,7 +71,7 @@ class SpvBnProb(C.Structure):
     _fields_ = [("X", C.c_void_p), ("ldx", C.c_int64), ("Y", C.c_void_p), ("ldy", C.c_int64), ("gamma", C.c_void_p), ("beta", C.c_void_p),
                 ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("stats", C.c_void_p), ("part", C.c_void_p),
                 ("dY", C.c_void_p), ("lddy", C.c_int64), ("dX", C.c_void_p), ("lddx", C.c_int64), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
-                ("N", C.c_int32)]
+                ("N", C.c_int32), ("img_hi", C.c_void_p), ("img_lo", C.c_void_p), ("ld_img", C.c_int64), ("img_rows", C.c_int32)]
 
 
 class SpvBnBatch(C.Structure):
@@ -111,7 +111,9 @@ class SpvPlanExpertArgs(C.Structure):
 
 class SpvZsplitArgs(C.Structure):
     _fields_ = [("priv", C.c_void_p * 2), ("poe", C.c_void_p * 2), ("zcat", C.c_void_p * 2), ("d_zcat", C.c_void_p * 2),
-                ("d_priv", C.c_void_p * 2), ("d_poe", C.c_void_p * 2), ("B", C.c_int32), ("n_p", C.c_int32), ("n_s", C.c_int32), ("ngroups", C.c_int32)]
+                ("d_priv", C.c_void_p * 2), ("d_poe", C.c_void_p * 2), ("B", C.c_int32), ("n_p", C.c_int32), ("n_s", C.c_int32), ("ngroups", C.c_int32),
+                ("am_hi", C.c_void_p * 2), ("am_lo", C.c_void_p * 2), ("ld_am", C.c_int64), ("am_col", C.c_int32), ("am_cols", C.c_int32),
+                ("aps_hi", C.c_void_p * 2), ("aps_lo", C.c_void_p * 2), ("Bp", C.c_int32)]
 
 
 class SpvFoldProb(C.Structure):

@@ -460,7 +460,9 @@ extern "C" int spv_bn_fwd(const spv_bn_batch* a, void* stream) {
   for (int i = 0; i < a->nprob; ++i) nmax = a->p[i].N > nmax ? a->p[i].N : nmax;
   if (a->training) hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(256), 0, s, *a);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((nmax + 63) / 64, a->nprob), dim3(256), 0, s, *a);
-  hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(256), 0, s, *a);
+  int rmax = a->B;
+  for (int i = 0; i < a->nprob; ++i) if (a->p[i].img_hi && a->p[i].img_rows > rmax) rmax = a->p[i].img_rows;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3((rmax + BN_ROWS - 1) / BN_ROWS, a->nprob), dim3(256), 0, s, *a);
   return launch_status("spv_bn_fwd");
 }
 extern "C" int spv_bn_bwd(const spv_bn_batch* a, void* stream) {
@@ -553,6 +555,15 @@ extern "C" int spv_zsplit_fwd(const spv_zsplit_args* a, void* stream) {
   for (int g = 0; g < a->ngroups; ++g) if (!a->priv[g] || !a->poe[g] || !a->zcat[g]) return fail(SPV_ERR_ARG, "spv_zsplit_fwd: null pointer%s");
   const long tot = (long)a->B * (a->n_p + a->n_s);
   hipLaunchKernelGGL(zsplit_fwd_kernel, dim3((unsigned)((tot + 255) / 256), a->ngroups), dim3(256), 0, (hipStream_t)stream, *a);
+  bool pack = false;
+  for (int g = 0; g < a->ngroups; ++g) pack = pack || a->am_hi[g] || a->aps_hi[g];
+  if (pack) {
+    if (a->Bp < a->B || a->n_p + 1 > SPV_DEC_KP || a->n_s + 1 > SPV_DEC_KS || a->am_cols < a->n_p + a->n_s + 1 || a->am_cols < 0 ||
+        a->ld_am < a->am_col + a->am_cols)
+      return fail(SPV_ERR_ARG, "spv_zsplit_fwd: bad operand-image shape%s");
+    const long tp = (long)a->Bp * (SPV_DEC_KP + SPV_DEC_KS + a->am_cols);
+    hipLaunchKernelGGL(zsplit_pack_kernel, dim3((unsigned)((tp + 255) / 256), a->ngroups), dim3(256), 0, (hipStream_t)stream, *a);
+  }
   return launch_status("spv_zsplit_fwd");
 }
 extern "C" int spv_zsplit_bwd(const spv_zsplit_args* a, void* stream) {

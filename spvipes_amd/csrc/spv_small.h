@@ -308,16 +308,26 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(BnBatch a) {
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(BnBatch a) {
   const BnProb& q = a.p[blockIdx.y];
-  const int b0 = blockIdx.x * BN_ROWS, b1 = min(b0 + BN_ROWS, a.B);
+  const int rows = (q.img_hi != nullptr && q.img_rows > a.B) ? q.img_rows : a.B;   // image rows beyond the batch are zero filled
+  const int b0 = blockIdx.x * BN_ROWS, b1 = min(b0 + BN_ROWS, rows);
   const int NC = pow2_at_least(q.N), RS = 256 / NC;
   const int c = threadIdx.x % NC, slot = threadIdx.x / NC;
-  if (c >= q.N) return;
+  if (c >= q.N || b0 >= rows) return;
   const float mean = q.stats[2 * c], sc = q.stats[2 * c + 1] * q.gamma[c], be = q.beta[c];
 #pragma unroll 4
   for (int b = b0 + slot; b < b1; b += RS) {
-    float v = (q.X[(long)b * q.ldx + c] - mean) * sc + be;
-    if (a.relu) v = fmaxf(v, 0.f);
-    q.Y[(long)b * q.ldy + c] = v;
+    float v = 0.f;
+    if (b < a.B) {
+      v = (q.X[(long)b * q.ldx + c] - mean) * sc + be;
+      if (a.relu) v = fmaxf(v, 0.f);
+      q.Y[(long)b * q.ldy + c] = v;
+    }
+    if (q.img_hi != nullptr) {
+      bf16_t hi, lo;
+      split_bf16(v, hi, lo);
+      q.img_hi[(long)b * q.ld_img + c] = hi;
+      if (q.img_lo != nullptr) q.img_lo[(long)b * q.ld_img + c] = lo;
+    }
   }
 }
 
@@ -739,6 +749,7 @@ __global__ __launch_bounds__(256) void plan_expert_bwd_kernel(ExpertArgs a) {
 // nn/networks.py:314,318 with scvi FCLayers' BatchNorm1d(eps 1e-3, momentum 0.01)).
 // ---------------------------------------------------------------------------------------------
 typedef spv_zsplit_args ZsplitArgs;
+constexpr int DEC_PACK_KP = 16, DEC_PACK_KPS = 48;   // = SPV_DEC_KP, SPV_DEC_KP + SPV_DEC_KS (layout of the regressor operand image)
 
 // Z = cat(private_log_z, poe_log_z); z_private = Z[:, n_s:n_s+n_p], z_shared = Z[:, :n_s]  (the A6 quirk)
 // zcat = [z_private | z_shared] (input of the mixing trunk, nn/networks.py:322)
@@ -751,6 +762,34 @@ __global__ __launch_bounds__(256) void zsplit_fwd_kernel(ZsplitArgs a) {
   const int zc = (c < a.n_p) ? a.n_s + c : c - a.n_p;  // column of Z
   const float v = (zc < a.n_p) ? a.priv[g][(long)b * a.n_p + zc] : a.poe[g][(long)b * a.n_s + zc - a.n_p];
   a.zcat[g][i] = v;
+}
+// the same latents as the decoder's packed bf16 operand images (see spv_zsplit_args): one thread per image element
+__global__ __launch_bounds__(256) void zsplit_pack_kernel(ZsplitArgs a) {
+  const int g = blockIdx.y;
+  const int nt = a.n_p + a.n_s;
+  const int wcols = DEC_PACK_KPS + a.am_cols;              // [ aps: 48 | am tail: am_cols ]
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)a.Bp * wcols) return;
+  const int b = (int)(i / wcols), c = (int)(i % wcols);
+  const float* z = a.zcat[g] + (long)b * nt;              // [z_private | z_shared], written by zsplit_fwd_kernel
+  float v = 0.f;
+  bf16_t* dh; bf16_t* dl; long o;
+  if (c < DEC_PACK_KPS) {
+    if (b < a.B) {
+      if (c < DEC_PACK_KP) v = (c < a.n_p) ? z[c] : (c == a.n_p ? 1.f : 0.f);
+      else { const int cs = c - DEC_PACK_KP; v = (cs < a.n_s) ? z[a.n_p + cs] : (cs == a.n_s ? 1.f : 0.f); }
+    }
+    dh = a.aps_hi[g]; dl = a.aps_lo[g]; o = (long)b * DEC_PACK_KPS + c;
+  } else {
+    const int cm = c - DEC_PACK_KPS;
+    if (b < a.B) v = (cm < nt) ? z[cm] : (cm == nt ? 1.f : 0.f);
+    dh = a.am_hi[g]; dl = a.am_lo[g]; o = (long)b * a.ld_am + a.am_col + cm;
+  }
+  if (dh == nullptr) return;
+  bf16_t hi, lo;
+  split_bf16(v, hi, lo);
+  dh[o] = hi;
+  if (dl != nullptr) dl[o] = lo;
 }
 __global__ __launch_bounds__(256) void zsplit_bwd_kernel(ZsplitArgs a) {
   const int g = blockIdx.y;

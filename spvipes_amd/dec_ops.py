@@ -86,10 +86,17 @@ class DecoderFused(torch.autograd.Function):
         za = SpvZsplitArgs()
         za.B, za.n_p, za.n_s, za.ngroups = B, n_p, n_s, NG
         keep = []
+        # ... and, from the same call, the decoder's packed bf16 operand images of these latents
+        Am_img = [_bf16_image(ws[g], "dec_Am", Bp, KMP, mlo) for g in range(NG)]
+        Aps_img = [_bf16_image(ws[g], "dec_Aps", Bp, DEC_KPS, True) for g in range(NG)]
+        fused_pack = bool(_ops.FUSED_PACK)
+        za.ld_am, za.am_col, za.am_cols, za.Bp = KMP, n_m, KMP - n_m, Bp
         for g in range(NG):
             pz, qz = cont(lat[g][0]), cont(lat[g][1])
             keep += [pz, qz]
             za.priv[g], za.poe[g], za.zcat[g] = ptr(pz), ptr(qz), ptr(zcat[g])
+            if fused_pack:
+                za.am_hi[g], za.am_lo[g], za.aps_hi[g], za.aps_lo[g] = ptr(Am_img[g][0]), ptr(Am_img[g][1]), ptr(Aps_img[g][0]), ptr(Aps_img[g][1])
         _abi.call("spv_zsplit_fwd", C.byref(za), stream_ptr())
         # ---- 2. batch statistics of z (column sums and z^T z) for the BatchNorm fold ---------------
         zsum = [[new(n_p), new(n_s)] for _ in range(NG)]
@@ -148,6 +155,8 @@ class DecoderFused(torch.autograd.Function):
             q.X, q.ldx, q.Y, q.ldy, q.gamma, q.beta = ptr(pre_a[g]), n_m, ptr(m[g]), n_m, ptr(par[g][8]), ptr(par[g][9])
             q.running_mean, q.running_var, q.stats, q.N = ptr(tb.running_mean), ptr(tb.running_var), ptr(tstat[g]), n_m
             q.part = ptr(ws[g].get("trunk_bn_part", (nblk, n_m, 2), torch.float32))
+            if fused_pack:  # m straight into the logits operand image
+                q.img_hi, q.img_lo, q.ld_img, q.img_rows = ptr(Am_img[g][0]), ptr(Am_img[g][1]), KMP, Bp
         _abi.call("spv_bn_fwd", C.byref(bn), stream_ptr())
         # ---- 5. per group: operand images, tables, logits GEMM, softmax statistics, likelihood ------
         if w_pad.numel() < Bp or w_pad.dtype != torch.float32 or not w_pad.is_contiguous():
@@ -166,12 +175,12 @@ class DecoderFused(torch.autograd.Function):
           with torch.cuda.stream(streams[g]):
               G, Gp, wsg = Gs[g], Gps[g], ws[g]
               (Wm_hi, Wm_lo), (gene_tab, cnt_tab) = Wm_img[g], tabs[g]
-              Am_hi, Am_lo = _bf16_image(wsg, "dec_Am", Bp, KMP, mlo)
-              _pack(m[g], Am_hi, Am_lo, dst_col_off=0, cslot=n_m)
-              _pack(zcat[g], Am_hi, Am_lo, extra_one=True, dst_col_off=n_m, cslot=KMP - n_m)
-              Aps_hi, Aps_lo = _bf16_image(wsg, "dec_Aps", Bp, DEC_KPS, True)
-              _pack(zcat[g][:, :n_p], Aps_hi, Aps_lo, extra_one=True, dst_col_off=0, cslot=DEC_KP)
-              _pack(zcat[g][:, n_p:], Aps_hi, Aps_lo, extra_one=True, dst_col_off=DEC_KP, cslot=DEC_KS)
+              (Am_hi, Am_lo), (Aps_hi, Aps_lo) = Am_img[g], Aps_img[g]
+              if not fused_pack:
+                  _pack(m[g], Am_hi, Am_lo, dst_col_off=0, cslot=n_m)
+                  _pack(zcat[g], Am_hi, Am_lo, extra_one=True, dst_col_off=n_m, cslot=KMP - n_m)
+                  _pack(zcat[g][:, :n_p], Aps_hi, Aps_lo, extra_one=True, dst_col_off=0, cslot=DEC_KP)
+                  _pack(zcat[g][:, n_p:], Aps_hi, Aps_lo, extra_one=True, dst_col_off=DEC_KP, cslot=DEC_KS)
               logits = wsg.get("dec_logits_" + ("f32" if mlo else "f16"), (Bp, Gp), torch.float32 if mlo else torch.float16)
               lse_first = bool(_ops.STAGGER and g % 2 == 1)  # group 1 runs its (VALU-bound) softmax statistics beside group 0's logits GEMM
               if not lse_first:
