@@ -276,23 +276,13 @@ class spVIPESmodule(nn.Module):
         self._step_inputs, self._kl_private, self._kl_poe = {}, {}, {}
         h1s, eps_enc = {}, {}
         H = self.n_hidden
-        streams, label_pre = None, None
-        for g, group in x.items():
-            counts, rows, B = self._counts_of(g, group)
-            self._step_inputs[g] = (counts, rows, B)
-            ep, es = self.encoders[g]["private"], self.encoders[g]["shared"]
-            ws = self._workspace(g, counts.X.device)
-            if streams is None:  # the groups' fc1 GEMMs are independent: group g > 0 runs on a side stream (autograd replays
-                streams = group_streams(counts.X.device, len(x))  # each node's backward on its forward stream as well)
-                fork(streams)  # (measured: also hoisting the label pairing onto a third stream here makes the step slower)
-            with torch.cuda.stream(streams[g % len(streams)]):
-                h1, lib = EncoderFC1.apply(counts, rows, B, ep.fc1.weight, ep.fc1.bias, es.fc1.weight, es.fc1.bias, self.nsplit, ws)
-            h1s[g] = h1
-            library[g] = lib.unsqueeze(1)
-        if streams is not None:
-            join(streams)
         groups_ = sorted(x.keys())
-        # every standard-normal draw of the step (encoder heads + PoE) comes out of ONE generator launch
+        for g, group in x.items():
+            self._step_inputs[g] = self._counts_of(g, group)
+        dev0 = self._step_inputs[groups_[0]][0].X.device
+        # Everything that does not depend on the encoders is issued BEFORE the fc1 GEMMs, so that it runs in the shadow of the
+        # step's first launches instead of on the critical chain between fc1 and the encoder tails:
+        # (1) every standard-normal draw of the step (encoder heads + PoE) out of ONE generator launch,
         n_p_, n_s_ = self.n_dimensions_private, self.n_dimensions_shared
         want = {}
         for g in groups_:
@@ -301,8 +291,7 @@ class spVIPESmodule(nn.Module):
         missing = [k for k in want if noise.get(k) is None]
         draws = {}
         if missing:
-            dev = h1s[groups_[0]].device
-            flat = torch.randn(sum(want[k][0] * want[k][1] for k in missing), device=dev)
+            flat = torch.randn(sum(want[k][0] * want[k][1] for k in missing), device=dev0)
             off = 0
             for k in missing:
                 n = want[k][0] * want[k][1]
@@ -311,6 +300,26 @@ class spVIPESmodule(nn.Module):
         draw = lambda k: noise[k] if noise.get(k) is not None else draws[k]
         for g in groups_:
             eps_enc[g] = (draw(f"enc_{g}_private"), draw(f"enc_{g}_shared"))
+        # (2) the dropout seed of this step,
+        if getattr(self, "_seed_dev", None) is None or self._seed_dev.device != dev0:
+            self._seed_dev = torch.zeros((), dtype=torch.int64, device=dev0)  # device-resident: survives hipGraph replay
+        if self.training and self.dropout_rate > 0:
+            self._seed_dev.add_(1)
+        label_pre = None  # (measured: hoisting the label pairing up here as well, on this or on a third stream, gains nothing)
+        streams = None
+        for g in groups_:
+            counts, rows, B = self._step_inputs[g]
+            ep, es = self.encoders[g]["private"], self.encoders[g]["shared"]
+            ws = self._workspace(g, counts.X.device)
+            if streams is None:  # the groups' fc1 GEMMs are independent: group g > 0 runs on a side stream (autograd replays
+                streams = group_streams(counts.X.device, len(x))  # each node's backward on its forward stream as well)
+                fork(streams)
+            with torch.cuda.stream(streams[g % len(streams)]):
+                h1, lib = EncoderFC1.apply(counts, rows, B, ep.fc1.weight, ep.fc1.bias, es.fc1.weight, es.fc1.bias, self.nsplit, ws)
+            h1s[g] = h1
+            library[g] = lib.unsqueeze(1)
+        if streams is not None:
+            join(streams)
         same_B = len({self._step_inputs[g][2] for g in groups_}) == 1
         if dropout_masks is None and same_B:
             # all four encoder tails (fc2, dropout, heads, BatchNorm, draw, KL) as a few batched HIP launches
@@ -319,11 +328,6 @@ class spVIPESmodule(nn.Module):
                 specs += [EncoderSpec(self.encoders[g]["private"], g, 0), EncoderSpec(self.encoders[g]["shared"], g, H)]
                 eps_list += [eps_enc[g][0], eps_enc[g][1]]
             flat = [p for s in specs for p in s.params()]
-            dev0 = h1s[groups_[0]].device
-            if getattr(self, "_seed_dev", None) is None or self._seed_dev.device != dev0:
-                self._seed_dev = torch.zeros((), dtype=torch.int64, device=dev0)  # device-resident: survives hipGraph replay
-            if self.training and self.dropout_rate > 0:
-                self._seed_dev.add_(1)
             outs = EncoderTails.apply(specs, eps_list, self.training, float(self.dropout_rate), self._seed_dev,
                                       self._workspace(groups_[0], h1s[groups_[0]].device), *[h1s[g] for g in groups_], *flat)
             for i, s in enumerate(specs):
