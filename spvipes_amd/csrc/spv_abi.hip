@@ -537,8 +537,12 @@ extern "C" int spv_poe_fuse_bwd(const spv_poe_args* a, void* stream) {
   if (rc) return rc;
   for (int g = 0; g < 2; ++g) if (!a->d_stats[g]) return fail(SPV_ERR_ARG, "spv_poe_fuse_bwd: null output%s");
   const int Bm = a->B[0] > a->B[1] ? a->B[0] : a->B[1];
+  const size_t bytes0 = (size_t)a->B[0] * a->ld[0] * sizeof(float);
+  const bool adjacent = reinterpret_cast<char*>(a->d_stats[0]) + bytes0 == reinterpret_cast<char*>(a->d_stats[1]);  // one buffer: one memset
   for (int g = 0; g < 2; ++g) {  // the kernel accumulates (own expert + partner's): start from zero
-    if (hipMemsetAsync(a->d_stats[g], 0, (size_t)a->B[g] * a->ld[g] * sizeof(float), (hipStream_t)stream) != hipSuccess)
+    const size_t bytes = (size_t)a->B[g] * a->ld[g] * sizeof(float);
+    if (g == 1 && adjacent) {
+    } else if (hipMemsetAsync(a->d_stats[g], 0, (g == 0 && adjacent) ? bytes0 + (size_t)a->B[1] * a->ld[1] * sizeof(float) : bytes, (hipStream_t)stream) != hipSuccess)
       return fail(SPV_ERR_LAUNCH, "spv_poe_fuse_bwd: memset failed%s");
     if (a->expert[g]) {
       if (!a->d_expert[g]) return fail(SPV_ERR_ARG, "spv_poe_fuse_bwd: d_expert missing%s");

@@ -310,6 +310,10 @@ class DecoderFused(torch.autograd.Function):
               # d px_r = exp(px_r) * d theta (theta = exp(px_r): module/spVIPESmodule.py:758)
               _add_red(red, S["dth"], Bp // 64, Gp, Gp, 1, G, pg[g][12][0], G, alpha=al, exp_scale=par[g][12])
         join(streams)
+        gk = None
+        if ctx.n_kl:  # d loss / d kl_i[b] = g * kl_weight / B for every KL vector: rides in the second reduction launch
+            gk = new(B)
+            _add_red(red2, ctx.gkl, 1, B, B, 1, B, gk, B, alpha=g_loss)
         _run_red(red)
         _run_red(red2)
         # The mixture-weight gradients (2 x [G, K_M] from dL^T A_m, the largest GEMMs of the backward) feed nothing but the
@@ -381,6 +385,5 @@ class DecoderFused(torch.autograd.Function):
         for g in range(NG):
             grads += [pg[g][j][1] for j in range(N_DEC_PARAMS)]
         if ctx.n_kl:
-            gk = ctx.gkl * g_loss  # d loss / d kl_i[b] = kl_weight / B for every KL vector
             grads += [gk] * ctx.n_kl
         return (None,) * 11 + tuple(grads)

@@ -319,7 +319,10 @@ class PoELabel(torch.autograd.Function):
         cont = lambda t: None if t is None else t.contiguous()
         a = SpvPoeArgs()
         a.n = n
-        d = [torch.empty(Bs[k], 2 * n, dtype=torch.float32, device=dev) for k in range(2)]  # zeroed by spv_poe_fuse_bwd
+        # both groups' gradient blocks in ONE allocation: spv_poe_fuse_bwd then zeroes them with a single memset
+        lds = [ctx.blocks[k][2] for k in range(2)]
+        dbuf = torch.empty(Bs[0] * lds[0] + Bs[1] * lds[1], dtype=torch.float32, device=dev)
+        d = [dbuf[:Bs[0] * lds[0]].view(Bs[0], lds[0]), dbuf[Bs[0] * lds[0]:].view(Bs[1], lds[1])]
         keep = []
         for k in range(2):
             gl, gv, gs, gz, _gt, gk = (cont(t) for t in g[6 * k: 6 * k + 6])
@@ -327,11 +330,7 @@ class PoELabel(torch.autograd.Function):
             a.stats[k], a.ld[k], a.partner[k], a.mode[k], a.eps[k], a.B[k] = ctx.blocks[k][1], ctx.blocks[k][2], ptr(ctx.partner[k]), ptr(ctx.mode[k]), ptr(ctx.eps[k]), Bs[k]
             a.loc[k], a.scale[k] = ptr(loc[k]), ptr(scale[k])
             a.g_loc[k], a.g_logvar[k], a.g_scale[k], a.g_logz[k], a.g_kl[k] = ptr(gl), ptr(gv), ptr(gs), ptr(gz), ptr(gk)
-        # d_stats must use the same pitch as stats: allocate [B][ld] when the inputs were views of a wider buffer
-        for k in range(2):
-            ld = ctx.blocks[k][2]
-            if ld != 2 * n:
-                d[k] = torch.empty(Bs[k], ld, dtype=torch.float32, device=dev)
+        for k in range(2):  # (d_stats uses the same pitch as stats, which may be views of a wider buffer)
             a.d_stats[k] = ptr(d[k])
         _abi.call("spv_poe_fuse_bwd", C.byref(a), stream_ptr())
         return (None, None, None, None, d[0][:, :n], d[0][:, n:2 * n], d[1][:, :n], d[1][:, n:2 * n])
