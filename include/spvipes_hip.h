@@ -71,18 +71,24 @@ int spv_pack_bf16(const float* src, int64_t ld_src, int32_t R, int32_t C,
  *              (bias2 == NULL: one vector)
  *   slabs    : fp32 workspace [splits][B][N1];  rowsum_ws: fp32 [splits][B]
  *   h1       : fp32 [B][N1];  library: fp32 [B]
- *   xb_out   : optional by-product (nsplit 1 only): bf16(log1p(x)) of the minibatch, [B][ld_xb], ld_xb >= round_up(G, 32);
- *              spv_enc_fc1_wgrad reads it instead of decoding the counts again */
+ *   xb_all, library_all : optional (nsplit 1 only): bf16(log1p(x)) of the WHOLE resident count matrix [n_cells][ld_xb] (zero
+ *              padded to ld_xb >= round_up(G, 128)) and log(sum_g log1p(x)) per cell, both from spv_prepare_log1p; the GEMM
+ *              then gathers plain bf16 rows through x->rows instead of decoding counts, and library is a table lookup */
 int spv_enc_fc1_fwd(const spv_counts* x, int32_t B, int32_t G,
                     const uint16_t* W1_hi, const uint16_t* W1_lo, int64_t ldw, int32_t N1,
                     const float* bias, const float* bias2, int32_t n_first, int32_t nsplit, int32_t splits,
                     float* slabs, float* rowsum_ws, float* h1, float* library,
-                    uint16_t* xb_out, int64_t ld_xb, void* stream);
+                    const uint16_t* xb_all, int64_t ld_xb, const float* library_all, void* stream);
+
+/* Once per resident count matrix: xb[c][g] = bf16(log1p(X[c][g])) (zero for g >= G, row pitch ld_xb) and
+ * library[c] = log(sum_g log1p(X[c][g])) (module/spVIPESmodule.py:428-435 evaluated for every cell of the data set).
+ * x->rows is ignored.                                                                                               */
+int spv_prepare_log1p(const spv_counts* x, int32_t n_cells, int32_t G, uint16_t* xb, int64_t ld_xb, float* library, void* stream);
 
 /* fc1 weight gradient (autograd of nn/networks.py:119):  dW1[N1][G] = dh^T @ log1p(X[rows]).
  *   dh_hi/lo : bf16 [round_up(B,64)][ld_dh] (ld_dh >= round_up(N1,128), zero padded)
- *   xb       : optional bf16 log1p image written by spv_enc_fc1_fwd ([round_up(B,64)][ld_xb], rows >= B and columns
- *              >= G zero, ld_xb >= round_up(G, 64)); NULL = decode the counts here
+ *   xb       : optional (nsplit 1): the resident bf16 log1p image of spv_prepare_log1p ([n_cells][ld_xb], gathered through
+ *              x->rows); NULL = decode the counts here
  *   dW2      : optional second destination: rows >= rows_first go to dW2[row - rows_first] (the shared
  *              encoder's weight gradient, stored apart from the private encoder's)  */
 int spv_enc_fc1_wgrad(const spv_counts* x, int32_t B, int32_t G,

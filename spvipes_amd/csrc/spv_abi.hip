@@ -96,7 +96,8 @@ extern "C" int spv_pack_bf16(const float* src, int64_t ld_src, int32_t R, int32_
 // encoder fc1
 // ---------------------------------------------------------------------------------------------
 __global__ void fc1_epilogue_kernel(const float* slabs, const float* rowsum_ws, int splits, int B, int N1, const float* bias,
-                                    const float* bias2, int n_first, float* h1, float* library) {
+                                    const float* bias2, int n_first, float* h1, float* library, const float* library_all,
+                                    const int* rows) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)B * N1;
   if (idx < total) {
@@ -106,9 +107,13 @@ __global__ void fc1_epilogue_kernel(const float* slabs, const float* rowsum_ws, 
     h1[idx] = fmaxf(v, 0.f);  // relu(fc1(x)), nn/networks.py:119
   }
   if (idx < B) {
-    float v = 0.f;
-    for (int s = 0; s < splits; ++s) v += rowsum_ws[(long)s * B + idx];
-    library[idx] = __logf(v);  // log(sum of log1p(x)), module/spVIPESmodule.py:435
+    if (library_all != nullptr) {  // precomputed per cell of the data set (spv_prepare_log1p)
+      library[idx] = library_all[rows ? rows[idx] : (int)idx];
+    } else {
+      float v = 0.f;
+      for (int s = 0; s < splits; ++s) v += rowsum_ws[(long)s * B + idx];
+      library[idx] = __logf(v);  // log(sum of log1p(x)), module/spVIPESmodule.py:435
+    }
   }
 }
 
@@ -130,8 +135,8 @@ static int fc1_bn(int N1) { return N1 <= 32 ? 32 : (N1 <= 128 ? 128 : 256); }
 
 extern "C" int spv_enc_fc1_fwd(const spv_counts* x, int32_t B, int32_t G, const uint16_t* W1_hi, const uint16_t* W1_lo,
                                int64_t ldw, int32_t N1, const float* bias, const float* bias2, int32_t n_first, int32_t nsplit,
-                               int32_t splits, float* slabs, float* rowsum_ws, float* h1, float* library, uint16_t* xb_out,
-                               int64_t ld_xb, void* stream) {
+                               int32_t splits, float* slabs, float* rowsum_ws, float* h1, float* library, const uint16_t* xb_all,
+                               int64_t ld_xb, const float* library_all, void* stream) {
   if (!x || !x->X || !W1_hi || !bias || !slabs || !rowsum_ws || !h1 || !library) return fail(SPV_ERR_ARG, "spv_enc_fc1_fwd: null pointer%s");
   if (B <= 0 || G <= 0 || N1 <= 0 || splits <= 0 || (ldw % 32) != 0 || ldw < ((G + 31) & ~31)) return fail(SPV_ERR_ARG, "spv_enc_fc1_fwd: bad shape%s");
   if (nsplit != 1 && nsplit != 3) return fail(SPV_ERR_ARG, "spv_enc_fc1_fwd: nsplit must be 1 or 3%s");
@@ -141,9 +146,9 @@ extern "C" int spv_enc_fc1_fwd(const spv_counts* x, int32_t B, int32_t G, const 
   p.B = W1_hi; p.B_lo = W1_lo; p.ldb = ldw;
   p.rows = x->rows; p.counts_aligned = counts_aligned(x); p.col_off = x->col_off; p.n_cells = B; p.n_genes = G;
   p.rowsum = rowsum_ws;
-  if (xb_out != nullptr) {
-    if (nsplit != 1 || ld_xb < ((G + 31) & ~31) || (ld_xb % 8)) return fail(SPV_ERR_ARG, "spv_enc_fc1_fwd: the bf16 log1p by-product needs nsplit 1 and ld_xb >= round_up(G, 32)%s");
-    p.xb_out = xb_out; p.ld_xb = ld_xb;
+  if (xb_all != nullptr) {  // log1p(x) of the whole data set is resident as bf16 (spv_prepare_log1p): plain gathered operand, no decode
+    if (nsplit != 1 || !library_all || ld_xb < ((G + 31) & ~31) || (ld_xb % 8)) return fail(SPV_ERR_ARG, "spv_enc_fc1_fwd: xb_all needs nsplit 1, library_all and ld_xb >= round_up(G, 32)%s");
+    p.A = xb_all; p.lda = ld_xb; p.rowsum = nullptr;
   }
   p.C = slabs; p.ldc = N1; p.slab_stride = (long)B * N1;
   p.M = B; p.N = N1; p.K = G;
@@ -152,12 +157,15 @@ extern "C" int spv_enc_fc1_fwd(const spv_counts* x, int32_t B, int32_t G, const 
   p.epi = EPI_STORE;
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  if (x->dtype == SPV_COUNT_U16) rc = (nsplit == 3) ? fc1_fwd_dispatch<unsigned short, 3>(p, N1, splits, s) : fc1_fwd_dispatch<unsigned short, 1>(p, N1, splits, s);
+  if (xb_all != nullptr) {
+    if (N1 <= 128) rc = launch_gemm<GemmCfg<64, 128, 2, 2, false, false, SRC_GATHER, SRC_PLAIN, unsigned short, 1, 32, 4>>(p, splits, s);
+    else rc = launch_gemm<GemmCfg<128, 256, 2, 2, false, false, SRC_GATHER, SRC_PLAIN, unsigned short, 1, 32, 4, 2>>(p, splits, s);
+  } else if (x->dtype == SPV_COUNT_U16) rc = (nsplit == 3) ? fc1_fwd_dispatch<unsigned short, 3>(p, N1, splits, s) : fc1_fwd_dispatch<unsigned short, 1>(p, N1, splits, s);
   else if (x->dtype == SPV_COUNT_F32) rc = (nsplit == 3) ? fc1_fwd_dispatch<float, 3>(p, N1, splits, s) : fc1_fwd_dispatch<float, 1>(p, N1, splits, s);
   else return fail(SPV_ERR_ARG, "spv_enc_fc1_fwd: unknown count dtype%s");
   if (rc != SPV_OK) return launch_status("spv_enc_fc1_fwd gemm");
   const long total = (long)B * N1;
-  hipLaunchKernelGGL(fc1_epilogue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, slabs, rowsum_ws, splits, B, N1, bias, bias2, n_first, h1, library);
+  hipLaunchKernelGGL(fc1_epilogue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, slabs, rowsum_ws, splits, B, N1, bias, bias2, n_first, h1, library, xb_all ? library_all : nullptr, x->rows);
   return launch_status("spv_enc_fc1_fwd epilogue");
 }
 
@@ -180,10 +188,10 @@ extern "C" int spv_enc_fc1_wgrad(const spv_counts* x, int32_t B, int32_t G, cons
   p.epi = EPI_STORE;
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  if (xb != nullptr) {  // log1p(x) of this minibatch already sits in HBM as bf16 (by-product of spv_enc_fc1_fwd): plain k-major GEMM
+  if (xb != nullptr) {  // resident bf16 log1p(x) of the data set (spv_prepare_log1p): gathered plain k-major operand, no decode
     if (nsplit != 1 || ld_xb < ((G + 63) & ~63) || (ld_xb % 8)) return fail(SPV_ERR_ARG, "spv_enc_fc1_wgrad: xb needs nsplit 1 and ld_xb >= round_up(G, 64)%s");
-    p.B = xb; p.ldb = ld_xb; p.rows = nullptr; p.col_off = 0;
-    rc = launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_PLAIN, unsigned short, 1, 64, 4>>(p, 1, s);
+    p.B = xb; p.ldb = ld_xb;
+    rc = launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_GATHER, unsigned short, 1, 64, 4>>(p, 1, s);
   } else if (x->dtype == SPV_COUNT_U16) {
     rc = (nsplit == 3) ? launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_COUNTS, unsigned short, 3, 64, 4>>(p, 1, s)
                        : launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_COUNTS, unsigned short, 1, 64, 4>>(p, 1, s);
@@ -744,5 +752,39 @@ extern "C" int spv_plan_expert_bwd(const spv_plan_expert_args* a, void* stream) 
   for (int g = 0; g < 2; ++g) if (!a->d_expert[g] || !a->d_stats[g]) return fail(SPV_ERR_ARG, "spv_plan_expert_bwd: null pointer%s");
   hipLaunchKernelGGL(plan_expert_bwd_kernel, dim3((a->B + 7) / 8, 2), dim3(256), 0, (hipStream_t)stream, *a);
   return launch_status("spv_plan_expert_bwd");
+}
+
+// bf16(log1p(x)) of a whole resident count matrix and library = log(sum_g log1p(x)) per cell, once per data set:
+// one workgroup per cell, fixed-order block reduction.
+__global__ __launch_bounds__(256) void prepare_log1p_kernel(const void* X, long ldx, int col_off, int is_u16, int G, bf16_t* xb, long ld_xb,
+                                                            float* library) {
+  __shared__ float s_sum[256];
+  const long cell = blockIdx.x;
+  float acc = 0.f;
+  for (int g = threadIdx.x; g < (int)ld_xb; g += 256) {
+    float v = 0.f;
+    if (g < G) {
+      const float c = is_u16 ? (float)reinterpret_cast<const unsigned short*>(X)[cell * ldx + col_off + g]
+                             : reinterpret_cast<const float*>(X)[cell * ldx + col_off + g];
+      v = log1p_count(c);
+    }
+    xb[cell * ld_xb + g] = f2bf(v);
+    acc += v;
+  }
+  s_sum[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) s_sum[threadIdx.x] += s_sum[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) library[cell] = __logf(s_sum[0]);
+}
+
+extern "C" int spv_prepare_log1p(const spv_counts* x, int32_t n_cells, int32_t G, uint16_t* xb, int64_t ld_xb, float* library, void* stream) {
+  if (!x || !x->X || !xb || !library || n_cells <= 0 || G <= 0 || ld_xb < G) return fail(SPV_ERR_ARG, "spv_prepare_log1p: bad arguments%s");
+  if (x->dtype != SPV_COUNT_U16 && x->dtype != SPV_COUNT_F32) return fail(SPV_ERR_ARG, "spv_prepare_log1p: unknown count dtype%s");
+  hipLaunchKernelGGL(prepare_log1p_kernel, dim3((unsigned)n_cells), dim3(256), 0, (hipStream_t)stream, x->X, (long)x->ld, x->col_off,
+                     (int)(x->dtype == SPV_COUNT_U16), G, xb, (long)ld_xb, library);
+  return launch_status("spv_prepare_log1p");
 }
 

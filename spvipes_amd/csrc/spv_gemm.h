@@ -28,7 +28,9 @@
 
 namespace spv {
 
-enum { SRC_PLAIN = 0, SRC_COUNTS = 1, SRC_TILED = 2 };
+enum { SRC_PLAIN = 0, SRC_COUNTS = 1, SRC_TILED = 2, SRC_GATHER = 3 };
+// SRC_GATHER: bf16 image of the WHOLE data set [all cells][ld] (zero padded along the genes), the minibatch's rows picked
+// through p.rows exactly like SRC_COUNTS does -- the precomputed bf16 log1p(x) of a resident count matrix.
 enum { EPI_STORE = 0, EPI_ATOMIC = 1, EPI_TILED_F16 = 2, EPI_TILED_F32 = 3 };
 
 struct GemmParams {
@@ -133,6 +135,11 @@ struct Stager {
           const u2v d2 = *reinterpret_cast<const u2v*>(reinterpret_cast<const bf16_t*>(ptr_lo) + off + 128);
           lo[i] = u4v{c2[0], c2[1], d2[0], d2[1]};
         }
+      } else if constexpr (SRC == SRC_GATHER) {
+        const int cell = KMAJ ? k0 + s : ext0 + s;
+        const int gene = KMAJ ? ext0 + 8 * f : k0 + 8 * f;
+        valid[i] = cell < p.n_cells;   // rows beyond the minibatch read row ridx = 0 and are zeroed in store()
+        hi[i] = *reinterpret_cast<const u4v*>(reinterpret_cast<const bf16_t*>(ptr) + (long)ridx[i] * ld + gene);
       } else if constexpr (SRC == SRC_PLAIN) {
         // natural: mem[ext0 + s][k0 + 8f]; k-major: mem[k0 + s][ext0 + 8f]; producer-padded
         const long off = KMAJ ? (long)(k0 + s) * ld + ext0 + 8 * f : (long)(ext0 + s) * ld + k0 + 8 * f;
@@ -177,12 +184,12 @@ struct Stager {
         }
       }
     }
-    if constexpr (SRC == SRC_COUNTS && KMAJ) prep_rows(p, ext0, k0 + Cfg::PF * Cfg::BK, tid);  // this stage's next tile
+    if constexpr ((SRC == SRC_COUNTS || SRC == SRC_GATHER) && KMAJ) prep_rows(p, ext0, k0 + Cfg::PF * Cfg::BK, tid);  // this stage's next tile
   }
 
   // row indices of the count chunks of tile (ext0, k0): fetched one use ahead so that load() never waits on them
   __device__ __forceinline__ void prep_rows(const GemmParams& p, int ext0, int k0, int tid) {
-    if constexpr (SRC == SRC_COUNTS) {
+    if constexpr (SRC == SRC_COUNTS || SRC == SRC_GATHER) {
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
         int s, f; bool ok;
@@ -237,6 +244,10 @@ struct Stager {
         if constexpr (!KMAJ && Cfg::NSPLIT == 1) {  // the weight-gradient GEMM re-reads log1p(x) as plain bf16 instead of decoding the counts again
           if (p.xb_out != nullptr && blockIdx.y == 0 && ext0 + s < p.n_cells) *reinterpret_cast<u4v*>(p.xb_out + (long)(ext0 + s) * p.ld_xb + k0 + 8 * f) = o_hi;
         }
+        continue;
+      }
+      if constexpr (SRC == SRC_GATHER) {
+        *reinterpret_cast<u4v*>(img_hi + s * PITCH + 8 * f) = valid[i] ? hi[i] : u4v{0u, 0u, 0u, 0u};
         continue;
       }
       *reinterpret_cast<u4v*>(img_hi + s * PITCH + 8 * f) = hi[i];

@@ -30,7 +30,7 @@ def to_group_counts(X, device, prefer_u16: bool = True, col_off: int = 0, G: Opt
         t = torch.from_numpy(np.ascontiguousarray(Xn.astype(np.uint16)).view(np.int16))
     else:
         t = torch.from_numpy(np.ascontiguousarray(Xn.astype(np.float32)))
-    return GroupCounts(t.to(device), G, col_off)
+    return GroupCounts(t.to(device), G, col_off, resident=True)
 
 
 @dataclass
@@ -64,7 +64,7 @@ def make_synthetic_group(g: int, n_cells: int, n_genes: int, device, n_labels: i
         cnt[:, 0] += (cnt.sum(1) == 0)  # no empty cell: library = log(sum log1p(x)) must be finite
         cnt = cnt.clamp_(max=65535.0)
         out[lo:hi] = cnt.to(torch.int32).to(torch.int16) if dtype == "u16" else cnt
-    return SyntheticGroup(GroupCounts(out, n_genes, 0), torch.tensor(labels, dtype=torch.float32, device=device))
+    return SyntheticGroup(GroupCounts(out, n_genes, 0, resident=True), torch.tensor(labels, dtype=torch.float32, device=device))
 
 
 class MinibatchSampler:

@@ -31,8 +31,10 @@ class GroupCounts:
     X: torch.Tensor
     G: int
     col_off: int = 0
+    resident: bool = False   # the matrix stays in HBM across steps (data sets, not per-call minibatches): derived images are worth building
 
     def __post_init__(self):
+        self._xb = None
         if not self.X.is_cuda or self.X.dim() != 2 or not self.X.is_contiguous():
             raise _abi.SpvError("GroupCounts needs a contiguous 2-D tensor resident in HBM")
         if self.X.dtype == torch.float32:
@@ -47,6 +49,18 @@ class GroupCounts:
     @property
     def n_cells(self) -> int:
         return self.X.shape[0]
+
+    def log1p_image(self):
+        """(bf16 log1p(x) of every cell [n_cells][round_up(G, 128)], library = log(sum_g log1p(x)) per cell), built on first use
+        by spv_prepare_log1p: the same arithmetic the reference does per minibatch (module/spVIPESmodule.py:428-435)."""
+        if self._xb is None:
+            ld = round_up(self.G, 128)
+            xb = torch.empty((self.n_cells, ld), dtype=torch.int16, device=self.X.device)
+            lib = torch.empty((self.n_cells,), dtype=torch.float32, device=self.X.device)
+            cs = self.c_struct(None)
+            _abi.call("spv_prepare_log1p", C.byref(cs), self.n_cells, self.G, ptr(xb), ld, ptr(lib), stream_ptr())
+            self._xb = (xb, lib)
+        return self._xb
 
     def c_struct(self, rows: Optional[torch.Tensor]) -> SpvCounts:
         if rows is not None and (rows.dtype != torch.int32 or not rows.is_cuda or not rows.is_contiguous()):
@@ -170,7 +184,7 @@ class EncoderFC1(torch.autograd.Function):
         H, G = w_priv.shape
         N1 = 2 * H
         bn = 32 if N1 <= 32 else (128 if N1 <= 128 else 256)
-        N1p, Gp = round_up(N1, bn), round_up(G, 32)
+        N1p, Gp = round_up(N1, bn), round_up(G, 64)
         W_hi, W_lo = _bf16_image(ws, "fc1_W", N1p, Gp, nsplit == 3)
         _pack(w_priv, W_hi, W_lo, dst_row_off=0, rows_cover=H)
         _pack(w_sh, W_hi, W_lo, dst_row_off=H, rows_cover=N1p - H)
@@ -182,14 +196,14 @@ class EncoderFC1(torch.autograd.Function):
         h1 = torch.empty((B, N1), dtype=torch.float32, device=w_priv.device)
         library = torch.empty((B,), dtype=torch.float32, device=w_priv.device)
         cs = counts.c_struct(rows)
-        # bf16 mode, training: the GEMM also leaves bf16(log1p(x)) of the minibatch in HBM so that the weight-gradient
-        # GEMM streams it as a plain operand instead of gathering + decoding the counts a second time
-        xb, ld_xb = None, 0
-        if nsplit == 1 and any(ctx.needs_input_grad):
-            ld_xb = round_up(G, 128)
-            xb = ws.get(f"fc1_xb_{B}", (round_up(B, 64), ld_xb), torch.int16, zero=True)  # rows >= B / columns >= G stay zero
+        # bf16 mode on a resident count matrix: log1p(x) of the whole data set sits in HBM as bf16 (built once, see
+        # GroupCounts.log1p_image) and both fc1 GEMMs gather plain rows from it instead of decoding counts every step
+        xb, ld_xb, lib_all = None, 0, None
+        if nsplit == 1 and counts.resident:
+            xb, lib_all = counts.log1p_image()
+            ld_xb = xb.shape[1]
         _abi.call("spv_enc_fc1_fwd", C.byref(cs), B, G, ptr(W_hi), ptr(W_lo), Gp, N1, ptr(b_priv), ptr(b_sh), H, nsplit, splits, ptr(slabs),
-                                  ptr(rowsum), ptr(h1), ptr(library), ptr(xb), ld_xb, stream_ptr())
+                                  ptr(rowsum), ptr(h1), ptr(library), ptr(xb), ld_xb, ptr(lib_all), stream_ptr())
         ctx.counts, ctx.rows, ctx.B, ctx.nsplit, ctx.ws, ctx.H, ctx.G = counts, rows, B, nsplit, ws, H, G
         ctx.xb, ctx.ld_xb = xb, ld_xb
         ctx.save_for_backward(h1, w_priv, b_priv, w_sh, b_sh)
