@@ -159,3 +159,33 @@ def test_fused_latent_gradient_matches_gemm_path(dev):
     assert res[0][0] == res[1][0]
     diff, scale = float((res[0][1] - res[1][1]).abs().max()), float(res[1][1].abs().max())
     assert diff < 1e-3 * scale, (diff, scale)   # same bf16 operands, different fp32 summation order
+
+
+@pytest.mark.parametrize("B,G,H,gather", [(100, 333, 64, True), (256, 1000, 128, True), (64, 2001, 16, False)])
+def test_fc1_resident_log1p_image_matches_count_decoding(dev, B, G, H, gather):
+    """bf16 mode: the fc1 GEMMs fed from the resident bf16 log1p image (spv_prepare_log1p + gathered plain operand) against
+    the same GEMMs decoding the counts on the fly -- identical bf16 operands, so only the fp32 summation order differs."""
+    from spvipes_amd import ops
+    rng = np.random.default_rng(B + G)
+    n_cells = B + 37
+    Xh = (rng.poisson(2.0, size=(n_cells, G)) * (rng.random((n_cells, G)) < 0.3)).astype(np.uint16)
+    Xh[:, 0] += 1
+    X = torch.tensor(Xh.view(np.int16)).to(dev)
+    rows = torch.tensor(rng.permutation(n_cells)[:B].astype(np.int32), device=dev) if gather else None
+    g = torch.Generator().manual_seed(0)
+    base = [(torch.randn(*s, generator=g) * 0.1) for s in ((H, G), (H,), (H, G), (H,))]
+    dh = torch.randn(B, 2 * H, generator=g).to(dev)
+    out = []
+    for resident in (True, False):
+        counts = ops.GroupCounts(X, G, 0, resident=resident)
+        params = [t.clone().to(dev).requires_grad_(True) for t in base]
+        h1, lib = ops.EncoderFC1.apply(counts, rows, B, *params, 1, ops.Workspace(dev))
+        (h1 * dh).sum().backward()
+        torch.cuda.synchronize()
+        out.append((h1.detach(), lib.detach(), [p.grad.clone() for p in params]))
+    torch.testing.assert_close(out[0][0], out[1][0], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(out[0][1], out[1][1], rtol=1e-6, atol=1e-6)
+    for a, b in zip(out[0][2], out[1][2]):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))
+    ref = torch.log(torch.log1p(torch.tensor(Xh[rows.cpu().numpy() if gather else np.arange(B)].astype(np.float64))).sum(1))
+    torch.testing.assert_close(out[0][1].double().cpu(), ref, rtol=1e-6, atol=1e-6)
