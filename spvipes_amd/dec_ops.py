@@ -48,6 +48,42 @@ def _run_red(b: SpvReduceBatch) -> None:
         _abi.call("spv_reduce_slabs", C.byref(b), stream_ptr())
 
 
+def _decoder_bwd_launches(g: int, P, S, Wps_g, wsg, B: int, Bp: int, G: int, Gp: int, nsplit: int, grads_f32: bool) -> dict:
+    """The data-parallel part of one group's decoder backward, on the current stream: the softmax fix (which in bf16 mode also
+    yields the latent gradient of the two rate heads) and the GEMMs over dL / tP / tS whose results something downstream
+    needs.  Nothing here depends on the upstream gradient of the loss (a scalar applied later by spv_reduce_slabs).
+    (Measured: issuing this from the forward pass right after the group's likelihood kernel, staggered so that the other
+    group's VALU-bound likelihood kernel runs beside these memory-bound kernels, changes nothing -- the step is already
+    the sum of its kernels' work.)"""
+    fused_dz = bool(_ops.FUSED_DZ and not grads_f32)
+    dz_part = wsg.get("dec_dz_part", (P.gene_splits, Bp, DEC_KPS), torch.float32) if fused_dz else None
+    _abi.call("spv_dec_softmax_bwd", C.byref(P), ptr(S["Tp"]), ptr(S["Ts"]), ptr(dz_part), stream_ptr())
+    if grads_f32:
+        def split(t, name):
+            hi, lo = _bf16_image(wsg, name, Bp, Gp, True)
+            _pack(t, hi, lo)
+            return hi, lo
+        (dL_hi, dL_lo), (tP_hi, tP_lo), (tS_hi, tS_lo) = split(S["dL"], "dec_dL_split"), split(S["tP"], "dec_tP_split"), split(S["tS"], "dec_tS_split")
+    else:
+        dL_hi, tP_hi, tS_hi, dL_lo, tP_lo, tS_lo = S["dL"], S["tP"], S["tS"], None, None, None
+    T = Gp // 32
+    # K splits (fp32 slabs, reduced in order by spv_reduce_slabs) sized for >= ~2 workgroups per CU: these
+    # GEMMs stream a [B,G] array once and are latency-bound with fewer resident workgroups
+    bt = Bp // 32
+    ksp_m, ksp_n = max(1, min(T // 8, -(-512 // max(Bp // 64, 1)))), max(1, min(T // 8, -(-512 // max(Bp // 128, 1))))
+    csp_m, csp_n = max(1, min(bt // 8, -(-512 // max(Gp // 64, 1)))), max(1, min(bt // 8, -(-512 // max(Gp // 128, 1))))
+    (Wm_hi, Wm_lo), (Am_hi, Am_lo), (Aps_hi, Aps_lo) = S["Wm"], S["Am"], S["Aps"]
+    out = dict(fused_dz=fused_dz, dz_part=dz_part, ksp_m=ksp_m, ksp_n=ksp_n, csp_m=csp_m, csp_n=csp_n, T=T,
+               late=(g, dL_hi, dL_lo, Am_hi, Am_lo, csp_m, T))   # d W_m (feeds only the optimiser) is launched later, see backward
+    out["d"] = _gemm_slabs(False, dL_hi, dL_lo, Gp, Wm_hi, Wm_lo, KMP, B, KMP, G, nsplit, ksp_m, wsg, "dec_dAm", a_tiles=T)
+    out["b"] = _gemm_slabs(True, tP_hi, tP_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KP, Bp, nsplit, csp_n, wsg, "dec_dWp", a_tiles=T)
+    out["c"] = _gemm_slabs(True, tS_hi, tS_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KS, Bp, nsplit, csp_n, wsg, "dec_dWs", b_col_off=DEC_KP, a_tiles=T)
+    if not fused_dz:
+        out["e"] = _gemm_slabs(False, tP_hi, tP_lo, Gp, Wps_g[0], Wps_g[1], DEC_KPS, B, DEC_KP, G, nsplit, ksp_n, wsg, "dec_dAp", a_tiles=T)
+        out["f"] = _gemm_slabs(False, tS_hi, tS_lo, Gp, Wps_g[0], Wps_g[1], DEC_KPS, B, DEC_KS, G, nsplit, ksp_n, wsg, "dec_dAs", b_col_off=DEC_KP, a_tiles=T)
+    return out
+
+
 class DecoderFused(torch.autograd.Function):
     """inputs : per group (private_log_z [B,n_p], poe_log_z [B,n_s]), per group its 13 parameters, then n_kl KL
              vectors [B] (module/spVIPESmodule.py:841-868) that the loss adds with weight kl_weight / B
@@ -260,39 +296,16 @@ class DecoderFused(torch.autograd.Function):
         red.nprob = red2.nprob = 0
         dWp, dWs = [new(Gs[g], DEC_KP) for g in range(NG)], [new(Gs[g], DEC_KS) for g in range(NG)]
         dAm, d_zcat = [new(B, n_m) for _ in range(NG)], [new(B, nt) for _ in range(NG)]
+        late = []
         streams = group_streams(dev, NG)  # (measured: also forking the dL GEMMs onto their own streams is slower)
         fork(streams)
-        late = []
         for g in range(NG):
           with torch.cuda.stream(streams[g]):
               G, Gp, wsg, S, P = Gs[g], Gps[g], ws[g], ctx.saved_g[g], ctx.P[g]
-              # bf16 gradients: the softmax fix also produces the latent gradient through the two rate heads (one slab per
-              # gene split), which replaces the two GEMMs over tP / tS further down
-              fused_dz = bool(_ops.FUSED_DZ and not ctx.grads_f32)
-              dz_part = wsg.get("dec_dz_part", (P.gene_splits, Bp, DEC_KPS), torch.float32) if fused_dz else None
-              _abi.call("spv_dec_softmax_bwd", C.byref(P), ptr(S["Tp"]), ptr(S["Ts"]), ptr(dz_part), stream_ptr())
-              if ctx.grads_f32:
-                  def split(t, name):
-                      hi, lo = _bf16_image(wsg, name, Bp, Gp, True)
-                      _pack(t, hi, lo)
-                      return hi, lo
-                  (dL_hi, dL_lo), (tP_hi, tP_lo), (tS_hi, tS_lo) = split(S["dL"], "dec_dL_split"), split(S["tP"], "dec_tP_split"), split(S["tS"], "dec_tS_split")
-              else:
-                  dL_hi, tP_hi, tS_hi, dL_lo, tP_lo, tS_lo = S["dL"], S["tP"], S["tS"], None, None, None
-              T = Gp // 32
-              # K splits (fp32 slabs, reduced in order by spv_reduce_slabs) sized for >= ~2 workgroups per CU: these
-              # GEMMs stream a [B,G] array once and are latency-bound with fewer resident workgroups
-              bt = Bp // 32
-              ksp_m, ksp_n = max(1, min(T // 8, -(-512 // max(Bp // 64, 1)))), max(1, min(T // 8, -(-512 // max(Bp // 128, 1))))
-              csp_m, csp_n = max(1, min(bt // 8, -(-512 // max(Gp // 64, 1)))), max(1, min(bt // 8, -(-512 // max(Gp // 128, 1))))
-              (Wm_hi, Wm_lo), (Am_hi, Am_lo), (Aps_hi, Aps_lo) = S["Wm"], S["Am"], S["Aps"]
-              late.append((g, dL_hi, dL_lo, Am_hi, Am_lo, csp_m, T))  # d W_m: nothing downstream needs it -> see below
-              d = _gemm_slabs(False, dL_hi, dL_lo, Gp, Wm_hi, Wm_lo, KMP, B, KMP, G, nsplit, ksp_m, wsg, "dec_dAm", a_tiles=T)
-              b_ = _gemm_slabs(True, tP_hi, tP_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KP, Bp, nsplit, csp_n, wsg, "dec_dWp", a_tiles=T)
-              c = _gemm_slabs(True, tS_hi, tS_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KS, Bp, nsplit, csp_n, wsg, "dec_dWs", b_col_off=DEC_KP, a_tiles=T)
-              if not fused_dz:
-                  e = _gemm_slabs(False, tP_hi, tP_lo, Gp, ctx.Wps[g][0], ctx.Wps[g][1], DEC_KPS, B, DEC_KP, G, nsplit, ksp_n, wsg, "dec_dAp", a_tiles=T)
-                  f = _gemm_slabs(False, tS_hi, tS_lo, Gp, ctx.Wps[g][0], ctx.Wps[g][1], DEC_KPS, B, DEC_KS, G, nsplit, ksp_n, wsg, "dec_dAs", b_col_off=DEC_KP, a_tiles=T)
+              W = _decoder_bwd_launches(g, P, S, ctx.Wps[g], wsg, B, Bp, G, Gp, nsplit, ctx.grads_f32)
+              late.append(W["late"])
+              fused_dz, dz_part, ksp_m, ksp_n, csp_n = W["fused_dz"], W["dz_part"], W["ksp_m"], W["ksp_n"], W["csp_n"]
+              d, b_, c = W["d"], W["b"], W["c"]
               # slab sums, scaled by the upstream gradient, straight into their consumers' buffers
               al = g_loss
               dwp, dws_, dam, dz = dWp[g], dWs[g], dAm[g], d_zcat[g]
@@ -305,8 +318,8 @@ class DecoderFused(torch.autograd.Function):
                   _add_red(red2, dz_part, P.gene_splits, Bp * DEC_KPS, DEC_KPS, B, n_p, dz, nt, accumulate=True, alpha=al)
                   _add_red(red2, dz_part, P.gene_splits, Bp * DEC_KPS, DEC_KPS, B, n_s, dz, nt, col_off=DEC_KP, dst_col=n_p, accumulate=True, alpha=al)
               else:
-                  _add_red(red2, e, ksp_n, B * DEC_KP, DEC_KP, B, n_p, dz, nt, accumulate=True, alpha=al)
-                  _add_red(red2, f, ksp_n, B * DEC_KS, DEC_KS, B, n_s, dz, nt, dst_col=n_p, accumulate=True, alpha=al)
+                  _add_red(red2, W["e"], ksp_n, B * DEC_KP, DEC_KP, B, n_p, dz, nt, accumulate=True, alpha=al)
+                  _add_red(red2, W["f"], ksp_n, B * DEC_KS, DEC_KS, B, n_s, dz, nt, dst_col=n_p, accumulate=True, alpha=al)
               # d px_r = exp(px_r) * d theta (theta = exp(px_r): module/spVIPESmodule.py:758)
               _add_red(red, S["dth"], Bp // 64, Gp, Gp, 1, G, pg[g][12][0], G, alpha=al, exp_scale=par[g][12])
         join(streams)
