@@ -49,3 +49,31 @@ def test_product_package_never_imports_the_oracle():
         if fn.endswith(".py"):
             text = open(os.path.join(pkg, fn)).read()
             assert "oracle" not in text.replace("# oracle", ""), f"{fn} mentions the oracle: the product path must not use it"
+
+
+def test_every_ctypes_struct_has_the_size_the_c_header_gives(tmp_path):
+    """Compile a few lines of C against include/spvipes_hip.h (plain gcc, no GPU) and compare sizeof() of every struct
+    with its ctypes mirror."""
+    import subprocess
+
+    from spvipes_amd import _abi
+
+    pairs = {
+        "spv_counts": _abi.SpvCounts, "spv_dec_params": _abi.SpvDecParams, "spv_linear_prob": _abi.SpvLinearProb,
+        "spv_linear_batch": _abi.SpvLinearBatch, "spv_bn_prob": _abi.SpvBnProb, "spv_bn_batch": _abi.SpvBnBatch,
+        "spv_sample_prob": _abi.SpvSampleProb, "spv_sample_batch": _abi.SpvSampleBatch, "spv_poe_args": _abi.SpvPoeArgs,
+        "spv_zsplit_args": _abi.SpvZsplitArgs, "spv_fold_prob": _abi.SpvFoldProb, "spv_fold_batch": _abi.SpvFoldBatch,
+        "spv_reduce_prob": _abi.SpvReduceProb, "spv_reduce_batch": _abi.SpvReduceBatch, "spv_plan": _abi.SpvPlan,
+        "spv_plan_expert_args": _abi.SpvPlanExpertArgs,
+    }
+    src = tmp_path / "sizes.c"
+    lines = ['#include <stdio.h>', f'#include "{os.path.join(ROOT, "include", "spvipes_hip.h")}"', "int main(void) {"]
+    lines += [f'  printf("{n} %zu\\n", sizeof({n}));' for n in pairs]
+    lines += ["  return 0;", "}"]
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-std=c99", "-o", str(exe), str(src)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    got = dict(line.split() for line in out.strip().splitlines())
+    for name, cls in pairs.items():
+        assert int(got[name]) == ctypes.sizeof(cls), f"{name}: C header {got[name]} bytes, ctypes {ctypes.sizeof(cls)}"
