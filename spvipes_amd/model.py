@@ -144,7 +144,7 @@ class spVIPES:
                           weight_decay=plan_kwargs.get("weight_decay", 1e-6), n_epochs_kl_warmup=n_epochs_kl_warmup,
                           n_steps_kl_warmup=n_steps_kl_warmup)
         trainer.minibatch = self._minibatch  # labels / components / plan indices of this AnnData
-        self.history = trainer.fit(sampler, max_epochs, log_every=trainer_kwargs.get("log_every", 1))
+        self.history = trainer.fit(sampler, max_epochs, log_every=trainer_kwargs.get("log_every", 1), use_graph=trainer_kwargs.get("use_graph", True))
         self.is_trained_ = True
 
     # ------------------------------------------------------------------------------------------

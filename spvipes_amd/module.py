@@ -45,6 +45,7 @@ class LossOutput:
     kl_local: Optional[dict] = None
     kl_global: Optional[torch.Tensor] = None
     extra_metrics: dict = field(default_factory=dict)
+    reconstruction_loss_mean: Optional[torch.Tensor] = None  # 0-dim: batch mean of the summed reconstruction terms (this build's extra)
 
 
 # ---- parameter containers with the reference's state_dict layout ---------------------------------
@@ -477,9 +478,10 @@ class spVIPESmodule(nn.Module):
         res = DecoderFused.apply([self._step_inputs[g][0] for g in (0, 1)], [self._step_inputs[g][1] for g in (0, 1)], B0,
                                  [self.decoders[g] for g in (0, 1)], [px[g].library for g in (0, 1)], w_pad, self.training, self.nsplit,
                                  [self._workspace(g, dev) for g in (0, 1)], klw, 4, *lat, *params, kl_p[0], kl_q[0], kl_p[1], kl_q[1])
-        loss, rec = res[0], [res[2], res[3]]
+        loss, rec_mean, rec = res[0], res[1], [res[2], res[3]]
         return LossOutput(
             loss=loss,
+            reconstruction_loss_mean=rec_mean,
             reconstruction_loss={"reconst_loss_groups_1_poe": rec[0], "reconst_loss_groups_2_poe": rec[1]},
             kl_local={
                 "kl_divergence_groups_1_private": kl_p[0], "kl_divergence_groups_1_poe": kl_q[0],

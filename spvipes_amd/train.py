@@ -170,19 +170,30 @@ class Trainer:
         self.global_step += 1
         return lo
 
-    def fit(self, sampler: MinibatchSampler, max_epochs: int, log_every: int = 0):
+    def fit(self, sampler: MinibatchSampler, max_epochs: int, log_every: int = 0, use_graph: bool = True):
+        """``max_epochs`` passes over the sampler.  The step is captured into a hipGraph at the first minibatch (the
+        sampler yields fixed-size batches); per-step metrics are accumulated ON DEVICE and read back once per epoch, so
+        logging costs one tiny launch per logged step and no host synchronisation."""
         self.module.train()
         for ep in range(max_epochs):
             self.epoch = ep
-            tot = rec = kl = 0.0
-            n = 0
+            acc = None  # device: [sum loss, sum reconstruction, sum kl, n]
             for rows in sampler.epoch():
-                lo = self.step(rows)
+                if use_graph and self.graph is None:
+                    self.capture(rows)
+                klw = kl_weight_at(self.epoch, self.global_step, self.n_epochs_kl_warmup, self.n_steps_kl_warmup)
+                lo = self.step(rows, kl_weight=klw)
                 if log_every and (self.global_step % log_every == 0):
-                    r = float(sum(v.mean() for v in lo.reconstruction_loss.values()))
-                    k = float(sum(v.mean() for v in lo.kl_local.values()))
-                    tot += float(lo.loss); rec += r; kl += k; n += 1
-            if n:
+                    loss = lo.loss.detach()
+                    rec = lo.reconstruction_loss_mean if lo.reconstruction_loss_mean is not None else sum(v.mean() for v in lo.reconstruction_loss.values())
+                    if klw > 1e-12:
+                        kl = (loss - rec) / klw   # loss = rec + kl_weight * mean_b(sum of the KL terms)
+                    else:
+                        kl = sum(v.detach().mean() for v in lo.kl_local.values())
+                    cur = torch.stack([loss, rec.detach(), kl, torch.ones_like(loss)])
+                    acc = cur if acc is None else acc + cur
+            if acc is not None:
+                tot, rec, kl, n = (float(v) for v in acc.cpu())
                 self.history["train_loss"].append(tot / n)
                 self.history["reconstruction_loss_train"].append(rec / n)
                 self.history["kl_local_train"].append(kl / n)
