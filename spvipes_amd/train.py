@@ -141,6 +141,7 @@ class Trainer:
             return
         self._static_rows = [r.clone() for r in rows]
         self._klw = torch.ones((), dtype=torch.float32, device=self.device)
+        self._klw_host = 1.0
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -159,7 +160,9 @@ class Trainer:
         if self.graph is not None:
             for s, r in zip(self._static_rows, rows):
                 s.copy_(r)
-            self._klw.fill_(float(kl_weight))
+            if float(kl_weight) != self._klw_host:  # (changes once per epoch during the warm-up, then never)
+                self._klw.fill_(float(kl_weight))
+                self._klw_host = float(kl_weight)
             self.graph.replay()
             lo = self._static_lo  # tensors are overwritten by the next replay
         else:
