@@ -1,0 +1,106 @@
+"""Odd shapes through the whole HIP path against the CPU oracle on the same inputs, parameters and noise:
+batch sizes and gene counts that are not multiples of any tile, wide and narrow layers, uint16 and fp32 counts,
+resident (Trainer) and per-call (module X tensors) input layouts."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from spvipes_amd import _abi
+    _abi.load()  # raises if libspvipes_hip.so is missing: no fallback
+    return torch.device("cuda:0")
+
+
+CASES = [  # B, G0, G1, H, n_s, n_p, counts dtype
+    (5, 20, 20, 8, 3, 2, "u16"),
+    (37, 45, 51, 16, 6, 3, "f32"),
+    (100, 333, 200, 64, 25, 10, "u16"),
+    (130, 1000, 777, 128, 12, 15, "u16"),
+    (64, 2001, 35, 32, 31, 4, "f32"),
+    (200, 129, 257, 256, 10, 5, "u16"),
+]
+
+
+def _move_relu_kinks_away(sd, counts_rows, margin=1e-4):
+    """Gradient checks between two fp32 implementations are ill-posed where a ReLU input is within rounding error of
+    zero (one flipped (cell, unit) mask changes a whole row of a weight gradient).  Shift each hidden unit's bias by the
+    smallest step that keeps every cell's fc1 / fc2 pre-activation at least `margin` away from zero (evaluated in
+    float64); both implementations then load the same shifted parameters."""
+    for g, c in enumerate(counts_rows):
+        x = torch.log1p(torch.tensor(c, dtype=torch.float64))
+        for kind in ("private", "shared"):
+            h = x
+            for layer in ("fc1", "fc2"):
+                W, b = sd[f"encoder_{g}_{kind}.{layer}.weight"], sd[f"encoder_{g}_{kind}.{layer}.bias"]
+                pre = h @ W.double().T + b.double()
+                cand = torch.arange(0, 400, dtype=torch.float64) * (2.5 * margin)                  # [S] candidate shifts
+                ok = ((pre.unsqueeze(0) + cand.view(-1, 1, 1)).abs() > margin).all(dim=1)             # [S, units]
+                assert bool(ok.any(dim=0).all())
+                shift = cand[ok.double().argmax(dim=0)]
+                b += shift.float()
+                h = torch.relu(pre + shift)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", CASES, ids=[f"B{c[0]}-G{c[1]}x{c[2]}-H{c[3]}-s{c[4]}p{c[5]}-{c[6]}" for c in CASES])
+def test_training_step_matches_oracle(dev, case, precision):
+    from oracle import spvipes_oracle as O
+    from spvipes_amd.module import spVIPESmodule
+    from spvipes_amd.ops import GroupCounts
+    from spvipes_amd.train import Trainer
+    B, G0, G1, H, n_s, n_p, cdt = case
+    rng = np.random.default_rng(B * 7 + G0)
+    Gs = (G0, G1)
+    n_cells = B + 11
+    counts_h = [(rng.poisson(3.0, size=(n_cells, G)) * (rng.random((n_cells, G)) < 0.35)).astype(np.float32) for G in Gs]
+    for c in counts_h:
+        c[:, 0] += 1
+        c[rng.integers(0, n_cells, 4), rng.integers(0, c.shape[1], 4)] += 90.0   # a few counts beyond the lgamma table
+    labels_h = [rng.integers(0, 4, size=n_cells).astype(np.float32), rng.integers(1, 6, size=n_cells).astype(np.float32)]
+    torch.manual_seed(B)
+    module = spVIPESmodule({0: G0, 1: G1}, use_labels=True, n_hidden=H, n_dimensions_shared=n_s, n_dimensions_private=n_p,
+                           dropout_rate=0.0, precision=precision).to(dev)
+    sd = {k: v.detach().cpu().clone() for k, v in module.state_dict().items()}
+    rows_h = [rng.permutation(n_cells)[:B].astype(np.int32) for _ in range(2)]
+    _move_relu_kinks_away(sd, [c[r] for c, r in zip(counts_h, rows_h)])
+    module.load_state_dict(sd)
+    gen = torch.Generator().manual_seed(1)
+    noise = {f"enc_{g}_{k}": torch.randn(B, n, generator=gen) for g in range(2) for k, n in (("private", n_p), ("shared", n_s))}
+    noise.update({f"poe_{g}": torch.randn(B, n_s, generator=gen) for g in range(2)})
+    to_dev = (lambda c: torch.tensor(c.astype(np.uint16).view(np.int16)).to(dev)) if cdt == "u16" else (lambda c: torch.tensor(c).to(dev))
+    counts = [GroupCounts(to_dev(c), c.shape[1], 0, resident=True) for c in counts_h]
+    trainer = Trainer(module, counts, labels=[torch.tensor(l, device=dev) for l in labels_h])
+    module.train()
+    rows = [torch.tensor(r, device=dev) for r in rows_h]
+    _, _, lo = module(trainer.minibatch(rows), inference_kwargs={"noise": {k: v.to(dev) for k, v in noise.items()}}, loss_kwargs={"kl_weight": 0.7})
+    lo.loss.backward()
+    torch.cuda.synchronize()
+    want = O.forward_loss(sd, [torch.tensor(c[r]) for c, r in zip(counts_h, rows_h)], n_dimensions_shared=n_s, n_dimensions_private=n_p,
+                          noise=noise, mode="label", labels=[torch.tensor(l[r]) for l, r in zip(labels_h, rows_h)], training=True, kl_weight=0.7)
+    got, ref = float(lo.loss.detach()), float(want["loss"])
+    tol = 2e-4 if precision == "fp32" else 2e-3   # north-star: rtol 1e-3 on the ELBO in fp32; bf16 operands get 2e-3 on these tiny layers
+    assert abs(got - ref) / abs(ref) < tol, (got, ref)
+    if precision == "fp32":
+        # gradients of a few parameters of every kind against the oracle's autograd
+        params = dict(module.named_parameters())
+        leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k in params}
+        sd2 = dict(sd); sd2.update(leaves)
+        out = O.forward_loss(sd2, [torch.tensor(c[r]) for c, r in zip(counts_h, rows_h)], n_dimensions_shared=n_s, n_dimensions_private=n_p,
+                             noise=noise, mode="label", labels=[torch.tensor(l[r]) for l, r in zip(labels_h, rows_h)], training=True, kl_weight=0.7)
+        out["loss"].backward()
+        gmax = max(float(v.grad.abs().max()) for v in leaves.values() if v.grad is not None)
+        bad = []
+        for k, p in params.items():
+            ref_g = leaves[k].grad
+            if ref_g is None:
+                continue
+            mine = torch.zeros_like(p) if p.grad is None else p.grad
+            err = float((mine.cpu() - ref_g).abs().max())
+            if not err < 5e-3 * float(ref_g.abs().max()) + 2e-4 * gmax:
+                bad.append(f"{k}: abs err {err:.3e} (max |g| {float(ref_g.abs().max()):.3e})")
+        assert not bad, "gradients off: " + "; ".join(bad)
