@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--count-dtype", default="u16", choices=["u16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--allreduce", default="auto", choices=["auto", "single", "overlap"],
+                    help="gradient all-reduce of a data-parallel job: one collective after the backward pass, or two buckets with the "
+                         "decoder bucket overlapped with the encoder half of the backward pass (auto: overlap when WORLD_SIZE > 1)")
     ap.add_argument("--cpu-batch", type=int, default=256)
     ap.add_argument("--cpu-steps", type=int, default=2)
     return ap.parse_args()
@@ -137,7 +140,8 @@ def main():
     groups = [make_synthetic_group(g, args.cells, args.genes, dev, dtype=args.count_dtype) for g in range(2)]
     module = spVIPESmodule({0: args.genes, 1: args.genes}, use_labels=True, n_hidden=args.n_hidden,
                            n_dimensions_shared=args.n_shared, n_dimensions_private=args.n_private, precision=args.precision).to(dev)
-    trainer = Trainer(module, [g.counts for g in groups], labels=[g.labels for g in groups])
+    trainer = Trainer(module, [g.counts for g in groups], labels=[g.labels for g in groups],
+                      overlap_allreduce=None if args.allreduce == "auto" else args.allreduce == "overlap")
     if world > 1:  # identical initial weights on every rank
         dist.broadcast(trainer.fp.flat, src=0)
     sampler = MinibatchSampler([args.cells, args.cells], args.batch_size, dev, seed=rank)
@@ -226,7 +230,9 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32(split-bf16)", "data": "synthetic",
             "config": {"workload": f"2 groups x {args.cells} cells x {G} genes per GPU, label-based PoE, n_shared={n_s} n_private={n_p} "
                                    f"n_hidden={H}, batch {B} cells/group/step/GPU, counts resident as {args.count_dtype} (BASELINE configs[1])",
-                       "parallelism": f"dp{world}", "precision": args.precision, "launch": "hipGraph replay, 2 streams" if use_graph else "eager"},
+                       "parallelism": f"dp{world}", "precision": args.precision, "launch": "hipGraph replay, 2 streams" if use_graph else "eager",
+                       "allreduce": ("none (1 rank)" if world == 1 else "2 buckets, decoder bucket overlapped with the encoder backward"
+                                     if trainer.overlap else "1 bucket after the backward pass")},
             "final_loss": loss,
             "roofline": roof,
         }

@@ -474,10 +474,19 @@ class spVIPESmodule(nn.Module):
         pr, po = inference_outputs["private_stats"], inference_outputs["poe_stats"]
         kl_p = [self._kl_private[g] if g in self._kl_private else kl_normal_std(pr[g]["logtheta_loc"], pr[g]["logtheta_scale"]) for g in (0, 1)]
         kl_q = [self._kl_poe[g] if g in self._kl_poe else kl_normal_std(po[g]["logtheta_loc"], po[g]["logtheta_qz"].scale) for g in (0, 1)]
+        kls = [kl_p[0], kl_q[0], kl_p[1], kl_q[1]]
+        self._cut = None
+        if getattr(self, "split_backward", False) and torch.is_grad_enabled():
+            # data-parallel training (train.Trainer): the decoder half of the backward pass ends at detached copies of
+            # the eight tensors that cross from the encoders into the decoder / loss; the encoder half is started from
+            # their gradients afterwards, so the decoder's gradient bucket can be all-reduced in between
+            cut = [t.detach().requires_grad_(True) for t in lat + kls]
+            self._cut = (lat + kls, cut)
+            lat, kls = cut[:4], cut[4:]
         # reconstruction + kl_weight * mean_b(sum of the four KL terms), assembled by one kernel (spv_loss_assemble)
         res = DecoderFused.apply([self._step_inputs[g][0] for g in (0, 1)], [self._step_inputs[g][1] for g in (0, 1)], B0,
                                  [self.decoders[g] for g in (0, 1)], [px[g].library for g in (0, 1)], w_pad, self.training, self.nsplit,
-                                 [self._workspace(g, dev) for g in (0, 1)], klw, 4, *lat, *params, kl_p[0], kl_q[0], kl_p[1], kl_q[1])
+                                 [self._workspace(g, dev) for g in (0, 1)], klw, 4, *lat, *params, *kls)
         loss, rec_mean, rec = res[0], res[1], [res[2], res[3]]
         return LossOutput(
             loss=loss,

@@ -7,9 +7,12 @@ epochs, or over ``n_steps_kl_warmup`` steps when given), ``max_epochs = min(roun
 400), 400)``.
 
 Data parallelism (the reference has none): one process per GPU, every rank draws its
-own minibatch from its shard of the cells, gradients live in ONE flat fp32 buffer that is summed
-with a single ``torch.distributed.all_reduce`` (backend "nccl" = RCCL over xGMI) per step; the
-1/world factor is folded into the Adam kernel.  BatchNorm statistics and PoE pairing stay rank-local.
+own minibatch from its shard of the cells, gradients live in ONE flat fp32 buffer (decoder
+parameters first, encoder parameters last) that is summed over the ranks with
+``torch.distributed.all_reduce`` (backend "nccl" = RCCL over xGMI) in two contiguous buckets: the
+decoder bucket is reduced while the encoder half of the backward pass still runs, the encoder bucket
+right after it; the 1/world factor is folded into the Adam kernel.  BatchNorm statistics and PoE
+pairing stay rank-local.
 """
 from __future__ import annotations
 
@@ -44,15 +47,21 @@ class FlatParams:
     """Re-homes every trainable parameter of a module into one contiguous fp32 buffer (and its
     gradient into a second one), so that the all-reduce and the optimiser each touch one array."""
 
-    def __init__(self, module: torch.nn.Module):
-        params = [p for p in module.parameters() if p.requires_grad]
-        if not params:
+    def __init__(self, module: torch.nn.Module, late=None):
+        """``late(name) -> bool`` marks parameters whose gradients are produced last in the backward pass; they are
+        placed at the end of the buffers and ``self.split`` is the offset of the first of them (bucket boundary of
+        the data-parallel all-reduce)."""
+        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        if not named:
             raise ValueError("module has no trainable parameters")
+        early = [p for n, p in named if late is None or not late(n)]
+        params = early + [p for n, p in named if late is not None and late(n)]
         dev = params[0].device
         sizes = [(p.numel() + 3) // 4 * 4 for p in params]  # keep every view 16-byte aligned
         total = sum(sizes)
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.split = sum(sizes[:len(early)])
         off = 0
         for p, n in zip(params, sizes):
             view = self.flat[off:off + p.numel()].view_as(p)
@@ -88,15 +97,18 @@ class Trainer:
 
     def __init__(self, module: spVIPESmodule, counts: Sequence[GroupCounts], labels: Optional[Sequence[torch.Tensor]] = None,
                  components: Optional[Sequence[torch.Tensor]] = None, lr: float = 1e-3, eps: float = 0.01,
-                 weight_decay: float = 1e-6, n_epochs_kl_warmup: Optional[int] = 400, n_steps_kl_warmup: Optional[int] = None):
+                 weight_decay: float = 1e-6, n_epochs_kl_warmup: Optional[int] = 400, n_steps_kl_warmup: Optional[int] = None,
+                 overlap_allreduce: Optional[bool] = None):
         self.module, self.counts, self.labels, self.components = module, list(counts), labels, components
         self.device = counts[0].X.device
-        self.fp = FlatParams(module)
+        self.fp = FlatParams(module, late=lambda name: name.startswith("encoder_"))
         self.opt = HipAdam(self.fp, lr=lr, eps=eps, weight_decay=weight_decay)
         self.n_epochs_kl_warmup, self.n_steps_kl_warmup = n_epochs_kl_warmup, n_steps_kl_warmup
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        # two gradient buckets with the backward pass split between them (default: whenever there is more than one rank)
+        self.overlap = (self.world > 1) if overlap_allreduce is None else bool(overlap_allreduce)
         self.global_step, self.epoch = 0, 0
-        self.graph = None
+        self.graph = self.graph2 = None
         self.history: Dict[str, List[float]] = {"train_loss": [], "elbo_train": [], "reconstruction_loss_train": [], "kl_local_train": []}
 
     def minibatch(self, rows: Sequence[torch.Tensor]):
@@ -116,12 +128,16 @@ class Trainer:
         return tuple(out)
 
     def _forward_backward(self, rows, kl_weight):
-        from . import nn_ops
+        """forward + loss + backward.  With ``self.overlap`` only the decoder half of the backward pass runs here (down
+        to the tensors that cross from the encoders into the decoder); ``_backward_encoders`` finishes it."""
+        from . import nn_ops, ops
 
         self.fp.grad.zero_()
-        _, _, lo = self.module(self.minibatch(rows), loss_kwargs={"kl_weight": kl_weight})
-        from . import ops
-
+        self.module.split_backward = self.overlap   # (only for this call: a plain module(...) elsewhere keeps one backward pass)
+        try:
+            _, _, lo = self.module(self.minibatch(rows), loss_kwargs={"kl_weight": kl_weight})
+        finally:
+            self.module.split_backward = False
         nn_ops.GRAD_SINK = True  # small-layer gradients land directly in the flat buffer (see nn_ops.grad_out)
         ops.DEFER_JOIN = True    # side-stream gradient GEMMs are joined here, after the whole backward pass
         try:
@@ -132,11 +148,29 @@ class Trainer:
             ops.join_pending()
         return lo
 
+    def _backward_encoders(self):
+        """second half of a split backward pass: PoE, encoder tails, fc1 (gradient bucket ``fp.grad[fp.split:]``)"""
+        from . import nn_ops, ops
+
+        outs, cut = self.module._cut
+        pairs = [(o, c.grad) for o, c in zip(outs, cut) if c.grad is not None and o.requires_grad]
+        nn_ops.GRAD_SINK = True
+        ops.DEFER_JOIN = True
+        try:
+            torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
+        finally:
+            nn_ops.GRAD_SINK = False
+            ops.DEFER_JOIN = False
+            ops.join_pending()
+        self.module._cut = None
+
     def capture(self, rows: Sequence[torch.Tensor], warmup: int = 3) -> None:
-        """Capture forward + loss + backward of one step into a hipGraph (``torch.cuda.CUDAGraph``): the ~150
+        """Capture forward + loss + backward of one step into a hipGraph (``torch.cuda.CUDAGraph``): the ~100
         launches of a step replay as one submission.  Everything that changes between steps lives in device
         memory: the row indices (copied into static buffers), the KL weight (0-dim tensor), the dropout seed
-        (module._seed_dev), the noise (graph-safe generator).  The all-reduce and Adam stay outside."""
+        (module._seed_dev), the noise (graph-safe generator).  The all-reduce and Adam stay outside; in a
+        data-parallel job the step is captured as TWO graphs (decoder half / encoder half of the backward pass, same
+        memory pool) so that the first gradient bucket is on the wire while the second graph runs."""
         if self.graph is not None:
             return
         self._static_rows = [r.clone() for r in rows]
@@ -147,11 +181,18 @@ class Trainer:
         with torch.cuda.stream(side):
             for _ in range(warmup):  # allocates every workspace buffer before the capture
                 self._forward_backward(self._static_rows, self._klw)
+                if self.overlap:
+                    self._backward_encoders()
         torch.cuda.current_stream().wait_stream(side)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self._static_lo = self._forward_backward(self._static_rows, self._klw)
         self.graph = g
+        if self.overlap:
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, pool=g.pool()):
+                self._backward_encoders()
+            self.graph2 = g2
 
     def step(self, rows: Sequence[torch.Tensor], kl_weight: Optional[float] = None):
         """forward + loss + backward + (all-reduce) + Adam for one minibatch; returns the LossOutput."""
@@ -167,8 +208,20 @@ class Trainer:
             lo = self._static_lo  # tensors are overwritten by the next replay
         else:
             lo = self._forward_backward(rows, kl_weight)
-        if self.world > 1:
-            dist.all_reduce(self.fp.grad, op=dist.ReduceOp.SUM)  # the step's only collective
+        if self.overlap:
+            # bucket 1 (decoders) is summed over the ranks while the encoder half of the backward pass runs
+            split = self.fp.split
+            w1 = dist.all_reduce(self.fp.grad[:split], op=dist.ReduceOp.SUM, async_op=True) if self.world > 1 else None
+            if self.graph is not None:
+                self.graph2.replay()
+            else:
+                self._backward_encoders()
+            if self.world > 1:
+                w2 = dist.all_reduce(self.fp.grad[split:], op=dist.ReduceOp.SUM, async_op=True)
+                w1.wait()
+                w2.wait()
+        elif self.world > 1:
+            dist.all_reduce(self.fp.grad, op=dist.ReduceOp.SUM)  # one collective for the whole flat buffer
         self.opt.step(grad_scale=1.0 / self.world)
         self.global_step += 1
         return lo

@@ -74,3 +74,17 @@ def test_flat_params_are_views_and_survive_load_state_dict():
         torch.testing.assert_close(v, ref[k])
     net.load_state_dict({k: v + 1 for k, v in ref.items()})
     assert abs(float(fp.flat[0]) - float(ref["0.weight"].flatten()[0]) - 1) < 1e-6  # still the same storage
+
+
+def test_late_parameters_form_the_second_bucket():
+    net = _net()
+    ref = {k: v.clone() for k, v in net.state_dict().items()}
+    fp = FlatParams(net, late=lambda name: name.startswith("0."))   # first layer last, like the encoders in train.Trainer
+    assert fp.split == 24 + 4  # 2.weight (21 -> padded 24) + 2.bias (3 -> padded 4)
+    assert net[2].weight.data_ptr() == fp.flat.data_ptr() and net[0].weight.data_ptr() == fp.flat.data_ptr() + 4 * fp.split
+    for k, v in net.state_dict().items():
+        torch.testing.assert_close(v, ref[k])
+    x, y = _batch(0)
+    fp.zero_grad()
+    ((net(x) - y) ** 2).mean().backward()
+    assert float(fp.grad[:fp.split].abs().max()) > 0 and float(fp.grad[fp.split:].abs().max()) > 0

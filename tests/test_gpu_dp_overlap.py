@@ -1,0 +1,143 @@
+"""Data-parallel step mechanics on the real kernels: the backward pass split at the encoder/decoder boundary with the
+two gradient buckets reduced separately (spvipes_amd.train.Trainer, overlap_allreduce) must give what the single
+backward pass + one all-reduce gives.  RCCL needs one device per rank, and the test box has one: the two-rank case
+runs both ranks on cuda:0 over gloo (device tensors staged through the host) -- same Trainer code path, other transport."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from spvipes_amd import _abi
+    _abi.load()  # raises if libspvipes_hip.so is missing: no fallback
+    return torch.device("cuda:0")
+
+
+def _setup(dev, overlap, G=(600, 500), n_cells=1024, precision="fp32"):
+    from spvipes_amd.data import make_synthetic_group
+    from spvipes_amd.module import spVIPESmodule
+    from spvipes_amd.train import Trainer
+    groups = [make_synthetic_group(g, n_cells, G[g], dev) for g in range(2)]
+    torch.manual_seed(0)
+    module = spVIPESmodule({0: G[0], 1: G[1]}, use_labels=True, n_hidden=64, n_dimensions_shared=10, n_dimensions_private=5,
+                           dropout_rate=0.1, precision=precision).to(dev)
+    trainer = Trainer(module, [g.counts for g in groups], labels=[g.labels for g in groups], lr=5e-3, overlap_allreduce=overlap)
+    module.train()
+    return module, trainer
+
+
+def _set_dropout_seed(module, dev, value):
+    """the device-resident dropout seed counter is created by the first forward pass (and captured by address)"""
+    if getattr(module, "_seed_dev", None) is None:
+        module._seed_dev = torch.zeros((), dtype=torch.int64, device=dev)
+    module._seed_dev.fill_(value)
+
+
+def _rows(dev, seed, n_cells=1024, B=256, steps=4):
+    gen = torch.Generator().manual_seed(seed)
+    return [[torch.randperm(n_cells, generator=gen)[:B].to(torch.int32).to(dev) for _ in range(2)] for _ in range(steps)]
+
+
+def test_flat_buffer_puts_the_encoders_last(dev):
+    module, trainer = _setup(dev, overlap=True)
+    fp = trainer.fp
+    base = fp.flat.data_ptr()
+    for name, p in module.named_parameters():
+        off = (p.data_ptr() - base) // 4
+        assert (off >= fp.split) == name.startswith("encoder_"), name
+        assert p.grad.data_ptr() - fp.grad.data_ptr() == p.data_ptr() - base
+    assert 0 < fp.split < fp.numel and fp.split % 4 == 0
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_split_backward_equals_single_backward(dev, use_graph):
+    """world = 1: same minibatches, same noise and dropout seeds -> bit-identical gradients, losses and parameters."""
+    batches = _rows(dev, 5)
+    got = {}
+    for overlap in (False, True):
+        module, trainer = _setup(dev, overlap)
+        if use_graph:
+            trainer.capture(batches[0])
+            assert (trainer.graph2 is not None) == overlap
+        torch.manual_seed(77)
+        _set_dropout_seed(module, dev, 0)
+        losses = [float(trainer.step(rows, kl_weight=0.5).loss.detach()) for rows in batches]
+        torch.cuda.synchronize()
+        names = [n for n, _ in module.named_parameters()]
+        got[overlap] = (losses, {n: p.detach().clone() for n, p in module.named_parameters()},
+                        {n: p.grad.detach().clone() for n, p in module.named_parameters()}, names)
+    assert got[False][0] == got[True][0]
+    for n in got[False][3]:
+        assert torch.equal(got[False][2][n], got[True][2][n]), f"gradient of {n}"
+        assert torch.equal(got[False][1][n], got[True][1][n]), f"parameter {n}"
+    assert any(float(g.abs().max()) > 0 for n, g in got[True][2].items() if n.startswith("encoder_"))
+
+
+def _worker(rank, world, port, use_graph, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        module, trainer = _setup(dev, overlap=None)          # default: overlapped buckets because world > 1
+        assert trainer.world == world and trainer.overlap
+        dist.broadcast(trainer.fp.flat, src=0)
+        batches = _rows(dev, 100 + rank, steps=3)
+        if use_graph:
+            trainer.capture(batches[0])
+        torch.manual_seed(1000 + rank)
+        _set_dropout_seed(module, dev, 50 * rank)
+        for rows in batches[:1]:
+            trainer.step(rows, kl_weight=1.0)
+        torch.cuda.synchronize()
+        mean_grad = (trainer.fp.grad / world).cpu()
+        for rows in batches[1:]:
+            trainer.step(rows, kl_weight=1.0)
+        torch.cuda.synchronize()
+        # numpy payloads: pickled by value (tensors travel as shared-memory handles that die with this process)
+        q.put((rank, mean_grad.numpy(), trainer.fp.flat.cpu().numpy(), [[r.cpu().numpy() for r in rows] for rows in batches[:1]]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_two_ranks_reduce_to_the_mean_gradient_and_stay_identical(dev, use_graph):
+    import torch.multiprocessing as mp
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, use_graph, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    got = [(r, torch.from_numpy(g), torch.from_numpy(f), [[torch.from_numpy(x) for x in rows] for rows in b]) for r, g, f, b in got]
+    assert torch.equal(got[0][2], got[1][2]), "replicas diverged"
+    assert torch.equal(got[0][1], got[1][1])
+    # single-process reference of step 1: each rank's gradient on its own minibatch (same noise / dropout seeds), averaged
+    module, ref = _setup(dev, overlap=False)
+    if use_graph:
+        ref.capture([r.to(dev) for r in got[0][3][0]])   # (moves BatchNorm running statistics like the ranks' capture did)
+    grads = []
+    for rank in range(world):
+        torch.manual_seed(1000 + rank)
+        _set_dropout_seed(module, dev, 50 * rank)
+        ref._forward_backward([r.to(dev) for r in got[rank][3][0]], 1.0)
+        torch.cuda.synchronize()
+        grads.append(ref.fp.grad.cpu().clone())
+    want = (grads[0] + grads[1]) / world
+    scale = float(want.abs().max())
+    assert float((got[0][1] - want).abs().max()) <= 1e-6 * scale
