@@ -127,7 +127,9 @@ template <typename CT, int NSPLIT>
 static int fc1_fwd_dispatch(const GemmParams& p, int N1, int splits, hipStream_t s) {
   if (N1 <= 32) return launch_gemm<GemmCfg<128, 32, 4, 1, false, false, SRC_COUNTS, SRC_PLAIN, CT, NSPLIT, 32, 4>>(p, splits, s);
   if (N1 <= 128) return launch_gemm<GemmCfg<64, 128, 2, 2, false, false, SRC_COUNTS, SRC_PLAIN, CT, NSPLIT, 32, 4>>(p, splits, s);
-  if (NSPLIT == 1 && p.M >= 1024) return launch_gemm<GemmCfg<128, 256, 2, 2, false, false, SRC_COUNTS, SRC_PLAIN, CT, NSPLIT, 32, 2, 2>>(p, splits, s);  // 64 x 128 wave tiles
+  if constexpr (NSPLIT == 1) {
+    if (p.M >= 1024) return launch_gemm<GemmCfg<128, 256, 2, 2, false, false, SRC_COUNTS, SRC_PLAIN, CT, NSPLIT, 32, 2, 2>>(p, splits, s);  // 64 x 128 wave tiles
+  }
   return launch_gemm<GemmCfg<64, 256, 1, 4, false, false, SRC_COUNTS, SRC_PLAIN, CT, NSPLIT, 32, 4>>(p, splits, s);
 }
 
@@ -152,14 +154,21 @@ extern "C" int spv_enc_fc1_fwd(const spv_counts* x, int32_t B, int32_t G, const 
   }
   p.C = slabs; p.ldc = N1; p.slab_stride = (long)B * N1;
   p.M = B; p.N = N1; p.K = G;
-  const int ktiles = (G + 31) / 32;
-  p.k_per_split = ((ktiles + splits - 1) / splits) * 32;
+  // resident-image path with both encoders' 2H > 128 columns: 128 x 256 tiles, 64-deep k steps and ONE register stage
+  // (the 64 x 128 wave tile holds 128 accumulator registers; a deeper prefetch ring spills at two workgroups per CU --
+  // measured 88 -> 62 us) when both images are zero padded to a multiple of 64 genes, else 32-deep steps
+  const int G64 = (G + 63) & ~63;
+  const bool wide64 = xb_all != nullptr && N1 > 128 && ld_xb >= G64 && ldw >= G64;
+  const int bk = wide64 ? 64 : 32;
+  const int ktiles = (G + bk - 1) / bk;
+  p.k_per_split = ((ktiles + splits - 1) / splits) * bk;
   p.epi = EPI_STORE;
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if (xb_all != nullptr) {
     if (N1 <= 128) rc = launch_gemm<GemmCfg<64, 128, 2, 2, false, false, SRC_GATHER, SRC_PLAIN, unsigned short, 1, 32, 4>>(p, splits, s);
-    else rc = launch_gemm<GemmCfg<128, 256, 2, 2, false, false, SRC_GATHER, SRC_PLAIN, unsigned short, 1, 32, 4, 2>>(p, splits, s);
+    else if (wide64) rc = launch_gemm<GemmCfg<128, 256, 2, 2, false, false, SRC_GATHER, SRC_PLAIN, unsigned short, 1, 64, 1, 2>>(p, splits, s);
+    else rc = launch_gemm<GemmCfg<128, 256, 2, 2, false, false, SRC_GATHER, SRC_PLAIN, unsigned short, 1, 32, 2, 2>>(p, splits, s);
   } else if (x->dtype == SPV_COUNT_U16) rc = (nsplit == 3) ? fc1_fwd_dispatch<unsigned short, 3>(p, N1, splits, s) : fc1_fwd_dispatch<unsigned short, 1>(p, N1, splits, s);
   else if (x->dtype == SPV_COUNT_F32) rc = (nsplit == 3) ? fc1_fwd_dispatch<float, 3>(p, N1, splits, s) : fc1_fwd_dispatch<float, 1>(p, N1, splits, s);
   else return fail(SPV_ERR_ARG, "spv_enc_fc1_fwd: unknown count dtype%s");
