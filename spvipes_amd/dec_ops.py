@@ -76,8 +76,14 @@ def _decoder_bwd_launches(g: int, P, S, Wps_g, wsg, B: int, Bp: int, G: int, Gp:
     out = dict(fused_dz=fused_dz, dz_part=dz_part, ksp_m=ksp_m, ksp_n=ksp_n, csp_m=csp_m, csp_n=csp_n, T=T,
                late=(g, dL_hi, dL_lo, Am_hi, Am_lo, csp_m, T))   # d W_m (feeds only the optimiser) is launched later, see backward
     out["d"] = _gemm_slabs(False, dL_hi, dL_lo, Gp, Wm_hi, Wm_lo, KMP, B, KMP, G, nsplit, ksp_m, wsg, "dec_dAm", a_tiles=T)
-    out["b"] = _gemm_slabs(True, tP_hi, tP_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KP, Bp, nsplit, csp_n, wsg, "dec_dWp", a_tiles=T)
-    out["c"] = _gemm_slabs(True, tS_hi, tS_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KS, Bp, nsplit, csp_n, wsg, "dec_dWs", b_col_off=DEC_KP, a_tiles=T)
+    # d [W'_p | c_p], d [W'_s | c_s] (contractions over the cells): first needed by the BatchNorm-fold backward, which sits
+    # behind the trunk backward -- with DEFER_BC they are launched from the side stream beside that chain (see backward)
+    bc = lambda: (_gemm_slabs(True, tP_hi, tP_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KP, Bp, nsplit, csp_n, wsg, "dec_dWp", a_tiles=T),
+                  _gemm_slabs(True, tS_hi, tS_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KS, Bp, nsplit, csp_n, wsg, "dec_dWs", b_col_off=DEC_KP, a_tiles=T))
+    if _ops.DEFER_BC:
+        out["bc"] = bc
+    else:
+        out["b"], out["c"] = bc()
     if not fused_dz:
         out["e"] = _gemm_slabs(False, tP_hi, tP_lo, Gp, Wps_g[0], Wps_g[1], DEC_KPS, B, DEC_KP, G, nsplit, ksp_n, wsg, "dec_dAp", a_tiles=T)
         out["f"] = _gemm_slabs(False, tS_hi, tS_lo, Gp, Wps_g[0], Wps_g[1], DEC_KPS, B, DEC_KS, G, nsplit, ksp_n, wsg, "dec_dAs", b_col_off=DEC_KP, a_tiles=T)
@@ -296,7 +302,7 @@ class DecoderFused(torch.autograd.Function):
         red.nprob = red2.nprob = 0
         dWp, dWs = [new(Gs[g], DEC_KP) for g in range(NG)], [new(Gs[g], DEC_KS) for g in range(NG)]
         dAm, d_zcat = [new(B, n_m) for _ in range(NG)], [new(B, nt) for _ in range(NG)]
-        late = []
+        late, late_bc = [], []
         streams = group_streams(dev, NG)  # (measured: also forking the dL GEMMs onto their own streams is slower)
         fork(streams)
         for g in range(NG):
@@ -305,12 +311,15 @@ class DecoderFused(torch.autograd.Function):
               W = _decoder_bwd_launches(g, P, S, ctx.Wps[g], wsg, B, Bp, G, Gp, nsplit, ctx.grads_f32)
               late.append(W["late"])
               fused_dz, dz_part, ksp_m, ksp_n, csp_n = W["fused_dz"], W["dz_part"], W["ksp_m"], W["ksp_n"], W["csp_n"]
-              d, b_, c = W["d"], W["b"], W["c"]
+              d = W["d"]
               # slab sums, scaled by the upstream gradient, straight into their consumers' buffers
               al = g_loss
               dwp, dws_, dam, dz = dWp[g], dWs[g], dAm[g], d_zcat[g]
-              _add_red(red, b_, csp_n, G * DEC_KP, DEC_KP, G, DEC_KP, dwp, DEC_KP, alpha=al)                    # d [W'_p | c_p]
-              _add_red(red, c, csp_n, G * DEC_KS, DEC_KS, G, DEC_KS, dws_, DEC_KS, alpha=al)                    # d [W'_s | c_s]
+              if "bc" in W:
+                  late_bc.append((g, W["bc"], csp_n))
+              else:
+                  _add_red(red, W["b"], csp_n, G * DEC_KP, DEC_KP, G, DEC_KP, dwp, DEC_KP, alpha=al)            # d [W'_p | c_p]
+                  _add_red(red, W["c"], csp_n, G * DEC_KS, DEC_KS, G, DEC_KS, dws_, DEC_KS, alpha=al)           # d [W'_s | c_s]
               _add_red(red, d, ksp_m, B * KMP, KMP, B, n_m, dam, n_m, alpha=al)                                 # d m (trunk output)
               # gradient reaching zcat directly: through the logits GEMM (columns n_m..) and the two regressors
               _add_red(red, d, ksp_m, B * KMP, KMP, B, nt, dz, nt, col_off=n_m, alpha=al)
@@ -327,15 +336,29 @@ class DecoderFused(torch.autograd.Function):
         if ctx.n_kl:  # d loss / d kl_i[b] = g * kl_weight / B for every KL vector: rides in the second reduction launch
             gk = new(B)
             _add_red(red2, ctx.gkl, 1, B, B, 1, B, gk, B, alpha=g_loss)
+        side = group_streams(dev, 3)[2] if _ops.DEFER_WM else torch.cuda.current_stream(dev)
+        if _ops.DEFER_WM:
+            side.wait_stream(torch.cuda.current_stream(dev))   # (before the reductions: the side work needs none of them)
         _run_red(red)
         _run_red(red2)
         # The mixture-weight gradients (2 x [G, K_M] from dL^T A_m, the largest GEMMs of the backward) feed nothing but the
         # optimiser: they go to a side stream that starts here, i.e. runs beside the ~30 tiny kernels of the trunk / PoE /
         # encoder-tail backward that follow and leave the GPU almost empty, and is joined at the end of the backward pass.
-        side = group_streams(dev, 3)[2] if _ops.DEFER_WM else torch.cuda.current_stream(dev)
-        if _ops.DEFER_WM:
-            side.wait_stream(torch.cuda.current_stream(dev))
+        bc_done = None
         with torch.cuda.stream(side):
+            if late_bc:
+                # the regressor weight gradients first: the main stream picks them up (event) before spv_bn_fold_bwd
+                red_bc = SpvReduceBatch()
+                red_bc.nprob = 0
+                for (g, bc, csp_n) in late_bc:
+                    G = Gs[g]
+                    b_, c = bc()
+                    _add_red(red_bc, b_, csp_n, G * DEC_KP, DEC_KP, G, DEC_KP, dWp[g], DEC_KP, alpha=g_loss)
+                    _add_red(red_bc, c, csp_n, G * DEC_KS, DEC_KS, G, DEC_KS, dWs[g], DEC_KS, alpha=g_loss)
+                _run_red(red_bc)
+                if side is not torch.cuda.current_stream(dev) and _ops.DEFER_WM:
+                    bc_done = torch.cuda.Event()
+                    bc_done.record(side)
             red3 = SpvReduceBatch()
             red3.nprob = 0
             for (g, dL_hi, dL_lo, Am_hi, Am_lo, csp_m, T) in late:
@@ -384,6 +407,8 @@ class DecoderFused(torch.autograd.Function):
                 q.red_part = ptr(ws[g].get(f"fold_red_{k}", (-(-Gs[g] // 256) + 1, n + n * n), torch.float32))
                 q.dz, q.lddz = _fptr(d_zcat[g], zoff), nt
                 i += 1
+        if bc_done is not None:
+            torch.cuda.current_stream(dev).wait_event(bc_done)
         _abi.call("spv_bn_fold_bwd", C.byref(fb), stream_ptr())
         # ---- latent slicing backward ------------------------------------------------------------------
         d_priv, d_poe = [new(B, n_p) for _ in range(NG)], [new(B, n_s) for _ in range(NG)]

@@ -126,6 +126,7 @@ STAGGER = os.environ.get("SPV_STAGGER", "1") != "0"  # group 1 orders its indepe
 FUSED_DZ = os.environ.get("SPV_FUSED_DZ", "1") != "0"  # softmax fix also produces the latent gradient of the rate heads
 FUSED_PACK = os.environ.get("SPV_FUSED_PACK", "1") != "0"  # latent / trunk kernels also write the decoder's bf16 operand images
 DEFER_WM = os.environ.get("SPV_DEFER_WM", "1") != "0"  # mixture-weight gradient GEMMs on the late side stream
+DEFER_BC = os.environ.get("SPV_DEFER_BC", "1") != "0"  # regressor weight-gradient GEMMs beside the trunk backward (side stream)
 _PENDING: list = []
 _PENDING_KEEP: list = []
 
