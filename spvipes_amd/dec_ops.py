@@ -48,46 +48,64 @@ def _run_red(b: SpvReduceBatch) -> None:
         _abi.call("spv_reduce_slabs", C.byref(b), stream_ptr())
 
 
-def _decoder_bwd_launches(g: int, P, S, Wps_g, wsg, B: int, Bp: int, G: int, Gp: int, nsplit: int, grads_f32: bool) -> dict:
-    """The data-parallel part of one group's decoder backward, on the current stream: the softmax fix (which in bf16 mode also
-    yields the latent gradient of the two rate heads) and the GEMMs over dL / tP / tS whose results something downstream
-    needs.  Nothing here depends on the upstream gradient of the loss (a scalar applied later by spv_reduce_slabs).
-    (Measured: issuing this from the forward pass right after the group's likelihood kernel, staggered so that the other
-    group's VALU-bound likelihood kernel runs beside these memory-bound kernels, changes nothing -- the step is already
-    the sum of its kernels' work.)"""
-    fused_dz = bool(_ops.FUSED_DZ and not grads_f32)
-    dz_part = wsg.get("dec_dz_part", (P.gene_splits, Bp, DEC_KPS), torch.float32) if fused_dz else None
-    _abi.call("spv_dec_softmax_bwd", C.byref(P), ptr(S["Tp"]), ptr(S["Ts"]), ptr(dz_part), stream_ptr())
-    if grads_f32:
-        def split(t, name):
-            hi, lo = _bf16_image(wsg, name, Bp, Gp, True)
-            _pack(t, hi, lo)
-            return hi, lo
-        (dL_hi, dL_lo), (tP_hi, tP_lo), (tS_hi, tS_lo) = split(S["dL"], "dec_dL_split"), split(S["tP"], "dec_tP_split"), split(S["tS"], "dec_tS_split")
-    else:
-        dL_hi, tP_hi, tS_hi, dL_lo, tP_lo, tS_lo = S["dL"], S["tP"], S["tS"], None, None, None
-    T = Gp // 32
-    # K splits (fp32 slabs, reduced in order by spv_reduce_slabs) sized for >= ~2 workgroups per CU: these
-    # GEMMs stream a [B,G] array once and are latency-bound with fewer resident workgroups
-    bt = Bp // 32
-    ksp_m, ksp_n = max(1, min(T // 8, -(-512 // max(Bp // 64, 1)))), max(1, min(T // 8, -(-512 // max(Bp // 128, 1))))
-    csp_m, csp_n = max(1, min(bt // 8, -(-512 // max(Gp // 64, 1)))), max(1, min(bt // 8, -(-512 // max(Gp // 128, 1))))
-    (Wm_hi, Wm_lo), (Am_hi, Am_lo), (Aps_hi, Aps_lo) = S["Wm"], S["Am"], S["Aps"]
-    out = dict(fused_dz=fused_dz, dz_part=dz_part, ksp_m=ksp_m, ksp_n=ksp_n, csp_m=csp_m, csp_n=csp_n, T=T,
-               late=(g, dL_hi, dL_lo, Am_hi, Am_lo, csp_m, T))   # d W_m (feeds only the optimiser) is launched later, see backward
-    out["d"] = _gemm_slabs(False, dL_hi, dL_lo, Gp, Wm_hi, Wm_lo, KMP, B, KMP, G, nsplit, ksp_m, wsg, "dec_dAm", a_tiles=T)
-    # d [W'_p | c_p], d [W'_s | c_s] (contractions over the cells): first needed by the BatchNorm-fold backward, which sits
-    # behind the trunk backward -- with DEFER_BC they are launched from the side stream beside that chain (see backward)
-    bc = lambda: (_gemm_slabs(True, tP_hi, tP_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KP, Bp, nsplit, csp_n, wsg, "dec_dWp", a_tiles=T),
-                  _gemm_slabs(True, tS_hi, tS_lo, Gp, Aps_hi, Aps_lo, DEC_KPS, G, DEC_KS, Bp, nsplit, csp_n, wsg, "dec_dWs", b_col_off=DEC_KP, a_tiles=T))
-    if _ops.DEFER_BC:
-        out["bc"] = bc
-    else:
-        out["b"], out["c"] = bc()
-    if not fused_dz:
-        out["e"] = _gemm_slabs(False, tP_hi, tP_lo, Gp, Wps_g[0], Wps_g[1], DEC_KPS, B, DEC_KP, G, nsplit, ksp_n, wsg, "dec_dAp", a_tiles=T)
-        out["f"] = _gemm_slabs(False, tS_hi, tS_lo, Gp, Wps_g[0], Wps_g[1], DEC_KPS, B, DEC_KS, G, nsplit, ksp_n, wsg, "dec_dAs", b_col_off=DEC_KP, a_tiles=T)
-    return out
+class _DecoderBwd:
+    """One group's decoder backward launches, as separately schedulable stages (none depends on the upstream gradient of
+    the loss: that scalar is applied later by spv_reduce_slabs):
+      softmax()  the softmax fix in place on tP / tS; in bf16 mode it also yields the latent gradient of the two rate heads
+      gemm_d()   d A_m = dL W_m (contraction over genes): feeds the trunk backward          -- needs only dL
+      gemm_bc()  d [W'_p | c_p], d [W'_s | c_s] (contractions over cells): feed the BatchNorm-fold backward -- after softmax()
+      gemm_a()   d W_m = dL^T A_m: feeds only the optimiser                                   -- needs only dL
+      gemm_ef()  fp32 mode only: the latent gradient of the rate heads as two GEMMs           -- after softmax()
+    (Measured: issuing these from the forward pass right after the group's likelihood kernel, staggered so that the other
+    group's VALU-bound likelihood kernel runs beside these memory-bound kernels, changes nothing.)"""
+
+    def __init__(self, g: int, P, S, Wps_g, wsg, B: int, Bp: int, G: int, Gp: int, nsplit: int, grads_f32: bool):
+        self.g, self.P, self.S, self.Wps_g, self.wsg = g, P, S, Wps_g, wsg
+        self.B, self.Bp, self.G, self.Gp, self.nsplit, self.grads_f32 = B, Bp, G, Gp, nsplit, grads_f32
+        self.fused_dz = bool(_ops.FUSED_DZ and not grads_f32)
+        self.dz_part = wsg.get("dec_dz_part", (P.gene_splits, Bp, DEC_KPS), torch.float32) if self.fused_dz else None
+        self.T = T = Gp // 32
+        bt = Bp // 32
+        # K splits (fp32 slabs, reduced in order by spv_reduce_slabs) sized for >= ~2 workgroups per CU: these
+        # GEMMs stream a [B,G] array once and are latency-bound with fewer resident workgroups
+        self.ksp_m, self.ksp_n = max(1, min(T // 8, -(-512 // max(Bp // 64, 1)))), max(1, min(T // 8, -(-512 // max(Bp // 128, 1))))
+        self.csp_m, self.csp_n = max(1, min(bt // 8, -(-512 // max(Gp // 64, 1)))), max(1, min(bt // 8, -(-512 // max(Gp // 128, 1))))
+        self._img = {}
+
+    def _operand(self, key: str):
+        """(hi, lo) operand image of dL / tP / tS: the bf16 tile array itself, or its split-bf16 pair in fp32 mode"""
+        if not self.grads_f32:
+            return self.S[key], None
+        if key not in self._img:
+            hi, lo = _bf16_image(self.wsg, f"dec_{key}_split", self.Bp, self.Gp, True)
+            _pack(self.S[key], hi, lo)
+            self._img[key] = (hi, lo)
+        return self._img[key]
+
+    def softmax(self):
+        _abi.call("spv_dec_softmax_bwd", C.byref(self.P), ptr(self.S["Tp"]), ptr(self.S["Ts"]), ptr(self.dz_part), stream_ptr())
+
+    def gemm_d(self):
+        (Wm_hi, Wm_lo), (dL_hi, dL_lo) = self.S["Wm"], self._operand("dL")
+        return _gemm_slabs(False, dL_hi, dL_lo, self.Gp, Wm_hi, Wm_lo, KMP, self.B, KMP, self.G, self.nsplit, self.ksp_m, self.wsg, "dec_dAm", a_tiles=self.T)
+
+    def gemm_bc(self):
+        (Aps_hi, Aps_lo), (tP_hi, tP_lo), (tS_hi, tS_lo) = self.S["Aps"], self._operand("tP"), self._operand("tS")
+        b = _gemm_slabs(True, tP_hi, tP_lo, self.Gp, Aps_hi, Aps_lo, DEC_KPS, self.G, DEC_KP, self.Bp, self.nsplit, self.csp_n, self.wsg, "dec_dWp", a_tiles=self.T)
+        c = _gemm_slabs(True, tS_hi, tS_lo, self.Gp, Aps_hi, Aps_lo, DEC_KPS, self.G, DEC_KS, self.Bp, self.nsplit, self.csp_n, self.wsg, "dec_dWs",
+                        b_col_off=DEC_KP, a_tiles=self.T)
+        return b, c
+
+    def gemm_a(self):
+        (Am_hi, Am_lo), (dL_hi, dL_lo) = self.S["Am"], self._operand("dL")
+        return _gemm_slabs(True, dL_hi, dL_lo, self.Gp, Am_hi, Am_lo, KMP, self.G, KMP, self.Bp, self.nsplit, self.csp_m, self.wsg, "dec_dWm", a_tiles=self.T)
+
+    def gemm_ef(self):
+        (tP_hi, tP_lo), (tS_hi, tS_lo) = self._operand("tP"), self._operand("tS")
+        e = _gemm_slabs(False, tP_hi, tP_lo, self.Gp, self.Wps_g[0], self.Wps_g[1], DEC_KPS, self.B, DEC_KP, self.G, self.nsplit, self.ksp_n, self.wsg, "dec_dAp", a_tiles=self.T)
+        f = _gemm_slabs(False, tS_hi, tS_lo, self.Gp, self.Wps_g[0], self.Wps_g[1], DEC_KPS, self.B, DEC_KS, self.G, self.nsplit, self.ksp_n, self.wsg, "dec_dAs",
+                        b_col_off=DEC_KP, a_tiles=self.T)
+        return e, f
 
 
 class DecoderFused(torch.autograd.Function):
@@ -302,77 +320,85 @@ class DecoderFused(torch.autograd.Function):
         red.nprob = red2.nprob = 0
         dWp, dWs = [new(Gs[g], DEC_KP) for g in range(NG)], [new(Gs[g], DEC_KS) for g in range(NG)]
         dAm, d_zcat = [new(B, n_m) for _ in range(NG)], [new(B, nt) for _ in range(NG)]
-        late, late_bc = [], []
-        streams = group_streams(dev, NG)  # (measured: also forking the dL GEMMs onto their own streams is slower)
+        # ---- schedule ---------------------------------------------------------------------------------------------
+        # group g's softmax fix and d A_m GEMM on group stream g; the regressor weight-gradient GEMMs (first needed by the
+        # BatchNorm-fold backward, which sits behind the ~15 small launches of the trunk backward) and then the
+        # mixture-weight GEMMs (which feed only the optimiser) on the side stream, beside the trunk / PoE / encoder-tail
+        # backward chain; the side stream is joined at the end of the backward pass (train.Trainer, DEFER_JOIN) or before
+        # returning.  Same-box A/B: SPV_DEFER_BC 1.90 -> 1.82 ms.  (Measured and left out: running the softmax fix BESIDE
+        # the d A_m GEMM + trunk backward instead of ahead of them, +0.01 ms.)
+        cur = torch.cuda.current_stream(dev)
+        streams = group_streams(dev, NG)
+        side = group_streams(dev, 3)[2] if _ops.DEFER_WM else cur
+        stages = [_DecoderBwd(g, ctx.P[g], ctx.saved_g[g], ctx.Wps[g], ws[g], B, Bp, Gs[g], Gps[g], nsplit, ctx.grads_f32) for g in range(NG)]
+        d_slabs, bc_slabs, ef_slabs = [None] * NG, [None] * NG, [None] * NG
         fork(streams)
         for g in range(NG):
-          with torch.cuda.stream(streams[g]):
-              G, Gp, wsg, S, P = Gs[g], Gps[g], ws[g], ctx.saved_g[g], ctx.P[g]
-              W = _decoder_bwd_launches(g, P, S, ctx.Wps[g], wsg, B, Bp, G, Gp, nsplit, ctx.grads_f32)
-              late.append(W["late"])
-              fused_dz, dz_part, ksp_m, ksp_n, csp_n = W["fused_dz"], W["dz_part"], W["ksp_m"], W["ksp_n"], W["csp_n"]
-              d = W["d"]
-              # slab sums, scaled by the upstream gradient, straight into their consumers' buffers
-              al = g_loss
-              dwp, dws_, dam, dz = dWp[g], dWs[g], dAm[g], d_zcat[g]
-              if "bc" in W:
-                  late_bc.append((g, W["bc"], csp_n))
-              else:
-                  _add_red(red, W["b"], csp_n, G * DEC_KP, DEC_KP, G, DEC_KP, dwp, DEC_KP, alpha=al)            # d [W'_p | c_p]
-                  _add_red(red, W["c"], csp_n, G * DEC_KS, DEC_KS, G, DEC_KS, dws_, DEC_KS, alpha=al)           # d [W'_s | c_s]
-              _add_red(red, d, ksp_m, B * KMP, KMP, B, n_m, dam, n_m, alpha=al)                                 # d m (trunk output)
-              # gradient reaching zcat directly: through the logits GEMM (columns n_m..) and the two regressors
-              _add_red(red, d, ksp_m, B * KMP, KMP, B, nt, dz, nt, col_off=n_m, alpha=al)
-              if fused_dz:
-                  _add_red(red2, dz_part, P.gene_splits, Bp * DEC_KPS, DEC_KPS, B, n_p, dz, nt, accumulate=True, alpha=al)
-                  _add_red(red2, dz_part, P.gene_splits, Bp * DEC_KPS, DEC_KPS, B, n_s, dz, nt, col_off=DEC_KP, dst_col=n_p, accumulate=True, alpha=al)
-              else:
-                  _add_red(red2, W["e"], ksp_n, B * DEC_KP, DEC_KP, B, n_p, dz, nt, accumulate=True, alpha=al)
-                  _add_red(red2, W["f"], ksp_n, B * DEC_KS, DEC_KS, B, n_s, dz, nt, dst_col=n_p, accumulate=True, alpha=al)
-              # d px_r = exp(px_r) * d theta (theta = exp(px_r): module/spVIPESmodule.py:758)
-              _add_red(red, S["dth"], Bp // 64, Gp, Gp, 1, G, pg[g][12][0], G, alpha=al, exp_scale=par[g][12])
+            with torch.cuda.stream(streams[g]):
+                stages[g].softmax()
+                d_slabs[g] = stages[g].gemm_d()
+                if not _ops.DEFER_BC:
+                    bc_slabs[g] = stages[g].gemm_bc()
+                if not stages[g].fused_dz:
+                    ef_slabs[g] = stages[g].gemm_ef()
         join(streams)
+        if _ops.DEFER_WM:
+            side.wait_stream(cur)   # (before the reductions: the side work needs none of them)
+        # slab sums, scaled by the upstream gradient, straight into their consumers' buffers
+        al = g_loss
+        for g in range(NG):
+            st, G, Gp = stages[g], Gs[g], Gps[g]
+            if bc_slabs[g] is not None:
+                _add_red(red, bc_slabs[g][0], st.csp_n, G * DEC_KP, DEC_KP, G, DEC_KP, dWp[g], DEC_KP, alpha=al)      # d [W'_p | c_p]
+                _add_red(red, bc_slabs[g][1], st.csp_n, G * DEC_KS, DEC_KS, G, DEC_KS, dWs[g], DEC_KS, alpha=al)      # d [W'_s | c_s]
+            _add_red(red, d_slabs[g], st.ksp_m, B * KMP, KMP, B, n_m, dAm[g], n_m, alpha=al)                          # d m (trunk output)
+            # gradient reaching zcat directly: through the logits GEMM (columns n_m..) and the two regressors
+            _add_red(red, d_slabs[g], st.ksp_m, B * KMP, KMP, B, nt, d_zcat[g], nt, col_off=n_m, alpha=al)
+            if st.fused_dz:
+                _add_red(red2, st.dz_part, st.P.gene_splits, Bp * DEC_KPS, DEC_KPS, B, n_p, d_zcat[g], nt, accumulate=True, alpha=al)
+                _add_red(red2, st.dz_part, st.P.gene_splits, Bp * DEC_KPS, DEC_KPS, B, n_s, d_zcat[g], nt, col_off=DEC_KP, dst_col=n_p, accumulate=True, alpha=al)
+            else:
+                _add_red(red2, ef_slabs[g][0], st.ksp_n, B * DEC_KP, DEC_KP, B, n_p, d_zcat[g], nt, accumulate=True, alpha=al)
+                _add_red(red2, ef_slabs[g][1], st.ksp_n, B * DEC_KS, DEC_KS, B, n_s, d_zcat[g], nt, dst_col=n_p, accumulate=True, alpha=al)
+            # d px_r = exp(px_r) * d theta (theta = exp(px_r): module/spVIPESmodule.py:758)
+            _add_red(red, ctx.saved_g[g]["dth"], Bp // 64, Gp, Gp, 1, G, pg[g][12][0], G, alpha=al, exp_scale=par[g][12])
         gk = None
         if ctx.n_kl:  # d loss / d kl_i[b] = g * kl_weight / B for every KL vector: rides in the second reduction launch
             gk = new(B)
             _add_red(red2, ctx.gkl, 1, B, B, 1, B, gk, B, alpha=g_loss)
-        side = group_streams(dev, 3)[2] if _ops.DEFER_WM else torch.cuda.current_stream(dev)
-        if _ops.DEFER_WM:
-            side.wait_stream(torch.cuda.current_stream(dev))   # (before the reductions: the side work needs none of them)
         _run_red(red)
         _run_red(red2)
-        # The mixture-weight gradients (2 x [G, K_M] from dL^T A_m, the largest GEMMs of the backward) feed nothing but the
-        # optimiser: they go to a side stream that starts here, i.e. runs beside the ~30 tiny kernels of the trunk / PoE /
-        # encoder-tail backward that follow and leave the GPU almost empty, and is joined at the end of the backward pass.
+        # side stream: the regressor weight gradients (the main stream picks them up with an event before
+        # spv_bn_fold_bwd), then the mixture-weight gradients (2 x [G, K_M] from dL^T A_m, the largest GEMMs of the backward
+        # pass, which feed nothing but the optimiser)
         bc_done = None
         with torch.cuda.stream(side):
-            if late_bc:
-                # the regressor weight gradients first: the main stream picks them up (event) before spv_bn_fold_bwd
+            if _ops.DEFER_BC:
                 red_bc = SpvReduceBatch()
                 red_bc.nprob = 0
-                for (g, bc, csp_n) in late_bc:
-                    G = Gs[g]
-                    b_, c = bc()
-                    _add_red(red_bc, b_, csp_n, G * DEC_KP, DEC_KP, G, DEC_KP, dWp[g], DEC_KP, alpha=g_loss)
-                    _add_red(red_bc, c, csp_n, G * DEC_KS, DEC_KS, G, DEC_KS, dWs[g], DEC_KS, alpha=g_loss)
+                for g in range(NG):
+                    st, G = stages[g], Gs[g]
+                    b_, c = st.gemm_bc()
+                    _add_red(red_bc, b_, st.csp_n, G * DEC_KP, DEC_KP, G, DEC_KP, dWp[g], DEC_KP, alpha=g_loss)
+                    _add_red(red_bc, c, st.csp_n, G * DEC_KS, DEC_KS, G, DEC_KS, dWs[g], DEC_KS, alpha=g_loss)
                 _run_red(red_bc)
-                if side is not torch.cuda.current_stream(dev) and _ops.DEFER_WM:
+                if side is not cur:
                     bc_done = torch.cuda.Event()
                     bc_done.record(side)
             red3 = SpvReduceBatch()
             red3.nprob = 0
-            for (g, dL_hi, dL_lo, Am_hi, Am_lo, csp_m, T) in late:
-                G, Gp = Gs[g], Gps[g]
-                a = _gemm_slabs(True, dL_hi, dL_lo, Gp, Am_hi, Am_lo, KMP, G, KMP, Bp, nsplit, csp_m, ws[g], "dec_dWm", a_tiles=T)
-                _add_red(red3, a, csp_m, G * KMP, KMP, G, KM - 1, pg[g][10][0], KM - 1, alpha=g_loss)                 # d W_m
-                _add_red(red3, a, csp_m, G * KMP, KMP, G, 1, pg[g][11][0], 1, col_off=KM - 1, alpha=g_loss)           # d b_m
+            for g in range(NG):
+                st, G = stages[g], Gs[g]
+                a = st.gemm_a()
+                _add_red(red3, a, st.csp_m, G * KMP, KMP, G, KM - 1, pg[g][10][0], KM - 1, alpha=g_loss)                 # d W_m
+                _add_red(red3, a, st.csp_m, G * KMP, KMP, G, 1, pg[g][11][0], 1, col_off=KM - 1, alpha=g_loss)           # d b_m
             _run_red(red3)
         if not _ops.DEFER_WM:
             pass
         elif _ops.DEFER_JOIN:
             _ops.defer(side, [g_loss])
         else:
-            torch.cuda.current_stream(dev).wait_stream(side)
+            cur.wait_stream(side)
         # ---- trunk backward (BatchNorm + relu, Linear) ----------------------------------------------
         nblk = -(-B // _abi.BN_ROWS)
         d_pre = [new(B, n_m) for _ in range(NG)]
@@ -408,7 +434,7 @@ class DecoderFused(torch.autograd.Function):
                 q.dz, q.lddz = _fptr(d_zcat[g], zoff), nt
                 i += 1
         if bc_done is not None:
-            torch.cuda.current_stream(dev).wait_event(bc_done)
+            cur.wait_event(bc_done)
         _abi.call("spv_bn_fold_bwd", C.byref(fb), stream_ptr())
         # ---- latent slicing backward ------------------------------------------------------------------
         d_priv, d_poe = [new(B, n_p) for _ in range(NG)], [new(B, n_s) for _ in range(NG)]
