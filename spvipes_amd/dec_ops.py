@@ -66,10 +66,11 @@ class _DecoderBwd:
         self.dz_part = wsg.get("dec_dz_part", (P.gene_splits, Bp, DEC_KPS), torch.float32) if self.fused_dz else None
         self.T = T = Gp // 32
         bt = Bp // 32
-        # K splits (fp32 slabs, reduced in order by spv_reduce_slabs) sized for >= ~2 workgroups per CU: these
-        # GEMMs stream a [B,G] array once and are latency-bound with fewer resident workgroups
-        self.ksp_m, self.ksp_n = max(1, min(T // 8, -(-512 // max(Bp // 64, 1)))), max(1, min(T // 8, -(-512 // max(Bp // 128, 1))))
-        self.csp_m, self.csp_n = max(1, min(bt // 8, -(-512 // max(Gp // 64, 1)))), max(1, min(bt // 8, -(-512 // max(Gp // 128, 1))))
+        # K splits (fp32 slabs, reduced in order by spv_reduce_slabs).  The 320-column GEMMs (d A_m, d W_m) get ~1 workgroup
+        # per CU: every extra split adds a [M, 320] fp32 slab to write and to re-read (at C2 8 -> 4 and 4 -> 2 splits:
+        # -0.05 ms per step, same-box A/B); the narrow ones (16 / 32 columns) stream their [B,G] operand with ~2 per CU
+        self.ksp_m, self.ksp_n = max(1, min(T // 8, -(-256 // max(Bp // 64, 1)))), max(1, min(T // 8, -(-512 // max(Bp // 128, 1))))
+        self.csp_m, self.csp_n = max(1, min(bt // 8, -(-256 // max(Gp // 64, 1)))), max(1, min(bt // 8, -(-512 // max(Gp // 128, 1))))
         self._img = {}
 
     def _operand(self, key: str):
