@@ -200,7 +200,11 @@ extern "C" int spv_enc_fc1_wgrad(const spv_counts* x, int32_t B, int32_t G, cons
   if (xb != nullptr) {  // resident bf16 log1p(x) of the data set (spv_prepare_log1p): gathered plain k-major operand, no decode
     if (nsplit != 1 || ld_xb < ((G + 63) & ~63) || (ld_xb % 8)) return fail(SPV_ERR_ARG, "spv_enc_fc1_wgrad: xb needs nsplit 1 and ld_xb >= round_up(G, 64)%s");
     p.B = xb; p.ldb = ld_xb;
-    rc = launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_GATHER, unsigned short, 1, 64, 4>>(p, 1, s);
+    // 96-gene tiles when the image rows are padded that far: at G = 10 000 that is 2 x 105 workgroups per group, so the two
+    // groups' GEMMs (two streams) are resident together in one round instead of 2 x 314 workgroups in two (-0.04 ms per
+    // step; alone the 64-gene tile is 4 us faster)
+    if (ld_xb >= (G + 95) / 96 * 96) rc = launch_gemm<GemmCfg<128, 96, 4, 1, true, true, SRC_PLAIN, SRC_GATHER, unsigned short, 1, 64, 4>>(p, 1, s);
+    else rc = launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_GATHER, unsigned short, 1, 64, 4>>(p, 1, s);
   } else if (x->dtype == SPV_COUNT_U16) {
     rc = (nsplit == 3) ? launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_COUNTS, unsigned short, 3, 64, 4>>(p, 1, s)
                        : launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_COUNTS, unsigned short, 1, 64, 4>>(p, 1, s);

@@ -51,10 +51,10 @@ class GroupCounts:
         return self.X.shape[0]
 
     def log1p_image(self):
-        """(bf16 log1p(x) of every cell [n_cells][round_up(G, 128)], library = log(sum_g log1p(x)) per cell), built on first use
+        """(bf16 log1p(x) of every cell [n_cells][ld >= round_up(G, 96), multiple of 128], library = log(sum_g log1p(x)) per cell), built on first use
         by spv_prepare_log1p: the same arithmetic the reference does per minibatch (module/spVIPESmodule.py:428-435)."""
         if self._xb is None:
-            ld = round_up(self.G, 128)
+            ld = round_up(round_up(self.G, 96), 128)   # (96: the gene tile of the fc1 weight-gradient GEMM)
             xb = torch.empty((self.n_cells, ld), dtype=torch.int16, device=self.X.device)
             lib = torch.empty((self.n_cells,), dtype=torch.float32, device=self.X.device)
             cs = self.c_struct(None)
