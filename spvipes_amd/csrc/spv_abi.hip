@@ -616,6 +616,8 @@ extern "C" int spv_bn_fold_fwd(const spv_fold_batch* a, void* stream) {
   for (int i = 0; i < a->nprob; ++i) {
     const spv_fold_prob& q = a->p[i];
     if (!q.img_hi || !q.img_lo || q.slot < q.K + 1 || q.col_off + q.slot > q.ld_img) return fail(SPV_ERR_ARG, "spv_bn_fold_fwd: bad image slot%s");
+    if ((q.slot | q.col_off | q.ld_img) % 8 || ((reinterpret_cast<uintptr_t>(q.img_hi) | reinterpret_cast<uintptr_t>(q.img_lo)) & 15))
+      return fail(SPV_ERR_ARG, "spv_bn_fold_fwd: slot, col_off, ld_img must be multiples of 8 elements and the images 16-byte aligned%s");
     gmax = q.Gp > gmax ? q.Gp : gmax;
   }
   hipLaunchKernelGGL(bn_fold_fwd_kernel, dim3((gmax + 255) / 256, a->nprob), dim3(256), 0, (hipStream_t)stream, *a);

@@ -826,18 +826,26 @@ __global__ __launch_bounds__(256) void bn_fold_fwd_kernel(FoldBatch a) {
   bf16_t* hi = q.img_hi + (long)g * q.ld_img + q.col_off;
   bf16_t* lo = q.img_lo + (long)g * q.ld_img + q.col_off;
   if (g >= q.G) {
-    for (int k = 0; k < q.slot; ++k) { hi[k] = 0; lo[k] = 0; }
+    for (int k8 = 0; k8 < q.slot; k8 += 8) { *reinterpret_cast<u4v*>(hi + k8) = u4v{0u, 0u, 0u, 0u}; *reinterpret_cast<u4v*>(lo + k8) = u4v{0u, 0u, 0u, 0u}; }
     return;
   }
   const float* w = q.W + (long)g * K;  // K <= 32 floats, L1-resident: re-read instead of a runtime-indexed register array
   float mean, var;
   if (a.training) {
     mean = 0.f; var = 0.f;
-    for (int k = 0; k < K; ++k) {
-      mean += w[k] * s_zbar[k];
-      float v = 0.f;
-      for (int l = 0; l < K; ++l) v += s_C[k * K + l] * w[l];
-      var += w[k] * v;
+    for (int k = 0; k < K; ++k) mean += w[k] * s_zbar[k];
+    for (int k0 = 0; k0 < K; k0 += 4) {   // four rows of C at a time: independent chains, one read of w[l] for the four
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      int row[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) row[u] = min(k0 + u, K - 1) * K;
+      for (int l = 0; l < K; ++l) {
+        const float wl = w[l];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] += s_C[row[u] + l] * wl;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) var += (k0 + u < K) ? w[k0 + u] * v[u] : 0.f;
     }
     var = fmaxf(var, 0.f);
     q.running_mean[g] = (1.f - a.momentum) * q.running_mean[g] + a.momentum * mean;
@@ -847,11 +855,20 @@ __global__ __launch_bounds__(256) void bn_fold_fwd_kernel(FoldBatch a) {
   }
   const float inv = q.gamma[g] * rsqrtf(var + a.eps);
   q.stat[2 * g] = mean; q.stat[2 * g + 1] = var;
-  for (int k = 0; k < q.slot; ++k) {
-    const float v = (k < K) ? w[k] * inv : (k == K ? q.beta[g] - mean * inv : 0.f);
-    bf16_t h, l;
-    split_bf16(v, h, l);
-    hi[k] = h; lo[k] = l;
+  const float cg = q.beta[g] - mean * inv;
+  for (int k8 = 0; k8 < q.slot; k8 += 8) {   // slot, ld_img and col_off are multiples of 8 elements: one 16-byte store per image
+    unsigned hw[4], lw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bf16_t h0, l0, h1, l1;
+      const int ka = k8 + 2 * j, kb = ka + 1;
+      split_bf16((ka < K) ? w[ka] * inv : (ka == K ? cg : 0.f), h0, l0);
+      split_bf16((kb < K) ? w[kb] * inv : (kb == K ? cg : 0.f), h1, l1);
+      hw[j] = (unsigned)h0 | ((unsigned)h1 << 16);
+      lw[j] = (unsigned)l0 | ((unsigned)l1 << 16);
+    }
+    *reinterpret_cast<u4v*>(hi + k8) = u4v{hw[0], hw[1], hw[2], hw[3]};
+    *reinterpret_cast<u4v*>(lo + k8) = u4v{lw[0], lw[1], lw[2], lw[3]};
   }
 }
 
@@ -859,7 +876,7 @@ __global__ __launch_bounds__(256) void bn_fold_fwd_kernel(FoldBatch a) {
 // per-block partial sums of d zbar [K] and d C [K][K]
 __global__ __launch_bounds__(256) void bn_fold_bwd_kernel(FoldBatch a) {
   const FoldProb& q = a.p[blockIdx.y];
-  __shared__ float s_zbar[FOLD_KMAX], s_C[FOLD_KMAX * FOLD_KMAX], s_w[256 * FOLD_KMAX], s_dm[256], s_dv[256];
+  __shared__ float s_zbar[FOLD_KMAX], s_C[FOLD_KMAX * FOLD_KMAX], s_w[256 * FOLD_KMAX], s_dm[256], s_dv[256], s_acc[3][17][64];
   const int K = q.K;
   const int nred = K + K * K;
   if (blockIdx.x * 256 >= q.G) return;  // (the grid is sized for the largest problem)
@@ -886,10 +903,19 @@ __global__ __launch_bounds__(256) void bn_fold_bwd_kernel(FoldBatch a) {
     if (a.training) {
       dmean = -gc * inv;
       dvar = dinv * gam * (-0.5f) * rs * rs * rs;
-      for (int k = 0; k < K; ++k) {
-        float v = 0.f;
-        for (int l = 0; l < K; ++l) v += s_C[k * K + l] * w[l];
-        q.dW[(long)g * K + k] = gW[k] * inv + dmean * s_zbar[k] + 2.0f * dvar * v;
+      for (int k0 = 0; k0 < K; k0 += 4) {   // four rows of C at a time (independent chains)
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        int row[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) row[u] = min(k0 + u, K - 1) * K;
+        for (int l = 0; l < K; ++l) {
+          const float wl = w[l];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] += s_C[row[u] + l] * wl;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (k0 + u < K) q.dW[(long)g * K + k0 + u] = gW[k0 + u] * inv + dmean * s_zbar[k0 + u] + 2.0f * dvar * v[u];
       }
     } else {
       for (int k = 0; k < K; ++k) q.dW[(long)g * K + k] = gW[k] * inv;
@@ -899,15 +925,36 @@ __global__ __launch_bounds__(256) void bn_fold_bwd_kernel(FoldBatch a) {
   // block partials of d zbar[k] = sum_g dmean_g w_gk and d C[k][l] = sum_g dvar_g w_gk w_gl, summed in gene order
   s_dm[threadIdx.x] = dmean; s_dv[threadIdx.x] = dvar;
   __syncthreads();
-  for (int i = threadIdx.x; i < nred; i += 256) {
-    float acc = 0.f;
-    if (i < K) {
-      for (int t = 0; t < 256; ++t) acc += s_dm[t] * s_w[t * FOLD_KMAX + i];
-    } else {
-      const int k = (i - K) / K, l = (i - K) % K;
-      for (int t = 0; t < 256; ++t) acc += s_dv[t] * s_w[t * FOLD_KMAX + k] * s_w[t * FOLD_KMAX + l];
+  // One exact-fp32 MFMA tile per wave (v_mfma_f32_32x32x2_f32, two genes per step): dC = (dv . W)^T W is a
+  // [K x 256] x [256 x K] product and d zbar rides along as row 0 of a second tile; the four waves' tiles are added in
+  // wave order.  (The scalar form -- every thread a 256-term chain of LDS reads per output -- made this the longest
+  // kernel of the small-kernel backward chain.)
+  {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
+    f16v accC;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accC[i] = 0.f;
+    f16v accM = accC;
+    for (int t = 64 * wave; t < 64 * wave + 64; t += 2) {
+      const float wv = (r < K) ? s_w[(t + h) * FOLD_KMAX + r] : 0.f;
+      accC = mfma_f32(s_dv[t + h] * wv, wv, accC);
+      accM = mfma_f32((r == 0) ? s_dm[t + h] : 0.f, wv, accM);
     }
-    q.red_part[(long)blockIdx.x * nred + i] = acc;
+    if (wave > 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s_acc[wave - 1][i][lane] = accC[i];
+      s_acc[wave - 1][16][lane] = accM[0];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    float* out = q.red_part + (long)blockIdx.x * nred;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = crow(i, h);
+      const float v = ((accC[i] + s_acc[0][i][lane]) + s_acc[1][i][lane]) + s_acc[2][i][lane];
+      if (row < K && r < K) out[K + row * K + r] = v;
+    }
+    if (h == 0 && r < K) out[r] = ((accM[0] + s_acc[0][16][lane]) + s_acc[1][16][lane]) + s_acc[2][16][lane];
   }
 }
 
