@@ -115,6 +115,23 @@ def _pmc_traffic():
     return (float(f.group(1)) + float(w.group(1))) * 1024.0, "profiles/" + os.path.basename(files[-1]) + " (raw FETCH_SIZE + WRITE_SIZE, KiB -> bytes)"
 
 
+def _pmc_valu_busy():
+    """Fraction of the dominant kernel's cycles in which a SIMD issues VALU work, from the same committed --pmc passes:
+    SQ_ACTIVE_INST_VALU (quad-cycles summed over the 1024 SIMDs) * 4 / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs.  The
+    likelihood kernel is bound by VALU / transcendental issue, not by HBM: this, not `frac`, is how close it runs to its
+    own ceiling."""
+    import glob, re
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_dec_nb_kernel.txt")))
+    if not files:
+        return None
+    txt = open(files[-1]).read()
+    a = re.search(r"SQ_ACTIVE_INST_VALU\s+n=\s*\d+\s+avg=\s*([0-9.]+)", txt)
+    g = re.search(r"GRBM_GUI_ACTIVE\s+n=\s*\d+\s+avg=\s*([0-9.]+)", txt)
+    if not (a and g):
+        return None
+    return (float(a.group(1)) * 4.0 / 1024.0) / (float(g.group(1)) / 8.0)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -220,6 +237,7 @@ def main():
         roof = {"kernel": "dec_nb_kernel (spv_dec_nb_fwd)", "bound": "hbm", "achieved": nb_bytes / (nb_avg * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nb_bytes / (nb_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": traffic_src,
+                "valu_busy_frac": _pmc_valu_busy(),
                 "avg_launch_ms": nb_avg, "algorithmic_bytes_per_launch": nb_bytes,
                 "mfma_view": {"achieved_TFLOPs": nb_flops / (nb_avg * 1e-3) / 1e12, "peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS,
                               "frac": nb_flops / (nb_avg * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS},
