@@ -271,6 +271,8 @@ static int to_dec(const spv_dec_params* q, DecParams& p) {
   p.nb_splits = q->nb_splits; p.nb_genes_per_split = q->nb_genes_per_split;
   if (p.B <= 0 || p.G <= 0 || p.Bp < p.B || p.Gp < p.G || (p.Bp % DEC_CELLS_PER_WG) || (p.Gp % 32))
     return fail(SPV_ERR_ARG, "decoder: Bp must be a multiple of 128 and Gp of 32%s");
+  if ((long)p.Bp * p.Gp >= (1L << 30) || p.Gp >= (1 << 24))   // the likelihood kernel addresses its [Bp][Gp] arrays with 32-bit byte offsets
+    return fail(SPV_ERR_ARG, "decoder: Bp * Gp must stay below 2^30 elements (and Gp below 2^24)%s");
   if (p.gene_splits <= 0 || (p.genes_per_split % 32) || (long)p.gene_splits * p.genes_per_split < p.G)
     return fail(SPV_ERR_ARG, "decoder: gene splits must be multiples of 32 covering G%s");
   if (!p.Wps_hi || !p.Wps_lo || !p.Aps_hi || !p.Aps_lo) return fail(SPV_ERR_ARG, "decoder: missing packed regressor operands%s");

@@ -263,38 +263,49 @@ __device__ __forceinline__ float2 gamma_terms_fixup(const DecParams& p, int g, f
 // K = 292 contraction out of this kernel frees ~100 registers per lane, and this kernel is bound by
 // VALU/transcendental issue, which wants waves, not registers.
 template <typename GT>
-__device__ __forceinline__ void store4(void* base, long off, const float (&v)[4]);
+__device__ __forceinline__ void store4(void* base, size_t off, const float (&v)[4]);
 template <>
-__device__ __forceinline__ void store4<bf16_t>(void* base, long off, const float (&v)[4]) {
+__device__ __forceinline__ void store4<bf16_t>(void* base, size_t off, const float (&v)[4]) {
   u2v w;
   w[0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
   w[1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
   *reinterpret_cast<u2v*>(reinterpret_cast<bf16_t*>(base) + off) = w;
 }
 template <>
-__device__ __forceinline__ void store4<float>(void* base, long off, const float (&v)[4]) {
+__device__ __forceinline__ void store4<float>(void* base, size_t off, const float (&v)[4]) {
   *reinterpret_cast<f4v*>(reinterpret_cast<float*>(base) + off) = f4v{v[0], v[1], v[2], v[3]};
 }
 
 template <typename LT>
-__device__ __forceinline__ void load4(const void* base, long off, float (&v)[4]);
+__device__ __forceinline__ void load4(const void* base, size_t off, float (&v)[4]);
 template <>
-__device__ __forceinline__ void load4<_Float16>(const void* base, long off, float (&v)[4]) {
+__device__ __forceinline__ void load4<_Float16>(const void* base, size_t off, float (&v)[4]) {
   typedef __attribute__((ext_vector_type(4))) _Float16 h4v;
   const h4v x = *reinterpret_cast<const h4v*>(reinterpret_cast<const _Float16*>(base) + off);
 #pragma unroll
   for (int j = 0; j < 4; ++j) v[j] = (float)x[j];
 }
 template <>
-__device__ __forceinline__ void load4<bf16_t>(const void* base, long off, float (&v)[4]) {
+__device__ __forceinline__ void load4<bf16_t>(const void* base, size_t off, float (&v)[4]) {
   const u2v x = *reinterpret_cast<const u2v*>(reinterpret_cast<const bf16_t*>(base) + off);
   v[0] = bf2f(x[0] & 0xFFFF); v[1] = bf2f(x[0] >> 16); v[2] = bf2f(x[1] & 0xFFFF); v[3] = bf2f(x[1] >> 16);
 }
 template <>
-__device__ __forceinline__ void load4<float>(const void* base, long off, float (&v)[4]) {
+__device__ __forceinline__ void load4<float>(const void* base, size_t off, float (&v)[4]) {
   const f4v x = *reinterpret_cast<const f4v*>(reinterpret_cast<const float*>(base) + off);
 #pragma unroll
   for (int j = 0; j < 4; ++j) v[j] = x[j];
+}
+
+// the same with a 32-bit BYTE offset: base (uniform, SGPRs) + zero-extended VGPR offset is an addressing mode of the
+// global loads / stores, so no 64-bit address has to be computed per access
+template <typename T>
+__device__ __forceinline__ void store4b(void* base, unsigned elem_off, const float (&v)[4]) {
+  store4<T>(reinterpret_cast<char*>(base) + (size_t)(elem_off * (unsigned)sizeof(T)), 0, v);
+}
+template <typename T>
+__device__ __forceinline__ void load4b(const void* base, unsigned elem_off, float (&v)[4]) {
+  load4<T>(reinterpret_cast<const char*>(base) + (size_t)(elem_off * (unsigned)sizeof(T)), 0, v);
 }
 
 // sum of v[q] over the 32 lanes of a wave half for all 16 q at once ("transposing" butterfly,
@@ -389,11 +400,16 @@ __global__ __launch_bounds__(256, 3) void dec_nb_kernel(DecParams p) {
     float rec = 0.f, tp_sum = 0.f, ts_sum = 0.f;
     // storage offset of this lane inside a 32x32 tile for gene half gh: qq = 2 gh + (gq >> 1), h = gq & 1
     const int lane_st = (16 * chh + c16 + 32 * (gq & 1)) * 4 + (gq >> 1) * 256;
-    const long tile_row = (long)cell_tile * p.n_gene_tiles;
-    auto tile_off = [&](int g0) { return (tile_row + (g0 >> 5)) * 1024 + ((g0 >> 4) & 1) * 512 + lane_st; };
+    // 32-bit element offsets (Bp * Gp < 2^31 is checked by the host): with the array base in SGPRs the loads / stores take
+    // a 32-bit VGPR offset and the per-chunk 64-bit address arithmetic disappears
+    const unsigned tile_row = (unsigned)cell_tile * (unsigned)p.n_gene_tiles;
+    auto tile_off = [&](int g0) { return (tile_row + (unsigned)(g0 >> 5)) * 1024u + (unsigned)(((g0 >> 4) & 1) * 512 + lane_st); };
     auto gather_tab = [&](const float (&c)[4], int g0, float2 (&tab)[4]) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) tab[j] = p.cnt_tab[(long)(int)fminf(c[j], (float)(NB_CMAX - 1)) * p.Gp + g0 + 4 * gq + j];
+      for (int j = 0; j < 4; ++j) {
+        const unsigned eo = __umul24((unsigned)(int)fminf(c[j], (float)(NB_CMAX - 1)), (unsigned)p.Gp) + (unsigned)(g0 + 4 * gq + j);   // (Gp < 2^24)
+        tab[j] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(p.cnt_tab) + (size_t)(eo * 8u));
+      }
     };
 
     // software pipeline: counts two chunks ahead (undecoded), logits and (count, gene) table rows one chunk ahead;
@@ -401,7 +417,7 @@ __global__ __launch_bounds__(256, 3) void dec_nb_kernel(DecParams p) {
     RawCounts<CM> rawA = load_counts4_raw<CM>(p, row_of_cell, gbeg + 4 * gq, cell_ok), rawB = rawA, rawC = rawA;
     float ellA[4];
     float2 tabA[4];
-    load4<LT>(p.logits, tile_off(gbeg), ellA);
+    load4b<LT>(p.logits, tile_off(gbeg), ellA);
     if (nchunks > 1) rawB = load_counts4_raw<CM>(p, row_of_cell, gbeg + 16 + 4 * gq, cell_ok);
     {
       float c0[4];
@@ -411,7 +427,7 @@ __global__ __launch_bounds__(256, 3) void dec_nb_kernel(DecParams p) {
 
     for (int c = 0; c < nchunks; ++c) {
       const int g0 = gbeg + 16 * c;
-      const long toff = tile_off(g0);
+      const unsigned toff = tile_off(g0);
       // ---- y_p, y_s for this chunk: A[row = gene][k = 8 gq + i] from the LDS slice ------------------------------
       const int wrow = (16 * c + c16) * NB_WPITCH + 8 * gq;
       const s8v wp_hi = *reinterpret_cast<const s8v*>(s_whi + wrow), wp_lo = *reinterpret_cast<const s8v*>(s_wlo + wrow);
@@ -428,7 +444,7 @@ __global__ __launch_bounds__(256, 3) void dec_nb_kernel(DecParams p) {
       float ellB[4];
       float2 tabB[4];
       rawC = load_counts4_raw<CM>(p, row_of_cell, g2 + 4 * gq, cell_ok);
-      load4<LT>(p.logits, tile_off(g1), ellB);
+      load4b<LT>(p.logits, tile_off(g1), ellB);
       {
         float cB[4];
         decode_counts4<CM>(p, rawB, row_of_cell, g1 + 4 * gq, cell_ok, cB);
@@ -494,9 +510,9 @@ __global__ __launch_bounds__(256, 3) void dec_nb_kernel(DecParams p) {
         }
       }
       if constexpr (TRAIN) {
-        store4<GT>(p.dL, toff, o_dl);
-        store4<GT>(p.tP, toff, o_tp);
-        store4<GT>(p.tS, toff, o_ts);
+        store4b<GT>(p.dL, toff, o_dl);
+        store4b<GT>(p.tP, toff, o_tp);
+        store4b<GT>(p.tS, toff, o_ts);
         // per-gene sums over this wave's 16 cells (lanes sharing gq): 4 values x 16 lanes -> lane keeps gene 2*b3 + b2
         const bool u3 = lane & 8, u2 = lane & 4;
         const float a0 = (u3 ? dth4[2] : dth4[0]) + __shfl_xor(u3 ? dth4[0] : dth4[2], 8, 64);
