@@ -465,9 +465,9 @@ __global__ __launch_bounds__(256, 3) void dec_nb_kernel(DecParams p) {
         const float F = tabA[j].x, Psi = tabA[j].y;
         const float el_ = ellA[j];
         const float mu1 = fast_exp(yp[j] + ap), mu2 = fast_exp(ys[j] + as_);
-        const float S1 = theta + mu1 + SPV_EPS_NB, S2 = theta + mu2 + SPV_EPS_NB;
-        const float L1 = fast_log(S1), L2 = fast_log(S2);
         const float e1 = mu1 + SPV_EPS_NB, e2 = mu2 + SPV_EPS_NB;
+        const float S1 = theta + e1, S2 = theta + e2;   // theta + mu + eps (one add fewer per component than the left-to-right sum)
+        const float L1 = fast_log(S1), L2 = fast_log(S2);
         const float nb1 = theta * (lt - L1) + x * (fast_log(e1) - L1);
         const float v2 = theta * (lt - L2) + x * (fast_log(e2) - L2) - el_;
         const float d = nb1 - v2, M = fmaxf(nb1, v2);
