@@ -45,7 +45,7 @@ struct DecParams {
   const bf16_t* Wps_hi; const bf16_t* Wps_lo;                         // [Gp][48]   W'_p|c_p|0.. W'_s|c_s|0..
   const bf16_t* Aps_hi; const bf16_t* Aps_lo;                         // [Bp][48]   z_p|1|0..   z_s|1|0..
   // per gene / per cell vectors
-  const float4* gene_tab;       // [Gp] {theta, log(theta+eps), 1/(theta+eps), 0}
+  const float4* gene_tab;       // [Gp] {theta, log(theta+eps), 1/(theta+eps), theta * log(theta+eps)}
   const float2* cnt_tab;        // [NB_CMAX][Gp] {F, Psi}
   const float* a_p; const float* a_s;   // [Bp] library - lse_k
   const float* lse_p; const float* lse_s;
@@ -71,7 +71,8 @@ __global__ void nb_tables_kernel(const float* px_r, int G, int Gp, float4* gene_
   }
   const float theta = fast_exp(px_r[g]);  // px_r = exp(param), module/spVIPESmodule.py:758
   if (c == 0) {
-    gene_tab[g] = make_float4(theta, fast_log(theta + SPV_EPS_NB), fast_rcp(theta + SPV_EPS_NB), 0.f);
+    const float lt = fast_log(theta + SPV_EPS_NB);
+    gene_tab[g] = make_float4(theta, lt, fast_rcp(theta + SPV_EPS_NB), theta * lt);
     cnt_tab[g] = make_float2(0.f, 0.f);  // x = 0: lgamma terms cancel exactly
     return;
   }
@@ -345,6 +346,7 @@ __device__ __forceinline__ float half_sum16(const float (&v)[16], int lane) {
 // per lane is live -- no 32-register tile to carry, no rotation -- and the next chunk's counts / logits are
 // fetched while this one is evaluated.  The [cells][genes] arrays stay in the 32x32 accumulator-tile order.
 typedef __attribute__((ext_vector_type(4))) float f4acc;
+constexpr float NB_LN2 = 0.6931471805599453f, NB_LOG2E = 1.4426950408889634f;
 constexpr int NB_GSPL_MAX = 160;     // genes per split: their regressor weights (hi/lo) and gene table live in LDS
 constexpr int NB_WPITCH = 56;        // LDS row pitch of the weight slice in bf16 (112 B: conflict-free 16-B row reads)
 constexpr int NB_CELLS_PER_WG = 64;  // 4 waves x one 16-cell tile
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(256, 3) void dec_nb_kernel(DecParams p) {
       for (int i = 0; i < 8; ++i) { bp_hi[i] = 0; bp_lo[i] = 0; }
     }
     const s8v bs_hi = *reinterpret_cast<const s8v*>(p.Aps_hi + aoff + DEC_KP), bs_lo = *reinterpret_cast<const s8v*>(p.Aps_lo + aoff + DEC_KP);
-    const float ap = p.a_p[cell], as_ = p.a_s[cell];
+    const float ap2 = p.a_p[cell] * NB_LOG2E, as2 = p.a_s[cell] * NB_LOG2E;   // a_k = library - lse_k, in base-2 units
     const float w = p.w_row[cell];
     const long row_of_cell = cell_ok ? (p.rows ? (long)p.rows[cell] : (long)cell) : 0;
     float rec = 0.f, tp_sum = 0.f, ts_sum = 0.f;
@@ -459,32 +461,36 @@ __global__ __launch_bounds__(256, 3) void dec_nb_kernel(DecParams p) {
         const int g = gq0 + j;
         const bool ok = cell_ok && (g < p.G);
         const float4 gt = s_gt[g - gbeg];
-        const float theta = gt.x, lt = gt.y, ith = gt.z;
+        // The hardware exp / log are base 2: the kernel keeps L_k = log2(theta + mu_k + eps) and log2(mu_k + eps) in base 2
+        // and folds the ln 2 into the few places that need natural units (the kernel is bound by VALU issue):
+        //   nb_k = theta (lt - ln S_k) + x (ln e_k - ln S_k) = theta lt + ln2 * (x log2 e_k - (theta + x) log2 S_k)
+        const float theta = gt.x, lt = gt.y, ith = gt.z, thlt = gt.w;
         const float cj = cntA[j];
         const float x = log1p_count(cj);
         const float F = tabA[j].x, Psi = tabA[j].y;
         const float el_ = ellA[j];
-        const float mu1 = fast_exp(yp[j] + ap), mu2 = fast_exp(ys[j] + as_);
+        const float mu1 = __builtin_amdgcn_exp2f(fmaf(yp[j], NB_LOG2E, ap2)), mu2 = __builtin_amdgcn_exp2f(fmaf(ys[j], NB_LOG2E, as2));
         const float e1 = mu1 + SPV_EPS_NB, e2 = mu2 + SPV_EPS_NB;
         const float S1 = theta + e1, S2 = theta + e2;   // theta + mu + eps (one add fewer per component than the left-to-right sum)
-        const float L1 = fast_log(S1), L2 = fast_log(S2);
-        const float nb1 = theta * (lt - L1) + x * (fast_log(e1) - L1);
-        const float v2 = theta * (lt - L2) + x * (fast_log(e2) - L2) - el_;
+        const float L1 = __builtin_amdgcn_logf(S1), L2 = __builtin_amdgcn_logf(S2);   // base 2
+        const float thx = theta + x;
+        const float nb1 = fmaf(NB_LN2, fmaf(x, __builtin_amdgcn_logf(e1), -thx * L1), thlt);
+        const float v2 = fmaf(NB_LN2, fmaf(x, __builtin_amdgcn_logf(e2), -thx * L2), thlt - el_);
         const float d = nb1 - v2, M = fmaxf(nb1, v2);
-        const float ed = fast_exp(-fabsf(d)), el = fast_exp(-fabsf(el_));
+        const float ed = __builtin_amdgcn_exp2f(-fabsf(d) * NB_LOG2E), el = __builtin_amdgcn_exp2f(-fabsf(el_) * NB_LOG2E);
         const float iol = fast_rcp(1.0f + el);
-        const float logp = M - fmaxf(-el_, 0.f) + fast_log((1.0f + ed) * iol) + F;
+        const float logp = fmaf(NB_LN2, __builtin_amdgcn_logf((1.0f + ed) * iol), M - fmaxf(-el_, 0.f) + F);
         rec -= ok ? logp : 0.f;
         if constexpr (TRAIN) {
           const float iod = fast_rcp(1.0f + ed);
           const float r1 = (d >= 0.f) ? iod : ed * iod, r2 = 1.0f - r1;
           const float sig = (el_ <= 0.f) ? iol : el * iol;  // sigmoid(-logit)
           const float iS1 = fast_rcp(S1), iS2 = fast_rcp(S2);
-          const float g1 = x * mu1 * fast_rcp(e1) - (theta + x) * mu1 * iS1;
-          const float g2 = x * mu2 * fast_rcp(e2) - (theta + x) * mu2 * iS2;
+          const float g1 = x * mu1 * fast_rcp(e1) - thx * mu1 * iS1;
+          const float g2 = x * mu2 * fast_rcp(e2) - thx * mu2 * iS2;
           const float t1 = r1 * g1, t2 = r2 * g2;
-          const float dn1 = (lt - L1) + theta * (ith - iS1) - x * iS1;
-          const float dn2 = (lt - L2) + theta * (ith - iS2) - x * iS2;
+          const float dn1 = fmaf(-NB_LN2, L1, lt) + theta * (ith - iS1) - x * iS1;
+          const float dn2 = fmaf(-NB_LN2, L2, lt) + theta * (ith - iS2) - x * iS2;
           const float wk = ok ? -w : 0.f;  // loss = sum_b w_b * (-sum_g logp)
           o_dl[j] = wk * (sig - r2);
           o_tp[j] = wk * t1;
