@@ -242,6 +242,12 @@ def main():
                 "mfma_view": {"achieved_TFLOPs": nb_flops / (nb_avg * 1e-3) / 1e12, "peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS,
                               "frac": nb_flops / (nb_avg * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS},
                 "per_entry_point": per_kernel}
+        fc1_ms = prof.get("spv_enc_fc1_fwd", [])
+        if fc1_ms:   # the encoder contraction SURVEY 8d prices against the MFMA roofline (entry point = split-K GEMM + bias/ReLU/slab-sum kernel)
+            fc1_avg, fc1_flops, fc1_bytes = float(np.mean(fc1_ms)), 2.0 * B * G * 2 * H, B * G * 2 + 2 * H * G * 2
+            roof["encoder_fc1_view"] = {"bound": "mfma", "achieved": fc1_flops / (fc1_avg * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                        "frac": fc1_flops / (fc1_avg * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "avg_launch_ms": fc1_avg,
+                                        "hbm_co_bound_GBs": fc1_bytes / (fc1_avg * 1e-3) / 1e9}
         out = {
             "metric": "cells/sec/training-step (2-group PoE VAE)", "value": value, "unit": "cells/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
