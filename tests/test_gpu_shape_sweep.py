@@ -104,3 +104,74 @@ def test_training_step_matches_oracle(dev, case, precision):
             if not err < 5e-3 * float(ref_g.abs().max()) + 2e-4 * gmax:
                 bad.append(f"{k}: abs err {err:.3e} (max |g| {float(ref_g.abs().max()):.3e})")
         assert not bad, "gradients off: " + "; ".join(bad)
+
+
+PLAN_CASES = [  # mode, B, G0, G1, H, n_s, n_p
+    ("paired", 37, 45, 51, 16, 6, 3),
+    ("paired", 130, 700, 333, 128, 12, 15),
+    ("cluster", 100, 333, 200, 64, 25, 10),
+    ("cluster", 67, 129, 257, 32, 10, 5),
+]
+
+
+@pytest.mark.parametrize("case", PLAN_CASES, ids=[f"{c[0]}-B{c[1]}-G{c[2]}x{c[3]}-H{c[4]}-s{c[5]}p{c[6]}" for c in PLAN_CASES])
+def test_transport_plan_modes_match_oracle_at_odd_shapes(dev, case):
+    """paired / cluster PoE through the module's own API (outer-joined X per call, dense plan handed to the constructor,
+    minibatch = arbitrary rows of the data set) against the oracle on the same parameters and noise: ELBO and every
+    parameter gradient, fp32."""
+    from oracle import spvipes_oracle as O
+    from spvipes_amd.module import spVIPESmodule
+    mode, B, G0, G1, H, n_s, n_p = case
+    rng = np.random.default_rng(B * 13 + G1)
+    Gs = (G0, G1)
+    n_cells = (B + 9, B + 23)
+    counts_h = [(rng.poisson(3.0, size=(n_cells[g], Gs[g])) * (rng.random((n_cells[g], Gs[g])) < 0.35)).astype(np.float32) for g in range(2)]
+    for c in counts_h:
+        c[:, 0] += 1
+    plan = (rng.random(n_cells) * (rng.random(n_cells) < 0.08)).astype(np.float32)
+    plan[rng.integers(0, n_cells[0], 5)] = 0.0          # rows without any partner: argmax -> 0 / zero row weights
+    idx_h = [rng.permutation(n_cells[g])[:B] for g in range(2)]
+    comp_h = [rng.integers(0, 5, size=n_cells[0]).astype(np.float32), rng.integers(1, 6, size=n_cells[1]).astype(np.float32)]
+    torch.manual_seed(B)
+    module = spVIPESmodule({0: G0, 1: G1}, transport_plan=torch.tensor(plan).to(dev), pair_data=(mode == "paired"), use_labels=False,
+                           n_hidden=H, n_dimensions_shared=n_s, n_dimensions_private=n_p, dropout_rate=0.0, precision="fp32").to(dev)
+    sd = {k: v.detach().cpu().clone() for k, v in module.state_dict().items()}
+    _move_relu_kinks_away(sd, [c[i] for c, i in zip(counts_h, idx_h)])
+    module.load_state_dict(sd)
+    module.train()
+    gen = torch.Generator().manual_seed(2)
+    noise = {f"enc_{g}_{k}": torch.randn(B, n, generator=gen) for g in range(2) for k, n in (("private", n_p), ("shared", n_s))}
+    noise.update({f"poe_{g}": torch.randn(B, n_s, generator=gen) for g in range(2)})
+    tensors = []
+    for g in range(2):
+        X = np.zeros((B, G0 + G1), np.float32)
+        X[:, (0 if g == 0 else G0):(G0 if g == 0 else G0 + G1)] = counts_h[g][idx_h[g]]
+        d = {"X": torch.tensor(X).to(dev), "batch": torch.zeros(B, 1, device=dev), "groups": torch.full((B, 1), float(g), device=dev),
+             "indices": torch.tensor(idx_h[g], dtype=torch.float32, device=dev).unsqueeze(1)}
+        if mode == "cluster":
+            d["processed_transport_labels"] = torch.tensor(comp_h[g][idx_h[g]], device=dev).unsqueeze(1)
+        tensors.append(d)
+    _, _, lo = module(tuple(tensors), inference_kwargs={"noise": {k: v.to(dev) for k, v in noise.items()}}, loss_kwargs={"kl_weight": 0.6})
+    lo.loss.backward()
+    torch.cuda.synchronize()
+    params = dict(module.named_parameters())
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k in params}
+    sd2 = dict(sd); sd2.update(leaves)
+    block = torch.tensor(plan[idx_h[0]][:, idx_h[1]])
+    out = O.forward_loss(sd2, [torch.tensor(c[i]) for c, i in zip(counts_h, idx_h)], n_dimensions_shared=n_s, n_dimensions_private=n_p, noise=noise,
+                         mode=mode, plan_block=block, components=[torch.tensor(comp_h[g][idx_h[g]]) for g in range(2)] if mode == "cluster" else None,
+                         training=True, kl_weight=0.6)
+    got, ref = float(lo.loss.detach()), float(out["loss"].detach())
+    assert abs(got - ref) / abs(ref) < 2e-4, (got, ref)
+    out["loss"].backward()
+    gmax = max(float(v.grad.abs().max()) for v in leaves.values() if v.grad is not None)
+    bad = []
+    for k, p in params.items():
+        ref_g = leaves[k].grad
+        if ref_g is None:
+            continue
+        mine = torch.zeros_like(p) if p.grad is None else p.grad
+        err = float((mine.cpu() - ref_g).abs().max())
+        if not err < 5e-3 * float(ref_g.abs().max()) + 2e-4 * gmax:
+            bad.append(f"{k}: abs err {err:.3e} (max |g| {float(ref_g.abs().max()):.3e})")
+    assert not bad, "gradients off: " + "; ".join(bad)
