@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void dec_lse_combine_kernel(const float* pmp, 
 __device__ __forceinline__ float2 gamma_terms_fixup(const DecParams& p, int g, float c) {
   const float theta = p.gene_tab[g].x, x = log1p_count(c);
   const LgammaDigamma a = lgamma_digamma(theta), b = lgamma_digamma(x + theta), d = lgamma_digamma(x + 1.0f);
-  const float2 t = p.cnt_tab[(long)(NB_CMAX - 1) * p.Gp + g];
+  const float2 t = p.cnt_tab[(long)(int)fminf(c, (float)(NB_CMAX - 1)) * p.Gp + g];   // the table row the main path used for this count
   return make_float2(b.lg - a.lg - d.lg - t.x, b.dg - a.dg - t.y);
 }
 
@@ -500,11 +500,16 @@ __global__ __launch_bounds__(256, 3) void dec_nb_kernel(DecParams p) {
           dth4[j] = wk * (r1 * dn1 + r2 * dn2 + Psi);
         }
       }
-      if (__builtin_expect(__any(fmaxf(fmaxf(cntA[0], cntA[1]), fmaxf(cntA[2], cntA[3])) >= (float)NB_CMAX), 0)) {
+      // counts the table does not cover: beyond its last row, or (fp32-stored matrices only) not integral -- the
+      // reference evaluates its lgamma terms at any float
+      bool off_table = fmaxf(fmaxf(cntA[0], cntA[1]), fmaxf(cntA[2], cntA[3])) >= (float)NB_CMAX;
+      if constexpr (CM == CNT_F32)
+        off_table = off_table || cntA[0] != floorf(cntA[0]) || cntA[1] != floorf(cntA[1]) || cntA[2] != floorf(cntA[2]) || cntA[3] != floorf(cntA[3]);
+      if (__builtin_expect(__any(off_table), 0)) {
 #pragma unroll 1
         for (int j = 0; j < 4; ++j) {
           const float cj = (j == 0) ? cntA[0] : (j == 1) ? cntA[1] : (j == 2) ? cntA[2] : cntA[3];
-          if (cj >= (float)NB_CMAX && cell_ok && gq0 + j < p.G) {
+          if ((cj >= (float)NB_CMAX || cj != floorf(cj)) && cell_ok && gq0 + j < p.G) {
             const float2 fx = gamma_terms_fixup(p, gq0 + j, cj);
             rec -= fx.x;
             if constexpr (TRAIN) {

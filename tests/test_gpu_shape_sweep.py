@@ -23,6 +23,7 @@ CASES = [  # B, G0, G1, H, n_s, n_p, counts dtype
     (130, 1000, 777, 128, 12, 15, "u16"),
     (64, 2001, 35, 32, 31, 4, "f32"),
     (200, 129, 257, 256, 10, 5, "u16"),
+    (70, 301, 150, 32, 8, 4, "f32frac"),   # non-integral "counts" (normalised data): the lgamma terms leave the integer table
 ]
 
 
@@ -46,6 +47,27 @@ def _move_relu_kinks_away(sd, counts_rows, margin=1e-4):
                 h = torch.relu(pre + shift)
 
 
+def _move_trunk_kinks_away(sd, forward64, n_s, n_p, margin=1e-4):
+    """The same for the decoder's mixing trunk relu(BN(zcat W_a^T + b_a)): its input depends on the sampled latents, so the
+    oracle is run once in float64 (``forward64(sd64) -> forward_loss output``) and each unit's BatchNorm bias is shifted
+    by the smallest step that keeps every cell's pre-activation `margin` away from zero (a bias shift changes nothing
+    upstream)."""
+    import torch.nn.functional as F
+    from oracle import spvipes_oracle as O
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    out = forward64(sd64)
+    L = "fc_layers.Layer 0"
+    for g in range(2):
+        zp, zs = O.split_latents(out["private_stats"][g]["log_z"], out["poe_stats"][g]["logtheta_log_z"], n_s, n_p)
+        zcat = torch.cat([zp, zs], dim=1)
+        pre = O.batch_norm(F.linear(zcat, sd64[f"decoder_{g}.sigmoid_decoder.{L}.0.weight"], sd64[f"decoder_{g}.sigmoid_decoder.{L}.0.bias"]),
+                           sd64, f"decoder_{g}.sigmoid_decoder.{L}.1", True, **O.BN_DEC).detach()
+        cand = torch.arange(0, 400, dtype=torch.float64) * (2.5 * margin)
+        ok = ((pre.unsqueeze(0) + cand.view(-1, 1, 1)).abs() > margin).all(dim=1)
+        assert bool(ok.any(dim=0).all())
+        sd[f"decoder_{g}.sigmoid_decoder.{L}.1.bias"] += cand[ok.double().argmax(dim=0)].float()
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 @pytest.mark.parametrize("case", CASES, ids=[f"B{c[0]}-G{c[1]}x{c[2]}-H{c[3]}-s{c[4]}p{c[5]}-{c[6]}" for c in CASES])
 def test_training_step_matches_oracle(dev, case, precision):
@@ -61,6 +83,8 @@ def test_training_step_matches_oracle(dev, case, precision):
     for c in counts_h:
         c[:, 0] += 1
         c[rng.integers(0, n_cells, 4), rng.integers(0, c.shape[1], 4)] += 90.0   # a few counts beyond the lgamma table
+    if cdt == "f32frac":
+        counts_h = [(c * rng.uniform(0.3, 1.7, size=c.shape)).astype(np.float32) for c in counts_h]
     labels_h = [rng.integers(0, 4, size=n_cells).astype(np.float32), rng.integers(1, 6, size=n_cells).astype(np.float32)]
     torch.manual_seed(B)
     module = spVIPESmodule({0: G0, 1: G1}, use_labels=True, n_hidden=H, n_dimensions_shared=n_s, n_dimensions_private=n_p,
@@ -68,10 +92,14 @@ def test_training_step_matches_oracle(dev, case, precision):
     sd = {k: v.detach().cpu().clone() for k, v in module.state_dict().items()}
     rows_h = [rng.permutation(n_cells)[:B].astype(np.int32) for _ in range(2)]
     _move_relu_kinks_away(sd, [c[r] for c, r in zip(counts_h, rows_h)])
-    module.load_state_dict(sd)
     gen = torch.Generator().manual_seed(1)
     noise = {f"enc_{g}_{k}": torch.randn(B, n, generator=gen) for g in range(2) for k, n in (("private", n_p), ("shared", n_s))}
     noise.update({f"poe_{g}": torch.randn(B, n_s, generator=gen) for g in range(2)})
+    _move_trunk_kinks_away(sd, lambda sd64: O.forward_loss(
+        sd64, [torch.tensor(c[r]).double() for c, r in zip(counts_h, rows_h)], n_dimensions_shared=n_s, n_dimensions_private=n_p,
+        noise={k: v.double() for k, v in noise.items()}, mode="label", labels=[torch.tensor(l[r]) for l, r in zip(labels_h, rows_h)],
+        training=True, kl_weight=0.7), n_s, n_p)
+    module.load_state_dict(sd)
     to_dev = (lambda c: torch.tensor(c.astype(np.uint16).view(np.int16)).to(dev)) if cdt == "u16" else (lambda c: torch.tensor(c).to(dev))
     counts = [GroupCounts(to_dev(c), c.shape[1], 0, resident=True) for c in counts_h]
     trainer = Trainer(module, counts, labels=[torch.tensor(l, device=dev) for l in labels_h])
@@ -137,11 +165,16 @@ def test_transport_plan_modes_match_oracle_at_odd_shapes(dev, case):
                            n_hidden=H, n_dimensions_shared=n_s, n_dimensions_private=n_p, dropout_rate=0.0, precision="fp32").to(dev)
     sd = {k: v.detach().cpu().clone() for k, v in module.state_dict().items()}
     _move_relu_kinks_away(sd, [c[i] for c, i in zip(counts_h, idx_h)])
-    module.load_state_dict(sd)
-    module.train()
     gen = torch.Generator().manual_seed(2)
     noise = {f"enc_{g}_{k}": torch.randn(B, n, generator=gen) for g in range(2) for k, n in (("private", n_p), ("shared", n_s))}
     noise.update({f"poe_{g}": torch.randn(B, n_s, generator=gen) for g in range(2)})
+    block = torch.tensor(plan[idx_h[0]][:, idx_h[1]])
+    comps = [torch.tensor(comp_h[g][idx_h[g]]) for g in range(2)] if mode == "cluster" else None
+    _move_trunk_kinks_away(sd, lambda sd64: O.forward_loss(
+        sd64, [torch.tensor(c[i]).double() for c, i in zip(counts_h, idx_h)], n_dimensions_shared=n_s, n_dimensions_private=n_p,
+        noise={k: v.double() for k, v in noise.items()}, mode=mode, plan_block=block.double(), components=comps, training=True, kl_weight=0.6), n_s, n_p)
+    module.load_state_dict(sd)
+    module.train()
     tensors = []
     for g in range(2):
         X = np.zeros((B, G0 + G1), np.float32)
@@ -157,10 +190,8 @@ def test_transport_plan_modes_match_oracle_at_odd_shapes(dev, case):
     params = dict(module.named_parameters())
     leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k in params}
     sd2 = dict(sd); sd2.update(leaves)
-    block = torch.tensor(plan[idx_h[0]][:, idx_h[1]])
     out = O.forward_loss(sd2, [torch.tensor(c[i]) for c, i in zip(counts_h, idx_h)], n_dimensions_shared=n_s, n_dimensions_private=n_p, noise=noise,
-                         mode=mode, plan_block=block, components=[torch.tensor(comp_h[g][idx_h[g]]) for g in range(2)] if mode == "cluster" else None,
-                         training=True, kl_weight=0.6)
+                         mode=mode, plan_block=block, components=comps, training=True, kl_weight=0.6)
     got, ref = float(lo.loss.detach()), float(out["loss"].detach())
     assert abs(got - ref) / abs(ref) < 2e-4, (got, ref)
     out["loss"].backward()
