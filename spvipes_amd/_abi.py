@@ -53,6 +53,7 @@ class SpvReduceBatch(C.Structure):
 
 
 SPV_MAXP = 8
+POE_LMAX = 1024  # label codes the pairing kernel accepts: integers in [0, POE_LMAX)
 BN_ROWS = 32  # rows per workgroup of the BatchNorm kernels (sizes their partial-sum workspace)
 
 

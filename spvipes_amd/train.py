@@ -100,6 +100,13 @@ class Trainer:
                  weight_decay: float = 1e-6, n_epochs_kl_warmup: Optional[int] = 400, n_steps_kl_warmup: Optional[int] = None,
                  overlap_allreduce: Optional[bool] = None):
         self.module, self.counts, self.labels, self.components = module, list(counts), labels, components
+        for what, codes in (("labels", labels), ("cluster components", components)):
+            if codes is None:   # (the pairing kernels index per-code tables: validated once, here, not per step)
+                continue
+            for g, l in enumerate(codes):
+                lf = l.flatten().to(torch.float32)
+                if lf.numel() and not bool(((lf >= 0) & (lf < _abi.POE_LMAX) & (lf == lf.floor())).all()):
+                    raise ValueError(f"{what} of group {g} must be integral codes in [0, {_abi.POE_LMAX})")
         self.device = counts[0].X.device
         self.fp = FlatParams(module, late=lambda name: name.startswith("encoder_"))
         self.opt = HipAdam(self.fp, lr=lr, eps=eps, weight_decay=weight_decay)

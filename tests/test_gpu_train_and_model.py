@@ -183,3 +183,14 @@ def test_graph_replay_matches_eager_steps(dev):
     assert np.isfinite(graph).all() and np.mean(graph[-4:]) < np.mean(graph[:4])
     # capture warm-up steps move the parameters of the graph run a little before step 0: compare trends, not bits
     assert abs(np.mean(graph[-4:]) - np.mean(eager[-4:])) / abs(np.mean(eager[-4:])) < 5e-2
+
+
+def test_trainer_rejects_label_codes_the_pairing_kernel_cannot_index(dev):
+    from spvipes_amd.data import make_synthetic_group
+    from spvipes_amd.module import spVIPESmodule
+    from spvipes_amd.train import Trainer
+    groups = [make_synthetic_group(g, 300, 64, dev) for g in range(2)]
+    module = spVIPESmodule({0: 64, 1: 64}, use_labels=True, n_hidden=16, n_dimensions_shared=4, n_dimensions_private=2).to(dev)
+    for bad in (torch.full((300,), 1024.0, device=dev), torch.full((300,), 2.5, device=dev), torch.full((300,), -1.0, device=dev)):
+        with pytest.raises(ValueError, match="integral codes"):
+            Trainer(module, [g.counts for g in groups], labels=[groups[0].labels, bad])
