@@ -23,6 +23,8 @@ CASES = [  # B, G0, G1, H, n_s, n_p, counts dtype
     (130, 1000, 777, 128, 12, 15, "u16"),
     (64, 2001, 35, 32, 31, 4, "f32"),
     (200, 129, 257, 256, 10, 5, "u16"),
+    (33, 100, 90, 50, 7, 3, "u16"),         # hidden width that is a multiple of nothing
+    (257, 64, 4100, 24, 31, 15, "u16"),      # the widest latents the regressor operands hold
     (70, 301, 150, 32, 8, 4, "f32frac"),   # non-integral "counts" (normalised data): the lgamma terms leave the integer table
 ]
 
