@@ -208,3 +208,47 @@ def test_transport_plan_modes_match_oracle_at_odd_shapes(dev, case):
         if not err < 5e-3 * float(ref_g.abs().max()) + 2e-4 * gmax:
             bad.append(f"{k}: abs err {err:.3e} (max |g| {float(ref_g.abs().max()):.3e})")
     assert not bad, "gradients off: " + "; ".join(bad)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", [(37, 45, 51, 16, 6, 3), (130, 1000, 777, 128, 12, 15)], ids=["B37", "B130"])
+def test_eval_mode_elbo_matches_oracle(dev, case, precision):
+    """eval mode (BatchNorm on running statistics that a few training steps have moved, no dropout): ELBO, per-cell
+    reconstruction terms and the PoE means against the oracle."""
+    from oracle import spvipes_oracle as O
+    from spvipes_amd.module import spVIPESmodule
+    B, G0, G1, H, n_s, n_p = case
+    rng = np.random.default_rng(B)
+    counts_h = [(rng.poisson(3.0, size=(B, G)) * (rng.random((B, G)) < 0.35)).astype(np.float32) for G in (G0, G1)]
+    for c in counts_h:
+        c[:, 0] += 1
+    labels_h = [rng.integers(0, 4, size=B).astype(np.float32), rng.integers(1, 6, size=B).astype(np.float32)]
+    torch.manual_seed(B)
+    module = spVIPESmodule({0: G0, 1: G1}, use_labels=True, n_hidden=H, n_dimensions_shared=n_s, n_dimensions_private=n_p,
+                           dropout_rate=0.1, precision=precision).to(dev)
+    tensors = []
+    for g in range(2):
+        X = np.zeros((B, G0 + G1), np.float32)
+        X[:, (0 if g == 0 else G0):(G0 if g == 0 else G0 + G1)] = counts_h[g]
+        tensors.append({"X": torch.tensor(X).to(dev), "batch": torch.zeros(B, 1, device=dev), "groups": torch.full((B, 1), float(g), device=dev),
+                        "indices": torch.arange(B, dtype=torch.float32, device=dev).unsqueeze(1), "labels": torch.tensor(labels_h[g], device=dev).unsqueeze(1)})
+    module.train()
+    for _ in range(3):   # move the running statistics of every BatchNorm away from their initial values
+        module(tuple(tensors))
+    module.eval()
+    sd = {k: v.detach().cpu().clone() for k, v in module.state_dict().items()}
+    gen = torch.Generator().manual_seed(4)
+    noise = {f"enc_{g}_{k}": torch.randn(B, n, generator=gen) for g in range(2) for k, n in (("private", n_p), ("shared", n_s))}
+    noise.update({f"poe_{g}": torch.randn(B, n_s, generator=gen) for g in range(2)})
+    with torch.no_grad():
+        inf, _, lo = module(tuple(tensors), inference_kwargs={"noise": {k: v.to(dev) for k, v in noise.items()}})
+    want = O.forward_loss(sd, [torch.tensor(c) for c in counts_h], n_dimensions_shared=n_s, n_dimensions_private=n_p, noise=noise, mode="label",
+                          labels=[torch.tensor(l) for l in labels_h], training=False, kl_weight=1.0)
+    tol = 2e-4 if precision == "fp32" else 2e-3
+    got, ref = float(lo.loss), float(want["loss"])
+    assert abs(got - ref) / abs(ref) < tol, (got, ref)
+    rec = list(lo.reconstruction_loss.values())
+    for g in range(2):
+        torch.testing.assert_close(rec[g].cpu(), want["reconstruction_loss"][g], rtol=5 * tol, atol=5 * tol * float(want["reconstruction_loss"][g].abs().max()))
+        lat = dict(rtol=1e-3, atol=2e-4) if precision == "fp32" else dict(rtol=5e-2, atol=5e-2)
+        torch.testing.assert_close(inf["poe_stats"][g]["logtheta_loc"].cpu(), want["poe_stats"][g]["logtheta_loc"], **lat)
