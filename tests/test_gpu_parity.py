@@ -255,3 +255,24 @@ def test_equal_batch_is_required_by_loss(dev):
     m, tensors, noise, _ = _build(g, dev, "fp32")
     with pytest.raises(RuntimeError):
         m(tensors, inference_kwargs={"noise": noise})
+
+
+@pytest.mark.parametrize("case", [c for c in LOSS_CASES if "train" in c])
+def test_running_statistics_match_reference_goldens(dev, case):
+    """After one training-mode forward pass every BatchNorm buffer of the HIP module (encoder heads: torch defaults; decoder
+    regressors and mixing trunk: eps 1e-3, momentum 0.01, unbiased running variance -- computed analytically by the
+    BatchNorm-fold kernel for the regressors) must hold what the reference's modules hold (get_loadings reads them)."""
+    g = Golden(case)
+    m, tensors, noise, dm = _build(g, dev, "fp32")
+    m(tensors, inference_kwargs={"noise": noise, "dropout_masks": dm}, loss_kwargs={"kl_weight": g.kl_weight})
+    torch.cuda.synchronize()
+    sd = m.state_dict()
+    checked = 0
+    for k, v in g.raw.items():
+        if k.startswith("bn/"):
+            name = k[3:]
+            want = torch.tensor(v)
+            tol = dict(rtol=2e-4, atol=2e-6) if "running_var" in name else dict(rtol=1e-4, atol=2e-6)
+            torch.testing.assert_close(sd[name].cpu().to(want.dtype), want, msg=lambda msg: f"{name}: {msg}", **tol)
+            checked += 1
+    assert checked > 0
