@@ -194,3 +194,55 @@ def test_trainer_rejects_label_codes_the_pairing_kernel_cannot_index(dev):
     for bad in (torch.full((300,), 1024.0, device=dev), torch.full((300,), 2.5, device=dev), torch.full((300,), -1.0, device=dev)):
         with pytest.raises(ValueError, match="integral codes"):
             Trainer(module, [g.counts for g in groups], labels=[groups[0].labels, bad])
+
+
+def test_five_optimiser_steps_follow_the_oracle_trajectory(dev):
+    """End to end over several steps: HIP forward/backward + spv_adam_step against the CPU oracle + torch.optim.Adam
+    (scvi TrainingPlan's settings: lr 1e-3, eps 0.01, weight_decay 1e-6) on the same minibatches and noise -- the loss of
+    every step and the parameters after the last one."""
+    from oracle import spvipes_oracle as O
+    from spvipes_amd.module import spVIPESmodule
+    from spvipes_amd.train import FlatParams, HipAdam
+    B, Gs, H, n_s, n_p, steps = 48, (70, 55), 16, 6, 3, 5
+    rng = np.random.default_rng(11)
+    torch.manual_seed(3)
+    module = spVIPESmodule({0: Gs[0], 1: Gs[1]}, use_labels=True, n_hidden=H, n_dimensions_shared=n_s, n_dimensions_private=n_p,
+                           dropout_rate=0.0, precision="fp32").to(dev)
+    module.train()
+    sd = {k: v.detach().cpu().clone() for k, v in module.state_dict().items()}
+    pnames = [k for k, _ in module.named_parameters()]
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in pnames}
+    ref_opt = torch.optim.Adam([leaves[k] for k in pnames], lr=1e-3, eps=0.01, weight_decay=1e-6)
+    fp = FlatParams(module)
+    opt = HipAdam(fp, lr=1e-3, eps=0.01, weight_decay=1e-6)
+    gen = torch.Generator().manual_seed(8)
+    for step in range(steps):
+        counts = [(rng.poisson(2.5, size=(B, G)) * (rng.random((B, G)) < 0.4)).astype(np.float32) for G in Gs]
+        for c in counts:
+            c[:, 0] += 1
+        labels = [rng.integers(0, 3, size=B).astype(np.float32), rng.integers(1, 4, size=B).astype(np.float32)]
+        noise = {f"enc_{g}_{k}": torch.randn(B, n, generator=gen) for g in range(2) for k, n in (("private", n_p), ("shared", n_s))}
+        noise.update({f"poe_{g}": torch.randn(B, n_s, generator=gen) for g in range(2)})
+        tensors = []
+        for g in range(2):
+            X = np.zeros((B, sum(Gs)), np.float32)
+            X[:, (0 if g == 0 else Gs[0]):(Gs[0] if g == 0 else sum(Gs))] = counts[g]
+            tensors.append({"X": torch.tensor(X).to(dev), "batch": torch.zeros(B, 1, device=dev), "groups": torch.full((B, 1), float(g), device=dev),
+                            "indices": torch.arange(B, dtype=torch.float32, device=dev).unsqueeze(1), "labels": torch.tensor(labels[g], device=dev).unsqueeze(1)})
+        fp.zero_grad()
+        _, _, lo = module(tuple(tensors), inference_kwargs={"noise": {k: v.to(dev) for k, v in noise.items()}}, loss_kwargs={"kl_weight": 0.5})
+        lo.loss.backward()
+        opt.step()
+        # oracle step (its BatchNorm running statistics are not needed in training mode)
+        sd_ref = dict(sd)
+        sd_ref.update(leaves)
+        ref_opt.zero_grad()
+        out = O.forward_loss(sd_ref, [torch.tensor(c) for c in counts], n_dimensions_shared=n_s, n_dimensions_private=n_p, noise=noise, mode="label",
+                             labels=[torch.tensor(l) for l in labels], training=True, kl_weight=0.5)
+        out["loss"].backward()
+        ref_opt.step()
+        got, want = float(lo.loss.detach()), float(out["loss"].detach())
+        assert abs(got - want) / abs(want) < 2e-4, (step, got, want)
+    torch.cuda.synchronize()
+    for k, p in module.named_parameters():
+        torch.testing.assert_close(p.detach().cpu(), leaves[k].detach(), rtol=2e-3, atol=2e-5, msg=lambda m: f"{k} after {steps} steps: {m}")
