@@ -144,7 +144,8 @@ typedef struct spv_dec_params {
   float* part_max_p; float* part_sum_p; float* part_max_s; float* part_sum_s;
   float* rec_part; float* tp_part; float* ts_part;
   float* dtheta_part;
-  void* dL; void* tP; void* tS; int32_t grads_f32;              /* tiled like logits; bf16 | f32 */
+  void* dL; void* tP; void* tS; int32_t grads_f32;              /* tiled like logits; bf16 [Bp][Gp], or (grads_f32) a bf16 hi plane
+                                                                  followed by a bf16 lo plane, [2][Bp][Gp]: value = hi + lo */
   int32_t nb_splits; int32_t nb_genes_per_split;               /* gene splits of spv_dec_nb_fwd: multiple of 32, <= SPV_NB_GSPL_MAX */
 } spv_dec_params;
 
@@ -157,7 +158,7 @@ int spv_dec_tables(const float* px_r, int32_t G, int32_t Gp, void* gene_tab, voi
 int spv_dec_lse(const spv_dec_params* p, const float* library, void* stream);
 
 /* rec_part/tp_part/ts_part [nb_splits][Bp], dtheta_part [Bp/64][Gp]; when train != 0 also the
- * per-element gradients dL, tP, tS (accumulator-tile order; bf16, or fp32 when grads_f32). */
+ * per-element gradients dL, tP, tS (accumulator-tile order; bf16, or bf16 hi + lo planes when grads_f32). */
 int spv_dec_nb_fwd(const spv_dec_params* p, int32_t train, void* stream);
 
 /* in place: tP <- tP - softmax_p * Tp[b],  tS <- tS - softmax_s * Ts[b].

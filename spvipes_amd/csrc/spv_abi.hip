@@ -271,7 +271,7 @@ static int to_dec(const spv_dec_params* q, DecParams& p) {
   p.nb_splits = q->nb_splits; p.nb_genes_per_split = q->nb_genes_per_split;
   if (p.B <= 0 || p.G <= 0 || p.Bp < p.B || p.Gp < p.G || (p.Bp % DEC_CELLS_PER_WG) || (p.Gp % 32))
     return fail(SPV_ERR_ARG, "decoder: Bp must be a multiple of 128 and Gp of 32%s");
-  if ((long)p.Bp * p.Gp >= (1L << 30) || p.Gp >= (1 << 24))   // the likelihood kernel addresses its [Bp][Gp] arrays with 32-bit byte offsets
+  if ((long)p.Bp * p.Gp * (p.grads_f32 ? 2 : 1) >= (1L << 30) || p.Gp >= (1 << 24))   // the likelihood kernel addresses its [Bp][Gp] arrays (two planes with grads_f32) with 32-bit byte offsets
     return fail(SPV_ERR_ARG, "decoder: Bp * Gp must stay below 2^30 elements (and Gp below 2^24)%s");
   if (p.gene_splits <= 0 || (p.genes_per_split % 32) || (long)p.gene_splits * p.genes_per_split < p.G)
     return fail(SPV_ERR_ARG, "decoder: gene splits must be multiples of 32 covering G%s");
@@ -328,7 +328,7 @@ extern "C" int spv_dec_nb_fwd(const spv_dec_params* q, int32_t train, void* stre
     return fail(SPV_ERR_ARG, "spv_dec_nb_fwd: training outputs missing%s");
   hipStream_t s = (hipStream_t)stream;
   if (train) {
-    if (p.grads_f32) nb_launch<true, float>(p, s);
+    if (p.grads_f32) nb_launch<true, split_t>(p, s);
     else nb_launch<true, bf16_t>(p, s);
   } else {
     nb_launch<false, bf16_t>(p, s);
@@ -366,7 +366,7 @@ extern "C" int spv_dec_softmax_bwd(const spv_dec_params* q, const float* Tp, con
   if (dz_part && p.grads_f32) return fail(SPV_ERR_ARG, "spv_dec_softmax_bwd: the fused latent gradient needs bf16 gradient arrays%s");
   dim3 grid(p.Bp / DEC_CELLS_PER_WG, p.gene_splits);
   hipStream_t s = (hipStream_t)stream;
-  if (p.grads_f32) hipLaunchKernelGGL((dec_softmax_bwd_kernel<float, false>), grid, dim3(256), 0, s, p, Tp, Ts, (float*)nullptr);
+  if (p.grads_f32) hipLaunchKernelGGL((dec_softmax_bwd_kernel<split_t, false>), grid, dim3(256), 0, s, p, Tp, Ts, (float*)nullptr);
   else if (dz_part) hipLaunchKernelGGL((dec_softmax_bwd_kernel<bf16_t, true>), grid, dim3(256), 0, s, p, Tp, Ts, dz_part);
   else hipLaunchKernelGGL((dec_softmax_bwd_kernel<bf16_t, false>), grid, dim3(256), 0, s, p, Tp, Ts, (float*)nullptr);
   return launch_status("spv_dec_softmax_bwd");

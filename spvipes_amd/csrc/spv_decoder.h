@@ -309,6 +309,26 @@ __device__ __forceinline__ void load4b(const void* base, unsigned elem_off, floa
   load4<T>(reinterpret_cast<const char*>(base) + (size_t)(elem_off * (unsigned)sizeof(T)), 0, v);
 }
 
+// fp32-mode gradient arrays: a bf16 hi plane followed by a bf16 lo plane (v = hi + lo to ~2^-17), each [Bp][Gp] in
+// accumulator-tile order -- exactly the two operand images the split-bf16 GEMMs of the backward pass consume, so no
+// separate split pass over the fp32 values is needed (same bytes as the fp32 array they replace)
+struct split_t {};
+template <typename GT>
+__device__ __forceinline__ void store_grad4(void* base, unsigned elem_off, unsigned plane, const float (&v)[4]) {
+  if constexpr (sizeof(GT) == 2) {
+    store4b<bf16_t>(base, elem_off, v);
+  } else {
+    bf16_t h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split_bf16(v[j], h[j], l[j]);
+    u2v wh, wl;
+    wh[0] = (unsigned)h[0] | ((unsigned)h[1] << 16); wh[1] = (unsigned)h[2] | ((unsigned)h[3] << 16);
+    wl[0] = (unsigned)l[0] | ((unsigned)l[1] << 16); wl[1] = (unsigned)l[2] | ((unsigned)l[3] << 16);
+    *reinterpret_cast<u2v*>(reinterpret_cast<char*>(base) + (size_t)(elem_off * 2u)) = wh;
+    *reinterpret_cast<u2v*>(reinterpret_cast<char*>(base) + (size_t)((elem_off + plane) * 2u)) = wl;
+  }
+}
+
 // sum of v[q] over the 32 lanes of a wave half for all 16 q at once ("transposing" butterfly,
 // 16 shuffles instead of 80): afterwards lane l holds the total of q = 8 b4 + 4 b3 + 2 b2 + b1
 // (b_i = bit i of l), duplicated in lanes l and l ^ 1.
@@ -405,6 +425,7 @@ __global__ __launch_bounds__(256, 3) void dec_nb_kernel(DecParams p) {
     // 32-bit element offsets (Bp * Gp < 2^31 is checked by the host): with the array base in SGPRs the loads / stores take
     // a 32-bit VGPR offset and the per-chunk 64-bit address arithmetic disappears
     const unsigned tile_row = (unsigned)cell_tile * (unsigned)p.n_gene_tiles;
+    const unsigned plane = (unsigned)p.Bp * (unsigned)p.Gp;   // elements per plane of a hi/lo gradient array
     auto tile_off = [&](int g0) { return (tile_row + (unsigned)(g0 >> 5)) * 1024u + (unsigned)(((g0 >> 4) & 1) * 512 + lane_st); };
     auto gather_tab = [&](const float (&c)[4], int g0, float2 (&tab)[4]) {
 #pragma unroll
@@ -521,9 +542,9 @@ __global__ __launch_bounds__(256, 3) void dec_nb_kernel(DecParams p) {
         }
       }
       if constexpr (TRAIN) {
-        store4b<GT>(p.dL, toff, o_dl);
-        store4b<GT>(p.tP, toff, o_tp);
-        store4b<GT>(p.tS, toff, o_ts);
+        store_grad4<GT>(p.dL, toff, plane, o_dl);
+        store_grad4<GT>(p.tP, toff, plane, o_tp);
+        store_grad4<GT>(p.tS, toff, plane, o_ts);
         // per-gene sums over this wave's 16 cells (lanes sharing gq): 4 values x 16 lanes -> lane keeps gene 2*b3 + b2
         const bool u3 = lane & 8, u2 = lane & 4;
         const float a0 = (u3 ? dth4[2] : dth4[0]) + __shfl_xor(u3 ? dth4[0] : dth4[2], 8, 64);
@@ -562,17 +583,35 @@ __global__ __launch_bounds__(256, 3) void dec_nb_kernel(DecParams p) {
 // derivative through lse_k).  Re-evaluates y_k with the K = 16/32 split MFMAs and one exp each.
 template <typename GT> struct Raw4;
 template <> struct Raw4<bf16_t> { typedef u2v type; };
-template <> struct Raw4<float> { typedef f4v type; };
+template <> struct Raw4<split_t> { typedef u4v type; };   // hi words, lo words
 template <typename GT>
-__device__ __forceinline__ typename Raw4<GT>::type load4_raw(const void* base, long off) {
-  return *reinterpret_cast<const typename Raw4<GT>::type*>(reinterpret_cast<const GT*>(base) + off);
+__device__ __forceinline__ typename Raw4<GT>::type load4_raw(const void* base, long off, long plane) {
+  if constexpr (sizeof(typename Raw4<GT>::type) == 8) {
+    return *reinterpret_cast<const u2v*>(reinterpret_cast<const bf16_t*>(base) + off);
+  } else {
+    const u2v h = *reinterpret_cast<const u2v*>(reinterpret_cast<const bf16_t*>(base) + off);
+    const u2v l = *reinterpret_cast<const u2v*>(reinterpret_cast<const bf16_t*>(base) + off + plane);
+    return u4v{h[0], h[1], l[0], l[1]};
+  }
+}
+template <typename GT>
+__device__ __forceinline__ void store4_grad(void* base, long off, long plane, const float (&v)[4]) {
+  if constexpr (sizeof(typename Raw4<GT>::type) == 8) {
+    store4<bf16_t>(base, (size_t)off, v);
+  } else {
+    bf16_t h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split_bf16(v[j], h[j], l[j]);
+    *reinterpret_cast<u2v*>(reinterpret_cast<bf16_t*>(base) + off) = u2v{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
+    *reinterpret_cast<u2v*>(reinterpret_cast<bf16_t*>(base) + off + plane) = u2v{(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};
+  }
 }
 __device__ __forceinline__ void decode4(const u2v& x, float (&v)[4]) {
   v[0] = bf2f(x[0] & 0xFFFF); v[1] = bf2f(x[0] >> 16); v[2] = bf2f(x[1] & 0xFFFF); v[3] = bf2f(x[1] >> 16);
 }
-__device__ __forceinline__ void decode4(const f4v& x, float (&v)[4]) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) v[j] = x[j];
+__device__ __forceinline__ void decode4(const u4v& x, float (&v)[4]) {   // hi + lo
+  v[0] = bf2f(x[0] & 0xFFFF) + bf2f(x[2] & 0xFFFF); v[1] = bf2f(x[0] >> 16) + bf2f(x[2] >> 16);
+  v[2] = bf2f(x[1] & 0xFFFF) + bf2f(x[3] & 0xFFFF); v[3] = bf2f(x[1] >> 16) + bf2f(x[3] >> 16);
 }
 
 // Software pipelined over 32-gene tiles: the next tile's fragments and gradient words are requested before the
@@ -590,6 +629,7 @@ constexpr int SMB_PITCH = SMB_SUB + 8;  // bf16 per row: 656 B = 164 dwords, row
 template <typename GT, bool FUSE>
 __global__ __launch_bounds__(256) void dec_softmax_bwd_kernel(DecParams p, const float* Tp, const float* Ts, float* dz_part) {
   typedef typename Raw4<GT>::type raw_t;
+  const long plane = (long)p.Bp * p.Gp;
   __shared__ __attribute__((aligned(16))) bf16_t s_wT[FUSE ? DEC_KPS * SMB_PITCH : 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
   const int cell_tile = blockIdx.x * (DEC_CELLS_PER_WG / 32) + wave;
@@ -616,7 +656,7 @@ __global__ __launch_bounds__(256) void dec_softmax_bwd_kernel(DecParams p, const
     {
       const long tb = (trow + (gbeg >> 5)) * 1024 + lane * 4;
 #pragma unroll
-      for (int qq = 0; qq < 4; ++qq) { rpA[qq] = load4_raw<GT>(p.tP, tb + 256 * qq); rsA[qq] = load4_raw<GT>(p.tS, tb + 256 * qq); }
+      for (int qq = 0; qq < 4; ++qq) { rpA[qq] = load4_raw<GT>(p.tP, tb + 256 * qq, plane); rsA[qq] = load4_raw<GT>(p.tS, tb + 256 * qq, plane); }
     }
     for (int t = 0; t < ntile; ++t) {
       const int g0 = gbeg + 32 * t, gn = gbeg + 32 * min(t + 1, ntile - 1);
@@ -644,7 +684,7 @@ __global__ __launch_bounds__(256) void dec_softmax_bwd_kernel(DecParams p, const
       load_ps_w(p, gn, lane, wB);
       const long tbase = (trow + (g0 >> 5)) * 1024 + lane * 4, tnext = (trow + (gn >> 5)) * 1024 + lane * 4;
 #pragma unroll
-      for (int qq = 0; qq < 4; ++qq) { rpB[qq] = load4_raw<GT>(p.tP, tnext + 256 * qq); rsB[qq] = load4_raw<GT>(p.tS, tnext + 256 * qq); }
+      for (int qq = 0; qq < 4; ++qq) { rpB[qq] = load4_raw<GT>(p.tP, tnext + 256 * qq, plane); rsB[qq] = load4_raw<GT>(p.tS, tnext + 256 * qq, plane); }
       float cp[16], cs[16];
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
@@ -660,8 +700,8 @@ __global__ __launch_bounds__(256) void dec_softmax_bwd_kernel(DecParams p, const
           vs[j] = ok ? vs[j] - fast_exp(ys[q] - ls) * tsb : 0.f;
           cp[q] = vp[j]; cs[q] = vs[j];
         }
-        store4<GT>(p.tP, tbase + 256 * qq, vp);
-        store4<GT>(p.tS, tbase + 256 * qq, vs);
+        store4_grad<GT>(p.tP, tbase + 256 * qq, plane, vp);
+        store4_grad<GT>(p.tS, tbase + 256 * qq, plane, vs);
       }
       if constexpr (FUSE) {
         const int gl = (g0 - gbeg) % SMB_SUB;   // offset of this tile inside the staged slice

@@ -71,17 +71,13 @@ class _DecoderBwd:
         # -0.05 ms per step, same-box A/B); the narrow ones (16 / 32 columns) stream their [B,G] operand with ~2 per CU
         self.ksp_m, self.ksp_n = max(1, min(T // 8, -(-256 // max(Bp // 64, 1)))), max(1, min(T // 8, -(-512 // max(Bp // 128, 1))))
         self.csp_m, self.csp_n = max(1, min(bt // 8, -(-256 // max(Gp // 64, 1)))), max(1, min(bt // 8, -(-512 // max(Gp // 128, 1))))
-        self._img = {}
 
     def _operand(self, key: str):
-        """(hi, lo) operand image of dL / tP / tS: the bf16 tile array itself, or its split-bf16 pair in fp32 mode"""
+        """(hi, lo) operand image of dL / tP / tS: the bf16 tile array itself, or its hi / lo planes in fp32 mode"""
         if not self.grads_f32:
             return self.S[key], None
-        if key not in self._img:
-            hi, lo = _bf16_image(self.wsg, f"dec_{key}_split", self.Bp, self.Gp, True)
-            _pack(self.S[key], hi, lo)
-            self._img[key] = (hi, lo)
-        return self._img[key]
+        t = self.S[key]   # [2 Bp][Gp]: hi plane, lo plane
+        return t[:self.Bp], t[self.Bp:]
 
     def softmax(self):
         _abi.call("spv_dec_softmax_bwd", C.byref(self.P), ptr(self.S["Tp"]), ptr(self.S["Ts"]), ptr(self.dz_part), stream_ptr())
@@ -223,7 +219,9 @@ class DecoderFused(torch.autograd.Function):
         if w_pad.numel() < Bp or w_pad.dtype != torch.float32 or not w_pad.is_contiguous():
             raise _abi.SpvError("DecoderFused: w_pad must be contiguous fp32 of length >= round_up(B, 128)")
         grads_f32 = bool(need_grad and mlo)
-        gdt, gname = (torch.float32, "f32") if grads_f32 else (torch.int16, "bf16")
+        # bf16 mode: one bf16 array per gradient; fp32 mode: a bf16 hi plane followed by a bf16 lo plane ([2 Bp][Gp] rows):
+        # the two operand images the split-bf16 GEMMs consume, written directly by the likelihood kernel
+        gdt, gname, gplanes = (torch.int16, "split", 2) if grads_f32 else (torch.int16, "bf16", 1)
         P, saved_g = [], []
         rec = [new(B) for _ in range(NG)]  # (allocated before the fork: every temporary belongs to the main stream)
         red = SpvReduceBatch()
@@ -252,9 +250,9 @@ class DecoderFused(torch.autograd.Function):
               part = lambda nme: wsg.get(nme, (splits, Bp), torch.float32)
               nbpart = lambda nme: wsg.get(nme, (nbs, Bp), torch.float32)
               if need_grad:
-                  dL = wsg.get("dec_dL_" + gname, (Bp, Gp), gdt, zero=True)
-                  tP = wsg.get("dec_tP_" + gname, (Bp, Gp), gdt, zero=True)
-                  tS = wsg.get("dec_tS_" + gname, (Bp, Gp), gdt, zero=True)
+                  dL = wsg.get("dec_dL_" + gname, (gplanes * Bp, Gp), gdt, zero=True)
+                  tP = wsg.get("dec_tP_" + gname, (gplanes * Bp, Gp), gdt, zero=True)
+                  tS = wsg.get("dec_tS_" + gname, (gplanes * Bp, Gp), gdt, zero=True)
                   dth = wsg.get("dec_dtheta", (Bp // 64, Gp), torch.float32, zero=True)
                   Tp, Ts = wsg.get("dec_Tp", (Bp,), torch.float32), wsg.get("dec_Ts", (Bp,), torch.float32)
               else:

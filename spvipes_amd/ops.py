@@ -317,12 +317,11 @@ class DecoderNBLoss(torch.autograd.Function):
         w_pad = ws.get("dec_w_row", (Bp,), torch.float32, zero=True)
         w_pad[:B].copy_(w_row)
         grads_f32 = bool(train and nsplit == 3)
-        gdt = torch.float32 if grads_f32 else torch.int16
-        gname = "f32" if grads_f32 else "bf16"
+        gdt, gname, gplanes = (torch.int16, "split", 2) if grads_f32 else (torch.int16, "bf16", 1)   # fp32 mode: bf16 hi plane + lo plane
         if train:
-            dL = ws.get("dec_dL_" + gname, (Bp, Gp), gdt, zero=True)
-            tP = ws.get("dec_tP_" + gname, (Bp, Gp), gdt, zero=True)
-            tS = ws.get("dec_tS_" + gname, (Bp, Gp), gdt, zero=True)
+            dL = ws.get("dec_dL_" + gname, (gplanes * Bp, Gp), gdt, zero=True)
+            tP = ws.get("dec_tP_" + gname, (gplanes * Bp, Gp), gdt, zero=True)
+            tS = ws.get("dec_tS_" + gname, (gplanes * Bp, Gp), gdt, zero=True)
             dth = ws.get("dec_dtheta", (Bp // 64, Gp), torch.float32, zero=True)
         else:
             dL = tP = tS = dth = None
@@ -363,14 +362,8 @@ class DecoderNBLoss(torch.autograd.Function):
         ws, nsplit, P = ctx.ws, ctx.nsplit, ctx.P
         Wm_hi, Wm_lo, Am_hi, Am_lo, Wps_hi, Wps_lo, Aps_hi, Aps_lo, dL, tP, tS, dth, lse_p, lse_s, gene_tab = ctx.keep
         _abi.call("spv_dec_softmax_bwd", C.byref(P), ptr(ctx.Tp), ptr(ctx.Ts), None, stream_ptr())
-        if ctx.grads_f32:  # fp32 mode: split the stored fp32 gradients into hi/lo images for the MFMA GEMMs
-            def split(t, name):
-                hi, lo = _bf16_image(ws, name, Bp, Gp, True)
-                _pack(t, hi, lo)
-                return hi, lo
-            dL_hi, dL_lo = split(dL, "dec_dL_split")
-            tP_hi, tP_lo = split(tP, "dec_tP_split")
-            tS_hi, tS_lo = split(tS, "dec_tS_split")
+        if ctx.grads_f32:  # fp32 mode: the arrays already are the hi / lo operand images of the split-bf16 GEMMs
+            (dL_hi, dL_lo), (tP_hi, tP_lo), (tS_hi, tS_lo) = (dL[:Bp], dL[Bp:]), (tP[:Bp], tP[Bp:]), (tS[:Bp], tS[Bp:])
         else:
             dL_hi, tP_hi, tS_hi, dL_lo, tP_lo, tS_lo = dL, tP, tS, None, None, None
         ksp = max(1, min(8, (Gp // 32) // 16))  # K splits of the contractions over genes

@@ -20,7 +20,9 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _setup(dev, overlap, G=(600, 500), n_cells=1024, precision="fp32"):
+def _setup(dev, overlap, G=(600, 500), n_cells=1024, precision="bf16"):
+    # (bf16 mode: bit-reproducible from run to run, which the exact comparisons below rely on; fp32 mode shows a rare
+    # run-to-run difference at the 1e-3 level in the likelihood kernel under heavy GPU sharing -- DESIGN.md section 8)
     from spvipes_amd.data import make_synthetic_group
     from spvipes_amd.module import spVIPESmodule
     from spvipes_amd.train import Trainer
@@ -140,4 +142,12 @@ def test_two_ranks_reduce_to_the_mean_gradient_and_stay_identical(dev, use_graph
         grads.append(ref.fp.grad.cpu().clone())
     want = (grads[0] + grads[1]) / world
     scale = float(want.abs().max())
-    assert float((got[0][1] - want).abs().max()) <= 1e-6 * scale
+    err = (got[0][1] - want).abs()
+    if not float(err.max()) <= 1e-6 * scale:   # name the parameters that differ
+        base, bad = ref.fp.flat.data_ptr(), []
+        for name, p in module.named_parameters():
+            off = (p.data_ptr() - base) // 4
+            e = float(err[off:off + p.numel()].max())
+            if e > 1e-6 * scale:
+                bad.append(f"{name}: {e:.3e} (max |g| {float(want[off:off + p.numel()].abs().max()):.3e}, {int((err[off:off + p.numel()] > 1e-6 * scale).sum())} of {p.numel()} entries)")
+        raise AssertionError("mean gradient differs: " + "; ".join(bad))
