@@ -30,7 +30,7 @@ def is_stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]   # (the flags live in this file)
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
@@ -40,6 +40,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     cmd = [
         _hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+        # No SLP vectorisation: the packed-fp32 (v_pk_*_f32 with op_sel) code it forms in the likelihood kernel gave results
+        # that were not bit-reproducible from run to run on gfx950 / ROCm 7.2 (one gradient element of the last 16 lanes of
+        # a wave, about 1 launch in 500 under GPU sharing).  Costs about 1 % of the step.
+        "-fno-slp-vectorize",
         *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB + ".tmp",
     ]
     if verbose:

@@ -21,8 +21,8 @@ def dev():
 
 
 def _setup(dev, overlap, G=(600, 500), n_cells=1024, precision="bf16"):
-    # (bf16 mode: bit-reproducible from run to run, which the exact comparisons below rely on; fp32 mode shows a rare
-    # run-to-run difference at the 1e-3 level in the likelihood kernel under heavy GPU sharing -- DESIGN.md section 8)
+    # (the exact comparisons below rely on bit-reproducible kernels: DESIGN.md section 8 has the history of the one case
+    # where that did not hold -- packed-fp32 code in the likelihood kernel, now built without SLP vectorisation)
     from spvipes_amd.data import make_synthetic_group
     from spvipes_amd.module import spVIPESmodule
     from spvipes_amd.train import Trainer
