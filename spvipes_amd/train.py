@@ -191,13 +191,20 @@ class Trainer:
                 if self.overlap:
                     self._backward_encoders()
         torch.cuda.current_stream().wait_stream(side)
+        # In a data-parallel job the process group's watchdog thread polls the events of collectives still in flight; a
+        # capture in the default "global" error mode makes such a call from ANOTHER thread an error (HIP refuses event
+        # queries while any global-mode capture is open).  Drain the device first and capture in thread-local mode.
+        mode = {}
+        if self.world > 1:
+            torch.cuda.synchronize(self.device)
+            mode = {"capture_error_mode": "thread_local"}
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, **mode):
             self._static_lo = self._forward_backward(self._static_rows, self._klw)
         self.graph = g
         if self.overlap:
             g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, pool=g.pool()):
+            with torch.cuda.graph(g2, pool=g.pool(), **mode):
                 self._backward_encoders()
             self.graph2 = g2
 

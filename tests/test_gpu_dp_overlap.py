@@ -151,3 +151,20 @@ def test_two_ranks_reduce_to_the_mean_gradient_and_stay_identical(dev, use_graph
             if e > 1e-6 * scale:
                 bad.append(f"{name}: {e:.3e} (max |g| {float(want[off:off + p.numel()].abs().max()):.3e}, {int((err[off:off + p.numel()] > 1e-6 * scale).sum())} of {p.numel()} entries)")
         raise AssertionError("mean gradient differs: " + "; ".join(bad))
+
+
+def test_rccl_rehearsal_on_one_rank(dev):
+    """The step of a multi-GPU rank over RCCL itself -- communicator start-up, the watchdog thread polling while the two
+    hipGraphs are captured, async bucket all-reduces between the graph replays -- driven through a one-rank "nccl" group
+    (tools/probes/rccl_one_rank.py; a separate process: a process group cannot be re-created inside this one)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "probes", "rccl_one_rank.py"), "20"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "one-rank RCCL rehearsal: 20 graph steps" in out.stdout
