@@ -45,7 +45,7 @@ struct DecParams {
   const bf16_t* Wps_hi; const bf16_t* Wps_lo;                         // [Gp][48]   W'_p|c_p|0.. W'_s|c_s|0..
   const bf16_t* Aps_hi; const bf16_t* Aps_lo;                         // [Bp][48]   z_p|1|0..   z_s|1|0..
   // per gene / per cell vectors
-  const float4* gene_tab;       // [Gp] {theta, log(theta+eps), 1/(theta+eps), theta * log(theta+eps)}
+  const float4* gene_tab;       // [Gp] {theta, lt = log(theta+eps), lt + theta/(theta+eps), theta * lt}
   const float2* cnt_tab;        // [NB_CMAX][Gp] {F, Psi}
   const float* a_p; const float* a_s;   // [Bp] library - lse_k
   const float* lse_p; const float* lse_s;
@@ -72,7 +72,7 @@ __global__ void nb_tables_kernel(const float* px_r, int G, int Gp, float4* gene_
   const float theta = fast_exp(px_r[g]);  // px_r = exp(param), module/spVIPESmodule.py:758
   if (c == 0) {
     const float lt = fast_log(theta + SPV_EPS_NB);
-    gene_tab[g] = make_float4(theta, lt, fast_rcp(theta + SPV_EPS_NB), theta * lt);
+    gene_tab[g] = make_float4(theta, lt, fmaf(theta, fast_rcp(theta + SPV_EPS_NB), lt), theta * lt);
     cnt_tab[g] = make_float2(0.f, 0.f);  // x = 0: lgamma terms cancel exactly
     return;
   }
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256, 3) void dec_nb_kernel(DecParams p) {
         // The hardware exp / log are base 2: the kernel keeps L_k = log2(theta + mu_k + eps) and log2(mu_k + eps) in base 2
         // and folds the ln 2 into the few places that need natural units (the kernel is bound by VALU issue):
         //   nb_k = theta (lt - ln S_k) + x (ln e_k - ln S_k) = theta lt + ln2 * (x log2 e_k - (theta + x) log2 S_k)
-        const float theta = gt.x, lt = gt.y, ith = gt.z, thlt = gt.w;
+        const float theta = gt.x, dlt = gt.z, thlt = gt.w;
         const float cj = cntA[j];
         const float x = log1p_count(cj);
         const float F = tabA[j].x, Psi = tabA[j].y;
@@ -503,22 +503,24 @@ __global__ __launch_bounds__(256, 3) void dec_nb_kernel(DecParams p) {
         const float logp = fmaf(NB_LN2, __builtin_amdgcn_logf((1.0f + ed) * iol), M - fmaxf(-el_, 0.f) + F);
         rec -= ok ? logp : 0.f;
         if constexpr (TRAIN) {
+          // d nb_k / d y_k = mu_k (x / e_k - (theta + x) / S_k);  d nb_k / d theta = [lt + theta / (theta + eps)] - ln S_k - (theta + x) / S_k
+          // (the bracket is the gene table's z); the row weight is folded into the responsibilities once
           const float iod = fast_rcp(1.0f + ed);
-          const float r1 = (d >= 0.f) ? iod : ed * iod, r2 = 1.0f - r1;
+          const float r1 = (d >= 0.f) ? iod : ed * iod;
           const float sig = (el_ <= 0.f) ? iol : el * iol;  // sigmoid(-logit)
-          const float iS1 = fast_rcp(S1), iS2 = fast_rcp(S2);
-          const float g1 = x * mu1 * fast_rcp(e1) - thx * mu1 * iS1;
-          const float g2 = x * mu2 * fast_rcp(e2) - thx * mu2 * iS2;
-          const float t1 = r1 * g1, t2 = r2 * g2;
-          const float dn1 = fmaf(-NB_LN2, L1, lt) + theta * (ith - iS1) - x * iS1;
-          const float dn2 = fmaf(-NB_LN2, L2, lt) + theta * (ith - iS2) - x * iS2;
+          const float q1 = thx * fast_rcp(S1), q2 = thx * fast_rcp(S2);
+          const float g1 = mu1 * fmaf(x, fast_rcp(e1), -q1);
+          const float g2 = mu2 * fmaf(x, fast_rcp(e2), -q2);
+          const float dn1 = fmaf(-NB_LN2, L1, dlt) - q1;
+          const float dn2 = fmaf(-NB_LN2, L2, dlt) - q2;
           const float wk = ok ? -w : 0.f;  // loss = sum_b w_b * (-sum_g logp)
-          o_dl[j] = wk * (sig - r2);
-          o_tp[j] = wk * t1;
-          o_ts[j] = wk * t2;
+          const float wr1 = wk * r1, wr2 = wk - wr1;   // w r_1, w r_2 (r_2 = 1 - r_1)
+          o_dl[j] = fmaf(wk, sig, -wr2);
+          o_tp[j] = wr1 * g1;
+          o_ts[j] = wr2 * g2;
           tp_sum += o_tp[j];
           ts_sum += o_ts[j];
-          dth4[j] = wk * (r1 * dn1 + r2 * dn2 + Psi);
+          dth4[j] = fmaf(wr1, dn1, fmaf(wr2, dn2, wk * Psi));
         }
       }
       // counts the table does not cover: beyond its last row, or (fp32-stored matrices only) not integral -- the
