@@ -41,6 +41,19 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return __builtin_bit_cast(bf16_t, b);
 }
 __device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float(((unsigned)b) << 16); }
+// two values -> one word (a in the low half): ONE v_cvt_pk_bf16_f32.  Written as a vector conversion because the library
+// is built without SLP vectorisation (build.py), which would otherwise be what pairs two scalar casts.
+__device__ __forceinline__ unsigned pack2bf(float a, float b) {
+  typedef float f2cv __attribute__((ext_vector_type(2)));
+  typedef __bf16 b2cv __attribute__((ext_vector_type(2)));
+  const b2cv r = __builtin_convertvector(f2cv{a, b}, b2cv);
+  return __builtin_bit_cast(unsigned, r);
+}
+// hi / lo words of two values (x = hi + lo to ~2^-17 relative)
+__device__ __forceinline__ void split2bf(float a, float b, unsigned& hi, unsigned& lo) {
+  hi = pack2bf(a, b);
+  lo = pack2bf(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xFFFF0000u));
+}
 
 __device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
   hi = f2bf(x);

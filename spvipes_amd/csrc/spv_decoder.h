@@ -268,8 +268,8 @@ __device__ __forceinline__ void store4(void* base, size_t off, const float (&v)[
 template <>
 __device__ __forceinline__ void store4<bf16_t>(void* base, size_t off, const float (&v)[4]) {
   u2v w;
-  w[0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-  w[1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+  w[0] = pack2bf(v[0], v[1]);
+  w[1] = pack2bf(v[2], v[3]);
   *reinterpret_cast<u2v*>(reinterpret_cast<bf16_t*>(base) + off) = w;
 }
 template <>
@@ -318,12 +318,10 @@ __device__ __forceinline__ void store_grad4(void* base, unsigned elem_off, unsig
   if constexpr (sizeof(GT) == 2) {
     store4b<bf16_t>(base, elem_off, v);
   } else {
-    bf16_t h[4], l[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) split_bf16(v[j], h[j], l[j]);
-    u2v wh, wl;
-    wh[0] = (unsigned)h[0] | ((unsigned)h[1] << 16); wh[1] = (unsigned)h[2] | ((unsigned)h[3] << 16);
-    wl[0] = (unsigned)l[0] | ((unsigned)l[1] << 16); wl[1] = (unsigned)l[2] | ((unsigned)l[3] << 16);
+    unsigned h0, l0, h1, l1;
+    split2bf(v[0], v[1], h0, l0);
+    split2bf(v[2], v[3], h1, l1);
+    const u2v wh = {h0, h1}, wl = {l0, l1};
     *reinterpret_cast<u2v*>(reinterpret_cast<char*>(base) + (size_t)(elem_off * 2u)) = wh;
     *reinterpret_cast<u2v*>(reinterpret_cast<char*>(base) + (size_t)((elem_off + plane) * 2u)) = wl;
   }
@@ -601,11 +599,12 @@ __device__ __forceinline__ void store4_grad(void* base, long off, long plane, co
   if constexpr (sizeof(typename Raw4<GT>::type) == 8) {
     store4<bf16_t>(base, (size_t)off, v);
   } else {
-    bf16_t h[4], l[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) split_bf16(v[j], h[j], l[j]);
-    *reinterpret_cast<u2v*>(reinterpret_cast<bf16_t*>(base) + off) = u2v{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
-    *reinterpret_cast<u2v*>(reinterpret_cast<bf16_t*>(base) + off + plane) = u2v{(unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16)};
+    unsigned h0, l0, h1, l1;
+    split2bf(v[0], v[1], h0, l0);
+    split2bf(v[2], v[3], h1, l1);
+    const u2v wh = {h0, h1}, wl = {l0, l1};
+    *reinterpret_cast<u2v*>(reinterpret_cast<bf16_t*>(base) + off) = wh;
+    *reinterpret_cast<u2v*>(reinterpret_cast<bf16_t*>(base) + off + plane) = wl;
   }
 }
 __device__ __forceinline__ void decode4(const u2v& x, float (&v)[4]) {
