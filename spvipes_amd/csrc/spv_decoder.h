@@ -45,7 +45,7 @@ struct DecParams {
   const bf16_t* Wps_hi; const bf16_t* Wps_lo;                         // [Gp][48]   W'_p|c_p|0.. W'_s|c_s|0..
   const bf16_t* Aps_hi; const bf16_t* Aps_lo;                         // [Bp][48]   z_p|1|0..   z_s|1|0..
   // per gene / per cell vectors
-  const float4* gene_tab;       // [Gp] {theta, lt = log(theta+eps), lt + theta/(theta+eps), theta * lt}
+  const float4* gene_tab;       // [Gp] {theta, lt = log(theta+eps), lt + theta/(theta+eps), theta * lt / ln 2}
   const float2* cnt_tab;        // [NB_CMAX][Gp] {F, Psi}
   const float* a_p; const float* a_s;   // [Bp] library - lse_k
   const float* lse_p; const float* lse_s;
@@ -72,7 +72,7 @@ __global__ void nb_tables_kernel(const float* px_r, int G, int Gp, float4* gene_
   const float theta = fast_exp(px_r[g]);  // px_r = exp(param), module/spVIPESmodule.py:758
   if (c == 0) {
     const float lt = fast_log(theta + SPV_EPS_NB);
-    gene_tab[g] = make_float4(theta, lt, fmaf(theta, fast_rcp(theta + SPV_EPS_NB), lt), theta * lt);
+    gene_tab[g] = make_float4(theta, lt, fmaf(theta, fast_rcp(theta + SPV_EPS_NB), lt), theta * lt * 1.4426950408889634f);   // (the likelihood kernel works in base-2 units)
     cnt_tab[g] = make_float2(0.f, 0.f);  // x = 0: lgamma terms cancel exactly
     return;
   }
@@ -482,8 +482,8 @@ __global__ __launch_bounds__(256, 3) void dec_nb_kernel(DecParams p) {
         const float4 gt = s_gt[g - gbeg];
         // The hardware exp / log are base 2: the kernel keeps L_k = log2(theta + mu_k + eps) and log2(mu_k + eps) in base 2
         // and folds the ln 2 into the few places that need natural units (the kernel is bound by VALU issue):
-        //   nb_k = theta (lt - ln S_k) + x (ln e_k - ln S_k) = theta lt + ln2 * (x log2 e_k - (theta + x) log2 S_k)
-        const float theta = gt.x, dlt = gt.z, thlt = gt.w;
+        //   nb_k = theta (lt - ln S_k) + x (ln e_k - ln S_k) = ln2 * (theta lt / ln2 + x log2 e_k - (theta + x) log2 S_k)
+        const float theta = gt.x, dlt = gt.z, thlt2 = gt.w;
         const float cj = cntA[j];
         const float x = log1p_count(cj);
         const float F = tabA[j].x, Psi = tabA[j].y;
@@ -493,12 +493,14 @@ __global__ __launch_bounds__(256, 3) void dec_nb_kernel(DecParams p) {
         const float S1 = theta + e1, S2 = theta + e2;   // theta + mu + eps (one add fewer per component than the left-to-right sum)
         const float L1 = __builtin_amdgcn_logf(S1), L2 = __builtin_amdgcn_logf(S2);   // base 2
         const float thx = theta + x;
-        const float nb1 = fmaf(NB_LN2, fmaf(x, __builtin_amdgcn_logf(e1), -thx * L1), thlt);
-        const float v2 = fmaf(NB_LN2, fmaf(x, __builtin_amdgcn_logf(e2), -thx * L2), thlt - el_);
+        // nb_k and the mixing logit stay in base-2 units (nb_k / ln 2) until the one multiply that forms logp
+        const float el2 = el_ * NB_LOG2E;
+        const float nb1 = fmaf(x, __builtin_amdgcn_logf(e1), fmaf(-thx, L1, thlt2));
+        const float v2 = fmaf(x, __builtin_amdgcn_logf(e2), fmaf(-thx, L2, thlt2 - el2));
         const float d = nb1 - v2, M = fmaxf(nb1, v2);
-        const float ed = __builtin_amdgcn_exp2f(-fabsf(d) * NB_LOG2E), el = __builtin_amdgcn_exp2f(-fabsf(el_) * NB_LOG2E);
+        const float ed = __builtin_amdgcn_exp2f(-fabsf(d)), el = __builtin_amdgcn_exp2f(-fabsf(el2));
         const float iol = fast_rcp(1.0f + el);
-        const float logp = fmaf(NB_LN2, __builtin_amdgcn_logf((1.0f + ed) * iol), M - fmaxf(-el_, 0.f) + F);
+        const float logp = fmaf(NB_LN2, __builtin_amdgcn_logf((1.0f + ed) * iol) + (M - fmaxf(-el2, 0.f)), F);
         rec -= ok ? logp : 0.f;
         if constexpr (TRAIN) {
           // d nb_k / d y_k = mu_k (x / e_k - (theta + x) / S_k);  d nb_k / d theta = [lt + theta / (theta + eps)] - ln S_k - (theta + x) / S_k
