@@ -7,12 +7,20 @@
 
 One "step" = one optimisation step of the hot path on one synthetic minibatch per group
 (forward through both encoders, label-based PoE, decoder + NB-mixture ELBO, backward, one gradient
-all-reduce when N > 1, Adam).  Workload = BASELINE.json configs[1]: 2 groups x 50 000 cells x
-10 000 genes, n_shared 25, n_private 10, n_hidden 128, bf16 MFMA operands with fp32 accumulation;
-the configuration does not fix the minibatch, we use 4096 cells per group per step (the batch size
-BASELINE.json names for its 8-GPU configuration).  Weak scaling: every rank holds its own
-50 000-cell shard per group and draws its own minibatches; value = cells processed by ALL ranks / s.
+all-reduce when N > 1, Adam).  Default workload (--config c2) = BASELINE.json configs[1]: 2 groups x
+50 000 cells x 10 000 genes, n_shared 25, n_private 10, n_hidden 128, bf16 MFMA operands with fp32
+accumulation; the configuration does not fix the minibatch, we use 4096 cells per group per step (the
+batch size BASELINE.json names for its 8-GPU configuration).  Weak scaling: every rank holds its own
+shard per group and draws its own minibatches; value = cells processed by ALL ranks / s.
 The count matrices are resident in HBM (uint16) before the timed region.
+
+Other workloads, one per BASELINE.json config, selected with --config:
+    c1  2 x 2 000 x 2 000, B 128, H 64, 10/5 (the reference's CPU plumbing case)
+    c3  one rank's shard of 2 x 200 000 x 20 000 on 8 GPUs: 25 000 cells x 20 000 genes per group, B 4096
+    c4  3 groups x 100 000 x 15 000 on 4 GPUs: 25 000 cells per group per rank, H 256, cluster-matched PoE
+        (throughput only: the reference cannot run 3 groups, data/prepare_adatas.py:94-95)
+    c5  one rank's shard of 2 x 500 000 x 30 000 on 8 GPUs: 62 500 cells x 30 000 genes, paired PoE on a sparse plan, fp32
+Explicit --cells / --genes / ... flags override the preset.
 
 Prints ONE JSON line on rank 0.
 """
@@ -35,18 +43,36 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
 
 
+CONFIGS = {
+    "c1": dict(cells=2_000, genes=2_000, batch_size=128, n_hidden=64, n_shared=10, n_private=5, groups=2, poe="label", precision="bf16",
+               what="BASELINE configs[0]"),
+    "c2": dict(cells=50_000, genes=10_000, batch_size=4096, n_hidden=128, n_shared=25, n_private=10, groups=2, poe="label", precision="bf16",
+               what="BASELINE configs[1]"),
+    "c3": dict(cells=25_000, genes=20_000, batch_size=4096, n_hidden=128, n_shared=25, n_private=10, groups=2, poe="label", precision="bf16",
+               what="BASELINE configs[2]: one rank's shard of 2 x 200 000 x 20 000 over 8 GPUs"),
+    "c4": dict(cells=25_000, genes=15_000, batch_size=4096, n_hidden=256, n_shared=25, n_private=10, groups=3, poe="cluster", precision="bf16",
+               what="BASELINE configs[3]: one rank's shard of 3 x 100 000 x 15 000 over 4 GPUs (throughput only)"),
+    "c5": dict(cells=62_500, genes=30_000, batch_size=4096, n_hidden=128, n_shared=25, n_private=10, groups=2, poe="paired", precision="fp32",
+               what="BASELINE configs[4]: one rank's shard of 2 x 500 000 x 30 000 over 8 GPUs"),
+}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--cells", type=int, default=50_000, help="cells per group per rank")
-    ap.add_argument("--genes", type=int, default=10_000, help="genes per group")
-    ap.add_argument("--batch-size", type=int, default=4096, help="cells per group per step per rank")
-    ap.add_argument("--n-hidden", type=int, default=128)
-    ap.add_argument("--n-shared", type=int, default=25)
-    ap.add_argument("--n-private", type=int, default=10)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--steps", type=int, default=50)     # >= 50 timed steps after 10 warm-up
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS), help="BASELINE.json workload preset (see the module docstring)")
+    ap.add_argument("--cells", type=int, default=None, help="cells per group per rank")
+    ap.add_argument("--genes", type=int, default=None, help="genes per group")
+    ap.add_argument("--batch-size", type=int, default=None, help="cells per group per step per rank")
+    ap.add_argument("--n-hidden", type=int, default=None)
+    ap.add_argument("--n-shared", type=int, default=None)
+    ap.add_argument("--n-private", type=int, default=None)
+    ap.add_argument("--groups", type=int, default=None, choices=[2, 3])
+    ap.add_argument("--poe", default=None, choices=["label", "paired", "cluster"])
+    ap.add_argument("--precision", default=None, choices=["bf16", "fp32"])
+    ap.add_argument("--no-elbo-delta", action="store_true", help="skip the one-step ELBO comparison against the CPU oracle")
     ap.add_argument("--count-dtype", default="u16", choices=["u16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a captured hipGraph")
@@ -55,7 +81,12 @@ def parse():
                          "decoder bucket overlapped with the encoder half of the backward pass (auto: overlap when WORLD_SIZE > 1)")
     ap.add_argument("--cpu-batch", type=int, default=256)
     ap.add_argument("--cpu-steps", type=int, default=2)
-    return ap.parse_args()
+    args = ap.parse_args()
+    preset = CONFIGS[args.config]
+    for k, v in preset.items():
+        if k != "what" and getattr(args, k) is None:
+            setattr(args, k, v)
+    return args
 
 
 def cpu_baseline(groups, args, n_threads):
@@ -98,38 +129,82 @@ def cpu_baseline(groups, args, n_threads):
 
 
 
-def _pmc_traffic():
-    """HBM bytes per launch of the dominant kernel = FETCH_SIZE + WRITE_SIZE (KiB) of the newest committed rocprofv3 --pmc
-    passes under profiles/ (separate passes of this same command; bench.py itself cannot run under the profiler).  The
-    kernel's reads are 8 B / lane: outside the access widths the gfx950 FETCH_SIZE correction is calibrated for, so the
-    raw counter is reported."""
+def _pmc_fields(args):
+    """HBM bytes per launch of the dominant kernel = FETCH_SIZE + WRITE_SIZE (KiB) and its VALU-busy fraction, from the newest
+    committed rocprofv3 --pmc passes under profiles/ (separate passes of this same command; bench.py itself cannot run
+    under the profiler).  Only reported when THIS run has the workload the passes were taken on (the profile file names
+    it in a `# workload:` line; files without one were taken on the default c2 / bf16 / u16 workload): any other
+    invocation gets nulls rather than another shape's counters.  The kernel's reads are 8 B / lane, outside the access
+    widths the gfx950 FETCH_SIZE correction is calibrated for, so the raw counter is reported."""
     import glob, re
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_dec_nb_kernel.txt")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_dec_nb_kernel.txt")))
     if not files:
-        return None, None
+        return None, None, None
     txt = open(files[-1]).read()
+    m = re.search(r"^# workload: (.*)$", txt, re.M)
+    tag = m.group(1).strip() if m else "c2 bf16 u16 B4096 G10000"
+    mine = f"{args.config} {args.precision} {args.count_dtype} B{args.batch_size} G{args.genes}"
+    if tag != mine:
+        return None, None, None
     f = re.search(r"FETCH_SIZE\s+n=\s*\d+\s+avg=\s*([0-9.]+)", txt)
     w = re.search(r"WRITE_SIZE\s+n=\s*\d+\s+avg=\s*([0-9.]+)", txt)
-    if not (f and w):
-        return None, None
-    return (float(f.group(1)) + float(w.group(1))) * 1024.0, "profiles/" + os.path.basename(files[-1]) + " (raw FETCH_SIZE + WRITE_SIZE, KiB -> bytes)"
-
-
-def _pmc_valu_busy():
-    """Fraction of the dominant kernel's cycles in which a SIMD issues VALU work, from the same committed --pmc passes:
-    SQ_ACTIVE_INST_VALU (quad-cycles summed over the 1024 SIMDs) * 4 / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs.  The
-    likelihood kernel is bound by VALU / transcendental issue, not by HBM: this, not `frac`, is how close it runs to its
-    own ceiling."""
-    import glob, re
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_dec_nb_kernel.txt")))
-    if not files:
-        return None
-    txt = open(files[-1]).read()
     a = re.search(r"SQ_ACTIVE_INST_VALU\s+n=\s*\d+\s+avg=\s*([0-9.]+)", txt)
     g = re.search(r"GRBM_GUI_ACTIVE\s+n=\s*\d+\s+avg=\s*([0-9.]+)", txt)
-    if not (a and g):
-        return None
-    return (float(a.group(1)) * 4.0 / 1024.0) / (float(g.group(1)) / 8.0)
+    traffic = (float(f.group(1)) + float(w.group(1))) * 1024.0 if (f and w) else None
+    # SQ_ACTIVE_INST_VALU: quad-cycles summed over the 1024 SIMDs; GRBM_GUI_ACTIVE: cycles summed over the 8 XCDs
+    busy = (float(a.group(1)) * 4.0 / 1024.0) / (float(g.group(1)) / 8.0) if (a and g) else None
+    return traffic, "profiles/" + os.path.basename(files[-1]) + " (raw FETCH_SIZE + WRITE_SIZE, KiB -> bytes)", busy
+
+
+def synthetic_plan(n0, n1, k=8, seed=2000):
+    """the transport plan of the OT configs, defined implicitly as a permutation + k random neighbours per
+    row (CSR, never densified)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    first = rng.permutation(n1)[:n0] if n1 >= n0 else rng.integers(0, n1, n0)
+    cols = np.concatenate([first[:, None], rng.integers(0, n1, (n0, k))], axis=1).reshape(-1)
+    rows = np.repeat(np.arange(n0), k + 1)
+    vals = (rng.random(n0 * (k + 1)) + 0.05).astype(np.float32)
+    m = sp.coo_matrix((vals, (rows, cols)), shape=(n0, n1)).tocsr()
+    m.data = m.data.astype(np.float32)
+    return m
+
+
+def elbo_delta(trainer, module, groups, rows, args, plan):
+    """|loss_build - loss_oracle| / |loss_oracle| at kl_weight = 1 for ONE training-mode step of this run's workload, same
+    parameters, minibatch and noise (SURVEY.md 8d "ELBO delta"; module/spVIPESmodule.py:809-899).  Dropout is switched
+    off for this one comparison step (the two implementations cannot share a dropout RNG stream); no optimiser step."""
+    from oracle import spvipes_oracle as O
+
+    B, n_p, n_s = args.batch_size, args.n_private, args.n_shared
+    gen = torch.Generator().manual_seed(12345)
+    noise = {f"enc_{g}_{k}": torch.randn(B, n, generator=gen) for g in range(2) for k, n in (("private", n_p), ("shared", n_s))}
+    noise.update({f"poe_{g}": torch.randn(B, n_s, generator=gen) for g in range(2)})
+    sd = {k: v.detach().cpu().clone() for k, v in module.state_dict().items()}
+    p_drop = module.dropout_rate
+    module.dropout_rate = 0.0
+    try:
+        lo = trainer.step(rows, kl_weight=1.0, noise={k: v.to(rows[0].device) for k, v in noise.items()}, optimizer_step=False)
+        got = float(lo.loss.detach())
+    finally:
+        module.dropout_rate = p_drop
+    counts = []
+    for g in range(2):
+        X = groups[g].counts.X[rows[g].long()].cpu()
+        counts.append(torch.from_numpy(X.numpy().view(np.uint16).astype(np.float32)) if X.dtype == torch.int16 else X)
+    kw = {}
+    if args.poe == "label":
+        kw["labels"] = [groups[g].labels[rows[g].long()].cpu() for g in range(2)]
+    else:
+        r0, r1 = rows[0].cpu().numpy(), rows[1].cpu().numpy()
+        kw["plan_block"] = torch.from_numpy(plan[r0][:, r1].toarray().astype(np.float32))
+        if args.poe == "cluster":
+            kw["components"] = [groups[g].labels[rows[g].long()].cpu() for g in range(2)]
+    with torch.no_grad():
+        want = float(O.forward_loss(sd, counts, n_dimensions_shared=n_s, n_dimensions_private=n_p, noise=noise, mode=args.poe,
+                                    training=True, kl_weight=1.0, **kw)["loss"])
+    return {"value": abs(got - want) / abs(want), "loss_build": got, "loss_oracle": want,
+            "what": f"one training-mode step of this workload (B {B} x G {args.genes}, {args.poe} PoE, {args.precision}), same parameters / rows / noise, dropout off, kl_weight 1"}
 
 
 def main():
@@ -154,14 +229,26 @@ def main():
 
     _abi.load()
     torch.manual_seed(0)
-    groups = [make_synthetic_group(g, args.cells, args.genes, dev, dtype=args.count_dtype) for g in range(2)]
-    module = spVIPESmodule({0: args.genes, 1: args.genes}, use_labels=True, n_hidden=args.n_hidden,
-                           n_dimensions_shared=args.n_shared, n_dimensions_private=args.n_private, precision=args.precision).to(dev)
-    trainer = Trainer(module, [g.counts for g in groups], labels=[g.labels for g in groups],
+    NG = args.groups
+    groups = [make_synthetic_group(g, args.cells, args.genes, dev, dtype=args.count_dtype) for g in range(NG)]
+    plan = None
+    mkw = {}
+    if args.poe == "label":
+        mkw = dict(use_labels=True)
+    else:
+        if NG == 2:
+            plan = synthetic_plan(args.cells, args.cells)
+            mkw = dict(transport_plan=plan, pair_data=(args.poe == "paired"))
+        else:   # N-group cluster matching: the experts are the per-component batch statistics, no pairwise plan is needed
+            mkw = dict(transport_plan="components", pair_data=False)
+    module = spVIPESmodule({g: args.genes for g in range(NG)}, n_hidden=args.n_hidden, n_dimensions_shared=args.n_shared,
+                           n_dimensions_private=args.n_private, precision=args.precision, **mkw).to(dev)
+    trainer = Trainer(module, [g.counts for g in groups], labels=[g.labels for g in groups] if args.poe == "label" else None,
+                      components=[g.labels for g in groups] if args.poe == "cluster" else None,
                       overlap_allreduce=None if args.allreduce == "auto" else args.allreduce == "overlap")
     if world > 1:  # identical initial weights on every rank
         dist.broadcast(trainer.fp.flat, src=0)
-    sampler = MinibatchSampler([args.cells, args.cells], args.batch_size, dev, seed=rank)
+    sampler = MinibatchSampler([args.cells] * NG, args.batch_size, dev, seed=rank)
     module.train()
 
     def batches():
@@ -173,6 +260,12 @@ def main():
     prof_names = ["spv_dec_nb_fwd", "spv_dec_logits", "spv_enc_fc1_fwd", "spv_enc_fc1_wgrad", "spv_dec_lse", "spv_dec_softmax_bwd",
                   "spv_gemm_bf16", "spv_adam_step"]
     use_graph = not args.no_graph
+    delta = None
+    if rank == 0 and world == 1 and NG == 2 and not args.no_elbo_delta:
+        try:
+            delta = elbo_delta(trainer, module, groups, next(it), args, plan)
+        except Exception as e:  # a reported extra; never lose the throughput number over it
+            delta = {"value": None, "what": f"failed: {e!r}"}
     prof = {}
     if use_graph:
         # A captured hipGraph cannot carry per-call events, so the per-kernel durations for the roofline line are
@@ -201,27 +294,44 @@ def main():
         dist.barrier()
     if not use_graph:
         _abi.profile_start(prof_names)  # HIP events on the launch stream around the C-ABI calls, inside the timed region
+    # per-step HIP events on the launch stream (no host synchronisation): the median step time SURVEY 8d defines
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     last = None
-    for _ in range(args.steps):
+    ev[0].record()
+    for i in range(args.steps):
         last = trainer.step(next(it), kl_weight=1.0)
+        ev[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if not use_graph:
         prof = _abi.profile_stop()
+    step_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2]
     prof_steps = args.steps if not use_graph else max(3, min(args.steps, 10))
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t)
     loss = float(last.loss)
+    # exposed all-reduce time per step (outside the timed region): GPU time between the end of the backward pass and the
+    # start of Adam, max over ranks
+    exposed = None
+    if world > 1:
+        ex = []
+        for _ in range(5):
+            trainer.step(next(it), kl_weight=1.0)
+            ex.append(trainer.last_allreduce_exposed_ms())
+        tt = torch.tensor([float(np.median(ex))], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        exposed = float(tt)
 
     if rank == 0:
         B, G, H = args.batch_size, args.genes, args.n_hidden
         n_s, n_p = args.n_shared, args.n_private
-        cells_per_step = 2 * B * world
+        cells_per_step = NG * B * world
         value = cells_per_step * args.steps / elapsed
         sx = 2 if args.count_dtype == "u16" else 4
         # dominant kernel = the fused decoder + NB-mixture likelihood forward (per group launch):
@@ -233,34 +343,41 @@ def main():
         nb_bytes = B * G * sx + G * (KM + 2 * (n_s + n_p + 2)) * 2 + B * KM * 2
         nb_flops = 2.0 * B * G * (KM + n_s + n_p + 2)
         per_kernel = {k: {"calls_per_step": len(v) / prof_steps, "avg_ms": float(np.mean(v))} for k, v in prof.items() if v}
-        traffic, traffic_src = _pmc_traffic()
+        traffic, traffic_src, valu_busy = _pmc_fields(args)
         roof = {"kernel": "dec_nb_kernel (spv_dec_nb_fwd)", "bound": "hbm", "achieved": nb_bytes / (nb_avg * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nb_bytes / (nb_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": traffic_src,
-                "valu_busy_frac": _pmc_valu_busy(),
+                "limiter": "VALU / transcendental issue and per-wave memory latency, not HBM bandwidth (DESIGN.md section 4)",
+                "valu_busy_frac": valu_busy,
                 "avg_launch_ms": nb_avg, "algorithmic_bytes_per_launch": nb_bytes,
                 "mfma_view": {"achieved_TFLOPs": nb_flops / (nb_avg * 1e-3) / 1e12, "peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS,
                               "frac": nb_flops / (nb_avg * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS},
                 "per_entry_point": per_kernel}
         fc1_ms = prof.get("spv_enc_fc1_fwd", [])
-        if fc1_ms:   # the encoder contraction SURVEY 8d prices against the MFMA roofline (entry point = split-K GEMM + bias/ReLU/slab-sum kernel)
+        if fc1_ms:   # the encoder contraction SURVEY 8d prices against the MFMA roofline (whole entry point, epilogue included)
             fc1_avg, fc1_flops, fc1_bytes = float(np.mean(fc1_ms)), 2.0 * B * G * 2 * H, B * G * 2 + 2 * H * G * 2
             roof["encoder_fc1_view"] = {"bound": "mfma", "achieved": fc1_flops / (fc1_avg * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                         "frac": fc1_flops / (fc1_avg * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, "avg_launch_ms": fc1_avg,
                                         "hbm_co_bound_GBs": fc1_bytes / (fc1_avg * 1e-3) / 1e9}
+        poe_txt = {"label": "label-based PoE", "paired": "paired-cells PoE on a sparse transport plan", "cluster": "cluster-matched PoE"}[args.poe]
         out = {
-            "metric": "cells/sec/training-step (2-group PoE VAE)", "value": value, "unit": "cells/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "metric": "cells/sec/training-step (2-group PoE VAE)" if NG == 2 else f"cells/sec/training-step ({NG}-group PoE VAE)",
+            "value": value, "unit": "cells/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_median": median_ms,
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32(split-bf16)", "data": "synthetic",
-            "config": {"workload": f"2 groups x {args.cells} cells x {G} genes per GPU, label-based PoE, n_shared={n_s} n_private={n_p} "
-                                   f"n_hidden={H}, batch {B} cells/group/step/GPU, counts resident as {args.count_dtype} (BASELINE configs[1])",
+            "config": {"workload": f"{NG} groups x {args.cells} cells x {G} genes per GPU, {poe_txt}, n_shared={n_s} n_private={n_p} "
+                                   f"n_hidden={H}, batch {B} cells/group/step/GPU, counts resident as {args.count_dtype} ({CONFIGS[args.config]['what']})",
+                       "preset": args.config,
                        "parallelism": f"dp{world}", "precision": args.precision, "launch": "hipGraph replay, 2 streams" if use_graph else "eager",
                        "allreduce": ("none (1 rank)" if world == 1 else "2 buckets, decoder bucket overlapped with the encoder backward"
-                                     if trainer.overlap else "1 bucket after the backward pass")},
+                                     if trainer.overlap else "1 bucket after the backward pass (north_star form)"),
+                       "allreduce_exposed_ms_per_step": exposed},
             "final_loss": loss,
+            "elbo_delta": delta,
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and NG == 2:
             try:
                 out["cpu_baseline"] = cpu_baseline(groups, args, min(os.cpu_count() or 1, 16))
             except Exception as e:  # the baseline is a reported extra; never lose the GPU number over it

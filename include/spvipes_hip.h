@@ -41,6 +41,9 @@ extern "C" {
 
 int spv_version(void);
 const char* spv_last_error(void);
+/* Fingerprint (32 hex digits) of the sources and compiler flags this library was built from; the Python binding refuses a
+ * library whose fingerprint differs from the sources next to it (spvipes_amd/build.py: build_id). */
+const char* spv_build_id(void);
 
 /* Count matrix of one group: X[cell][gene], row-major, resident in HBM.
  * rows == NULL means "cells 0..B-1"; otherwise cell b of the minibatch is row rows[b]

@@ -133,6 +133,7 @@ class SpvFoldBatch(C.Structure):
 _SIGNATURES = {
     "spv_version": (C.c_int, []),
     "spv_last_error": (C.c_char_p, []),
+    "spv_build_id": (C.c_char_p, []),
     "spv_pack_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                 C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "spv_enc_fc1_fwd": (C.c_int, [C.POINTER(SpvCounts), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
@@ -200,6 +201,13 @@ def load() -> C.CDLL:
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export the symbol
         fn.restype, fn.argtypes = res, args
+    # a library built from other sources or with other compiler flags than the ones next to it never loads silently
+    from .build import build_id
+
+    have, want = (lib.spv_build_id() or b"").decode(), build_id()
+    if have != want and os.environ.get("SPV_ALLOW_STALE_LIB", "0") != "1":
+        raise SpvError(f"{LIB_PATH} is stale (built from fingerprint {have}, the sources and flags now give {want}): "
+                       "rebuild with `python -m spvipes_amd.build`")
     _lib = lib
     return lib
 

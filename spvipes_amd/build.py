@@ -19,6 +19,28 @@ SOURCES = ["spv_abi.hip"]
 HEADERS = ["spv_common.h", "spv_gemm.h", "spv_decoder.h", "spv_small.h", os.path.join("..", "..", "include", "spvipes_hip.h")]
 
 
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+    # No SLP vectorisation: see DESIGN.md section 8 (run-to-run reproducibility of the likelihood kernel's gradients) and
+    # tests/test_isa_invariants.py, which pins what the built code object may contain.
+    "-fno-slp-vectorize",
+]
+
+
+def build_id() -> str:
+    """Fingerprint of everything the library is built from: every source / header byte plus the compiler flags.  It is
+    compiled into the library (``spv_build_id()``) and ``_abi.load()`` refuses a library whose fingerprint differs from
+    the sources next to it -- a .so built from other sources or with other flags never loads silently."""
+    import hashlib
+
+    h = hashlib.sha256()
+    h.update(" ".join(FLAGS).encode())
+    for name in sorted(SOURCES + HEADERS):
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.replace(os.sep, "/").encode() + b"\0" + f.read())
+    return h.hexdigest()[:32]
+
+
 def _hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -26,12 +48,19 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (need ROCm >= 7 with gfx950 support)")
 
 
+def lib_build_id(path: str = LIB) -> str:
+    """the fingerprint compiled into an existing library, read from the file without loading it ('' if absent)"""
+    import re
+
+    if not os.path.exists(path):
+        return ""
+    with open(path, "rb") as f:
+        m = re.search(rb"SPV_BUILD_ID=([0-9a-f]{32})", f.read())
+    return m.group(1).decode() if m else ""
+
+
 def is_stale() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]   # (the flags live in this file)
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    return lib_build_id() != build_id()
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
@@ -39,11 +68,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     cmd = [
-        _hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-        # No SLP vectorisation: the packed-fp32 (v_pk_*_f32 with op_sel) code it forms in the likelihood kernel gave results
-        # that were not bit-reproducible from run to run on gfx950 / ROCm 7.2 (one gradient element of the last 16 lanes of
-        # a wave, about 1 launch in 500 under GPU sharing).  Costs about 1 % of the step.
-        "-fno-slp-vectorize",
+        _hipcc(), *FLAGS, f'-DSPV_BUILD_ID="{build_id()}"',
         *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB + ".tmp",
     ]
     if verbose:

@@ -24,7 +24,12 @@ static int launch_status(const char* what) {
   return SPV_OK;
 }
 
-extern "C" int spv_version(void) { return 1; }
+#ifndef SPV_BUILD_ID
+#define SPV_BUILD_ID "00000000000000000000000000000000"
+#endif
+static const char g_build_id[] = "SPV_BUILD_ID=" SPV_BUILD_ID;   // (the tagged form is also what build.lib_build_id() greps out of the file)
+extern "C" int spv_version(void) { return 2; }
+extern "C" const char* spv_build_id(void) { return g_build_id + 13; }
 extern "C" const char* spv_last_error(void) { return g_err; }
 
 // ---------------------------------------------------------------------------------------------

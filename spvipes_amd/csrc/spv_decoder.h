@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void dec_lse_combine_kernel(const float* pmp, 
 __device__ __forceinline__ float2 gamma_terms_fixup(const DecParams& p, int g, float c) {
   const float theta = p.gene_tab[g].x, x = log1p_count(c);
   const LgammaDigamma a = lgamma_digamma(theta), b = lgamma_digamma(x + theta), d = lgamma_digamma(x + 1.0f);
-  const float2 t = p.cnt_tab[(long)(int)fminf(c, (float)(NB_CMAX - 1)) * p.Gp + g];   // the table row the main path used for this count
+  const float2 t = p.cnt_tab[(long)(int)__builtin_amdgcn_fmed3f(c, 0.f, (float)(NB_CMAX - 1)) * p.Gp + g];   // the table row the main path used for this count
   return make_float2(b.lg - a.lg - d.lg - t.x, b.dg - a.dg - t.y);
 }
 
@@ -369,8 +369,20 @@ constexpr int NB_GSPL_MAX = 160;     // genes per split: their regressor weights
 constexpr int NB_WPITCH = 56;        // LDS row pitch of the weight slice in bf16 (112 B: conflict-free 16-B row reads)
 constexpr int NB_CELLS_PER_WG = 64;  // 4 waves x one 16-cell tile
 
+#ifndef SPV_NB_ABLATE
+#define SPV_NB_ABLATE 0   // dev only (tools/probes/nb_bench.hip): 1 no gradient stores, 2 table gather from row 0 only, 4 no logits load, 8 no d-theta reduction, 16 one count row for all
+#endif
+#ifdef SPV_NB_STAMPS   // dev only: s_memtime stamps of workgroup phases (tools/probes/nb_bench.hip); never defined in the library build
+__device__ unsigned long long* g_nb_stamps;
+#define NB_STAMP(i) do { if (threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_nb_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = t_; } } while (0)
+#else
+#define NB_STAMP(i) do { } while (0)
+#endif
+#ifndef SPV_NB_OCC
+#define SPV_NB_OCC 3   // waves per SIMD the likelihood kernel's register budget is sized for (tools/probes/nb_bench.hip sweeps it)
+#endif
 template <bool TRAIN, typename GT, typename LT, int CM>
-__global__ __launch_bounds__(256, 3) void dec_nb_kernel(DecParams p) {
+__global__ __launch_bounds__(256, SPV_NB_OCC) void dec_nb_kernel(DecParams p) {
   __shared__ __attribute__((aligned(16))) bf16_t s_whi[NB_GSPL_MAX * NB_WPITCH], s_wlo[NB_GSPL_MAX * NB_WPITCH];
   __shared__ float4 s_gt[NB_GSPL_MAX];
   __shared__ float s_dth[TRAIN ? 4 : 1][NB_GSPL_MAX];
@@ -382,6 +394,7 @@ __global__ __launch_bounds__(256, 3) void dec_nb_kernel(DecParams p) {
   if (gend > p.Gp) gend = p.Gp;
   if (gend > ((p.G + 15) & ~15)) gend = (p.G + 15) & ~15;
   const int ng = gend - gbeg;
+  NB_STAMP(0);
   if (ng <= 0) {  // a split made of padding genes only: its partials are zeros
     const int cell = blockIdx.x * NB_CELLS_PER_WG + tid;
     if (cell < p.Bp) {
@@ -399,6 +412,7 @@ __global__ __launch_bounds__(256, 3) void dec_nb_kernel(DecParams p) {
   }
   for (int i = tid; i < ng; i += 256) s_gt[i] = p.gene_tab[gbeg + i];
   __syncthreads();
+  NB_STAMP(1);
   const int nchunks = ng >> 4;
 
   {
@@ -416,7 +430,7 @@ __global__ __launch_bounds__(256, 3) void dec_nb_kernel(DecParams p) {
     const s8v bs_hi = *reinterpret_cast<const s8v*>(p.Aps_hi + aoff + DEC_KP), bs_lo = *reinterpret_cast<const s8v*>(p.Aps_lo + aoff + DEC_KP);
     const float ap2 = p.a_p[cell] * NB_LOG2E, as2 = p.a_s[cell] * NB_LOG2E;   // a_k = library - lse_k, in base-2 units
     const float w = p.w_row[cell];
-    const long row_of_cell = cell_ok ? (p.rows ? (long)p.rows[cell] : (long)cell) : 0;
+    const long row_of_cell = ((SPV_NB_ABLATE & 16) != 0) ? 0 : (cell_ok ? (p.rows ? (long)p.rows[cell] : (long)cell) : 0);
     float rec = 0.f, tp_sum = 0.f, ts_sum = 0.f;
     // storage offset of this lane inside a 32x32 tile for gene half gh: qq = 2 gh + (gq >> 1), h = gq & 1
     const int lane_st = (16 * chh + c16 + 32 * (gq & 1)) * 4 + (gq >> 1) * 256;
@@ -425,10 +439,13 @@ __global__ __launch_bounds__(256, 3) void dec_nb_kernel(DecParams p) {
     const unsigned tile_row = (unsigned)cell_tile * (unsigned)p.n_gene_tiles;
     const unsigned plane = (unsigned)p.Bp * (unsigned)p.Gp;   // elements per plane of a hi/lo gradient array
     auto tile_off = [&](int g0) { return (tile_row + (unsigned)(g0 >> 5)) * 1024u + (unsigned)(((g0 >> 4) & 1) * 512 + lane_st); };
+    // (count, gene) table row = the count clamped to [0, NB_CMAX - 1] with one v_med3_f32: a negative value in an fp32-stored
+    // matrix (which the host rejects for resident data sets) can then never index outside the table
     auto gather_tab = [&](const float (&c)[4], int g0, float2 (&tab)[4]) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const unsigned eo = __umul24((unsigned)(int)fminf(c[j], (float)(NB_CMAX - 1)), (unsigned)p.Gp) + (unsigned)(g0 + 4 * gq + j);   // (Gp < 2^24)
+        unsigned eo = __umul24((unsigned)(int)__builtin_amdgcn_fmed3f(c[j], 0.f, (float)(NB_CMAX - 1)), (unsigned)p.Gp) + (unsigned)(g0 + 4 * gq + j);   // (Gp < 2^24)
+        if constexpr ((SPV_NB_ABLATE & 2) != 0) eo = (unsigned)(g0 + 4 * gq + j);
         tab[j] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(p.cnt_tab) + (size_t)(eo * 8u));
       }
     };
@@ -446,7 +463,9 @@ __global__ __launch_bounds__(256, 3) void dec_nb_kernel(DecParams p) {
       gather_tab(c0, gbeg, tabA);
     }
 
+    NB_STAMP(2);
     for (int c = 0; c < nchunks; ++c) {
+      if (c == 1) NB_STAMP(3);
       const int g0 = gbeg + 16 * c;
       const unsigned toff = tile_off(g0);
       // ---- y_p, y_s for this chunk: A[row = gene][k = 8 gq + i] from the LDS slice ------------------------------
@@ -465,7 +484,8 @@ __global__ __launch_bounds__(256, 3) void dec_nb_kernel(DecParams p) {
       float ellB[4];
       float2 tabB[4];
       rawC = load_counts4_raw<CM>(p, row_of_cell, g2 + 4 * gq, cell_ok);
-      load4b<LT>(p.logits, tile_off(g1), ellB);
+      if constexpr ((SPV_NB_ABLATE & 4) != 0) { ellB[0] = ellA[1]; ellB[1] = ellA[2]; ellB[2] = ellA[3]; ellB[3] = ellA[0]; }
+      else load4b<LT>(p.logits, tile_off(g1), ellB);
       {
         float cB[4];
         decode_counts4<CM>(p, rawB, row_of_cell, g1 + 4 * gq, cell_ok, cB);
@@ -544,10 +564,16 @@ __global__ __launch_bounds__(256, 3) void dec_nb_kernel(DecParams p) {
         }
       }
       if constexpr (TRAIN) {
+        if constexpr ((SPV_NB_ABLATE & 1) != 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(o_dl[j]), "v"(o_tp[j]), "v"(o_ts[j]));
+        } else {
         store_grad4<GT>(p.dL, toff, plane, o_dl);
         store_grad4<GT>(p.tP, toff, plane, o_tp);
         store_grad4<GT>(p.tS, toff, plane, o_ts);
+        }
         // per-gene sums over this wave's 16 cells (lanes sharing gq): 4 values x 16 lanes -> lane keeps gene 2*b3 + b2
+        if constexpr ((SPV_NB_ABLATE & 8) != 0) { asm volatile("" ::"v"(dth4[0]), "v"(dth4[1]), "v"(dth4[2]), "v"(dth4[3])); } else {
         const bool u3 = lane & 8, u2 = lane & 4;
         const float a0 = (u3 ? dth4[2] : dth4[0]) + __shfl_xor(u3 ? dth4[0] : dth4[2], 8, 64);
         const float a1 = (u3 ? dth4[3] : dth4[1]) + __shfl_xor(u3 ? dth4[1] : dth4[3], 8, 64);
@@ -555,11 +581,14 @@ __global__ __launch_bounds__(256, 3) void dec_nb_kernel(DecParams p) {
         s += __shfl_xor(s, 2, 64);
         s += __shfl_xor(s, 1, 64);
         if ((lane & 3) == 0) s_dth[wave][16 * c + 4 * gq + 2 * ((lane >> 3) & 1) + ((lane >> 2) & 1)] = s;
+        }
       }
+
 #pragma unroll
       for (int j = 0; j < 4; ++j) { ellA[j] = ellB[j]; tabA[j] = tabB[j]; }
       rawA = rawB; rawB = rawC;
     }
+    NB_STAMP(4);
     // the four gene groups of a cell sit in lanes c16, c16+16, c16+32, c16+48
     rec += __shfl_xor(rec, 16, 64); rec += __shfl_xor(rec, 32, 64);
     if constexpr (TRAIN) {
@@ -577,6 +606,7 @@ __global__ __launch_bounds__(256, 3) void dec_nb_kernel(DecParams p) {
     for (int i = tid; i < ng; i += 256)
       p.dtheta_part[(long)blockIdx.x * p.Gp + gbeg + i] = ((s_dth[0][i] + s_dth[1][i]) + s_dth[2][i]) + s_dth[3][i];
   }
+  NB_STAMP(5);
 }
 
 // ---- backward helper: finish the softmax backward in place -------------------------------------

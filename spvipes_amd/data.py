@@ -26,6 +26,8 @@ def to_group_counts(X, device, prefer_u16: bool = True, col_off: int = 0, G: Opt
     else:
         Xn = np.asarray(X)
     G = Xn.shape[1] - col_off if G is None else G
+    if Xn.size and float(Xn.min()) < 0:
+        raise ValueError("count matrices must be non-negative (the likelihood is evaluated at log1p(count); the reference gives NaN for counts <= -1)")
     if prefer_u16 and Xn.size and float(Xn.min()) >= 0 and float(Xn.max()) < 65536 and np.all(Xn == np.floor(Xn)):
         t = torch.from_numpy(np.ascontiguousarray(Xn.astype(np.uint16)).view(np.int16))
     else:

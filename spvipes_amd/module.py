@@ -48,6 +48,13 @@ class LossOutput:
     reconstruction_loss_mean: Optional[torch.Tensor] = None  # 0-dim: batch mean of the summed reconstruction terms (this build's extra)
 
 
+def kl_normal_std(loc: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    """KL(N(loc, scale) || N(0, 1)) summed over the latent dimension (spVIPESmodule.py:841-868) for encoder outputs that did
+    not come out of the fused kernels (injected-mask / ragged inference batches)."""
+    var = scale * scale
+    return (0.5 * (var + loc * loc - 1.0 - torch.log(var))).sum(dim=1)
+
+
 # ---- parameter containers with the reference's state_dict layout ---------------------------------
 class _LazyMeans(dict):
     """extra_metrics of LossOutput (spVIPESmodule.py:884-897): batch means, evaluated when first read so that a
@@ -268,8 +275,6 @@ class spVIPESmodule(nn.Module):
                   dropout_masks: Optional[dict] = None, **kwargs):
         """Runs the encoders and the PoE (spVIPESmodule.py:425-472).  ``noise`` optionally injects the
         standard-normal draws ("enc_{g}_private", "enc_{g}_shared", "poe_{g}") for parity tests."""
-        from . import poe as P
-
         from .nn_ops import EncoderSpec, EncoderTails, PoELabel
 
         noise = noise or {}
@@ -365,10 +370,10 @@ class spVIPESmodule(nn.Module):
                                             ("logtheta_log_z", log_z), ("logtheta_theta", theta)])
                 self._kl_poe[g] = kl
         else:
-            poe_stats = self._supervised_poe(shared_stats, global_indices, processed_labels, labels, noise, P)
+            poe_stats = self._supervised_poe(shared_stats, global_indices, processed_labels, labels, noise)
         return {"private_stats": private_stats, "shared_stats": shared_stats, "poe_stats": poe_stats, "library": library}
 
-    def _supervised_poe(self, shared_stats, global_indices, processed_labels, labels, noise, P):
+    def _supervised_poe(self, shared_stats, global_indices, processed_labels, labels, noise):
         """Dispatch of spVIPESmodule.py:484-509 (same priorities and errors); label-based PoE, first in that order, has
         already been taken by ``inference``."""
         if self.use_transport_plan:
@@ -451,7 +456,6 @@ class spVIPESmodule(nn.Module):
     def loss(self, tensors_by_group, inference_outputs, generative_outputs, kl_weight: float = 1.0):
         """spVIPESmodule.py:809-899."""
         from .dec_ops import DecoderFused, decoder_params
-        from .poe import kl_normal_std
 
         B0, B1 = self._step_inputs[0][2], self._step_inputs[1][2]
         if B0 != B1:

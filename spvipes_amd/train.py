@@ -3,7 +3,7 @@
 Stands in for what the reference delegates to scvi-tools + Lightning
 (/root/reference/src/spVIPES/model/base/training_mixin.py:89-123): ``TrainingPlan`` = Adam(lr 1e-3,
 eps 0.01, weight_decay 1e-6) with a linear KL warm-up (0 -> 1 over ``n_epochs_kl_warmup`` = 400
-epochs, or over ``n_steps_kl_warmup`` steps when given), ``max_epochs = min(round(20000 / n_obs *
+epochs; over ``n_steps_kl_warmup`` steps only when no epoch count is given), ``max_epochs = min(round(20000 / n_obs *
 400), 400)``.
 
 Data parallelism (the reference has none): one process per GPU, every rank draws its
@@ -29,12 +29,18 @@ from .ops import GroupCounts
 
 def kl_weight_at(epoch: int, step: int, n_epochs_kl_warmup: Optional[int], n_steps_kl_warmup: Optional[int],
                  max_kl_weight: float = 1.0, min_kl_weight: float = 0.0) -> float:
-    """scvi TrainingPlan.kl_weight (steps take precedence over epochs)."""
+    """KL weight of scvi-tools 0.20.0 ``TrainingPlan.kl_weight`` (``_compute_kl_weight`` in scvi/train/_trainingplans.py,
+    the library version pinned by the reference's pyproject): the EPOCH criterion is checked first and the step criterion
+    is used only when ``n_epochs_kl_warmup`` is None / 0 -- the reference's own docstring (training_mixin.py:67-68, "steps
+    take precedence") describes the opposite of what the library it calls does; with its default n_epochs_kl_warmup=400 a
+    user-supplied n_steps_kl_warmup is therefore ignored, and so it is here."""
     slope = max_kl_weight - min_kl_weight
-    if n_steps_kl_warmup:
-        return min_kl_weight + slope * min(1.0, step / n_steps_kl_warmup)
     if n_epochs_kl_warmup:
-        return min_kl_weight + slope * min(1.0, epoch / n_epochs_kl_warmup)
+        if epoch < n_epochs_kl_warmup:
+            return min_kl_weight + slope * (epoch / n_epochs_kl_warmup)
+    elif n_steps_kl_warmup:
+        if step < n_steps_kl_warmup:
+            return min_kl_weight + slope * (step / n_steps_kl_warmup)
     return max_kl_weight
 
 
@@ -116,6 +122,7 @@ class Trainer:
         self.overlap = (self.world > 1) if overlap_allreduce is None else bool(overlap_allreduce)
         self.global_step, self.epoch = 0, 0
         self.graph = self.graph2 = None
+        self.last_outputs = None
         self.history: Dict[str, List[float]] = {"train_loss": [], "elbo_train": [], "reconstruction_loss_train": [], "kl_local_train": []}
 
     def minibatch(self, rows: Sequence[torch.Tensor]):
@@ -134,15 +141,18 @@ class Trainer:
             out.append(d)
         return tuple(out)
 
-    def _forward_backward(self, rows, kl_weight):
+    def _forward_backward(self, rows, kl_weight, noise=None):
         """forward + loss + backward.  With ``self.overlap`` only the decoder half of the backward pass runs here (down
-        to the tensors that cross from the encoders into the decoder); ``_backward_encoders`` finishes it."""
+        to the tensors that cross from the encoders into the decoder); ``_backward_encoders`` finishes it.
+        ``noise``: injected standard-normal draws (parity tests; see spVIPESmodule.inference)."""
         from . import nn_ops, ops
 
         self.fp.grad.zero_()
         self.module.split_backward = self.overlap   # (only for this call: a plain module(...) elsewhere keeps one backward pass)
         try:
-            _, _, lo = self.module(self.minibatch(rows), loss_kwargs={"kl_weight": kl_weight})
+            inf, gen, lo = self.module(self.minibatch(rows), inference_kwargs=({"noise": noise} if noise is not None else None),
+                                       loss_kwargs={"kl_weight": kl_weight})
+            self.last_outputs = (inf, gen)   # (inference_outputs, generative_outputs) of the latest step
         finally:
             self.module.split_backward = False
         nn_ops.GRAD_SINK = True  # small-layer gradients land directly in the flat buffer (see nn_ops.grad_out)
@@ -208,8 +218,12 @@ class Trainer:
                 self._backward_encoders()
             self.graph2 = g2
 
-    def step(self, rows: Sequence[torch.Tensor], kl_weight: Optional[float] = None):
-        """forward + loss + backward + (all-reduce) + Adam for one minibatch; returns the LossOutput."""
+    def step(self, rows: Sequence[torch.Tensor], kl_weight: Optional[float] = None, noise=None, optimizer_step: bool = True):
+        """forward + loss + backward + (all-reduce) + Adam for one minibatch; returns the LossOutput.  ``noise`` (eager steps
+        only) injects the step's standard-normal draws; ``optimizer_step=False`` stops before Adam, leaving the reduced
+        gradients in ``self.fp.grad`` (parity tests)."""
+        if noise is not None and self.graph is not None:
+            raise ValueError("injected noise needs an eager step (the captured graph draws its own)")
         if kl_weight is None:
             kl_weight = kl_weight_at(self.epoch, self.global_step, self.n_epochs_kl_warmup, self.n_steps_kl_warmup)
         if self.graph is not None:
@@ -221,7 +235,11 @@ class Trainer:
             self.graph.replay()
             lo = self._static_lo  # tensors are overwritten by the next replay
         else:
-            lo = self._forward_backward(rows, kl_weight)
+            lo = self._forward_backward(rows, kl_weight, noise)
+        timed = self.world > 1
+        if timed:   # GPU-time bracket of what the collectives leave exposed after the backward pass (bench.py reports it)
+            if getattr(self, "_ev_ar", None) is None:
+                self._ev_ar = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         if self.overlap:
             # bucket 1 (decoders) is summed over the ranks while the encoder half of the backward pass runs
             split = self.fp.split
@@ -231,14 +249,27 @@ class Trainer:
             else:
                 self._backward_encoders()
             if self.world > 1:
+                self._ev_ar[0].record()
                 w2 = dist.all_reduce(self.fp.grad[split:], op=dist.ReduceOp.SUM, async_op=True)
                 w1.wait()
                 w2.wait()
+                self._ev_ar[1].record()
         elif self.world > 1:
-            dist.all_reduce(self.fp.grad, op=dist.ReduceOp.SUM)  # one collective for the whole flat buffer
-        self.opt.step(grad_scale=1.0 / self.world)
-        self.global_step += 1
+            self._ev_ar[0].record()
+            dist.all_reduce(self.fp.grad, op=dist.ReduceOp.SUM)  # ONE collective for the whole flat buffer (the north_star form)
+            self._ev_ar[1].record()
+        if optimizer_step:
+            self.opt.step(grad_scale=1.0 / self.world)
+            self.global_step += 1
         return lo
+
+    def last_allreduce_exposed_ms(self) -> float:
+        """GPU time of the latest step between the end of the backward pass and the point where Adam may start (what the
+        gradient all-reduce leaves exposed).  Synchronises; 0 on a single rank."""
+        if self.world <= 1 or getattr(self, "_ev_ar", None) is None:
+            return 0.0
+        self._ev_ar[1].synchronize()
+        return float(self._ev_ar[0].elapsed_time(self._ev_ar[1]))
 
     def fit(self, sampler: MinibatchSampler, max_epochs: int, log_every: int = 0, use_graph: bool = True):
         """``max_epochs`` passes over the sampler.  The step is captured into a hipGraph at the first minibatch (the

@@ -7,10 +7,10 @@ Replaces /root/reference/src/spVIPES/module/spVIPESmodule.py:
     _get_batch_transport_plans :474-482             -> batch_transport_plan
     KL terms of loss :841-868                       -> kl_normal_std
 
-The product path runs all three pairings in HIP (nn_ops.PoELabel / PoEPaired / PoECluster over csrc/spv_small.h); the
-functions below are the same arithmetic in plain torch tensor ops.  They are what the HIP kernels were first validated
-against on the GPU and what tests/test_poe_host_logic.py checks against the reference's goldens; ``kl_normal_std`` is still
-used by ``module.loss`` for encoder outputs that did not come out of the fused kernels.
+TEST INFRASTRUCTURE (lives under tests/, imported by no product file).  The product path runs all three pairings in HIP
+(spvipes_amd.nn_ops.PoELabel / PoEPaired / PoECluster over csrc/spv_small.h); the functions below are the same arithmetic
+in plain torch tensor ops: what the HIP kernels were first validated against on the GPU, and what
+tests/test_poe_host_logic.py checks against the reference's goldens as a second, independent restatement.
 
 The reference walks labels and cells in Python (three ``.item()`` syncs per cell, :685-701) and
 allocates its outputs on the CPU (:661-709); here the pairing is a rank-within-label computed

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 import torch
 
+from tests import _hip_harness as H
 from tests._golden import LOSS_CASES, INFER_CASES, Golden
 
 pytestmark = pytest.mark.gpu
@@ -52,7 +53,7 @@ def test_gemm_bf16(dev, a_kmajor, nsplit, M, N, K, splits):
         lda = Kp
     B_hi, B_lo = ops._bf16_image(ws, "B", Kp, Np, True)
     ops._pack(Bm.to(dev), B_hi, B_lo)
-    out = ops._gemm(a_kmajor, A_hi, A_lo if nsplit == 3 else None, lda, B_hi, B_lo if nsplit == 3 else None, Np, M, N, K, nsplit, splits, ws, "C")
+    out = H._gemm(a_kmajor, A_hi, A_lo if nsplit == 3 else None, lda, B_hi, B_lo if nsplit == 3 else None, Np, M, N, K, nsplit, splits, ws, "C")
     torch.cuda.synchronize()
     if nsplit == 1:
         want = _bf16_round(A).double() @ _bf16_round(Bm).double()
@@ -150,7 +151,7 @@ def test_decoder_nb_loss_forward_backward(dev, precision, B, G, n_p, n_s, dtype)
     names = ["zp", "zs", "m", "Wp", "cp", "Ws", "cs", "Wm", "bm", "px_r"]
     dparams = [t[k].clone().to(dev).requires_grad_(True) for k in names]
     ws = ops.Workspace(dev)
-    loss, rec = ops.DecoderNBLoss.apply(counts, None, B, *dparams, lib.to(dev), w.to(dev), nsplit, True, ws)
+    loss, rec = H.DecoderNBLoss.apply(counts, None, B, *dparams, lib.to(dev), w.to(dev), nsplit, True, ws)
     loss.backward()
     torch.cuda.synchronize()
     want_loss, want_rec, want_g = _decoder_ref(Xh, t, lib, w)
@@ -164,7 +165,7 @@ def test_decoder_nb_loss_forward_backward(dev, precision, B, G, n_p, n_s, dtype)
         assert err < gtol, f"{precision} d/d{k}: rel-to-max err {err:.3e}"
     # eval-mode (no grad) forward gives the same value
     with torch.no_grad():
-        loss2, _ = ops.DecoderNBLoss.apply(counts, None, B, *[p.detach() for p in dparams], lib.to(dev), w.to(dev), nsplit, False, ws)
+        loss2, _ = H.DecoderNBLoss.apply(counts, None, B, *[p.detach() for p in dparams], lib.to(dev), w.to(dev), nsplit, False, ws)
     assert abs(float(loss2) - float(loss)) <= 1e-6 * abs(float(loss))
 
 

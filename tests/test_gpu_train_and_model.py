@@ -3,6 +3,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests import _hip_harness as H
+
 pytestmark = pytest.mark.gpu
 
 
@@ -122,7 +124,7 @@ def test_full_size_invariances(dev, precision):
 
     def run(rows, t, lib, w, counts=grp.counts):
         with torch.no_grad():
-            loss, rec = ops.DecoderNBLoss.apply(counts, rows, B, *t.values(), lib, w, nsplit, False, ws)
+            loss, rec = H.DecoderNBLoss.apply(counts, rows, B, *t.values(), lib, w, nsplit, False, ws)
         return float(loss), rec.clone()
 
     base_loss, base_rec = run(rows, t, lib, w)

@@ -1,9 +1,9 @@
-"""CPU tests of the device-agnostic PoE pairing/fusion logic (spvipes_amd/poe.py) against the
+"""CPU tests of the device-agnostic PoE pairing/fusion logic (tests/_torch_poe.py, test infrastructure) against the
 golden vectors produced by the reference, and of the module's parameter layout."""
 import pytest
 import torch
 
-from spvipes_amd import poe as P
+from tests import _torch_poe as P
 from tests._golden import ALL_CASES, Golden
 
 

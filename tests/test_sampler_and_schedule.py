@@ -44,6 +44,7 @@ def test_sequential_eval_order_keeps_last_partial_batch():
 
 def test_kl_warmup_and_epoch_heuristic():
     assert kl_weight_at(0, 0, 400, None) == 0.0 and kl_weight_at(200, 0, 400, None) == 0.5 and kl_weight_at(999, 0, 400, None) == 1.0
-    assert kl_weight_at(5, 50, 400, 100) == 0.5  # steps take precedence
+    assert kl_weight_at(5, 50, 400, 100) == 5 / 400  # scvi-tools 0.20.0 _compute_kl_weight: the epoch criterion is checked first
+    assert kl_weight_at(5, 50, None, 100) == 0.5 and kl_weight_at(5, 150, None, 100) == 1.0  # steps only without an epoch count
     assert kl_weight_at(3, 7, None, None) == 1.0
     assert default_max_epochs(50_000) == 160 and default_max_epochs(1_000) == 400  # training_mixin.py:89-91

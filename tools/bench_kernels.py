@@ -4,6 +4,7 @@ import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spvipes_amd import _abi, ops
+from tests import _hip_harness as H
 from spvipes_amd.data import make_synthetic_group
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
@@ -24,7 +25,7 @@ w = torch.full((B,), 1.0 / B, device=dev)
 names = list(_abi._SIGNATURES)
 def step():
     h1, lib = ops.EncoderFC1.apply(grp.counts, rows, B, *enc, nsplit, ws)
-    loss, rec = ops.DecoderNBLoss.apply(grp.counts, rows, B, *dec.values(), lib, w, nsplit, True, ws)
+    loss, rec = H.DecoderNBLoss.apply(grp.counts, rows, B, *dec.values(), lib, w, nsplit, True, ws)
     (loss + h1.sum() * 1e-6).backward()
 for _ in range(3): step()
 torch.cuda.synchronize()
