@@ -164,6 +164,13 @@ int spv_dec_lse(const spv_dec_params* p, const float* library, void* stream);
  * per-element gradients dL, tP, tS (accumulator-tile order; bf16, or bf16 hi + lo planes when grads_f32). */
 int spv_dec_nb_fwd(const spv_dec_params* p, int32_t train, void* stream);
 
+/* Materialises the decoder outputs the reference's generative() returns (module/spVIPESmodule.py:751-768,
+ * nn/networks.py:314-325) for one group: px_scale_k = softmax_G(BN(z_k W_k^T)), px_rate_k = exp(library) * px_scale_k
+ * (k = private, shared) and the mixing logits, as row-major fp32 [B][ld] (ld >= G).  Off the hot path: the fused
+ * likelihood (spv_dec_nb_fwd) never stores them.  Needs spv_dec_logits and spv_dec_lse to have run on `p`. */
+int spv_dec_materialize(const spv_dec_params* p, float* scale_private, float* scale_shared, float* rate_private, float* rate_shared,
+                        float* mixing_logits, int64_t ld, void* stream);
+
 /* in place: tP <- tP - softmax_p * Tp[b],  tS <- tS - softmax_s * Ts[b].
  * dz_part (optional, bf16 gradient arrays only): fp32 [gene_splits][Bp][48]; per gene split the gradient reaching the latents
  * through the two rate heads, columns 0..15 = sum_g tP[b][g] * W'_p[g][.], columns 16..47 = sum_g tS[b][g] * W'_s[g][.]
@@ -194,6 +201,8 @@ typedef struct spv_linear_prob {
   float* dX; int64_t lddx;         /* backward: [B][K]                           */
   float* dW; float* db;            /* backward: [N][K], [N] (db may be NULL)     */
   int32_t N, K;
+  const float* keep;               /* forward, drop_p > 0 only: optional [B][N] keep-mask (1 = keep, row pitch N) used INSTEAD of the
+                                      counter-based draw -- the dropout mask of nn/networks.py:121 injected by a caller (parity tests) */
 } spv_linear_prob;
 typedef struct spv_linear_batch {
   spv_linear_prob p[SPV_MAXP];

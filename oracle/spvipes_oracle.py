@@ -476,3 +476,14 @@ def forward_loss(
 def param_names(sd: SD) -> List[str]:
     """Trainable entries of a state_dict (everything except BN buffers)."""
     return [k for k in sd if not (k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked"))]
+
+
+def get_loadings(sd: SD, dataset: int, type_latent: str, eps: float = 1e-3) -> Tensor:
+    """spVIPESmodule.get_loadings (spVIPESmodule.py:773-807): diag(gamma / sqrt(running_var + eps)) @ W of one factor
+    regressor ([genes, latent dims]); the BatchNorm eps is the scvi FCLayers value 1e-3."""
+    if type_latent not in ["shared", "private"]:
+        raise ValueError(f"Invalid value for type_latent: {type_latent}. It can only be 'shared' or 'private'")
+    L = "fc_layers.Layer 0"
+    pre = f"decoder_{dataset}.factor_regressor_{type_latent}.{L}"
+    b = sd[pre + ".1.weight"] / torch.sqrt(sd[pre + ".1.running_var"] + eps)
+    return torch.matmul(torch.diag(b), sd[pre + ".0.weight"]).detach()

@@ -60,7 +60,7 @@ BN_ROWS = 32  # rows per workgroup of the BatchNorm kernels (sizes their partial
 class SpvLinearProb(C.Structure):
     _fields_ = [("X", C.c_void_p), ("ldx", C.c_int64), ("W", C.c_void_p), ("bias", C.c_void_p), ("Y", C.c_void_p), ("ldy", C.c_int64),
                 ("dY", C.c_void_p), ("lddy", C.c_int64), ("dX", C.c_void_p), ("lddx", C.c_int64), ("dW", C.c_void_p), ("db", C.c_void_p),
-                ("N", C.c_int32), ("K", C.c_int32)]
+                ("N", C.c_int32), ("K", C.c_int32), ("keep", C.c_void_p)]
 
 
 class SpvLinearBatch(C.Structure):
@@ -151,6 +151,7 @@ _SIGNATURES = {
     "spv_dec_nb_fwd": (C.c_int, [C.POINTER(SpvDecParams), C.c_int32, C.c_void_p]),
     "spv_dec_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                  C.c_void_p, C.c_int32, C.c_void_p]),
+    "spv_dec_materialize": (C.c_int, [C.POINTER(SpvDecParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "spv_dec_softmax_bwd": (C.c_int, [C.POINTER(SpvDecParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "spv_linear_fwd": (C.c_int, [C.POINTER(SpvLinearBatch), C.c_void_p]),
     "spv_linear_dgrad": (C.c_int, [C.POINTER(SpvLinearBatch), C.c_void_p]),

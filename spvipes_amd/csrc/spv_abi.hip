@@ -362,6 +362,21 @@ extern "C" int spv_dec_logits(const uint16_t* Am_hi, const uint16_t* Am_lo, cons
   return launch_status("spv_dec_logits");
 }
 
+extern "C" int spv_dec_materialize(const spv_dec_params* q, float* scale_p, float* scale_s, float* rate_p, float* rate_s,
+                                   float* logits_out, int64_t ld, void* stream) {
+  DecParams p;
+  int rc = to_dec(q, p);
+  if (rc != SPV_OK) return rc;
+  if (!scale_p || !scale_s || !rate_p || !rate_s || !logits_out || ld < p.G || !p.logits || !p.lse_p || !p.lse_s || !p.a_p || !p.a_s)
+    return fail(SPV_ERR_ARG, "spv_dec_materialize: null pointer / ld < G%s");
+  if (p.n_gene_tiles != p.Gp / 32) return fail(SPV_ERR_ARG, "spv_dec_materialize: n_gene_tiles must be Gp / 32%s");
+  dim3 grid(p.Bp / DEC_CELLS_PER_WG, p.gene_splits);
+  hipStream_t s = (hipStream_t)stream;
+  if (p.logits_f32) hipLaunchKernelGGL((dec_materialize_kernel<float>), grid, dim3(256), 0, s, p, scale_p, scale_s, rate_p, rate_s, logits_out, (long)ld);
+  else hipLaunchKernelGGL((dec_materialize_kernel<_Float16>), grid, dim3(256), 0, s, p, scale_p, scale_s, rate_p, rate_s, logits_out, (long)ld);
+  return launch_status("spv_dec_materialize");
+}
+
 extern "C" int spv_dec_softmax_bwd(const spv_dec_params* q, const float* Tp, const float* Ts, float* dz_part, void* stream) {
   DecParams p;
   int rc = to_dec(q, p);

@@ -609,6 +609,53 @@ __global__ __launch_bounds__(256, SPV_NB_OCC) void dec_nb_kernel(DecParams p) {
   NB_STAMP(5);
 }
 
+// ---- materialising path: the decoder outputs the reference's generative() returns ---------------------------------
+//   px_scale_k = softmax_G(y_k),  px_rate_k = exp(library) * px_scale_k   (nn/networks.py:314-320),  mixing logits
+// (:322-325) as plain row-major fp32 [B][ld].  Off the hot path (the fused likelihood never stores them): same y_k
+// evaluation as dec_lse_kernel (split-bf16 K = 16 / 32 MFMAs), needs lse_k / a_k from spv_dec_lse and the tile-ordered
+// logits from spv_dec_logits.  Lane = cell, registers = genes: every lane writes 16-byte pieces of its own row.
+template <typename LT>
+__global__ __launch_bounds__(256) void dec_materialize_kernel(DecParams p, float* scale_p, float* scale_s, float* rate_p, float* rate_s,
+                                                              float* logits_out, long ld) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
+  const int cell_tile = blockIdx.x * (DEC_CELLS_PER_WG / 32) + wave;
+  const int cell0 = cell_tile * 32, cell = cell0 + r;
+  PsFrags cf;
+  load_ps_cell_frags(p, cell0, lane, cf);
+  const float lp = p.lse_p[cell], ls = p.lse_s[cell], ap = p.a_p[cell], as = p.a_s[cell];
+  const int gbeg = blockIdx.y * p.genes_per_split;
+  int gend = gbeg + p.genes_per_split;
+  if (gend > p.Gp) gend = p.Gp;
+  if (gend > ((p.G + 31) & ~31)) gend = (p.G + 31) & ~31;
+  for (int g0 = gbeg; g0 < gend; g0 += 32) {
+    PsW w;
+    load_ps_w(p, g0, lane, w);
+    f16v yp, ys;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { yp[q] = 0.f; ys[q] = 0.f; }
+    yp = mfma32_split<3>(w.hi[0], w.lo[0], cf.hi[0], cf.lo[0], yp);
+    ys = mfma32_split<3>(w.hi[1], w.lo[1], cf.hi[1], cf.lo[1], ys);
+    ys = mfma32_split<3>(w.hi[2], w.lo[2], cf.hi[2], cf.lo[2], ys);
+    const size_t tbase = ((size_t)cell_tile * p.n_gene_tiles + (g0 >> 5)) * 1024 + lane * 4;
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      float el[4];
+      load4<LT>(p.logits, tbase + 256 * qq, el);
+      const int g = g0 + 8 * qq + 4 * h;
+      if (cell >= p.B) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (g + j >= p.G) continue;
+        const int q = 4 * qq + j;
+        const size_t o = (size_t)cell * ld + g + j;
+        scale_p[o] = __expf(yp[q] - lp); scale_s[o] = __expf(ys[q] - ls);
+        rate_p[o] = __expf(yp[q] + ap);  rate_s[o] = __expf(ys[q] + as);
+        logits_out[o] = el[j];
+      }
+    }
+  }
+}
+
 // ---- backward helper: finish the softmax backward in place -------------------------------------
 //   d/dy_k[b,g] = t_k[b,g] - softmax_k[b,g] * T_k[b],   T_k[b] = sum_g t_k[b,g]
 // (t_k came out of dec_nb_kernel with a_k = library - lse_k held fixed; the second term is the

@@ -88,7 +88,11 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(LinearBatch a) {
     if (b >= a.B) continue;
     float v = acc[i] + bias;
     if (a.relu) v = fmaxf(v, 0.f);
-    if (a.drop_p > 0.f) v = dropout_keep(a.seed + (a.seed_ptr ? *a.seed_ptr : 0ull), blockIdx.z, (long)b * q.N + col, a.drop_p) ? v * (1.0f / (1.0f - a.drop_p)) : 0.f;
+    if (a.drop_p > 0.f) {
+      const bool keep = q.keep ? (q.keep[(long)b * q.N + col] != 0.f)   // injected mask (nn/networks.py:121 with a recorded draw)
+                               : dropout_keep(a.seed + (a.seed_ptr ? *a.seed_ptr : 0ull), blockIdx.z, (long)b * q.N + col, a.drop_p);
+      v = keep ? v * (1.0f / (1.0f - a.drop_p)) : 0.f;
+    }
     q.Y[(long)b * q.ldy + col] = v;
   }
 }

@@ -108,19 +108,71 @@ class MinibatchSampler:
             raise ValueError("batch_size larger than a group's training shard")
         self.steps_per_epoch = max(self.batches_per_group)
 
-    def epoch(self):
-        """Yields a list (one int32 [batch_size] row-index tensor per group) per training step."""
-        perms = [t[torch.randperm(len(t), device=self.device, generator=self._gen)] for t in self._train_dev]
+    def draw_permutations(self):
+        """one fresh permutation of every group's training rows (the per-epoch reshuffle of the reference's train loaders)"""
+        return [t[torch.randperm(len(t), device=self.device, generator=self._gen)] for t in self._train_dev]
+
+    def epoch_from_permutations(self, perms):
+        """The steps of one epoch given each group's visiting order: drop_last batches; the group with the most batches
+        leads; a group that runs out REPLAYS the batches of its first pass in order (ConcatDataLoader wraps the shorter
+        loaders in itertools.cycle, dataloaders/_concat_dataloader.py:108-110)."""
         B = self.batch_size
         for step in range(self.steps_per_epoch):
             out = []
             for g, p in enumerate(perms):
-                i = step % self.batches_per_group[g]  # replay of the first pass once exhausted
+                i = step % self.batches_per_group[g]
                 out.append(p[i * B:(i + 1) * B].contiguous())
             yield out
+
+    def epoch(self):
+        """Yields a list (one int32 [batch_size] row-index tensor per group) per training step."""
+        yield from self.epoch_from_permutations(self.draw_permutations())
 
     @staticmethod
     def sequential(indices: Sequence[int], batch_size: int, device):
         idx = torch.as_tensor(np.asarray(indices), dtype=torch.int32, device=device)
         for lo in range(0, len(idx), batch_size):
             yield idx[lo:lo + batch_size].contiguous()
+
+
+def latent_steps(local: Sequence[Sequence[int]], batch_size: int, drop_last: bool, use_cycling: bool):
+    """The (group-0 rows, group-1 rows) pairs get_latent_representation feeds to the module, in order
+    (model/spvipes.py:497-523 and the cycling path :578-626): sequential batches, last partial batch kept unless
+    ``drop_last``; the group with more batches leads (the first on ties) and the other one's batches are replayed
+    cyclically; with ``use_cycling`` the cells are first cut into chunks of min(n0, n1) cells per group, the shorter group's
+    cells wrapping around, and every chunk is batched on its own with the partial batch kept."""
+    def batches(idx, dl):
+        idx = np.asarray(idx)
+        out = [idx[lo:lo + batch_size] for lo in range(0, len(idx), batch_size)]
+        if dl and out and len(out[-1]) < batch_size:
+            out.pop()
+        return out
+
+    n0, n1 = len(local[0]), len(local[1])
+    if use_cycling:
+        mn, mx = min(n0, n1), max(n0, n1)
+        if mn == 0:
+            raise ValueError("One of the groups is empty")
+        a0, a1 = np.asarray(local[0]), np.asarray(local[1])
+        chunks = [(a0[(s + np.arange(mn)) % n0], a1[(s + np.arange(mn)) % n1]) for s in range(0, mx, mn)]
+        dl = False
+    else:
+        chunks, dl = [(local[0], local[1])], drop_last
+    steps = []
+    for c0, c1 in chunks:
+        b0, b1 = batches(c0, dl), batches(c1, dl)
+        if not b0 or not b1:
+            continue   # (a loader without a batch ends the reference's zip() at once)
+        n = max(len(b0), len(b1))   # the loader with the most batches leads, the other is replayed cyclically
+        steps += [(b0[i % len(b0)], b1[i % len(b1)]) for i in range(n)]
+    return steps
+
+
+def format_latent_results(private0, private1, shared0, shared1, indices1, n0: int, n1: int) -> dict:
+    """model/spvipes.py:628-650: per-step arrays concatenated, truncated to the group sizes; the ``*_reordered`` entries sort
+    GROUP 1 ONLY by its 'indices' column (group 0 is returned as is)."""
+    i1 = np.concatenate(indices1).flatten()[:n1]
+    p = {0: np.concatenate(private0)[:n0], 1: np.concatenate(private1)[:n1]}
+    s = {0: np.concatenate(shared0)[:n0], 1: np.concatenate(shared1)[:n1]}
+    order = np.argsort(i1)
+    return {"shared": s, "private": p, "shared_reordered": {0: s[0], 1: s[1][order]}, "private_reordered": {0: p[0], 1: p[1][order]}}

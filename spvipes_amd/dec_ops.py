@@ -450,3 +450,92 @@ class DecoderFused(torch.autograd.Function):
         if ctx.n_kl:
             grads += [gk] * ctx.n_kl
         return (None,) * 11 + tuple(grads)
+
+
+@torch.no_grad()
+def materialize_decoder(decoder, px_r: torch.Tensor, private_log_z: torch.Tensor, poe_log_z: torch.Tensor, library: torch.Tensor,
+                        training: bool, nsplit: int, ws: Workspace) -> dict:
+    """The decoder outputs the reference's ``generative`` returns for ONE group (module/spVIPESmodule.py:751-768,
+    nn/networks.py:314-325): {"px_scale_private", "px_scale_shared", "px_rate_private", "px_rate_shared", "px_mixing"}
+    as fp32 [B, G] tensors + "px_r" = exp(px_r).  The training step never needs them (the fused likelihood kernel consumes
+    the same quantities in registers); this runs the same operand preparation as ``DecoderFused.forward`` for one group
+    -- latent slicing quirk, BatchNorm fold (batch statistics in training mode, WITHOUT touching the running statistics:
+    momentum 0), mixing trunk, logits GEMM, softmax statistics -- and then ``spv_dec_materialize``."""
+    dev = private_log_z.device
+    cont = lambda t: t if (t.is_contiguous() and t.dtype == torch.float32) else t.contiguous().float()
+    par = decoder_params(decoder, px_r)
+    pz, qz = cont(private_log_z), cont(poe_log_z)
+    B, n_p, n_s = pz.shape[0], pz.shape[1], qz.shape[1]
+    nt = n_p + n_s
+    if n_p + 1 > DEC_KP or n_s + 1 > DEC_KS:
+        raise _abi.SpvError(f"decoder kernels support n_private <= {DEC_KP - 1} and n_shared <= {DEC_KS - 1}")
+    n_m = par[6].shape[0]
+    G = par[0].shape[0]
+    Bp, Gp = round_up(B, DEC_CELLS_PER_WG), round_up(G, 256)
+    mlo = nsplit == 3
+    new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    zcat = new(B, nt)
+    Am_hi, Am_lo = _bf16_image(ws, "mat_Am", Bp, KMP, mlo)
+    Aps_hi, Aps_lo = _bf16_image(ws, "mat_Aps", Bp, DEC_KPS, True)
+    za = SpvZsplitArgs()
+    za.B, za.n_p, za.n_s, za.ngroups = B, n_p, n_s, 1
+    za.ld_am, za.am_col, za.am_cols, za.Bp = KMP, n_m, KMP - n_m, Bp
+    za.priv[0], za.poe[0], za.zcat[0] = ptr(pz), ptr(qz), ptr(zcat)
+    za.am_hi[0], za.am_lo[0], za.aps_hi[0], za.aps_lo[0] = ptr(Am_hi), ptr(Am_lo), ptr(Aps_hi), ptr(Aps_lo)
+    _abi.call("spv_zsplit_fwd", C.byref(za), stream_ptr())
+    zsum, zz = [new(n_p), new(n_s)], [new(n_p, n_p), new(n_s, n_s)]
+    if training:
+        b = _lin_batch(B)
+        for k, (off, n) in enumerate(((0, n_p), (n_p, n_s))):
+            _add_lin(b, N=n, K=n, W=ptr(zz[k]), X=_fptr(zcat, off), ldx=nt, dY=_fptr(zcat, off), lddy=nt, dW=ptr(zz[k]), db=ptr(zsum[k]))
+        _wgrad(b, ws)
+    Wps_hi, Wps_lo = _bf16_image(ws, "mat_Wps", Gp, DEC_KPS, True)
+    fstat = [new(G, 2), new(G, 2)]
+    fb = SpvFoldBatch()
+    fb.nprob, fb.B, fb.training, fb.eps, fb.momentum = 0, B, int(training), 1e-3, 0.0   # momentum 0: running statistics untouched
+    fp, fs = decoder.factor_regressor_private, decoder.factor_regressor_shared
+    for k, (reg, W, gam, bet, off, slot, n, zoff) in enumerate(((fp, par[0], par[1], par[2], 0, DEC_KP, n_p, 0),
+                                                                (fs, par[3], par[4], par[5], DEC_KP, DEC_KS, n_s, n_p))):
+        q = fb.p[fb.nprob]
+        q.W, q.gamma, q.beta, q.running_mean, q.running_var = ptr(W), ptr(gam), ptr(bet), ptr(reg.bn.running_mean), ptr(reg.bn.running_var)
+        q.zsum, q.zz, q.z, q.ldz, q.stat = ptr(zsum[k]), ptr(zz[k]), _fptr(zcat, zoff), nt, ptr(fstat[k])
+        q.img_hi, q.img_lo, q.ld_img, q.col_off, q.slot = ptr(Wps_hi), ptr(Wps_lo), DEC_KPS, off, slot
+        q.G, q.Gp, q.K = G, Gp, n
+        fb.nprob += 1
+    _abi.call("spv_bn_fold_fwd", C.byref(fb), stream_ptr())
+    Wm_hi, Wm_lo = _bf16_image(ws, "mat_Wm", Gp, KMP, mlo)
+    _pack(cont(par[10]), Wm_hi, Wm_lo, extra_col=cont(par[11]))
+    # mixing trunk
+    pre_a, m, tstat = new(B, n_m), new(B, n_m), new(n_m, 2)
+    b = _lin_batch(B)
+    _add_lin(b, N=n_m, K=nt, W=ptr(par[6]), bias=ptr(par[7]), X=ptr(zcat), ldx=nt, Y=ptr(pre_a), ldy=n_m)
+    _abi.call("spv_linear_fwd", C.byref(b), stream_ptr())
+    nblk = -(-B // _abi.BN_ROWS)
+    bn = SpvBnBatch()
+    bn.nprob, bn.B, bn.training, bn.relu, bn.eps, bn.momentum = 1, B, int(training), 1, 1e-3, 0.0
+    tb = decoder.sigmoid_decoder.bn
+    q = bn.p[0]
+    q.X, q.ldx, q.Y, q.ldy, q.gamma, q.beta = ptr(pre_a), n_m, ptr(m), n_m, ptr(par[8]), ptr(par[9])
+    q.running_mean, q.running_var, q.stats, q.N = ptr(tb.running_mean), ptr(tb.running_var), ptr(tstat), n_m
+    q.part = ptr(ws.get("mat_bn_part", (nblk, n_m, 2), torch.float32))
+    q.img_hi, q.img_lo, q.ld_img, q.img_rows = ptr(Am_hi), ptr(Am_lo), KMP, Bp
+    _abi.call("spv_bn_fwd", C.byref(bn), stream_ptr())
+    logits = ws.get("mat_logits_" + ("f32" if mlo else "f16"), (Bp, Gp), torch.float32 if mlo else torch.float16)
+    _abi.call("spv_dec_logits", ptr(Am_hi), ptr(Am_lo), ptr(Wm_hi), ptr(Wm_lo), KMP, Bp, Gp, nsplit, ptr(logits), int(mlo), stream_ptr())
+    splits, per = _gene_splits(Bp, Gp)
+    vec = lambda nme: ws.get(nme, (Bp,), torch.float32)
+    part = lambda nme: ws.get(nme, (splits, Bp), torch.float32)
+    lse_p, lse_s, a_p, a_s = vec("mat_lse_p"), vec("mat_lse_s"), vec("mat_a_p"), vec("mat_a_s")
+    p = SpvDecParams(
+        X=None, ldx=0, rows=None, col_off=0, count_is_u16=0, B=B, G=G, Bp=Bp, Gp=Gp, logits=ptr(logits), n_gene_tiles=Gp // 32, logits_f32=int(mlo),
+        Wps_hi=ptr(Wps_hi), Wps_lo=ptr(Wps_lo), Aps_hi=ptr(Aps_hi), Aps_lo=ptr(Aps_lo), gene_tab=None, cnt_tab=None,
+        a_p=ptr(a_p), a_s=ptr(a_s), lse_p=ptr(lse_p), lse_s=ptr(lse_s), w_row=None, gene_splits=splits, genes_per_split=per,
+        part_max_p=ptr(part("mat_pmp")), part_sum_p=ptr(part("mat_psp")), part_max_s=ptr(part("mat_pms")), part_sum_s=ptr(part("mat_pss")),
+        rec_part=None, tp_part=None, ts_part=None, dtheta_part=None, dL=None, tP=None, tS=None, grads_f32=0, nb_splits=1, nb_genes_per_split=32,
+    )
+    _abi.call("spv_dec_lse", C.byref(p), ptr(cont(library.flatten())), stream_ptr())
+    out = {k: new(B, G) for k in ("px_scale_private", "px_scale_shared", "px_rate_private", "px_rate_shared", "px_mixing")}
+    _abi.call("spv_dec_materialize", C.byref(p), ptr(out["px_scale_private"]), ptr(out["px_scale_shared"]), ptr(out["px_rate_private"]),
+              ptr(out["px_rate_shared"]), ptr(out["px_mixing"]), G, stream_ptr())
+    out["px_r"] = torch.exp(cont(par[12]))
+    return out

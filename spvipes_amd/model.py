@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import _abi
-from .data import MinibatchSampler, to_group_counts
+from .data import MinibatchSampler, format_latent_results, latent_steps, to_group_counts
 from .module import spVIPESmodule
 from .train import Trainer, default_max_epochs
 
@@ -133,70 +133,87 @@ class spVIPES:
               use_gpu=None, train_size: float = 0.9, validation_size: Optional[float] = None, early_stopping: bool = False,
               plan_kwargs: Optional[dict] = None, n_steps_kl_warmup: Optional[int] = None, n_epochs_kl_warmup: Optional[int] = 400,
               seed: int = 0, **trainer_kwargs) -> None:
-        """training_mixin.py:19-123 (signature kept; ``use_gpu``/``early_stopping`` accepted and ignored)."""
+        """training_mixin.py:19-123, same signature.  ``validation_size`` / ``train_size`` hold cells out exactly as
+        MultiGroupDataSplitter does; ``early_stopping`` monitors ``elbo_validation`` with scvi-tools' defaults (patience 45;
+        ``early_stopping_patience`` / ``early_stopping_min_delta`` / ``check_val_every_n_epoch`` in ``trainer_kwargs`` as for
+        scvi's Trainer).  ``use_gpu`` is accepted and ignored (the path only runs on the GPU).  Inside an initialised
+        ``torch.distributed`` job every rank trains on its own shard of the training cells from identical
+        initial weights (rank 0's are broadcast)."""
+        import torch.distributed as dist
+
         if max_epochs is None:
             max_epochs = default_max_epochs(self.adata.n_obs)
         plan_kwargs = dict(plan_kwargs or {})
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        rank = dist.get_rank() if world > 1 else 0
         local = [self._local_rows(g, group_indices_list[g]) for g in range(2)]
         sampler = MinibatchSampler([len(l) for l in local], batch_size, self.device, seed=seed, train_size=train_size,
-                                   validation_size=validation_size, group_indices_list=local)
+                                   validation_size=validation_size, group_indices_list=local, rank=rank, world=world)
         trainer = Trainer(self.module, self.counts, lr=plan_kwargs.get("lr", 1e-3), eps=plan_kwargs.get("eps", 0.01),
                           weight_decay=plan_kwargs.get("weight_decay", 1e-6), n_epochs_kl_warmup=n_epochs_kl_warmup,
                           n_steps_kl_warmup=n_steps_kl_warmup)
+        if world > 1:
+            dist.broadcast(trainer.fp.flat, src=0)
         trainer.minibatch = self._minibatch  # labels / components / plan indices of this AnnData
-        self.history = trainer.fit(sampler, max_epochs, log_every=trainer_kwargs.get("log_every", 1), use_graph=trainer_kwargs.get("use_graph", True))
+        self.trainer_, self.sampler_ = trainer, sampler
+        self.history = trainer.fit(sampler, max_epochs, log_every=trainer_kwargs.get("log_every", 1), use_graph=trainer_kwargs.get("use_graph", True),
+                                   early_stopping=bool(trainer_kwargs.get("early_stopping", early_stopping)),
+                                   early_stopping_patience=trainer_kwargs.get("early_stopping_patience", 45),
+                                   early_stopping_min_delta=trainer_kwargs.get("early_stopping_min_delta", 0.0),
+                                   check_val_every_n_epoch=trainer_kwargs.get("check_val_every_n_epoch"))
         self.is_trained_ = True
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
     def get_latent_representation(self, group_indices_list: List[List[int]], adata=None, indices=None, normalized: bool = False,
                                   give_mean: bool = True, mc_samples: int = 5000, batch_size: Optional[int] = None,
-                                  drop_last: Optional[bool] = None) -> dict:
+                                  drop_last: Optional[bool] = None, _noise=None) -> dict:
         """model/spvipes.py:424-650.  Returns the SAMPLED ``log_z`` (as the reference does) as
-        {"shared","private","shared_reordered","private_reordered"} -> {0: ndarray, 1: ndarray}."""
+        {"shared","private","shared_reordered","private_reordered"} -> {0: ndarray, 1: ndarray}.  ``_noise`` (tests only):
+        callable (step, B0, B1) -> dict of injected standard-normal draws for module.inference."""
         if normalized:
             raise NotImplementedError("normalized=True is broken in the reference (nothing is collected for the shared latents, :542-544)")
         batch_size = batch_size or 128
         drop_last = bool(drop_last) if drop_last is not None else False
         n1, n2 = (len(g) for g in group_indices_list)
         local = [self._local_rows(g, group_indices_list[g]) for g in range(2)]
-        use_cycling = self.module.use_transport_plan and self.module.pair_data and not drop_last and not self.module.use_labels
-        if use_cycling:  # :578-626
-            mn, mx = min(n1, n2), max(n1, n2)
-            if mn == 0:
-                raise ValueError("One of the groups is empty")
-            chunks = [([local[0][(s + i) % n1] for i in range(mn)], [local[1][(s + i) % n2] for i in range(mn)]) for s in range(0, mx, mn)]
-        else:
-            chunks = [(local[0], local[1])]
+        use_cycling = self.module.use_transport_plan and self.module.pair_data and not drop_last and not self.module.use_labels   # :497-503
         res = {k: [] for k in ("s0", "s1", "p0", "p1", "i1")}
         was_training = self.module.training
         self.module.eval()
-        for c0, c1 in chunks:
-            it0 = list(MinibatchSampler.sequential(c0, batch_size, self.device))
-            it1 = list(MinibatchSampler.sequential(c1, batch_size, self.device))
-            if drop_last:
-                it0 = [b for b in it0 if len(b) == batch_size]
-                it1 = [b for b in it1 if len(b) == batch_size]
-            n_steps = max(len(it0), len(it1))  # ConcatDataLoader: the longer loader leads, the shorter one is cycled
-            for s in range(n_steps):
-                rows = [it0[s % len(it0)], it1[s % len(it1)]]
-                tensors = self._minibatch(rows)
-                out = self.module.inference(**self.module._get_inference_input(tensors))
-                res["s0"].append(out["poe_stats"][0]["logtheta_log_z"].cpu())
-                res["s1"].append(out["poe_stats"][1]["logtheta_log_z"].cpu())
-                res["p0"].append(out["private_stats"][0]["log_z"].cpu())
-                res["p1"].append(out["private_stats"][1]["log_z"].cpu())
-                res["i1"].append(tensors[1]["indices"].cpu())
+        for step, (r0, r1) in enumerate(latent_steps(local, batch_size, drop_last, use_cycling)):
+            rows = [torch.as_tensor(r, dtype=torch.int32, device=self.device) for r in (r0, r1)]
+            tensors = self._minibatch(rows)
+            kw = {} if _noise is None else {"noise": _noise(step, len(r0), len(r1))}
+            out = self.module.inference(**self.module._get_inference_input(tensors), **kw)
+            res["s0"].append(out["poe_stats"][0]["logtheta_log_z"].cpu().numpy())
+            res["s1"].append(out["poe_stats"][1]["logtheta_log_z"].cpu().numpy())
+            res["p0"].append(out["private_stats"][0]["log_z"].cpu().numpy())
+            res["p1"].append(out["private_stats"][1]["log_z"].cpu().numpy())
+            res["i1"].append(tensors[1]["indices"].cpu().numpy())
         self.module.train(was_training)
-        i1 = torch.cat(res["i1"]).numpy().flatten()[:n2]
-        p = {0: torch.cat(res["p0"]).numpy()[:n1], 1: torch.cat(res["p1"]).numpy()[:n2]}
-        s = {0: torch.cat(res["s0"]).numpy()[:n1], 1: torch.cat(res["s1"]).numpy()[:n2]}
-        order = np.argsort(i1)
-        return {"shared": s, "private": p, "shared_reordered": {0: s[0], 1: s[1][order]}, "private_reordered": {0: p[0], 1: p[1][order]}}
+        return format_latent_results(res["p0"], res["p1"], res["s0"], res["s1"], res["i1"], n1, n2)
 
     def get_loadings(self) -> dict:
-        """:652-677 (plain arrays instead of DataFrames: pandas indices need var_names, which duck-typed inputs may lack)."""
-        return {(i, t): self.module.get_loadings(i, t) for i in range(2) for t in ("private", "shared")}
+        """:652-677: per-gene weights of the linear decoder, {(group, "private" | "shared"): DataFrame [genes, latent dims]}
+        with the reference's column names ``Z_private_{n}`` / ``Z_shared_{n}`` and the group's own var_names as the index
+        (``adata.var_names``, or ``adata.uns["groups_var_names"]``; a plain RangeIndex when the duck-typed input has neither)."""
+        import pandas as pd
+
+        out = {}
+        var_idx = [np.asarray(v) for v in self.adata.uns["groups_var_indices"]]
+        for i in range(len(self.module.input_dims)):
+            names = None
+            if getattr(self.adata, "var_names", None) is not None:
+                names = np.asarray(self.adata.var_names)[var_idx[i]]
+            elif self.adata.uns.get("groups_var_names") is not None:
+                gv = self.adata.uns["groups_var_names"]
+                names = np.asarray(gv[i] if not isinstance(gv, dict) else list(gv.values())[i])
+            cols = {"private": [f"Z_private_{n}" for n in range(self.module.n_dimensions_private)],
+                    "shared": [f"Z_shared_{n}" for n in range(self.module.n_dimensions_shared)]}
+            for t in ("private", "shared"):
+                out[(i, t)] = pd.DataFrame(self.module.get_loadings(i, t), index=names, columns=cols[t])
+        return out
 
     # ------------------------------------------------------------------------------------------
     def save(self, path: str) -> None:

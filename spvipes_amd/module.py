@@ -26,7 +26,6 @@ from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from . import _abi
@@ -126,11 +125,61 @@ class LinearDecoderSPVIPE(nn.Module):
 
 
 class LazyNBMixture:
-    """What ``generative`` hands to ``loss`` in place of scvi's NegativeBinomialMixture: the decoder
-    inputs; the likelihood itself is evaluated by the fused HIP kernel inside ``loss``."""
+    """What ``generative`` hands to ``loss`` in place of scvi's NegativeBinomialMixture (spVIPESmodule.py:759): the decoder
+    inputs.  The training step evaluates the likelihood in the fused HIP kernel inside ``loss`` and never materialises a
+    [B, G] rate; reading ``mu1`` / ``mu2`` / ``theta1`` / ``mixture_logits`` (the attributes of the scvi distribution) runs the
+    materialising HIP path (dec_ops.materialize_decoder -> spv_dec_materialize) once and caches the result."""
 
-    def __init__(self, group: int, private_log_z, poe_log_z, library):
+    def __init__(self, group: int, private_log_z, poe_log_z, library, module=None):
         self.group, self.private_log_z, self.poe_log_z, self.library = group, private_log_z, poe_log_z, library
+        self._module, self._cache = module, None
+
+    def materialize(self) -> dict:
+        if self._cache is None:
+            from .dec_ops import materialize_decoder
+
+            m = self._module
+            if m is None:
+                raise _abi.SpvError("this LazyNBMixture was built without its module and cannot materialise the decoder outputs")
+            self._cache = materialize_decoder(m.decoders[self.group], m.px_r[self.group], self.private_log_z.detach(), self.poe_log_z.detach(),
+                                              self.library.detach(), m.training, m.nsplit, m._workspace(self.group, self.library.device))
+        return self._cache
+
+    mu1 = property(lambda self: self.materialize()["px_rate_private"])
+    mu2 = property(lambda self: self.materialize()["px_rate_shared"])
+    theta1 = property(lambda self: self.materialize()["px_r"])
+    mixture_logits = property(lambda self: self.materialize()["px_mixing"])
+
+
+class _GenerativeGroup(dict):
+    """One group's entry of generative()["private_poe"] with the reference's keys and key order (spVIPESmodule.py:760-767):
+    px_scale_private, px_scale_shared, px_rate_private, px_rate_shared, px, pz.  The four [B, G] tensors are produced on
+    first access (LazyNBMixture.materialize); ``loss`` only reads "px"."""
+
+    _LAZY = ("px_scale_private", "px_scale_shared", "px_rate_private", "px_rate_shared")
+
+    def __init__(self, px: LazyNBMixture, pz):
+        super().__init__()
+        for k in self._LAZY:
+            dict.__setitem__(self, k, None)
+        dict.__setitem__(self, "px", px)
+        dict.__setitem__(self, "pz", pz)
+
+    def __getitem__(self, k):
+        v = dict.__getitem__(self, k)
+        if v is None and k in self._LAZY:
+            v = dict.__getitem__(self, "px").materialize()[k]
+            dict.__setitem__(self, k, v)
+        return v
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def values(self):
+        return [self[k] for k in self.keys()]
 
 
 class spVIPESmodule(nn.Module):
@@ -254,23 +303,6 @@ class spVIPESmodule(nn.Module):
             "batch_index": [group.get(BATCH_KEY) for group in tensors_by_group],
         }
 
-    def _encoder_tail(self, enc: Encoder, h1: torch.Tensor, eps: torch.Tensor, drop_mask):
-        """nn/networks.py:120-129 after fc1: fc2+relu, dropout, BN'd heads, reparameterised draw."""
-        h = F.relu(enc.fc2(h1))
-        if self.training and enc.dropout > 0:
-            if drop_mask is None:
-                h = F.dropout(h, enc.dropout, True)
-            else:
-                h = h * drop_mask / (1.0 - enc.dropout)
-        loc = enc.mu_encoder(h)
-        logvar = enc.lvar_encoder(h)
-        scale = (0.5 * logvar).exp()
-        log_z = loc + scale * eps
-        return OrderedDict([
-            ("logtheta_loc", loc), ("logtheta_logvar", logvar), ("logtheta_scale", scale),
-            ("log_z", log_z), ("theta", F.softmax(log_z, -1)), ("qz", torch.distributions.Normal(loc, scale, validate_args=False)),
-        ])
-
     def inference(self, x, batch_index, groups, global_indices, noise: Optional[dict] = None,
                   dropout_masks: Optional[dict] = None, **kwargs):
         """Runs the encoders and the PoE (spVIPESmodule.py:425-472).  ``noise`` optionally injects the
@@ -326,30 +358,32 @@ class spVIPESmodule(nn.Module):
             library[g] = lib.unsqueeze(1)
         if streams is not None:
             join(streams)
+        # all encoder tails (fc2, dropout, heads, BatchNorm, draw, KL) as a few batched HIP launches: one batch over the
+        # four encoders when the groups' minibatches have the same size (training), one batch per group otherwise (ragged
+        # inference batches: the last step of get_latent_representation).  Injected dropout keep-masks (parity tests)
+        # replace the kernels' counter-based draw.
+        dm = dropout_masks or {}
         same_B = len({self._step_inputs[g][2] for g in groups_}) == 1
-        if dropout_masks is None and same_B:
-            # all four encoder tails (fc2, dropout, heads, BatchNorm, draw, KL) as a few batched HIP launches
-            specs, eps_list = [], []
-            for g in groups_:
-                specs += [EncoderSpec(self.encoders[g]["private"], g, 0), EncoderSpec(self.encoders[g]["shared"], g, H)]
+        for gset in ([groups_] if same_B else [[g] for g in groups_]):
+            specs, eps_list, masks = [], [], []
+            for slot, g in enumerate(gset):
+                specs += [EncoderSpec(self.encoders[g]["private"], slot, 0), EncoderSpec(self.encoders[g]["shared"], slot, H)]
                 eps_list += [eps_enc[g][0], eps_enc[g][1]]
+                masks += [dm.get(f"enc_{g}_private"), dm.get(f"enc_{g}_shared")]
             flat = [p for s in specs for p in s.params()]
             outs = EncoderTails.apply(specs, eps_list, self.training, float(self.dropout_rate), self._seed_dev,
-                                      self._workspace(groups_[0], h1s[groups_[0]].device), *[h1s[g] for g in groups_], *flat)
+                                      self._workspace(gset[0], h1s[gset[0]].device), masks if dropout_masks else None,
+                                      *[h1s[g] for g in gset], *flat)
             for i, s in enumerate(specs):
+                g = gset[s.h1_group]
                 loc, logvar, scale, log_z, theta, kl = outs[6 * i: 6 * i + 6]
                 st = OrderedDict([("logtheta_loc", loc), ("logtheta_logvar", logvar), ("logtheta_scale", scale), ("log_z", log_z),
                                   ("theta", theta), ("qz", torch.distributions.Normal(loc, scale, validate_args=False))])
                 if i % 2 == 0:
-                    private_stats[s.h1_group] = st
-                    self._kl_private[s.h1_group] = kl
+                    private_stats[g] = st
+                    self._kl_private[g] = kl
                 else:
-                    shared_stats[s.h1_group] = st
-        else:  # ragged minibatches (inference only) or injected dropout masks: per-encoder torch glue
-            dm = dropout_masks or {}
-            for g in groups_:
-                private_stats[g] = self._encoder_tail(self.encoders[g]["private"], h1s[g][:, :H], eps_enc[g][0], dm.get(f"enc_{g}_private"))
-                shared_stats[g] = self._encoder_tail(self.encoders[g]["shared"], h1s[g][:, H:], eps_enc[g][1], dm.get(f"enc_{g}_shared"))
+                    shared_stats[g] = st
 
         labels = processed_labels = None
         if self.use_labels and "labels" in kwargs:
@@ -445,12 +479,18 @@ class spVIPESmodule(nn.Module):
             )
         out = {}
         for g in (0, 1):
-            # Z = cat(private_log_z, poe_log_z) and the slicing quirk of :733,:753-754 happen inside the fused
-            # decoder op (spv_zsplit_fwd); the lazy object only carries the two latents and the library
-            out[str(g)] = {
-                "px": LazyNBMixture(g, private_stats[g]["log_z"], poe_stats[g]["logtheta_log_z"], library[g]),
-                "pz": None,
-            }
+            # Z = cat(private_log_z, poe_log_z) and the slicing quirk of :733,:753-754 happen inside the fused decoder op
+            # (spv_zsplit_fwd); the lazy entry carries the two latents and the library, and materialises px_scale_* /
+            # px_rate_* / the mixing logits through spv_dec_materialize only if somebody reads them
+            pl, ql = private_stats[g]["log_z"], poe_stats[g]["logtheta_log_z"]
+            nz = pl.shape[1] + ql.shape[1]
+            key = (pl.shape[0], nz, pl.device)
+            cache = self.__dict__.setdefault("_pz_cache", {})
+            if key not in cache:   # pz = Normal(0, 1) over the concatenated latent (:760): constant, built once per shape
+                cache[key] = torch.distributions.Normal(torch.zeros((pl.shape[0], nz), device=pl.device),
+                                                        torch.ones((pl.shape[0], nz), device=pl.device), validate_args=False)
+            pz = cache[key]
+            out[str(g)] = _GenerativeGroup(LazyNBMixture(g, pl, ql, library[g], module=self), pz)
         return {"private_shared": {}, "private_poe": out}
 
     def loss(self, tensors_by_group, inference_outputs, generative_outputs, kl_weight: float = 1.0):

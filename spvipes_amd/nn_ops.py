@@ -30,9 +30,9 @@ def _lin_batch(B: int, relu: bool = False, drop_p: float = 0.0, seed=0, accumula
 
 
 def _add_lin(b: SpvLinearBatch, *, N: int, K: int, W=None, X=None, ldx=0, bias=None, Y=None, ldy=0, dY=None, lddy=0, dX=None, lddx=0,
-             dW=None, db=None) -> None:
+             dW=None, db=None, keep=None) -> None:
     q = b.p[b.nprob]
-    q.X, q.ldx, q.W, q.bias, q.Y, q.ldy = X, ldx, W, bias, Y, ldy
+    q.X, q.ldx, q.W, q.bias, q.Y, q.ldy, q.keep = X, ldx, W, bias, Y, ldy, keep
     q.dY, q.lddy, q.dX, q.lddx, q.dW, q.db, q.N, q.K = dY, lddy, dX, lddx, dW, db, N, K
     b.nprob += 1
 
@@ -93,7 +93,8 @@ class EncoderTails(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, specs: Sequence[EncoderSpec], eps: Sequence[torch.Tensor], training: bool, drop_p: float, seed: int, ws, *tensors):
+    def forward(ctx, specs: Sequence[EncoderSpec], eps: Sequence[torch.Tensor], training: bool, drop_p: float, seed: int, ws, masks, *tensors):
+        """``masks``: None, or one optional [B, H] keep-mask (1 = keep) per encoder replacing the counter-based dropout draw."""
         ctx.set_materialize_grads(False)  # outputs nobody differentiates (scale, unused loc/logvar) arrive as None, not as zero fills
         n_groups = max(s.h1_group for s in specs) + 1
         h1 = tensors[:n_groups]
@@ -112,8 +113,15 @@ class EncoderTails(torch.autograd.Function):
         dp = float(drop_p) if training else 0.0
         # 1. fc2 + relu (+ dropout)
         b = _lin_batch(B, relu=True, drop_p=dp, seed=seed)
-        for s, p, y in zip(specs, par, h2):
-            _add_lin(b, N=H, K=H, W=ptr(p[0]), bias=ptr(p[1]), X=_fptr(h1[s.h1_group], s.h1_col), ldx=h1[s.h1_group].shape[1], Y=ptr(y), ldy=H)
+        keep_masks = []
+        for i, (s, p, y) in enumerate(zip(specs, par, h2)):
+            mk = None
+            if masks is not None and masks[i] is not None and dp > 0:
+                mk = masks[i].to(dev, torch.float32).contiguous()
+                if mk.shape != (B, H):
+                    raise _abi.SpvError("dropout mask must be [B, n_hidden]")
+                keep_masks.append(mk)
+            _add_lin(b, N=H, K=H, W=ptr(p[0]), bias=ptr(p[1]), X=_fptr(h1[s.h1_group], s.h1_col), ldx=h1[s.h1_group].shape[1], Y=ptr(y), ldy=H, keep=ptr(mk))
         _abi.call("spv_linear_fwd", C.byref(b), stream_ptr())
         # 2. mu / logvar heads into the two halves of `pre`
         b = _lin_batch(B)
@@ -240,7 +248,7 @@ class EncoderTails(torch.autograd.Function):
         grads: List[Optional[torch.Tensor]] = list(dh1)
         for i in range(E):
             grads += [pg[i][j][1] for j in range(N_ENC_PARAMS)]
-        return (None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, None, *grads)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -271,10 +271,47 @@ class Trainer:
         self._ev_ar[1].synchronize()
         return float(self._ev_ar[0].elapsed_time(self._ev_ar[1]))
 
-    def fit(self, sampler: MinibatchSampler, max_epochs: int, log_every: int = 0, use_graph: bool = True):
+    @torch.no_grad()
+    def validation_metrics(self, sampler: MinibatchSampler):
+        """Mean loss / reconstruction / KL over the held-out validation cells (module in eval mode, kl_weight 1, full batches
+        in the reference's loader order: the validation loader is built like the training one, drop_last=True,
+        data/_multi_datasplitter.py:81-98).  None when a group has no full validation batch.  In a data-parallel job every
+        rank evaluates the same cells (validation rows are not sharded), so all ranks reach the same early-stopping decision."""
+        B = sampler.batch_size
+        nb = [len(v) // B for v in sampler.val_idx]
+        if not nb or min(nb) == 0:
+            return None
+        was_training = self.module.training
+        self.module.eval()
+        val = [torch.as_tensor(v, dtype=torch.int32, device=self.device) for v in sampler.val_idx]
+        acc = None
+        for step in range(max(nb)):
+            rows = [v[(step % n) * B:(step % n + 1) * B].contiguous() for v, n in zip(val, nb)]
+            _, _, lo = self.module(self.minibatch(rows), loss_kwargs={"kl_weight": 1.0})
+            rec = lo.reconstruction_loss_mean
+            cur = torch.stack([lo.loss, rec, lo.loss - rec])
+            acc = cur if acc is None else acc + cur
+        self.module.train(was_training)
+        tot, rec, kl = (float(v) / max(nb) for v in acc.cpu())
+        return {"elbo_validation": rec + kl, "reconstruction_loss_validation": rec, "kl_local_validation": kl, "validation_loss": tot}
+
+    def fit(self, sampler: MinibatchSampler, max_epochs: int, log_every: int = 0, use_graph: bool = True, early_stopping: bool = False,
+            early_stopping_patience: int = 45, early_stopping_min_delta: float = 0.0, check_val_every_n_epoch: Optional[int] = None):
         """``max_epochs`` passes over the sampler.  The step is captured into a hipGraph at the first minibatch (the
         sampler yields fixed-size batches); per-step metrics are accumulated ON DEVICE and read back once per epoch, so
-        logging costs one tiny launch per logged step and no host synchronisation."""
+        logging costs one tiny launch per logged step and no host synchronisation.
+
+        Validation / early stopping follow scvi-tools' TrainRunner defaults (what the reference's ``train`` forwards to,
+        training_mixin.py:112-123): with held-out cells the validation metrics are evaluated every
+        ``check_val_every_n_epoch`` epochs (every epoch when early stopping is on, else never unless asked), and
+        ``early_stopping`` monitors ``elbo_validation`` (mode min, patience 45, min_delta 0)."""
+        if check_val_every_n_epoch is None:
+            check_val_every_n_epoch = 1 if early_stopping else 0
+        if early_stopping and (not sampler.val_idx or min(len(v) // sampler.batch_size for v in sampler.val_idx) == 0):
+            raise ValueError("early_stopping needs at least one full validation batch per group (train_size < 1 / validation_size > 0)")
+        for k in ("elbo_validation", "reconstruction_loss_validation", "kl_local_validation", "validation_loss"):
+            self.history.setdefault(k, [])
+        best, bad_epochs = float("inf"), 0
         self.module.train()
         for ep in range(max_epochs):
             self.epoch = ep
@@ -299,5 +336,18 @@ class Trainer:
                 self.history["reconstruction_loss_train"].append(rec / n)
                 self.history["kl_local_train"].append(kl / n)
                 self.history["elbo_train"].append((rec + kl) / n)
+            if check_val_every_n_epoch and (ep + 1) % check_val_every_n_epoch == 0:
+                vm = self.validation_metrics(sampler)
+                if vm is not None:
+                    for k, v in vm.items():
+                        self.history[k].append(v)
+                    if early_stopping:
+                        if vm["elbo_validation"] < best - early_stopping_min_delta:
+                            best, bad_epochs = vm["elbo_validation"], 0
+                        else:
+                            bad_epochs += 1
+                            if bad_epochs >= early_stopping_patience:
+                                self.stopped_epoch = ep
+                                break
         self.module.eval()  # scvi's TrainRunner leaves the module in eval mode
         return self.history

@@ -266,6 +266,11 @@ def run_case(ref, name, *, B, G, H, n_s, n_p, mode, training=True, dropout=0.0, 
         for k, v in module.state_dict().items():
             if k.endswith("running_mean") or k.endswith("running_var"):
                 out["bn/" + k] = v.detach().numpy()
+    # per-gene loadings diag(gamma / sqrt(running_var + eps)) W of the four factor regressors (spVIPESmodule.py:773-807), read
+    # from the module AFTER this forward pass (in training mode the running statistics have just been updated)
+    for g in range(2):
+        for t in ("private", "shared"):
+            out[f"out/loadings_{g}_{t}"] = np.asarray(module.get_loadings(g, t))
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
     print(f"{name}: loss={float(lo.loss.detach()):.6f} draws={len(normals)} -> {os.path.relpath(path, ROOT)} "

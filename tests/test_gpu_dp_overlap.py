@@ -153,6 +153,52 @@ def test_two_ranks_reduce_to_the_mean_gradient_and_stay_identical(dev, use_graph
         raise AssertionError("mean gradient differs: " + "; ".join(bad))
 
 
+def _api_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from spvipes_amd.model import spVIPES
+        from tests._duck import make_duck
+        ad = make_duck(n=(256, 192), seed=4)
+        spVIPES.setup_anndata(ad, groups_key="groups", label_key="cell_type")
+        torch.manual_seed(10 + rank)   # different initial weights per rank: train() must broadcast rank 0's
+        model = spVIPES(ad, n_hidden=16, n_dimensions_shared=6, n_dimensions_private=3, precision="bf16")
+        gi = [list(ad.uns["groups_obs_indices"][0]), list(ad.uns["groups_obs_indices"][1])]
+        model.train(gi, batch_size=32, max_epochs=2, train_size=1.0, use_graph=(rank >= 0))
+        torch.cuda.synchronize()
+        q.put((rank, model.trainer_.fp.flat.cpu().numpy(), [t.tolist() for t in model.sampler_.train_idx], model.trainer_.global_step,
+               model.history["train_loss"]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_user_api_train_is_data_parallel_aware(dev):
+    """spVIPES.train inside a 2-rank job (both ranks on the one GPU, gloo): the ranks draw minibatches from DISJOINT shards of
+    every group's training cells, start from rank 0's weights and end with bit-identical replicas."""
+    import torch.multiprocessing as mp
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_api_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert np.array_equal(got[0][1], got[1][1]), "replicas diverged"
+    for g in range(2):
+        a, b = set(got[0][2][g]), set(got[1][2][g])
+        assert a and b and not (a & b) and len(a) == len(b), "ranks must train on disjoint, equally sized shards"
+    assert got[0][3] == got[1][3] == 2 * (128 // 32)   # 256 training cells of the larger group / 2 ranks / batch 32, 2 epochs
+    assert all(np.isfinite(got[r][4]).all() for r in range(2))
+
+
 def test_rccl_rehearsal_on_one_rank(dev):
     """The step of a multi-GPU rank over RCCL itself -- communicator start-up, the watchdog thread polling while the two
     hipGraphs are captured, async bucket all-reduces between the graph replays -- driven through a one-rank "nccl" group

@@ -239,6 +239,42 @@ def test_module_matches_reference_goldens(dev, case, precision):
                     torch.testing.assert_close(sd[k[3:]].cpu(), torch.tensor(v), rtol=2e-3, atol=2e-5, msg=lambda s: f"{k}: {s}")
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", LOSS_CASES)
+def test_generative_outputs_match_reference_goldens(dev, case, precision):
+    """generative() returns what the reference returns (spVIPESmodule.py:751-768): px_scale_* / px_rate_* [B, G], a ``px``
+    carrying mu1 / mu2 / theta1 / mixture_logits, and ``pz``; the [B, G] tensors come from the materialising HIP path
+    (spv_dec_materialize) and are compared with the decoder outputs the reference produced (goldens out/dec_*).  Reading them
+    must not move any BatchNorm running statistic (the training step's own forward pass does that, once)."""
+    g = Golden(case)
+    m, tensors, noise, dm = _build(g, dev, precision)
+    before = {k: v.clone() for k, v in m.state_dict().items() if "running" in k and "decoder" in k}
+    with torch.no_grad():
+        inf, gen = m(tensors, inference_kwargs={"noise": noise, "dropout_masks": dm}, compute_loss=False)
+    assert gen["private_shared"] == {} and list(gen["private_poe"].keys()) == ["0", "1"]
+    tol = dict(rtol=2e-4, atol=1e-7) if precision == "fp32" else dict(rtol=3e-2, atol=1e-5)
+    ltol = dict(rtol=2e-4, atol=2e-4) if precision == "fp32" else dict(rtol=2e-2, atol=3e-2)
+    for grp in range(2):
+        out = gen["private_poe"][str(grp)]
+        assert list(out.keys()) == ["px_scale_private", "px_scale_shared", "px_rate_private", "px_rate_shared", "px", "pz"]
+        torch.testing.assert_close(out["px_rate_private"].cpu(), g.t(f"out/dec_{grp}/rate_private"), **tol)
+        torch.testing.assert_close(out["px_rate_shared"].cpu(), g.t(f"out/dec_{grp}/rate_shared"), **tol)
+        torch.testing.assert_close(out["px"].mixture_logits.cpu(), g.t(f"out/dec_{grp}/mix_logits"), **ltol)
+        torch.testing.assert_close(out["px"].mu1, out["px_rate_private"])
+        lib = inf["library"][grp]
+        for k in ("private", "shared"):   # px_scale = softmax over genes; px_rate = exp(library) * px_scale (nn/networks.py:315-320)
+            sc = out[f"px_scale_{k}"]
+            torch.testing.assert_close(sc.sum(1), torch.ones_like(sc[:, 0]), rtol=1e-4, atol=1e-4)
+            torch.testing.assert_close(out[f"px_rate_{k}"], torch.exp(lib) * sc, rtol=1e-4, atol=1e-8)
+        torch.testing.assert_close(out["px"].theta1.cpu(), torch.exp(g.state_dict()[f"px_r.{grp}"]), rtol=1e-5, atol=1e-7)
+        B = g.raw[f"in/counts{grp}"].shape[0]
+        assert out["pz"].loc.shape == (B, g.n_s + g.n_p) and float(out["pz"].loc.abs().max()) == 0.0 and float(out["pz"].scale.min()) == 1.0
+    torch.cuda.synchronize()
+    after = m.state_dict()
+    for k, v in before.items():
+        assert torch.equal(after[k], v), f"materialising the decoder outputs moved {k}"
+
+
 @pytest.mark.parametrize("case", INFER_CASES)
 def test_ragged_inference_matches_reference(dev, case):
     g = Golden(case)
@@ -277,3 +313,9 @@ def test_running_statistics_match_reference_goldens(dev, case):
             torch.testing.assert_close(sd[name].cpu().to(want.dtype), want, msg=lambda msg: f"{name}: {msg}", **tol)
             checked += 1
     assert checked > 0
+    # ... and get_loadings (spVIPESmodule.py:773-807), which reads those statistics, must return the reference's values
+    for grp in range(2):
+        for t in ("private", "shared"):
+            torch.testing.assert_close(torch.tensor(m.get_loadings(grp, t)), g.t(f"out/loadings_{grp}_{t}"), rtol=2e-4, atol=1e-6)
+    with pytest.raises(ValueError):
+        m.get_loadings(0, "both")

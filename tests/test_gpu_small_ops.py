@@ -43,7 +43,7 @@ def test_encoder_tails_match_torch(dev, training, B, H, ns):
     eps = [torch.randn(B, n, device=dev) for n in ns]
     specs = [EncoderSpec(encs[0], 0, 0), EncoderSpec(encs[1], 0, H), EncoderSpec(encs[2], 1, 0), EncoderSpec(encs[3], 1, H)]
     flat = [p for s in specs for p in s.params()]
-    outs = EncoderTails.apply(specs, eps, training, 0.0, 0, Workspace(dev), *h1, *flat)
+    outs = EncoderTails.apply(specs, eps, training, 0.0, 0, Workspace(dev), None, *h1, *flat)
     want = []
     for i, (e, s) in enumerate(zip(refs, specs)):
         want += list(_torch_tail(e, h1r[s.h1_group][:, s.h1_col:s.h1_col + H], eps[i], training))
@@ -79,7 +79,7 @@ def test_dropout_mask_is_reproducible_and_has_the_right_rate(dev):
     h1 = torch.randn(B, 2 * H, device=dev).requires_grad_(True)
     eps = [torch.randn(B, 5, device=dev)]
     spec = [EncoderSpec(enc, 0, 0)]
-    run = lambda seed: EncoderTails.apply(spec, eps, True, 0.25, seed, Workspace(dev), h1, *spec[0].params())
+    run = lambda seed: EncoderTails.apply(spec, eps, True, 0.25, seed, Workspace(dev), None, h1, *spec[0].params())
     a, b, c = run(7), run(7), run(8)
     assert torch.equal(a[3], b[3]) and not torch.equal(a[3], c[3])
     # drop rate: compare kept fraction of the positive fc2 activations through a backward pass

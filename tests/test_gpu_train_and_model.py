@@ -37,28 +37,7 @@ def test_hip_adam_matches_torch_adam(dev):
         torch.testing.assert_close(pa, pb, rtol=1e-5, atol=1e-7)
 
 
-class DuckAnnData:
-    """The fields of prepare_adatas' output that the model reads (data/prepare_adatas.py:97-132)."""
-
-    def __init__(self, X, obs, uns):
-        self.X, self.obs, self.uns, self.layers = X, obs, uns, {}
-        self.n_obs, self.n_vars = X.shape
-
-
-def _duck(n=(300, 260), G=(96, 80), seed=0, with_plan=False):
-    rng = np.random.default_rng(seed)
-    X = np.zeros((n[0] + n[1], G[0] + G[1]), np.float32)
-    X[: n[0], : G[0]] = rng.poisson(2.0, (n[0], G[0])) * (rng.random((n[0], G[0])) < 0.3)
-    X[n[0]:, G[0]:] = rng.poisson(2.0, (n[1], G[1])) * (rng.random((n[1], G[1])) < 0.3)
-    X[: n[0], 0] += 1
-    X[n[0]:, G[0]] += 1
-    obs = {"groups": np.array(["a"] * n[0] + ["b"] * n[1]), "indices": np.concatenate([np.arange(n[0]), np.arange(n[1])]).astype(np.int32),
-           "cell_type": np.concatenate([rng.integers(0, 4, n[0]), rng.integers(1, 5, n[1])])}
-    uns = {"groups_lengths": {0: G[0], 1: G[1]}, "groups_var_indices": [np.arange(G[0]), G[0] + np.arange(G[1])],
-           "groups_obs_indices": [np.arange(n[0]), n[0] + np.arange(n[1])], "groups_obs_names": None, "groups_var_names": None}
-    if with_plan:
-        uns["plan"] = (rng.random(n) * (rng.random(n) < 0.1)).astype(np.float32)
-    return DuckAnnData(X, obs, uns)
+from tests._duck import DuckAnnData, make_duck as _duck  # noqa: E402
 
 
 def test_user_api_train_and_latents(dev):
@@ -76,8 +55,10 @@ def test_user_api_train_and_latents(dev):
     assert lat["shared"][0].shape == (300, 10) and lat["shared"][1].shape == (260, 10)
     assert lat["private"][0].shape == (300, 5) and lat["private_reordered"][1].shape == (260, 5)
     assert all(np.isfinite(v).all() for d in lat.values() for v in d.values())
-    load = model.get_loadings()
+    load = model.get_loadings()   # DataFrames with the reference's column names (model/spvipes.py:652-677)
     assert load[(0, "shared")].shape == (96, 10) and load[(1, "private")].shape == (80, 5)
+    assert list(load[(0, "shared")].columns[:2]) == ["Z_shared_0", "Z_shared_1"] and list(load[(1, "private")].columns) == [f"Z_private_{n}" for n in range(5)]
+    np.testing.assert_allclose(load[(1, "private")].to_numpy(), model.module.get_loadings(1, "private"))
 
 
 def test_user_api_paired_transport_plan_cycling(dev):
@@ -90,6 +71,82 @@ def test_user_api_paired_transport_plan_cycling(dev):
     model.train(gi, batch_size=32, max_epochs=2, train_size=1.0)
     lat = model.get_latent_representation(gi, batch_size=32)  # unequal groups -> cycling path (:578-626)
     assert lat["shared"][0].shape == (96, 6) and lat["shared"][1].shape == (64, 6)
+
+
+@pytest.mark.parametrize("mode", ["label", "paired"])
+def test_get_latent_representation_values_follow_the_oracle(dev, mode):
+    """SURVEY 8 f-2, value level: with the noise pinned to zero (sampled log_z = loc) the four dictionaries returned by
+    get_latent_representation must equal what the reference's batch loop produces -- oracle encoders + PoE (eval mode)
+    on the batch pairs of oracle/host_semantics.latent_steps (ConcatDataLoader order; cycling chunks for the paired PoE
+    with unequal groups), assembled by its restatement of _format_results (model/spvipes.py:424-650)."""
+    from oracle import host_semantics as HS
+    from oracle import spvipes_oracle as O
+    from spvipes_amd.model import spVIPES
+    n = (75, 52)
+    ad = _duck(n=n, seed=3, with_plan=(mode == "paired"))
+    rng = np.random.default_rng(9)
+    ad.obs["indices"] = np.concatenate([rng.permutation(n[0]), rng.permutation(n[1])]).astype(np.int32)  # not sorted: the reorder must do work
+    if mode == "label":
+        spVIPES.setup_anndata(ad, groups_key="groups", label_key="cell_type")
+    else:
+        spVIPES.setup_anndata(ad, groups_key="groups", transport_plan_key="plan")
+    torch.manual_seed(5)
+    n_s, n_p, B = 6, 3, 32
+    model = spVIPES(ad, n_hidden=16, n_dimensions_shared=n_s, n_dimensions_private=n_p, precision="fp32")
+    gi = [list(ad.uns["groups_obs_indices"][0]), list(ad.uns["groups_obs_indices"][1])]
+    zeros = lambda step, b0, b1: {**{f"enc_{g}_{k}": torch.zeros(b, d, device=dev) for g, b in ((0, b0), (1, b1)) for k, d in (("private", n_p), ("shared", n_s))},
+                                  **{f"poe_{g}": torch.zeros(b, n_s, device=dev) for g, b in ((0, b0), (1, b1))}}
+    got = model.get_latent_representation(gi, batch_size=B, _noise=zeros)
+    # ---- the reference's loop, restated ----------------------------------------------------------------------
+    sd = {k: v.detach().cpu() for k, v in model.module.state_dict().items()}
+    var_idx = ad.uns["groups_var_indices"]
+    labels = np.unique(ad.obs["cell_type"], return_inverse=True)[1].astype(np.float32)
+    res = {k: [] for k in ("groups_1_latent", "groups_2_latent", "groups_1_latent_shared", "groups_2_latent_shared", "groups_2_original_indices")}
+    steps = HS.latent_steps(gi, B, False, use_cycling=(mode == "paired"))
+    assert len(steps) >= 3
+    for r0, r1 in steps:
+        rows = [np.asarray(r0), np.asarray(r1)]
+        x = [torch.log1p(torch.tensor(ad.X[rows[g]][:, var_idx[g]])) for g in range(2)]
+        z = lambda g, d: torch.zeros(len(rows[g]), d)
+        priv = [O.encoder_forward(sd, f"encoder_{g}_private", x[g], z(g, n_p), False) for g in range(2)]
+        sh = [O.encoder_forward(sd, f"encoder_{g}_shared", x[g], z(g, n_s), False) for g in range(2)]
+        if mode == "label":
+            p0, p1 = O.poe_label(sh[0], sh[1], torch.tensor(labels[rows[0]]), torch.tensor(labels[rows[1]]))
+        else:
+            i0, i1 = ad.obs["indices"][rows[0]], ad.obs["indices"][rows[1]]
+            p0, p1 = O.poe_paired(sh[0], sh[1], torch.tensor(ad.uns["plan"])[i0][:, i1])
+        res["groups_1_latent"].append(priv[0]["log_z"].numpy())
+        res["groups_2_latent"].append(priv[1]["log_z"].numpy())
+        res["groups_1_latent_shared"].append(O.poe_sample(p0, z(0, n_s), mode == "paired")["logtheta_log_z"].numpy())
+        res["groups_2_latent_shared"].append(O.poe_sample(p1, z(1, n_s), mode == "paired")["logtheta_log_z"].numpy())
+        res["groups_2_original_indices"].append(ad.obs["indices"][rows[1]][:, None].astype(np.float32))
+    want = HS.format_results(res, n[0], n[1])
+    for k in ("shared", "private", "shared_reordered", "private_reordered"):
+        for g in (0, 1):
+            np.testing.assert_allclose(got[k][g], want[k][g], rtol=1e-3, atol=2e-4, err_msg=f"{mode} {k}[{g}]")
+
+
+def test_validation_metrics_and_early_stopping(dev):
+    """train_size < 1 holds cells out as MultiGroupDataSplitter does; validation metrics are logged per epoch and early stopping
+    (scvi-tools defaults: monitor elbo_validation, mode min) ends training when they stop improving."""
+    from spvipes_amd.model import spVIPES
+    ad = _duck(n=(320, 288))
+    spVIPES.setup_anndata(ad, groups_key="groups", label_key="cell_type")
+    torch.manual_seed(0)
+    model = spVIPES(ad, n_hidden=32, n_dimensions_shared=10, n_dimensions_private=5, precision="fp32")
+    gi = [list(ad.uns["groups_obs_indices"][0]), list(ad.uns["groups_obs_indices"][1])]
+    model.train(gi, batch_size=32, max_epochs=6, train_size=0.75, n_epochs_kl_warmup=None, plan_kwargs={"lr": 5e-3}, check_val_every_n_epoch=1)
+    h = model.history
+    assert len(h["elbo_validation"]) == 6 and np.isfinite(h["elbo_validation"]).all() and h["train_loss"][-1] < h["train_loss"][0]
+    assert abs(h["elbo_validation"][-1] - h["elbo_train"][-1]) / h["elbo_train"][-1] < 0.2   # held-out cells of the same distribution
+    assert len(model.sampler_.val_idx[0]) == 80 and len(model.sampler_.train_idx[0]) == 240   # ceil(0.75 * 320) training cells
+    # with an unreachable min_delta only the first epoch counts as an improvement: patience 2 stops after epoch index 2
+    model2 = spVIPES(ad, n_hidden=32, n_dimensions_shared=10, n_dimensions_private=5, precision="fp32")
+    model2.train(gi, batch_size=32, max_epochs=10, train_size=0.75, early_stopping=True, early_stopping_patience=2,
+                 early_stopping_min_delta=1e9, n_epochs_kl_warmup=None)
+    assert len(model2.history["elbo_validation"]) == 3 and model2.trainer_.stopped_epoch == 2
+    with pytest.raises(ValueError, match="early_stopping needs"):
+        spVIPES(ad, n_hidden=32, n_dimensions_shared=10, n_dimensions_private=5).train(gi, batch_size=32, max_epochs=1, train_size=1.0, early_stopping=True)
 
 
 def test_setup_errors_match_reference(dev):

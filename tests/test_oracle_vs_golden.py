@@ -104,3 +104,19 @@ def test_float64_oracle_agrees_with_float32_goldens():
     g = Golden("label_train")
     _, out = _run(g, dtype=torch.float64)
     assert abs(float(out["loss"]) - float(g.raw["out/loss"])) / abs(float(g.raw["out/loss"])) < 1e-5
+
+
+@pytest.mark.parametrize("case", LOSS_CASES)
+def test_loadings_match_reference(case):
+    """get_loadings (spVIPESmodule.py:773-807) on the state the reference module holds AFTER the recorded forward pass: the
+    golden's state_dict with, in training mode, the running statistics the oracle's own forward pass produces."""
+    g = Golden(case)
+    sd, out = _run(g)
+    sd = {k: v.detach() for k, v in sd.items()}
+    if g.training:
+        sd.update(out["new_running_stats"])
+    for grp in range(2):
+        for t in ("private", "shared"):
+            torch.testing.assert_close(O.get_loadings(sd, grp, t), g.t(f"out/loadings_{grp}_{t}"), rtol=1e-5, atol=1e-7)
+    with pytest.raises(ValueError):
+        O.get_loadings(sd, 0, "both")

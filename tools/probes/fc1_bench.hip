@@ -1,0 +1,82 @@
+// Probe (dev tool): the LDS-DMA encoder fc1 forward kernel (spv_fc1.h) alone at the C2 / C3 shapes: correctness against a
+// naive fp32 kernel on the same bf16 operands, and time per launch of the GEMM and of its epilogue.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -o fc1_bench fc1_bench.hip && ./fc1_bench [B G splits]
+#include "../../spvipes_amd/csrc/spv_fc1.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+
+using namespace spv;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+static unsigned short f2bf_host(float f) { unsigned u; std::memcpy(&u, &f, 4); u += 0x7FFF + ((u >> 16) & 1); return (unsigned short)(u >> 16); }
+template <typename T> static T* dalloc(size_t n) { T* p; CK(hipMalloc(&p, n * sizeof(T))); CK(hipMemset(p, 0, n * sizeof(T))); return p; }
+template <typename T> static T* upload(const std::vector<T>& v) { T* p = dalloc<T>(v.size()); CK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice)); return p; }
+
+__global__ void naive_kernel(const unsigned short* A, long lda, const int* rows, const unsigned short* W, long ldw, int M, int N, int K, float* out) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+  if (n >= N || m >= M) return;
+  const unsigned short* a = A + (long)rows[m] * lda;
+  const unsigned short* w = W + (long)n * ldw;
+  float s = 0.f;
+  for (int k = 0; k < K; ++k) s += bf2f(a[k]) * bf2f(w[k]);
+  out[(long)m * N + n] = fmaxf(s, 0.f);
+}
+
+int main(int argc, char** argv) {
+  const int B = argc > 1 ? atoi(argv[1]) : 4096, G = argc > 2 ? atoi(argv[2]) : 10000;
+  int splits = argc > 3 ? atoi(argv[3]) : 0;
+  const int NCELLS = 30000, N1 = 256;
+  const long lda = ((G + 95) / 96 * 96 + 127) / 128 * 128, ldw = (G + 63) / 64 * 64;
+  std::mt19937 rng(3);
+  std::uniform_real_distribution<float> uni(0.f, 1.f);
+  std::normal_distribution<float> nrm(0.f, 1.f);
+  std::vector<unsigned short> A((size_t)NCELLS * lda, 0), W((size_t)N1 * ldw, 0);
+  for (int c = 0; c < NCELLS; ++c)
+    for (int g = 0; g < G; ++g) A[(size_t)c * lda + g] = uni(rng) < 0.8f ? 0 : f2bf_host(logf(1.f + (float)(1 + (int)(-3.f * logf(uni(rng) + 1e-6f)))));
+  for (int n = 0; n < N1; ++n)
+    for (int g = 0; g < G; ++g) W[(size_t)n * ldw + g] = f2bf_host(0.02f * nrm(rng));
+  std::vector<int> rows(B);
+  for (auto& r : rows) r = (int)(uni(rng) * (NCELLS - 1));
+  std::vector<float> bias(N1, 0.f), lib_all(NCELLS, 1.f);
+  unsigned short* dA = upload(A); unsigned short* dW = upload(W); int* drows = upload(rows);
+  float* dbias = upload(bias); float* dlib = upload(lib_all);
+  const int mtiles = (B + F1_BM - 1) / F1_BM;
+  const int ktiles = (G + F1_BK - 1) / F1_BK;
+  if (splits <= 0) splits = std::max(1, std::min(16, std::min(256 / mtiles, ktiles / 4)));
+  const long slab_elems = (long)mtiles * F1_BM * F1_BN;
+  float* slabs = dalloc<float>((size_t)splits * slab_elems);
+  float* h1 = dalloc<float>((size_t)B * N1); float* lib = dalloc<float>(B); float* ref = dalloc<float>((size_t)B * N1);
+  GemmParams p{};
+  p.A = dA; p.lda = lda; p.rows = drows; p.B = dW; p.ldb = ldw; p.C = slabs; p.M = B; p.N = N1; p.K = G;
+  p.k_per_split = ((ktiles + splits - 1) / splits) * F1_BK;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(fc1_fwd_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F1_LDS_BYTES));
+  auto gemm = [&]() { hipLaunchKernelGGL(fc1_fwd_dma_kernel, dim3(mtiles, 1, splits), dim3(512), F1_LDS_BYTES, 0, p); };
+  auto epi = [&]() { hipLaunchKernelGGL(fc1_epilogue_tiled_kernel, dim3((unsigned)((slab_elems / 4 + 255) / 256)), dim3(256), 0, 0, slabs, splits, slab_elems, B, dbias, (const float*)nullptr, 0, h1, lib, dlib, drows); };
+  gemm(); epi();
+  CK(hipDeviceSynchronize());
+  hipLaunchKernelGGL(naive_kernel, dim3((N1 + 255) / 256, B), dim3(256), 0, 0, dA, lda, drows, dW, ldw, B, N1, G, ref);
+  CK(hipDeviceSynchronize());
+  std::vector<float> hh((size_t)B * N1), hr((size_t)B * N1);
+  CK(hipMemcpy(hh.data(), h1, hh.size() * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(hr.data(), ref, hr.size() * 4, hipMemcpyDeviceToHost));
+  double maxerr = 0, maxref = 0; size_t bad = 0;
+  for (size_t i = 0; i < hh.size(); ++i) { const double e = fabs((double)hh[i] - hr[i]); maxerr = std::max(maxerr, e); maxref = std::max(maxref, (double)fabs(hr[i])); if (e > 1e-3 + 1e-3 * fabs(hr[i])) ++bad; }
+  printf("fc1_fwd_dma B=%d G=%d splits=%d grid=%dx%d: max |err| %.3e (max |ref| %.3e), %zu of %zu outside tolerance\n", B, G, splits, mtiles, splits, maxerr, maxref, bad, hh.size());
+  hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
+  const int reps = 50;
+  for (int i = 0; i < 5; ++i) { gemm(); epi(); }
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < reps; ++i) gemm();
+  CK(hipEventRecord(e1));
+  for (int i = 0; i < reps; ++i) epi();
+  CK(hipEventRecord(e2)); CK(hipEventSynchronize(e2));
+  float ms1, ms2; CK(hipEventElapsedTime(&ms1, e0, e1)); CK(hipEventElapsedTime(&ms2, e1, e2));
+  const double us1 = ms1 * 1e3 / reps, us2 = ms2 * 1e3 / reps, fl = 2.0 * B * (double)G * N1;
+  printf("  gemm %.1f us (%.0f TFLOP/s = %.1f %% of 2500; A stream %.2f TB/s)   epilogue %.1f us   total %.1f us\n", us1, fl / us1 / 1e6, fl / us1 / 1e6 / 25.0,
+         (double)B * G * 2 / us1 / 1e6, us2, us1 + us2);
+  return bad ? 1 : 0;
+}

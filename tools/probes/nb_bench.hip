@@ -79,6 +79,11 @@ int main(int argc, char** argv) {
   CK(hipDeviceSynchronize());
 
   dim3 grid((Bp + NB_CELLS_PER_WG - 1) / NB_CELLS_PER_WG, nbs);
+#ifdef SPV_NB_STAMPS
+  unsigned long long* d_st = dalloc<unsigned long long>((size_t)grid.x * grid.y * 8);   // set BEFORE the first launch: every launch of this build stamps
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(g_nb_stamps), &d_st, sizeof(d_st)));
+  CK(hipDeviceSynchronize());
+#endif
   auto launch = [&]() { hipLaunchKernelGGL((dec_nb_kernel<true, bf16_t, _Float16, CNT_U16_ALIGNED>), grid, dim3(256), 0, 0, p); };
   for (int i = 0; i < 5; ++i) launch();
   CK(hipDeviceSynchronize());
@@ -91,8 +96,6 @@ int main(int argc, char** argv) {
   const double us = ms * 1e3 / reps;
 #ifdef SPV_NB_STAMPS
   {  // phases of a workgroup's lifetime (wave 0), median over workgroups, in shader cycles
-    unsigned long long* d_st = dalloc<unsigned long long>((size_t)grid.x * grid.y * 8);
-    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_nb_stamps), &d_st, sizeof(d_st)));
     launch(); CK(hipDeviceSynchronize());
     std::vector<unsigned long long> st((size_t)grid.x * grid.y * 8);
     CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));

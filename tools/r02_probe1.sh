@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-2 probe 1: VALU issue microbench + likelihood kernel occupancy sweep (built on the GPU box)
-set -e
+set -e -o pipefail
 cd "$(dirname "$0")/probes"
 O=../../gpurun_out/r02_probe1; mkdir -p $O
 hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_issue valu_issue.hip 2>/dev/null

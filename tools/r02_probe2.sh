@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-2 probe 2: ablations of the likelihood kernel (what are its waves waiting for?)
-set -e
+set -e -o pipefail
 cd "$(dirname "$0")/probes"
 O=../../gpurun_out/r02_probe2; mkdir -p $O
 for a in 0 1 2 4 8 16 3 7 31; do
