@@ -66,6 +66,12 @@ int spv_pack_bf16(const float* src, int64_t ld_src, int32_t R, int32_t C,
                   uint16_t* dst_hi, uint16_t* dst_lo, int64_t ld_dst, int32_t dst_col_off,
                   int32_t Rp, int32_t cslot, void* stream);
 
+/* 1 when spv_enc_fc1_fwd will take its LDS-DMA kernel for these shapes (resident bf16 log1p image, N1 = 256, nsplit 1, operand rows
+ * zero padded to multiples of 64 genes).  The caller needs to know because that path wants `slabs` sized
+ * [splits][round_up(B, 128)][N1] fp32 (it keeps the partial sums in MFMA accumulator-tile order) and splits chosen as
+ * clamp(256 / ceil(B / 128), 1, 16) with at least four 64-gene steps per split. */
+int spv_enc_fc1_fwd_uses_dma(int32_t B, int32_t G, int32_t N1, int32_t nsplit, int32_t have_xb, int64_t ldw, int64_t ld_xb);
+
 /* A1 + first layer of both encoders of a group (module/spVIPESmodule.py:428-435,
  * nn/networks.py:119):  h1 = relu(log1p(X[rows]) @ W1^T + b1) for the concatenated
  * [private ; shared] fc1 (N1 = 2 * n_hidden output columns), library = log(sum_g log1p(x)).

@@ -136,6 +136,7 @@ _SIGNATURES = {
     "spv_build_id": (C.c_char_p, []),
     "spv_pack_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                 C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "spv_enc_fc1_fwd_uses_dma": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64]),
     "spv_enc_fc1_fwd": (C.c_int, [C.POINTER(SpvCounts), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                   C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -2,6 +2,7 @@
 #include "../../include/spvipes_hip.h"
 #include "spv_common.h"
 #include "spv_gemm.h"
+#include "spv_fc1.h"
 #include "spv_decoder.h"
 #include "spv_small.h"
 
@@ -138,6 +139,14 @@ static int fc1_fwd_dispatch(const GemmParams& p, int N1, int splits, hipStream_t
   return launch_gemm<GemmCfg<64, 256, 1, 4, false, false, SRC_COUNTS, SRC_PLAIN, CT, NSPLIT, 32, 4>>(p, splits, s);
 }
 
+// Shapes the LDS-DMA fc1 forward kernel (spv_fc1.h) takes: the resident bf16 log1p image, both encoders' 2H = 256 output columns,
+// operand images zero padded to multiples of 64 genes with 16-byte aligned rows.  The host asks through this entry point
+// because the path fixes the slab workspace: [splits][round_up(B, 128)][256] fp32 in accumulator-tile order.
+extern "C" int spv_enc_fc1_fwd_uses_dma(int32_t B, int32_t G, int32_t N1, int32_t nsplit, int32_t have_xb, int64_t ldw, int64_t ld_xb) {
+  const long G64 = (G + 63) & ~63L;
+  return have_xb && nsplit == 1 && N1 == F1_BN && B > 0 && G > 0 && ldw >= G64 && ld_xb >= G64 && (ldw % 8) == 0 && (ld_xb % 8) == 0;
+}
+
 static int fc1_bn(int N1) { return N1 <= 32 ? 32 : (N1 <= 128 ? 128 : 256); }
 
 extern "C" int spv_enc_fc1_fwd(const spv_counts* x, int32_t B, int32_t G, const uint16_t* W1_hi, const uint16_t* W1_lo,
@@ -170,6 +179,20 @@ extern "C" int spv_enc_fc1_fwd(const spv_counts* x, int32_t B, int32_t G, const 
   p.epi = EPI_STORE;
   hipStream_t s = (hipStream_t)stream;
   int rc;
+  if (spv_enc_fc1_fwd_uses_dma(B, G, N1, nsplit, xb_all != nullptr, ldw, ld_xb) && ((reinterpret_cast<uintptr_t>(xb_all) | reinterpret_cast<uintptr_t>(W1_hi)) & 15) == 0) {
+    // LDS-DMA kernel (spv_fc1.h): 128-cell tiles, K split `splits` ways, slabs in accumulator-tile order [splits][Mp128][256]
+    const int mtiles = (B + F1_BM - 1) / F1_BM, kt = (G + F1_BK - 1) / F1_BK;
+    p.k_per_split = ((kt + splits - 1) / splits) * F1_BK;
+    p.c_split_row = splits;
+    static bool raised = false;
+    if (!raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fc1_fwd_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F1_LDS_BYTES); raised = true; }
+    hipLaunchKernelGGL(fc1_fwd_dma_kernel, dim3(mtiles * splits), dim3(512), F1_LDS_BYTES, s, p);
+    if (hipGetLastError() != hipSuccess) return launch_status("spv_enc_fc1_fwd dma gemm");
+    const long slab_elems = (long)mtiles * F1_BM * F1_BN;
+    hipLaunchKernelGGL(fc1_epilogue_tiled_kernel, dim3((unsigned)((slab_elems / 4 + 255) / 256)), dim3(256), 0, s, slabs, splits, slab_elems, B, bias, bias2, n_first, h1, library,
+                       library_all, x->rows);
+    return launch_status("spv_enc_fc1_fwd dma epilogue");
+  }
   if (xb_all != nullptr) {
     if (N1 <= 128) rc = launch_gemm<GemmCfg<64, 128, 2, 2, false, false, SRC_GATHER, SRC_PLAIN, unsigned short, 1, 32, 4>>(p, splits, s);
     else if (wide64) rc = launch_gemm<GemmCfg<128, 256, 2, 2, false, false, SRC_GATHER, SRC_PLAIN, unsigned short, 1, 64, 1, 2>>(p, splits, s);
@@ -205,6 +228,17 @@ extern "C" int spv_enc_fc1_wgrad(const spv_counts* x, int32_t B, int32_t G, cons
   if (xb != nullptr) {  // resident bf16 log1p(x) of the data set (spv_prepare_log1p): gathered plain k-major operand, no decode
     if (nsplit != 1 || ld_xb < ((G + 63) & ~63) || (ld_xb % 8)) return fail(SPV_ERR_ARG, "spv_enc_fc1_wgrad: xb needs nsplit 1 and ld_xb >= round_up(G, 64)%s");
     p.B = xb; p.ldb = ld_xb;
+    const int Kpad = (B + FW_BK - 1) / FW_BK * FW_BK;
+    if (N1 == FW_BM && ld_dh == FW_BM && rows_first == FW_BM / 2 && dW2 != nullptr && fw_lds_bytes(64, Kpad) <= 160 * 1024 &&
+        ((reinterpret_cast<uintptr_t>(xb) | reinterpret_cast<uintptr_t>(dh_hi)) & 15) == 0) {
+      // LDS-DMA kernel (spv_fc1.h): all 256 rows x 64 genes per workgroup over the whole batch, results straight into dW / dW2
+      // (measured at C2, tools/probes/fc1w_bench.hip: 51 us alone against 75 us for the register-staged kernel below)
+      void (*kfn)(GemmParams) = fc1_wgrad_dma_kernel<64>;
+      const int lds = fw_lds_bytes(64, Kpad);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL(kfn, dim3((G + 63) / 64), dim3(512), lds, s, p);
+      return launch_status("spv_enc_fc1_wgrad dma");
+    }
     // 96-gene tiles when the image rows are padded that far: at G = 10 000 that is 2 x 105 workgroups per group, so the two
     // groups' GEMMs (two streams) are resident together in one round instead of 2 x 314 workgroups in two (-0.04 ms per
     // step; alone the 64-gene tile is 4 us faster)

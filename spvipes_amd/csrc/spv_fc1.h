@@ -22,6 +22,12 @@
 
 namespace spv {
 
+#ifndef F1_SPREAD
+#define F1_SPREAD 1
+#endif
+#ifndef F1_PIPE
+#define F1_PIPE 1   // measured at C2 (tools/probes/fc1_bench.hip): 28.1 -> 26.7 us; G = 20 000: 50.0 -> 48.2 us
+#endif
 constexpr int F1_BM = 128, F1_BN = 256, F1_BK = 64, F1_NBUF = 3;
 constexpr int F1_A_BYTES = F1_BM * F1_BK * 2, F1_B_BYTES = F1_BN * F1_BK * 2, F1_STAGE = F1_A_BYTES + F1_B_BYTES;
 constexpr int F1_LDS_BYTES = F1_STAGE * F1_NBUF;   // 147 456 B: one workgroup per CU
@@ -30,16 +36,32 @@ constexpr int F1_PIECES_PER_WAVE = (F1_A_BYTES + F1_B_BYTES) / 1024 / 8;   // 6 
 typedef __attribute__((address_space(3))) unsigned char lds_byte;
 typedef __attribute__((address_space(1))) const unsigned char glb_byte;
 
+// Target builtins behind plain (non-template) device functions: a kernel TEMPLATE that names them directly cannot be instantiated in
+// the host pass of the compilation (the builtins do not exist there), and its launch stub silently goes missing.
+__device__ __forceinline__ void dma16(const glb_byte* src, lds_byte* dst) { __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0); }
+__device__ __forceinline__ int uniform_wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+__device__ __forceinline__ void raw_barrier() { __builtin_amdgcn_s_barrier(); }
+// Transposed LDS reads as inline asm.  Through the builtin (__builtin_amdgcn_ds_read_tr16_b64_v4i16) hipcc (ROCm 7.2) puts an
+// s_waitcnt vmcnt(0) in front of the first transposed read of every K tile -- it cannot tell the read from the LDS-DMA
+// writes still in flight -- which drains the two-tile DMA pipeline once per tile.  The asm form is invisible to that pass:
+// the reads of one k-step are issued, then ONE wait statement that names every destination (so no consumer is scheduled
+// above it; cdna_hip_programming.md 5.7 form (ii)).  Byte addresses inside LDS, 8-byte aligned.
+__device__ __forceinline__ unsigned lds_addr_of(const unsigned char* p) { return (unsigned)(size_t)((lds_byte*)p); }
+__device__ __forceinline__ void tr_issue(s4v& d, unsigned addr) { asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(d) : "v"(addr)); }
+__device__ __forceinline__ s8v join8(const s4v& v0, const s4v& v1) { return s8v{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]}; }
+
 // p.A = bf16 image [n_cells_total][lda] (zero padded to a multiple of 64 genes), p.rows = minibatch row index (nullable),
 // p.B = W bf16 [256][ldb] (zero padded likewise), p.C = slabs in tile order, p.M = cells in the minibatch, p.K = genes,
-// p.k_per_split multiple of 64.  grid = (ceil(M / 128), 1, splits), 512 threads.
+// p.k_per_split multiple of 64, p.c_split_row = number of K splits.  grid = ceil(M / 128) * splits (1-D), 512 threads.
 __global__ __launch_bounds__(512) void fc1_fwd_dma_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char f1_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: the LDS-DMA destination must be
   const int wm = wave >> 2, wn = wave & 3;
-  const int m0 = blockIdx.x * F1_BM;
-  const int split = blockIdx.z;
+  // 1-D grid, split fastest: workgroups are dealt round-robin over the 8 XCDs (MI355X_MICROARCH.md), so with 8 splits every
+  // XCD works on ONE K range and its slice of W (256 x k_per_split bf16 = 640 KB at C2) stays resident in that XCD's L2
+  const int split = blockIdx.x % p.c_split_row, mtile = blockIdx.x / p.c_split_row;   // (c_split_row carries the split count)
+  const int m0 = mtile * F1_BM;
   const int kbeg = split * p.k_per_split;
   const int Kpad = (p.K + F1_BK - 1) / F1_BK * F1_BK;
   int kend = kbeg + p.k_per_split;
@@ -68,12 +90,13 @@ __global__ __launch_bounds__(512) void fc1_fwd_dma_kernel(GemmParams p) {
     dst_off[2 + i] = F1_A_BYTES + piece * 1024;
   }
   lds_byte* const lds = (lds_byte*)(f1_smem);
-  auto issue = [&](int t) {   // tile t of this split -> buffer t % 3
+  auto issue2 = [&](int t, int i0) {   // pieces i0, i0 + 1 of tile t of this split -> buffer t % 3
     const int stage = (t % F1_NBUF) * F1_STAGE;
 #pragma unroll
-    for (int i = 0; i < F1_PIECES_PER_WAVE; ++i)
+    for (int i = i0; i < i0 + 2; ++i)
       __builtin_amdgcn_global_load_lds(src[i] + (long)t * (F1_BK * 2), lds + stage + dst_off[i], 16, 0, 0);
   };
+  auto issue = [&](int t) { issue2(t, 0); issue2(t, 2); issue2(t, 4); };
 
   f16v acc[2][2];
 #pragma unroll
@@ -93,10 +116,46 @@ __global__ __launch_bounds__(512) void fc1_fwd_dma_kernel(GemmParams p) {
     if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (t + 2 < ntiles) issue(t + 2);
+    const bool more = t + 2 < ntiles;
     const unsigned char* st = f1_smem + (t % F1_NBUF) * F1_STAGE;
+#if F1_PIPE
+    // fragments of k-step ks + 1 are requested before the MFMAs of k-step ks; tile t + 2's six DMA pieces go out two at a
+    // time behind the MFMAs of the first three k-steps.  Order pinned with sched_group_barrier (DS read 0x100, MFMA 0x8,
+    // VMEM 0x10): left alone the scheduler hoists all six DMAs to the top of the tile, where both waves of every SIMD
+    // issue them in lockstep right after the barrier while the matrix pipe idles.
+    s8v fa[2][2], fb[2][2];
+    auto frags = [&](int ks, s8v (&a)[2], s8v (&b)[2]) {
+      const int cpos = ((2 * ks + h) ^ sw) * 16;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const s8v*>(st + a_row_off + i * 32 * 128 + cpos);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const s8v*>(st + b_row_off + j * 32 * 128 + cpos);
+    };
+    frags(0, fa[0], fb[0]);
 #pragma unroll
     for (int ks = 0; ks < F1_BK / 16; ++ks) {
+      if (ks + 1 < F1_BK / 16) frags(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
+      if (more && ks < 3) issue2(t + 2, 2 * ks);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int ks = 0; ks < F1_BK / 16; ++ks) {
+      if (ks + 1 < F1_BK / 16) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      if (ks < 3) __builtin_amdgcn_sched_group_barrier(0x010, 2, 0);
+    }
+#else
+#pragma unroll
+    for (int ks = 0; ks < F1_BK / 16; ++ks) {
+      // tile t + 2's six DMA pieces go out two at a time BEHIND the first three k-steps' MFMAs (F1_SPREAD), not in one
+      // burst right after the barrier while both waves of every SIMD leave the matrix pipe idle
+      if (F1_SPREAD ? (ks > 0) : (ks == 0)) {
+        if (more) { if (F1_SPREAD) issue2(t + 2, 2 * (ks - 1)); else issue(t + 2); }
+      }
       const int cpos = ((2 * ks + h) ^ sw) * 16;
       s8v a[2], b[2];
 #pragma unroll
@@ -107,17 +166,19 @@ __global__ __launch_bounds__(512) void fc1_fwd_dma_kernel(GemmParams p) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+      if (F1_SPREAD) __builtin_amdgcn_sched_barrier(0);   // keep the DMA pieces where they are written, between the k-steps
     }
+#endif
   }
 
   // ---- partial slab in accumulator-tile order: S[split][row / 32][col / 32][qq][lane][4] ------------------------------------
-  const long mtiles = gridDim.x * (F1_BM / 32);
+  const long mtiles = (long)(gridDim.x / p.c_split_row) * (F1_BM / 32);
   float* slab = p.C + (long)split * mtiles * (F1_BN / 32) * 1024;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const long tm = (long)blockIdx.x * (F1_BM / 32) + wm * 2 + i, tn = wn * 2 + j;
+      const long tm = (long)mtile * (F1_BM / 32) + wm * 2 + i, tn = wn * 2 + j;
       float* o = slab + (tm * (F1_BN / 32) + tn) * 1024 + lane * 4;
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq)
@@ -149,6 +210,167 @@ __global__ __launch_bounds__(256) void fc1_epilogue_tiled_kernel(const float* sl
       if (row0 + jj < M) h1[(row0 + jj) * F1_BN + col] = fmaxf(s[jj] + bv, 0.f);   // relu(fc1(x)), nn/networks.py:119
   }
   if (idx < M) library[idx] = library_all[rows ? rows[idx] : (int)idx];   // log(sum_g log1p(x)), module/spVIPESmodule.py:435
+}
+
+// ---- fc1 weight gradient:  dW[n1][gene] = sum_cell dh[cell][n1] * log1p(X)[rows[cell]][gene]   (backward of nn/networks.py:119) -------
+// M = 256 output units (both encoders), N = genes, K = cells: both operands are k-major in memory (dh image [cell][256],
+// gathered image rows [cell][gene]), so the MFMA fragments come out of LDS by transposed reads (ds_read_b64_tr_b16).  Same
+// skeleton as the forward kernel: LDS-DMA staging into three tile buffers (one K tile = 64 cells), counted vmcnt, one
+// barrier per tile, 8 waves as 4 (M) x 2 (N).  One workgroup owns ALL 256 rows x WG_BN genes over the whole K range: no
+// split-K, the fp32 result goes straight to the two encoders' gradient arrays.  The gather's row indices (they change with
+// every K tile) are staged once into an LDS table, so that the loop issues no register-destination global load (hipcc would
+// drain the DMA queue with vmcnt(0) at its first use).
+//   LDS images are lane-linear copies of the global rows (512-byte dh rows, 2 WG_BN-byte gene rows); the four k rows a
+//   transposed read touches would fall on the same banks, so the 64-byte granule index inside a row is XOR-ed with
+//   (row & 3) (128-byte rows: (row >> 1) & 1) on the DMA's source address and again on the read.
+constexpr int FW_BM = 256, FW_BK = 64, FW_NBUF = 3;
+template <int WG_BN>
+struct FwCfg {
+  static constexpr int A_BYTES = FW_BK * FW_BM * 2, B_ROW = WG_BN * 2, B_BYTES = FW_BK * B_ROW, STAGE = A_BYTES + B_BYTES;
+  static constexpr int A_PIECES = A_BYTES / 1024 / 8, B_PIECES = B_BYTES / 1024 / 8, PIECES = A_PIECES + B_PIECES;   // per wave
+  static constexpr int TN = WG_BN / 2 / 32;   // 32-gene MFMA tiles per wave (2 wave columns)
+  static constexpr int ROWS_PER_BPIECE = 1024 / B_ROW;   // 4 (WG_BN 128) or 8 (WG_BN 64)
+  static_assert(WG_BN == 64 || WG_BN == 128, "gene tile");
+};
+__host__ __device__ constexpr int fw_lds_bytes(int wg_bn, int kpad) { return (FW_BK * FW_BM * 2 + FW_BK * wg_bn * 2) * FW_NBUF + kpad * 4; }
+
+// p.A = dh image bf16 [Kpad][256] (rows >= n_cells zero), p.B = image [cells_total][ldb], p.rows, p.n_cells = K = cells of the
+// minibatch, p.N = genes, p.C / p.C2 = dW of the first / second 128 rows, p.ldc.  grid = ceil(N / WG_BN), 512 threads,
+// dynamic LDS = fw_lds_bytes(WG_BN, Kpad).
+template <int WG_BN>
+__global__ __launch_bounds__(512) void fc1_wgrad_dma_kernel(GemmParams p) {
+  typedef FwCfg<WG_BN> Cfg;
+  extern __shared__ __attribute__((aligned(16))) unsigned char fw_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uniform_wave_id();
+  const int wm = wave >> 1, wn = wave & 1;
+  const int n0 = blockIdx.x * WG_BN;
+  const int Kpad = (p.n_cells + FW_BK - 1) / FW_BK * FW_BK, ntiles = Kpad / FW_BK;
+  int* rowtab = reinterpret_cast<int*>(fw_smem + Cfg::STAGE * FW_NBUF);
+  for (int k = tid; k < Kpad; k += 512) {
+    const int c = k < p.n_cells ? k : p.n_cells - 1;   // padding cells re-read the last row: their dh rows are zero
+    rowtab[k] = p.rows ? p.rows[c] : c;
+  }
+  __syncthreads();
+
+  lds_byte* const lds = (lds_byte*)(fw_smem);
+  // A pieces (2 dh rows of 512 B each): wave w owns pieces 4w .. 4w + 3 = rows 8w .. 8w + 7 of the K tile
+  const glb_byte* srcA[Cfg::A_PIECES];
+#pragma unroll
+  for (int i = 0; i < Cfg::A_PIECES; ++i) {
+    const int piece = Cfg::A_PIECES * wave + i, row = 2 * piece + (lane >> 5), ch = lane & 31;
+    const int chs = (((ch >> 2) ^ (row & 3)) << 2) | (ch & 3);
+    srcA[i] = (glb_byte*)(p.A) + ((long)row * FW_BM) * 2 + chs * 16;
+  }
+  // B pieces: rows of 2 WG_BN bytes; wave w owns rows 8w .. 8w + 7 as well
+  int browB[Cfg::B_PIECES], bcolB[Cfg::B_PIECES];
+#pragma unroll
+  for (int i = 0; i < Cfg::B_PIECES; ++i) {
+    const int piece = Cfg::B_PIECES * wave + i;
+    if constexpr (WG_BN == 128) {
+      const int row = 4 * piece + (lane >> 4), ch = lane & 15;
+      browB[i] = row; bcolB[i] = ((((ch >> 2) ^ (row & 3)) << 2) | (ch & 3)) * 16;
+    } else {
+      const int row = 8 * piece + (lane >> 3), ch = lane & 7;
+      browB[i] = row; bcolB[i] = ((((ch >> 2) ^ ((row >> 1) & 1)) << 2) | (ch & 3)) * 16;
+    }
+  }
+  const glb_byte* const Bbase = (glb_byte*)(p.B) + (long)n0 * 2;
+  auto issueA = [&](int t, int i) {   // A piece i of tile t
+    dma16(srcA[i] + (long)t * (FW_BK * FW_BM * 2), lds + (t % FW_NBUF) * Cfg::STAGE + (Cfg::A_PIECES * wave + i) * 1024);
+  };
+  auto issueB = [&](int t) {          // all B pieces of tile t (their row indices come out of the LDS table)
+#pragma unroll
+    for (int i = 0; i < Cfg::B_PIECES; ++i) {
+      const long ridx = rowtab[t * FW_BK + browB[i]];
+      dma16(Bbase + ridx * p.ldb * 2 + bcolB[i], lds + (t % FW_NBUF) * Cfg::STAGE + Cfg::A_BYTES + (Cfg::B_PIECES * wave + i) * 1024);
+    }
+  };
+  auto issue = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < Cfg::A_PIECES; ++i) issueA(t, i);
+    issueB(t);
+  };
+
+  f16v acc[2][Cfg::TN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  if (ntiles > 0) issue(0);
+  if (ntiles > 1) issue(1);
+  const int gi = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3, h = lane >> 5;
+  const int in_gran = 32 * (gi & 1) + 8 * p4;   // byte offset inside the 64-byte granule (32 columns of one k row)
+  const unsigned lds0 = lds_addr_of(fw_smem);
+  for (int t = 0; t < ntiles; ++t) {
+    if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::PIECES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    raw_barrier();
+    const bool more = t + 2 < ntiles;
+    if (more) issueB(t + 2);   // (first: its LDS-table reads are compiler-visible and must not sit between the asm reads below and their waits)
+    const unsigned stA = lds0 + (t % FW_NBUF) * Cfg::STAGE, stB = stA + Cfg::A_BYTES;
+    // fragments of k-step ks + 1 are requested before the MFMAs of k-step ks (two register sets); one A piece of tile
+    // t + 2 goes out behind each k-step's MFMAs
+    s4v ra[2][2][2], rb[2][Cfg::TN][2];
+    auto reads = [&](int ks, int set) {
+      const int row = 16 * ks + 8 * h + q4;   // (row & 3) == q4
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const unsigned ad = stA + row * 512 + (((wm * 2 + i) ^ q4) * 64) + in_gran;
+        tr_issue(ra[set][i][0], ad);
+        tr_issue(ra[set][i][1], ad + 4 * 512);
+      }
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j) {
+        const int f = (WG_BN == 128) ? q4 : ((row >> 1) & 1);
+        const unsigned ad = stB + row * Cfg::B_ROW + (((wn * Cfg::TN + j) ^ f) * 64) + in_gran;
+        tr_issue(rb[set][j][0], ad);
+        tr_issue(rb[set][j][1], ad + 4 * Cfg::B_ROW);
+      }
+    };
+    reads(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < FW_BK / 16; ++ks) {
+      const int set = ks & 1;
+      if (ks + 1 < FW_BK / 16) {
+        reads(ks + 1, set ^ 1);
+        // all but the newest 4 + 2 TN reads (k-step ks + 1's) are back
+        if constexpr (Cfg::TN == 2)
+          asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(ra[set][0][0]), "+v"(ra[set][0][1]), "+v"(ra[set][1][0]), "+v"(ra[set][1][1]), "+v"(rb[set][0][0]), "+v"(rb[set][0][1]), "+v"(rb[set][1][0]), "+v"(rb[set][1][1]));
+        else
+          asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(ra[set][0][0]), "+v"(ra[set][0][1]), "+v"(ra[set][1][0]), "+v"(ra[set][1][1]), "+v"(rb[set][0][0]), "+v"(rb[set][0][1]));
+      } else {
+        if constexpr (Cfg::TN == 2)
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[set][0][0]), "+v"(ra[set][0][1]), "+v"(ra[set][1][0]), "+v"(ra[set][1][1]), "+v"(rb[set][0][0]), "+v"(rb[set][0][1]), "+v"(rb[set][1][0]), "+v"(rb[set][1][1]));
+        else
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[set][0][0]), "+v"(ra[set][0][1]), "+v"(ra[set][1][0]), "+v"(ra[set][1][1]), "+v"(rb[set][0][0]), "+v"(rb[set][0][1]));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j) acc[i][j] = mfma32(join8(ra[set][i][0], ra[set][i][1]), join8(rb[set][j][0], rb[set][j][1]), acc[i][j]);
+      if (more) issueA(t + 2, ks);   // A_PIECES == 4 == k-steps per tile
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // ---- dW rows 0 .. 127 -> p.C, rows 128 .. 255 -> p.C2 (the two encoders' weight gradients), fp32 [128][ldc] ----------------------
+  const int r = lane & 31;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) {
+      const int col = n0 + wn * (WG_BN / 2) + 32 * j + r;
+      if (col >= p.N) continue;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = wm * 64 + 32 * i + crow(q, h);
+        float* dst = (row >= p.c_split_row) ? p.C2 + (long)(row - p.c_split_row) * p.ldc + col : p.C + (long)row * p.ldc + col;
+        *dst = acc[i][j][q];
+      }
+    }
 }
 
 }  // namespace spv

@@ -191,9 +191,6 @@ class EncoderFC1(torch.autograd.Function):
         _pack(w_sh, W_hi, W_lo, dst_row_off=H, rows_cover=N1p - H)
         f32c = lambda t: t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
         b_priv, b_sh = f32c(b_priv), f32c(b_sh)
-        splits = _fc1_splits(B, G, N1)
-        slabs = ws.get("fc1_slabs", (splits, B, N1), torch.float32)
-        rowsum = ws.get("fc1_rowsum", (splits, B), torch.float32)
         h1 = torch.empty((B, N1), dtype=torch.float32, device=w_priv.device)
         library = torch.empty((B,), dtype=torch.float32, device=w_priv.device)
         cs = counts.c_struct(rows)
@@ -203,6 +200,15 @@ class EncoderFC1(torch.autograd.Function):
         if nsplit == 1 and counts.resident:
             xb, lib_all = counts.log1p_image()
             ld_xb = xb.shape[1]
+        if _abi.load().spv_enc_fc1_fwd_uses_dma(B, G, N1, nsplit, int(xb is not None), Gp, ld_xb):
+            # LDS-DMA kernel (csrc/spv_fc1.h): 128-cell tiles x all 256 columns, K split so that ~one workgroup lands on every CU
+            mt = -(-B // 128)
+            splits = max(1, min(16, 256 // mt, (-(-G // 64)) // 4))
+            slabs = ws.get("fc1_slabs_tiled", (splits, mt * 128, N1), torch.float32)
+        else:
+            splits = _fc1_splits(B, G, N1)
+            slabs = ws.get("fc1_slabs", (splits, B, N1), torch.float32)
+        rowsum = ws.get("fc1_rowsum", (splits, B), torch.float32)
         _abi.call("spv_enc_fc1_fwd", C.byref(cs), B, G, ptr(W_hi), ptr(W_lo), Gp, N1, ptr(b_priv), ptr(b_sh), H, nsplit, splits, ptr(slabs),
                                   ptr(rowsum), ptr(h1), ptr(library), ptr(xb), ld_xb, ptr(lib_all), stream_ptr())
         ctx.counts, ctx.rows, ctx.B, ctx.nsplit, ctx.ws, ctx.H, ctx.G = counts, rows, B, nsplit, ws, H, G

@@ -109,6 +109,45 @@ def test_encoder_fc1_forward_backward(dev, dtype, nsplit, B, G, H, gather):
     torch.testing.assert_close(db, b.grad, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("B,G,gather", [(100, 333, True), (257, 1000, True), (128, 64, False), (1000, 3001, True), (4096, 2050, True)])
+def test_encoder_fc1_resident_image_dma_path(dev, B, G, gather):
+    """bf16 mode on a RESIDENT count matrix with the default n_hidden = 128 (2H = 256 columns): the forward pass runs the
+    LDS-DMA kernel (csrc/spv_fc1.h) on the data set's bf16 log1p image, the weight gradient its DMA counterpart.  Checked
+    against fp64 on the same bf16-rounded operands (module/spVIPESmodule.py:428-435, nn/networks.py:119), ragged B and G."""
+    from spvipes_amd import _abi, ops
+    H = 128
+    rng = np.random.default_rng(B + G)
+    n_cells = B + 37
+    Xh = (rng.poisson(2.0, size=(n_cells, G)) * (rng.random((n_cells, G)) < 0.3)).astype(np.float32)
+    Xh[:, 0] += 1
+    counts = ops.GroupCounts(torch.tensor(Xh.astype(np.uint16).view(np.int16)).to(dev), G, 0, resident=True)
+    rows_h = rng.permutation(n_cells)[:B] if gather else np.arange(B)
+    rows = torch.tensor(rows_h, dtype=torch.int32, device=dev) if gather else None
+    g = torch.Generator().manual_seed(1)
+    mk = lambda *s: (torch.randn(*s, generator=g) * 0.05)
+    wp, bp, wsh, bs = mk(H, G), mk(H), mk(H, G), mk(H)
+    params = [t.clone().to(dev).requires_grad_(True) for t in (wp, bp, wsh, bs)]
+    ws = ops.Workspace(dev)
+    xb, _ = counts.log1p_image()
+    assert _abi.load().spv_enc_fc1_fwd_uses_dma(B, G, 2 * H, 1, 1, _abi.round_up(G, 64), xb.shape[1]) == 1
+    h1, lib = ops.EncoderFC1.apply(counts, rows, B, *params, 1, ws)
+    dh = torch.randn(B, 2 * H, generator=g)
+    (h1 * dh.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    x = torch.log1p(torch.tensor(Xh[rows_h]).double())
+    xr = _bf16_round(torch.log1p(torch.tensor(Xh[rows_h])).float()).double()   # the image holds bf16(fp32 log1p)
+    W = _bf16_round(torch.cat([wp, wsh])).double()
+    b = torch.cat([bp, bs]).double()
+    h_ref = torch.relu(xr @ W.t() + b)
+    torch.testing.assert_close(h1.detach().cpu().double(), h_ref, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(lib.cpu().double(), torch.log(x.sum(1)), rtol=1e-5, atol=1e-5)
+    dpre = dh.double() * (h1.detach().cpu().double() > 0)
+    want = _bf16_round(dpre.float()).double().t() @ xr
+    dW = torch.cat([params[0].grad, params[2].grad]).cpu().double()
+    torch.testing.assert_close(dW, want, rtol=1e-4, atol=1e-4 * float(want.abs().max()))
+    torch.testing.assert_close(torch.cat([params[1].grad, params[3].grad]).cpu().double(), dpre.sum(0), rtol=1e-4, atol=1e-4)
+
+
 def _decoder_case(dev, B, G, n_p, n_s, seed, dtype="f32"):
     from spvipes_amd import ops
     rng = np.random.default_rng(seed)

@@ -40,7 +40,8 @@ int main(int argc, char** argv) {
   for (int n = 0; n < N1; ++n)
     for (int g = 0; g < G; ++g) W[(size_t)n * ldw + g] = f2bf_host(0.02f * nrm(rng));
   std::vector<int> rows(B);
-  for (auto& r : rows) r = (int)(uni(rng) * (NCELLS - 1));
+  const int distinct = getenv("F1_DISTINCT_ROWS") ? atoi(getenv("F1_DISTINCT_ROWS")) : NCELLS;   // e.g. 128: the A operand becomes L2-resident (is the loop bound by HBM latency?)
+  for (auto& r : rows) r = (int)(uni(rng) * (distinct - 1));
   std::vector<float> bias(N1, 0.f), lib_all(NCELLS, 1.f);
   unsigned short* dA = upload(A); unsigned short* dW = upload(W); int* drows = upload(rows);
   float* dbias = upload(bias); float* dlib = upload(lib_all);
@@ -52,9 +53,9 @@ int main(int argc, char** argv) {
   float* h1 = dalloc<float>((size_t)B * N1); float* lib = dalloc<float>(B); float* ref = dalloc<float>((size_t)B * N1);
   GemmParams p{};
   p.A = dA; p.lda = lda; p.rows = drows; p.B = dW; p.ldb = ldw; p.C = slabs; p.M = B; p.N = N1; p.K = G;
-  p.k_per_split = ((ktiles + splits - 1) / splits) * F1_BK;
+  p.k_per_split = ((ktiles + splits - 1) / splits) * F1_BK; p.c_split_row = splits;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(fc1_fwd_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F1_LDS_BYTES));
-  auto gemm = [&]() { hipLaunchKernelGGL(fc1_fwd_dma_kernel, dim3(mtiles, 1, splits), dim3(512), F1_LDS_BYTES, 0, p); };
+  auto gemm = [&]() { hipLaunchKernelGGL(fc1_fwd_dma_kernel, dim3(mtiles * splits), dim3(512), F1_LDS_BYTES, 0, p); };
   auto epi = [&]() { hipLaunchKernelGGL(fc1_epilogue_tiled_kernel, dim3((unsigned)((slab_elems / 4 + 255) / 256)), dim3(256), 0, 0, slabs, splits, slab_elems, B, dbias, (const float*)nullptr, 0, h1, lib, dlib, drows); };
   gemm(); epi();
   CK(hipDeviceSynchronize());
