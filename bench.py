@@ -79,8 +79,8 @@ def parse():
     ap.add_argument("--allreduce", default="auto", choices=["auto", "single", "overlap"],
                     help="gradient all-reduce of a data-parallel job: one collective after the backward pass, or two buckets with the "
                          "decoder bucket overlapped with the encoder half of the backward pass (auto: overlap when WORLD_SIZE > 1)")
-    ap.add_argument("--cpu-batch", type=int, default=256)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=1024, help="cells per group of the CPU baseline sample (about 10 s of CPU work at C2)")
+    ap.add_argument("--cpu-steps", type=int, default=3)
     args = ap.parse_args()
     preset = CONFIGS[args.config]
     for k, v in preset.items():
@@ -89,7 +89,7 @@ def parse():
     return args
 
 
-def cpu_baseline(groups, args, n_threads):
+def cpu_baseline(groups, args, n_threads, plan=None):
     """The CPU oracle (oracle/spvipes_oracle.py, a port of the reference path pinned by goldens
     generated from the reference) timed on this box's host cores: forward + loss + backward + Adam
     on a bounded sample of the same workload."""
@@ -106,18 +106,22 @@ def cpu_baseline(groups, args, n_threads):
     gen = torch.Generator().manual_seed(0)
     times = []
     for step in range(args.cpu_steps + 1):
-        counts, labels = [], []
+        counts, labels, picked = [], [], []
         for g in groups:
             rows = torch.randint(0, g.counts.n_cells, (B,), generator=gen)
             X = g.counts.X[rows.to(g.counts.X.device)].cpu()
             X = torch.from_numpy(X.numpy().view(np.uint16).astype(np.float32)) if X.dtype == torch.int16 else X
             counts.append(X)
             labels.append(g.labels[rows.to(g.labels.device)].cpu())
+            picked.append(rows.numpy())
+        kw = {"labels": labels} if args.poe == "label" else {"plan_block": torch.from_numpy(plan[picked[0]][:, picked[1]].toarray().astype(np.float32))}
+        if args.poe == "cluster":
+            kw["components"] = labels
         noise = {f"enc_{i}_{k}": torch.randn(B, n, generator=gen) for i in range(2) for k, n in (("private", args.n_private), ("shared", args.n_shared))}
         noise.update({f"poe_{i}": torch.randn(B, args.n_shared, generator=gen) for i in range(2)})
         t0 = time.perf_counter()
         out = O.forward_loss(sd, counts, n_dimensions_shared=args.n_shared, n_dimensions_private=args.n_private, noise=noise,
-                             mode="label", labels=labels, training=True)
+                             mode=args.poe, training=True, **kw)
         opt.zero_grad()
         out["loss"].backward()
         opt.step()
@@ -240,7 +244,7 @@ def main():
             plan = synthetic_plan(args.cells, args.cells)
             mkw = dict(transport_plan=plan, pair_data=(args.poe == "paired"))
         else:   # N-group cluster matching: the experts are the per-component batch statistics, no pairwise plan is needed
-            mkw = dict(transport_plan="components", pair_data=False)
+            mkw = dict(transport_plan="components", pair_data=False, allow_more_groups=True, n_components=10)
     module = spVIPESmodule({g: args.genes for g in range(NG)}, n_hidden=args.n_hidden, n_dimensions_shared=args.n_shared,
                            n_dimensions_private=args.n_private, precision=args.precision, **mkw).to(dev)
     trainer = Trainer(module, [g.counts for g in groups], labels=[g.labels for g in groups] if args.poe == "label" else None,
@@ -379,7 +383,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and NG == 2:
             try:
-                out["cpu_baseline"] = cpu_baseline(groups, args, min(os.cpu_count() or 1, 16))
+                out["cpu_baseline"] = cpu_baseline(groups, args, min(os.cpu_count() or 1, 16), plan)
             except Exception as e:  # the baseline is a reported extra; never lose the GPU number over it
                 out["cpu_baseline"] = {"value": None, "unit": "cells/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
         print(json.dumps(out), flush=True)

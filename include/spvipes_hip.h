@@ -177,6 +177,11 @@ int spv_dec_nb_fwd(const spv_dec_params* p, int32_t train, void* stream);
 int spv_dec_materialize(const spv_dec_params* p, float* scale_private, float* scale_shared, float* rate_private, float* rate_shared,
                         float* mixing_logits, int64_t ld, void* stream);
 
+/* The latent gradient of the two rate heads alone: what spv_dec_softmax_bwd computes into dz_part, WITHOUT the in-place correction of
+ * tP / tS (a read-only pass: bf16 gradient arrays only).  Lets the caller put the write-back pass, which only the regressor
+ * weight-gradient GEMMs wait for, beside the backward pass's critical chain instead of on it. */
+int spv_dec_dz(const spv_dec_params* p, const float* Tp, const float* Ts, float* dz_part, void* stream);
+
 /* in place: tP <- tP - softmax_p * Tp[b],  tS <- tS - softmax_s * Ts[b].
  * dz_part (optional, bf16 gradient arrays only): fp32 [gene_splits][Bp][48]; per gene split the gradient reaching the latents
  * through the two rate heads, columns 0..15 = sum_g tP[b][g] * W'_p[g][.], columns 16..47 = sum_g tS[b][g] * W'_s[g][.]
@@ -293,6 +298,33 @@ typedef struct spv_poe_args {
 } spv_poe_args;
 int spv_poe_fuse_fwd(const spv_poe_args* a, void* stream);
 int spv_poe_fuse_bwd(const spv_poe_args* a, void* stream);
+
+/* N-group cluster-matched Product of Experts (BASELINE config 4: 3 groups; the N-expert generalisation of
+ * _product_of_experts, module/spVIPESmodule.py:573-581, that SURVEY.md 8d prescribes -- throughput only, the reference stops
+ * at two groups: data/prepare_adatas.py:94-95).  For cell i of group g with component c: experts = N(0, 1) prior, the cell's
+ * own shared-encoder posterior, and for every other group h with cells of component c in its minibatch the COMPONENT MEAN of
+ * h's (loc, logvar).  Fixed-order reductions (no atomics).  Up to SPV_POE_MAXG groups, latent dimension <= 32, component codes
+ * integral in [0, ncomp), ncomp <= SPV_POE_COMP_CMAX.                                                                   */
+#define SPV_POE_MAXG 4
+#define SPV_POE_COMP_SEG 16
+#define SPV_POE_COMP_CMAX 64
+typedef struct spv_poe_comp_args {
+  int32_t ngroups, n, ncomp, pad_;
+  int32_t B[SPV_POE_MAXG];
+  const float* stats[SPV_POE_MAXG]; int64_t ld[SPV_POE_MAXG];   /* (loc | logvar) rows [B][ld], logvar at column n      */
+  const float* comp[SPV_POE_MAXG];                               /* component code of every cell [B] (fp32, integral)     */
+  const float* eps[SPV_POE_MAXG];                                /* [B][n] standard-normal draws                         */
+  float* part;   /* workspace fp32 [ngroups][SPV_POE_COMP_SEG][ncomp][2n + 1]                                              */
+  float* mean;   /* workspace fp32 [ngroups][ncomp][2n + 1]: mean loc | mean logvar | count (kept for the backward pass)   */
+  float* loc[SPV_POE_MAXG]; float* logvar[SPV_POE_MAXG]; float* scale[SPV_POE_MAXG]; float* logz[SPV_POE_MAXG];
+  float* theta[SPV_POE_MAXG]; float* kl[SPV_POE_MAXG];
+  const float* g_loc[SPV_POE_MAXG]; const float* g_logvar[SPV_POE_MAXG]; const float* g_scale[SPV_POE_MAXG];
+  const float* g_logz[SPV_POE_MAXG]; const float* g_kl[SPV_POE_MAXG];
+  float* dpn[SPV_POE_MAXG];       /* backward workspace [B][2n]                                                           */
+  float* d_stats[SPV_POE_MAXG];   /* backward output, layout as stats                                                     */
+} spv_poe_comp_args;
+int spv_poe_comp_fwd(const spv_poe_comp_args* a, void* stream);
+int spv_poe_comp_bwd(const spv_poe_comp_args* a, void* stream);
 
 /* Sparse transport plan: CSR of the plan (rows = dataset cells of group 0, int32 indptr / column
  * indices, fp32 values >= 0) and CSR of its transpose (rows = dataset cells of group 1).  Replaces the dense

@@ -99,6 +99,17 @@ class SpvPoeArgs(C.Structure):
                 ("d_expert", C.c_void_p * 2)]
 
 
+SPV_POE_MAXG, POE_COMP_SEG, POE_COMP_CMAX = 4, 16, 64
+
+
+class SpvPoeCompArgs(C.Structure):
+    _fields_ = ([("ngroups", C.c_int32), ("n", C.c_int32), ("ncomp", C.c_int32), ("pad_", C.c_int32), ("B", C.c_int32 * SPV_POE_MAXG),
+                 ("stats", C.c_void_p * SPV_POE_MAXG), ("ld", C.c_int64 * SPV_POE_MAXG), ("comp", C.c_void_p * SPV_POE_MAXG),
+                 ("eps", C.c_void_p * SPV_POE_MAXG), ("part", C.c_void_p), ("mean", C.c_void_p)]
+                + [(k, C.c_void_p * SPV_POE_MAXG) for k in ("loc", "logvar", "scale", "logz", "theta", "kl", "g_loc", "g_logvar", "g_scale", "g_logz", "g_kl",
+                                                            "dpn", "d_stats")])
+
+
 class SpvPlan(C.Structure):
     _fields_ = [("ptr0", C.c_void_p), ("ind0", C.c_void_p), ("val0", C.c_void_p), ("n0", C.c_int32),
                 ("ptr1", C.c_void_p), ("ind1", C.c_void_p), ("val1", C.c_void_p), ("n1", C.c_int32)]
@@ -153,6 +164,7 @@ _SIGNATURES = {
     "spv_dec_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                  C.c_void_p, C.c_int32, C.c_void_p]),
     "spv_dec_materialize": (C.c_int, [C.POINTER(SpvDecParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "spv_dec_dz": (C.c_int, [C.POINTER(SpvDecParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "spv_dec_softmax_bwd": (C.c_int, [C.POINTER(SpvDecParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "spv_linear_fwd": (C.c_int, [C.POINTER(SpvLinearBatch), C.c_void_p]),
     "spv_linear_dgrad": (C.c_int, [C.POINTER(SpvLinearBatch), C.c_void_p]),
@@ -170,6 +182,8 @@ _SIGNATURES = {
                                   C.c_void_p, C.c_void_p]),
     "spv_plan_expert_fwd": (C.c_int, [C.POINTER(SpvPlanExpertArgs), C.c_void_p]),
     "spv_plan_expert_bwd": (C.c_int, [C.POINTER(SpvPlanExpertArgs), C.c_void_p]),
+    "spv_poe_comp_fwd": (C.c_int, [C.POINTER(SpvPoeCompArgs), C.c_void_p]),
+    "spv_poe_comp_bwd": (C.c_int, [C.POINTER(SpvPoeCompArgs), C.c_void_p]),
     "spv_zsplit_fwd": (C.c_int, [C.POINTER(SpvZsplitArgs), C.c_void_p]),
     "spv_zsplit_bwd": (C.c_int, [C.POINTER(SpvZsplitArgs), C.c_void_p]),
     "spv_bn_fold_fwd": (C.c_int, [C.POINTER(SpvFoldBatch), C.c_void_p]),

@@ -5,6 +5,7 @@
 #include "spv_fc1.h"
 #include "spv_decoder.h"
 #include "spv_small.h"
+#include "spv_poe_n.h"
 
 #include <cstdio>
 #include <cstring>
@@ -411,6 +412,17 @@ extern "C" int spv_dec_materialize(const spv_dec_params* q, float* scale_p, floa
   return launch_status("spv_dec_materialize");
 }
 
+extern "C" int spv_dec_dz(const spv_dec_params* q, const float* Tp, const float* Ts, float* dz_part, void* stream) {
+  DecParams p;
+  int rc = to_dec(q, p);
+  if (rc != SPV_OK) return rc;
+  if (!Tp || !Ts || !p.tP || !p.tS || !p.lse_p || !p.lse_s || !dz_part) return fail(SPV_ERR_ARG, "spv_dec_dz: null pointer%s");
+  if (p.n_gene_tiles != p.Gp / 32) return fail(SPV_ERR_ARG, "spv_dec_dz: n_gene_tiles must be Gp / 32%s");
+  if (p.grads_f32) return fail(SPV_ERR_UNSUPPORTED, "spv_dec_dz: needs bf16 gradient arrays%s");
+  hipLaunchKernelGGL((dec_softmax_bwd_kernel<bf16_t, true, false>), dim3(p.Bp / DEC_CELLS_PER_WG, p.gene_splits), dim3(256), 0, (hipStream_t)stream, p, Tp, Ts, dz_part);
+  return launch_status("spv_dec_dz");
+}
+
 extern "C" int spv_dec_softmax_bwd(const spv_dec_params* q, const float* Tp, const float* Ts, float* dz_part, void* stream) {
   DecParams p;
   int rc = to_dec(q, p);
@@ -629,6 +641,43 @@ extern "C" int spv_poe_fuse_bwd(const spv_poe_args* a, void* stream) {
   }
   hipLaunchKernelGGL(poe_fuse_bwd_kernel, dim3((Bm + 7) / 8, 2), dim3(256), 0, (hipStream_t)stream, *a);
   return launch_status("spv_poe_fuse_bwd");
+}
+
+// ---------------------------------------------------------------------------------------------
+// N-group cluster-matched PoE (spv_poe_n.h)
+// ---------------------------------------------------------------------------------------------
+static int check_poe_comp(const spv_poe_comp_args* a, const char* who, bool bwd) {
+  if (!a || a->ngroups < 2 || a->ngroups > SPV_POE_MAXG || a->n <= 0 || a->n > 32 || a->ncomp <= 0 || a->ncomp > SPV_POE_COMP_CMAX || !a->part || !a->mean)
+    return fail(SPV_ERR_ARG, "%s: bad shape (2..4 groups, latent dimension <= 32, <= 64 components)", who);
+  for (int g = 0; g < a->ngroups; ++g) {
+    if (a->B[g] <= 0 || !a->stats[g] || a->ld[g] < 2 * a->n || !a->comp[g] || !a->eps[g] || !a->loc[g] || !a->scale[g]) return fail(SPV_ERR_ARG, "%s: null pointer / bad pitch", who);
+    if (!bwd && (!a->logvar[g] || !a->logz[g] || !a->theta[g] || !a->kl[g])) return fail(SPV_ERR_ARG, "%s: null output", who);
+    if (bwd && (!a->dpn[g] || !a->d_stats[g])) return fail(SPV_ERR_ARG, "%s: null backward buffer", who);
+  }
+  return SPV_OK;
+}
+extern "C" int spv_poe_comp_fwd(const spv_poe_comp_args* a, void* stream) {
+  int rc = check_poe_comp(a, "spv_poe_comp_fwd", false);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  int Bm = 0;
+  for (int g = 0; g < a->ngroups; ++g) Bm = a->B[g] > Bm ? a->B[g] : Bm;
+  const int W = 2 * a->n + 1;
+  hipLaunchKernelGGL(pn_stats_kernel, dim3(PN_SEG, a->ngroups), dim3(128), 0, s, *a);
+  hipLaunchKernelGGL(pn_means_kernel, dim3((a->ncomp * W + 255) / 256, a->ngroups), dim3(256), 0, s, *a);
+  hipLaunchKernelGGL(pn_fuse_fwd_kernel, dim3((Bm + 7) / 8, a->ngroups), dim3(256), 0, s, *a);
+  return launch_status("spv_poe_comp_fwd");
+}
+extern "C" int spv_poe_comp_bwd(const spv_poe_comp_args* a, void* stream) {
+  int rc = check_poe_comp(a, "spv_poe_comp_bwd", true);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  int Bm = 0;
+  for (int g = 0; g < a->ngroups; ++g) Bm = a->B[g] > Bm ? a->B[g] : Bm;
+  hipLaunchKernelGGL(pn_cell_bwd_kernel, dim3((Bm + 7) / 8, a->ngroups), dim3(256), 0, s, *a);
+  hipLaunchKernelGGL(pn_comp_bwd_kernel, dim3(PN_SEG, a->ngroups), dim3(64), 0, s, *a);
+  hipLaunchKernelGGL(pn_apply_bwd_kernel, dim3((Bm + 7) / 8, a->ngroups), dim3(256), 0, s, *a);
+  return launch_status("spv_poe_comp_bwd");
 }
 
 extern "C" int spv_zsplit_fwd(const spv_zsplit_args* a, void* stream) {

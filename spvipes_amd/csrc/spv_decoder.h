@@ -706,7 +706,10 @@ __device__ __forceinline__ void decode4(const u4v& x, float (&v)[4]) {   // hi +
 constexpr int SMB_SUB = 320;            // genes of the transposed slice resident in LDS at a time
 constexpr int SMB_PITCH = SMB_SUB + 8;  // bf16 per row: 656 B = 164 dwords, rows 16 / 32 lanes apart fall on different banks
 
-template <typename GT, bool FUSE>
+// WRITE = false: read-only variant (FUSE only): the latent gradient alone, t_P / t_S stay uncorrected.  The backward pass's
+// critical chain (latent gradient -> trunk / PoE / encoder backward) then waits for a pass that only READS the two gradient
+// arrays; the in-place correction the regressor weight-gradient GEMMs need runs beside that chain on the side stream.
+template <typename GT, bool FUSE, bool WRITE = true>
 __global__ __launch_bounds__(256) void dec_softmax_bwd_kernel(DecParams p, const float* Tp, const float* Ts, float* dz_part) {
   typedef typename Raw4<GT>::type raw_t;
   const long plane = (long)p.Bp * p.Gp;
@@ -780,8 +783,10 @@ __global__ __launch_bounds__(256) void dec_softmax_bwd_kernel(DecParams p, const
           vs[j] = ok ? vs[j] - fast_exp(ys[q] - ls) * tsb : 0.f;
           cp[q] = vp[j]; cs[q] = vs[j];
         }
-        store4_grad<GT>(p.tP, tbase + 256 * qq, plane, vp);
-        store4_grad<GT>(p.tS, tbase + 256 * qq, plane, vs);
+        if constexpr (WRITE) {
+          store4_grad<GT>(p.tP, tbase + 256 * qq, plane, vp);
+          store4_grad<GT>(p.tS, tbase + 256 * qq, plane, vs);
+        }
       }
       if constexpr (FUSE) {
         const int gl = (g0 - gbeg) % SMB_SUB;   // offset of this tile inside the staged slice

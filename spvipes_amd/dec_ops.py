@@ -82,6 +82,14 @@ class _DecoderBwd:
     def softmax(self):
         _abi.call("spv_dec_softmax_bwd", C.byref(self.P), ptr(self.S["Tp"]), ptr(self.S["Ts"]), ptr(self.dz_part), stream_ptr())
 
+    def dz_only(self):
+        """read-only pass: the latent gradient of the rate heads (into dz_part), tP / tS left uncorrected"""
+        _abi.call("spv_dec_dz", C.byref(self.P), ptr(self.S["Tp"]), ptr(self.S["Ts"]), ptr(self.dz_part), stream_ptr())
+
+    def softmax_fix(self):
+        """the in-place correction of tP / tS alone (what gemm_bc consumes)"""
+        _abi.call("spv_dec_softmax_bwd", C.byref(self.P), ptr(self.S["Tp"]), ptr(self.S["Ts"]), None, stream_ptr())
+
     def gemm_d(self):
         (Wm_hi, Wm_lo), (dL_hi, dL_lo) = self.S["Wm"], self._operand("dL")
         return _gemm_slabs(False, dL_hi, dL_lo, self.Gp, Wm_hi, Wm_lo, KMP, self.B, KMP, self.G, self.nsplit, self.ksp_m, self.wsg, "dec_dAm", a_tiles=self.T)
@@ -108,14 +116,16 @@ class _DecoderBwd:
 class DecoderFused(torch.autograd.Function):
     """inputs : per group (private_log_z [B,n_p], poe_log_z [B,n_s]), per group its 13 parameters, then n_kl KL
              vectors [B] (module/spVIPESmodule.py:841-868) that the loss adds with weight kl_weight / B
-    outputs: (loss, sum_g sum_b w_b rec_gb, rec_0 [B], rec_1 [B])   -- all but loss detached
+    outputs: (loss, sum_g sum_b w_b rec_gb, rec_0 [B][, rec_1 [B]])   -- all but loss detached; one or two groups per call
     ``w_pad``: the per-cell weights of the reconstruction term, length >= Bp, zero beyond B.
     ``klw``  : 0-dim fp32 device tensor (read at run time: a captured graph sees later updates)."""
 
     @staticmethod
     def forward(ctx, counts: Sequence[GroupCounts], rows, B: int, decoders, library: Sequence[torch.Tensor], w_pad: torch.Tensor,
                 training: bool, nsplit: int, ws: Sequence[Workspace], klw: torch.Tensor, n_kl: int, *tensors):
-        NG = 2
+        NG = len(counts)   # one or two groups per call (the batched kernels carry two slots; spVIPESmodule.loss chunks more)
+        if NG not in (1, 2):
+            raise _abi.SpvError("DecoderFused takes one or two groups per call")
         ctx.set_materialize_grads(False)
         lat = [(tensors[2 * g], tensors[2 * g + 1]) for g in range(NG)]
         par = [tensors[2 * NG + g * N_DEC_PARAMS: 2 * NG + (g + 1) * N_DEC_PARAMS] for g in range(NG)]
@@ -285,10 +295,11 @@ class DecoderFused(torch.autograd.Function):
         _run_red(red)
         loss, rec_sum, gkl = new(()), new(()), new(B)
         klp = (C.c_void_p * 4)(*[ptr(k) for k in kls], *([None] * (4 - n_kl)))
-        _abi.call("spv_loss_assemble", ptr(rec[0]), ptr(rec[1]), ptr(w_pad), klp, n_kl, B, ptr(klw), ptr(loss), ptr(rec_sum), ptr(gkl), stream_ptr())
+        _abi.call("spv_loss_assemble", ptr(rec[0]), ptr(rec[1]) if NG > 1 else None, ptr(w_pad), klp, n_kl, B, ptr(klw), ptr(loss), ptr(rec_sum), ptr(gkl), stream_ptr())
         if need_grad:
             ctx.P, ctx.saved_g, ctx.ws, ctx.decoders, ctx.training, ctx.nsplit = P, saved_g, ws, decoders, training, nsplit
             ctx.dims = (B, Bp, Gs, Gps, n_p, n_s, n_m, KM)
+            ctx.NG = NG
             ctx.grads_f32, ctx.done, ctx.keep = grads_f32, False, keep
             ctx.Wps, ctx.fb = Wps, fb
             ctx.small = (zcat, zsum, zz, fstat, pre_a, m, tstat)
@@ -302,7 +313,7 @@ class DecoderFused(torch.autograd.Function):
         if ctx.done:
             raise _abi.SpvError("DecoderFused.backward may run once per forward (gradient buffers are consumed in place)")
         ctx.done = True
-        NG = 2
+        NG = ctx.NG
         tensors = ctx.saved_tensors
         par = [tensors[2 * NG + g * N_DEC_PARAMS: 2 * NG + (g + 1) * N_DEC_PARAMS] for g in range(NG)]
         B, Bp, Gs, Gps, n_p, n_s, n_m, KM = ctx.dims
@@ -331,10 +342,17 @@ class DecoderFused(torch.autograd.Function):
         side = group_streams(dev, 3)[2] if _ops.DEFER_WM else cur
         stages = [_DecoderBwd(g, ctx.P[g], ctx.saved_g[g], ctx.Wps[g], ws[g], B, Bp, Gs[g], Gps[g], nsplit, ctx.grads_f32) for g in range(NG)]
         d_slabs, bc_slabs, ef_slabs = [None] * NG, [None] * NG, [None] * NG
+        # bf16 mode with the regressor GEMMs deferred to the side stream: the critical chain only needs the latent gradient, which
+        # the READ-ONLY pass spv_dec_dz gives (168 MB read per group instead of 336 MB read + written); the in-place fix of
+        # tP / tS runs on the side stream right before the GEMMs that consume it
+        split_fix = bool(_ops.DZ_ONLY and _ops.DEFER_BC and _ops.DEFER_WM and all(st.fused_dz for st in stages))
         fork(streams)
         for g in range(NG):
             with torch.cuda.stream(streams[g]):
-                stages[g].softmax()
+                if split_fix:
+                    stages[g].dz_only()
+                else:
+                    stages[g].softmax()
                 d_slabs[g] = stages[g].gemm_d()
                 if not _ops.DEFER_BC:
                     bc_slabs[g] = stages[g].gemm_bc()
@@ -377,6 +395,8 @@ class DecoderFused(torch.autograd.Function):
                 red_bc.nprob = 0
                 for g in range(NG):
                     st, G = stages[g], Gs[g]
+                    if split_fix:
+                        st.softmax_fix()
                     b_, c = st.gemm_bc()
                     _add_red(red_bc, b_, st.csp_n, G * DEC_KP, DEC_KP, G, DEC_KP, dWp[g], DEC_KP, alpha=g_loss)
                     _add_red(red_bc, c, st.csp_n, G * DEC_KS, DEC_KS, G, DEC_KS, dWs[g], DEC_KS, alpha=g_loss)

@@ -208,6 +208,8 @@ class spVIPESmodule(nn.Module):
         log_variational_generative: bool = True,
         dispersion: str = "gene",
         precision: str = "bf16",
+        allow_more_groups: bool = False,
+        n_components: Optional[int] = None,
     ):
         super().__init__()
         if n_batch > 1:
@@ -217,8 +219,11 @@ class spVIPESmodule(nn.Module):
         if precision not in ("bf16", "fp32"):
             raise ValueError("precision must be 'bf16' or 'fp32'")
         lengths = list(groups_lengths.values()) if isinstance(groups_lengths, dict) else list(groups_lengths)
-        if len(lengths) != 2:
+        if len(lengths) != 2 and not (allow_more_groups and 2 < len(lengths) <= 4):
             raise ValueError(f"Number of groups is {len(lengths)}, the only supported value is 2")
+        # More than two groups (BASELINE config 4) is this build's throughput-only extension: the reference stops at two
+        # (data/prepare_adatas.py:94-95).  It runs the cluster-matched PoE with component-mean experts (nn_ops.PoEComponents).
+        self.n_groups, self.n_components = len(lengths), n_components
         self.n_dimensions_shared, self.n_dimensions_private = n_dimensions_shared, n_dimensions_private
         self.n_batch, self.n_hidden, self.dropout_rate = n_batch, n_hidden, dropout_rate
         self.input_dims = {i: g for i, g in enumerate(lengths)}
@@ -226,7 +231,7 @@ class spVIPESmodule(nn.Module):
         self.groups_obs_indices = groups_obs_indices
         if groups_var_indices is None:
             offs = np.concatenate([[0], np.cumsum(lengths)])
-            groups_var_indices = [np.arange(offs[i], offs[i + 1]) for i in range(2)]
+            groups_var_indices = [np.arange(offs[i], offs[i + 1]) for i in range(len(lengths))]
         self.groups_var_indices = [np.asarray(v) for v in groups_var_indices]
         self.dispersion, self.precision = dispersion, precision
         self.use_batch_norm, self.use_layer_norm = use_batch_norm, use_layer_norm
@@ -364,7 +369,7 @@ class spVIPESmodule(nn.Module):
         # replace the kernels' counter-based draw.
         dm = dropout_masks or {}
         same_B = len({self._step_inputs[g][2] for g in groups_}) == 1
-        for gset in ([groups_] if same_B else [[g] for g in groups_]):
+        for gset in ([groups_[i:i + 2] for i in range(0, len(groups_), 2)] if same_B else [[g] for g in groups_]):   # (the batched kernels carry 8 problem slots: two groups)
             specs, eps_list, masks = [], [], []
             for slot, g in enumerate(gset):
                 specs += [EncoderSpec(self.encoders[g]["private"], slot, 0), EncoderSpec(self.encoders[g]["shared"], slot, H)]
@@ -390,7 +395,9 @@ class spVIPESmodule(nn.Module):
             labels = dict(enumerate(kwargs["labels"]))
         if self.use_transport_plan and not self.pair_data:
             processed_labels = kwargs.get("processed_labels")
-        if self.use_labels and labels is not None:
+        if self.n_groups > 2:
+            poe_stats = self._components_poe_hip(shared_stats, processed_labels if processed_labels is not None else (list(labels.values()) if labels else None), noise)
+        elif self.use_labels and labels is not None:
             # label-based PoE (priority as spVIPESmodule.py:492-493): pairing + fusion + draw + KL in HIP
             dev = shared_stats[0]["logtheta_loc"].device
             e = [draw(f"poe_{g}") for g in (0, 1)]
@@ -470,15 +477,39 @@ class spVIPESmodule(nn.Module):
             self._kl_poe[g] = kl
         return out
 
+    def _components_poe_hip(self, shared_stats, components, noise):
+        """N-group cluster-matched PoE with component-mean experts (csrc/spv_poe_n.h): this build's extension for more than
+        two groups, throughput only."""
+        from .nn_ops import PoEComponents
+
+        if components is None:
+            raise ValueError("Processed labels are required when using transport plan.")
+        gs = sorted(shared_stats.keys())
+        dev = shared_stats[gs[0]]["logtheta_loc"].device
+        e = [noise.get(f"poe_{g}") for g in gs]
+        e = [torch.randn_like(shared_stats[g]["logtheta_loc"]) if e[i] is None else e[i] for i, g in enumerate(gs)]
+        if self.n_components is None:
+            raise ValueError("n_components must be given to the module for more than two groups")
+        flat = [t for g in gs for t in (shared_stats[g]["logtheta_loc"], shared_stats[g]["logtheta_logvar"])]
+        o = PoEComponents.apply([components[g] for g in gs], int(self.n_components), e, self._workspace(gs[0], dev), *flat)
+        out = {}
+        for i, g in enumerate(gs):
+            loc, logvar, scale, log_z, theta, kl, qscale = o[7 * i: 7 * i + 7]
+            out[g] = OrderedDict([("logtheta_loc", loc), ("logtheta_logvar", logvar), ("logtheta_scale", scale),
+                                  ("logtheta_qz", torch.distributions.Normal(loc, qscale, validate_args=False)),
+                                  ("logtheta_log_z", log_z), ("logtheta_theta", theta)])
+            self._kl_poe[g] = kl
+        return out
+
     def generative(self, private_stats, shared_stats, poe_stats, library, groups, batch_index):
         """spVIPESmodule.py:720-771: latent concatenation + slicing quirk; the decoder itself is
         evaluated (fused with the likelihood) in ``loss``."""
-        if (len(private_stats.items()) > 2) or (len(shared_stats.items()) > 2):
+        if ((len(private_stats.items()) > 2) or (len(shared_stats.items()) > 2)) and self.n_groups <= 2:
             raise ValueError(
                 f"Number of groups passed to `generative` is shared:{len(shared_stats.keys())}, private:{len(private_stats.keys())}, the only supported value is 2"
             )
         out = {}
-        for g in (0, 1):
+        for g in sorted(private_stats.keys()):
             # Z = cat(private_log_z, poe_log_z) and the slicing quirk of :733,:753-754 happen inside the fused decoder op
             # (spv_zsplit_fwd); the lazy entry carries the two latents and the library, and materialises px_scale_* /
             # px_rate_* / the mixing logits through spv_dec_materialize only if somebody reads them
@@ -497,10 +528,12 @@ class spVIPESmodule(nn.Module):
         """spVIPESmodule.py:809-899."""
         from .dec_ops import DecoderFused, decoder_params
 
-        B0, B1 = self._step_inputs[0][2], self._step_inputs[1][2]
-        if B0 != B1:
-            raise RuntimeError(f"The size of tensor a ({B0}) must match the size of tensor b ({B1}) at non-singleton dimension 0")
-        dev = inference_outputs["library"][0].device
+        gs = sorted(self._step_inputs.keys())
+        B0 = self._step_inputs[gs[0]][2]
+        for g in gs[1:]:
+            if self._step_inputs[g][2] != B0:
+                raise RuntimeError(f"The size of tensor a ({B0}) must match the size of tensor b ({self._step_inputs[g][2]}) at non-singleton dimension 0")
+        dev = inference_outputs["library"][gs[0]].device
         Bp = round_up(B0, DEC_CELLS_PER_WG)
         cache = getattr(self, "_w_cache", None)
         if cache is None or cache[0] != (B0, dev):
@@ -512,38 +545,42 @@ class spVIPESmodule(nn.Module):
             klw = kl_weight if (kl_weight.dtype == torch.float32 and kl_weight.device == dev) else kl_weight.to(dev, torch.float32)
         else:
             klw = torch.full((), float(kl_weight), dtype=torch.float32, device=dev)
-        px = [generative_outputs["private_poe"][str(g)]["px"] for g in (0, 1)]
-        lat = [t for g in (0, 1) for t in (px[g].private_log_z, px[g].poe_log_z)]
-        params = [t for g in (0, 1) for t in decoder_params(self.decoders[g], self.px_r[g])]
+        px = {g: generative_outputs["private_poe"][str(g)]["px"] for g in gs}
         pr, po = inference_outputs["private_stats"], inference_outputs["poe_stats"]
-        kl_p = [self._kl_private[g] if g in self._kl_private else kl_normal_std(pr[g]["logtheta_loc"], pr[g]["logtheta_scale"]) for g in (0, 1)]
-        kl_q = [self._kl_poe[g] if g in self._kl_poe else kl_normal_std(po[g]["logtheta_loc"], po[g]["logtheta_qz"].scale) for g in (0, 1)]
-        kls = [kl_p[0], kl_q[0], kl_p[1], kl_q[1]]
+        kl_p = {g: self._kl_private[g] if g in self._kl_private else kl_normal_std(pr[g]["logtheta_loc"], pr[g]["logtheta_scale"]) for g in gs}
+        kl_q = {g: self._kl_poe[g] if g in self._kl_poe else kl_normal_std(po[g]["logtheta_loc"], po[g]["logtheta_qz"].scale) for g in gs}
+        lat = [t for g in gs for t in (px[g].private_log_z, px[g].poe_log_z)]
+        kls = [t for g in gs for t in (kl_p[g], kl_q[g])]
         self._cut = None
         if getattr(self, "split_backward", False) and torch.is_grad_enabled():
             # data-parallel training (train.Trainer): the decoder half of the backward pass ends at detached copies of
-            # the eight tensors that cross from the encoders into the decoder / loss; the encoder half is started from
-            # their gradients afterwards, so the decoder's gradient bucket can be all-reduced in between
+            # the tensors that cross from the encoders into the decoder / loss (two latents and two KL vectors per group);
+            # the encoder half is started from their gradients afterwards, so the decoder's gradient bucket can be
+            # all-reduced in between
             cut = [t.detach().requires_grad_(True) for t in lat + kls]
             self._cut = (lat + kls, cut)
-            lat, kls = cut[:4], cut[4:]
-        # reconstruction + kl_weight * mean_b(sum of the four KL terms), assembled by one kernel (spv_loss_assemble)
-        res = DecoderFused.apply([self._step_inputs[g][0] for g in (0, 1)], [self._step_inputs[g][1] for g in (0, 1)], B0,
-                                 [self.decoders[g] for g in (0, 1)], [px[g].library for g in (0, 1)], w_pad, self.training, self.nsplit,
-                                 [self._workspace(g, dev) for g in (0, 1)], klw, 4, *lat, *params, *kls)
-        loss, rec_mean, rec = res[0], res[1], [res[2], res[3]]
+            lat, kls = cut[:len(lat)], cut[len(lat):]
+        # reconstruction + kl_weight * mean_b(sum of the KL terms), assembled by one kernel (spv_loss_assemble) per chunk of
+        # two groups (the reference has exactly one such chunk)
+        loss = rec_mean = None
+        rec = {}
+        for c0 in range(0, len(gs), 2):
+            ch = gs[c0:c0 + 2]
+            params = [t for g in ch for t in decoder_params(self.decoders[g], self.px_r[g])]
+            res = DecoderFused.apply([self._step_inputs[g][0] for g in ch], [self._step_inputs[g][1] for g in ch], B0,
+                                     [self.decoders[g] for g in ch], [px[g].library for g in ch], w_pad, self.training, self.nsplit,
+                                     [self._workspace(g, dev) for g in ch], klw, 2 * len(ch), *lat[2 * c0: 2 * c0 + 2 * len(ch)], *params,
+                                     *kls[2 * c0: 2 * c0 + 2 * len(ch)])
+            loss = res[0] if loss is None else loss + res[0]
+            rec_mean = res[1] if rec_mean is None else rec_mean + res[1]
+            for i, g in enumerate(ch):
+                rec[g] = res[2 + i]
         return LossOutput(
             loss=loss,
             reconstruction_loss_mean=rec_mean,
-            reconstruction_loss={"reconst_loss_groups_1_poe": rec[0], "reconst_loss_groups_2_poe": rec[1]},
-            kl_local={
-                "kl_divergence_groups_1_private": kl_p[0], "kl_divergence_groups_1_poe": kl_q[0],
-                "kl_divergence_groups_2_private": kl_p[1], "kl_divergence_groups_2_poe": kl_q[1],
-            },
-            extra_metrics=_LazyMeans({
-                "kl_divergence_private_groups_1": kl_p[0], "kl_divergence_poe_groups_1": kl_q[0],
-                "kl_divergence_private_groups_2": kl_p[1], "kl_divergence_poe_groups_2": kl_q[1],
-            }),
+            reconstruction_loss={f"reconst_loss_groups_{g + 1}_poe": rec[g] for g in gs},
+            kl_local={k: v for g in gs for k, v in ((f"kl_divergence_groups_{g + 1}_private", kl_p[g]), (f"kl_divergence_groups_{g + 1}_poe", kl_q[g]))},
+            extra_metrics=_LazyMeans({k: v for g in gs for k, v in ((f"kl_divergence_private_groups_{g + 1}", kl_p[g]), (f"kl_divergence_poe_groups_{g + 1}", kl_q[g]))}),
         )
 
     def forward(self, tensors, inference_kwargs=None, generative_kwargs=None, loss_kwargs=None, compute_loss=True):

@@ -501,3 +501,74 @@ class PoECluster(torch.autograd.Function):
         _abi.call("spv_plan_expert_bwd", C.byref(ea), stream_ptr())
         return (None, None, None, None, None, d[0][:, :n], d[0][:, n:2 * n], d[1][:, :n], d[1][:, n:2 * n])
 
+
+
+class PoEComponents(torch.autograd.Function):
+    """N-group cluster-matched PoE (csrc/spv_poe_n.h; BASELINE config 4, throughput only: the reference stops at two groups).
+    inputs : per group (loc_g, logvar_g) of the shared encoders; ``comp``: per-group component codes [B] (fp32, integral in
+    [0, n_comp)); outputs per group (loc*, logvar*, scale*, log_z, theta, kl, qscale) -- theta and qscale not differentiable."""
+
+    @staticmethod
+    def forward(ctx, comp: Sequence[torch.Tensor], n_comp: int, eps: Sequence[torch.Tensor], ws, *stats):
+        from ._abi import POE_COMP_CMAX, POE_COMP_SEG, SPV_POE_MAXG, SpvPoeCompArgs
+        ctx.set_materialize_grads(False)
+        NG = len(comp)
+        if not (2 <= NG <= SPV_POE_MAXG) or len(stats) != 2 * NG:
+            raise _abi.SpvError(f"PoEComponents supports 2..{SPV_POE_MAXG} groups")
+        if n_comp > POE_COMP_CMAX:
+            raise _abi.SpvError(f"PoEComponents supports at most {POE_COMP_CMAX} components")
+        dev = stats[0].device
+        n = stats[0].shape[1]
+        Bs = [stats[2 * g].shape[0] for g in range(NG)]
+        blocks = [_loc_logvar_block(stats[2 * g], stats[2 * g + 1]) for g in range(NG)]
+        comp = [c.flatten().contiguous().float() for c in comp]
+        eps = [e.contiguous() for e in eps]
+        new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        W = 2 * n + 1
+        part = ws.get("poen_part", (NG, POE_COMP_SEG, n_comp, W), torch.float32)
+        mean = new(NG, n_comp, W)
+        out = {k: [new(Bs[g], n) for g in range(NG)] for k in ("loc", "logvar", "scale", "logz", "theta")}
+        kl = [new(Bs[g]) for g in range(NG)]
+        a = SpvPoeCompArgs()
+        a.ngroups, a.n, a.ncomp, a.part, a.mean = NG, n, n_comp, ptr(part), ptr(mean)
+        for g in range(NG):
+            a.B[g], a.stats[g], a.ld[g], a.comp[g], a.eps[g] = Bs[g], blocks[g][1], blocks[g][2], ptr(comp[g]), ptr(eps[g])
+            a.loc[g], a.logvar[g], a.scale[g], a.logz[g], a.theta[g] = (ptr(out[k][g]) for k in ("loc", "logvar", "scale", "logz", "theta"))
+            a.kl[g] = ptr(kl[g])
+        _abi.call("spv_poe_comp_fwd", C.byref(a), stream_ptr())
+        ctx.blocks, ctx.comp, ctx.eps, ctx.n, ctx.Bs, ctx.NG, ctx.n_comp, ctx.ws, ctx.mean = blocks, comp, eps, n, Bs, NG, n_comp, ws, mean
+        ctx.save_for_backward(*out["loc"], *out["scale"])
+        res = []
+        for g in range(NG):
+            qscale = out["scale"][g].clamp(min=1e-6)
+            res += [out["loc"][g], out["logvar"][g], out["scale"][g], out["logz"][g], out["theta"][g], kl[g], qscale]
+            ctx.mark_non_differentiable(out["theta"][g], qscale)
+        return tuple(res)
+
+    @staticmethod
+    def backward(ctx, *g):
+        from ._abi import POE_COMP_SEG, SpvPoeCompArgs
+        NG, n, Bs = ctx.NG, ctx.n, ctx.Bs
+        loc, scale = ctx.saved_tensors[:NG], ctx.saved_tensors[NG:2 * NG]
+        dev = loc[0].device
+        cont = lambda t: None if t is None else t.contiguous()
+        a = SpvPoeCompArgs()
+        W = 2 * n + 1
+        part = ctx.ws.get("poen_part", (NG, POE_COMP_SEG, ctx.n_comp, W), torch.float32)
+        a.ngroups, a.n, a.ncomp, a.part, a.mean = NG, n, ctx.n_comp, ptr(part), ptr(ctx.mean)
+        keep, d = [], []
+        for k in range(NG):
+            gl, gv, gs, gz, _gt, gk, _gq = (cont(t) for t in g[7 * k: 7 * k + 7])
+            dk = torch.empty((Bs[k], ctx.blocks[k][2]), dtype=torch.float32, device=dev)
+            dpn = torch.empty((Bs[k], 2 * n), dtype=torch.float32, device=dev)
+            keep += [gl, gv, gs, gz, gk, dpn]
+            d.append(dk)
+            a.B[k], a.stats[k], a.ld[k], a.comp[k], a.eps[k] = Bs[k], ctx.blocks[k][1], ctx.blocks[k][2], ptr(ctx.comp[k]), ptr(ctx.eps[k])
+            a.loc[k], a.scale[k] = ptr(loc[k]), ptr(scale[k])
+            a.g_loc[k], a.g_logvar[k], a.g_scale[k], a.g_logz[k], a.g_kl[k] = ptr(gl), ptr(gv), ptr(gs), ptr(gz), ptr(gk)
+            a.dpn[k], a.d_stats[k] = ptr(dpn), ptr(dk)
+        _abi.call("spv_poe_comp_bwd", C.byref(a), stream_ptr())
+        grads = []
+        for k in range(NG):
+            grads += [d[k][:, :n], d[k][:, n:2 * n]]
+        return (None, None, None, None, *grads)

@@ -127,6 +127,7 @@ FUSED_DZ = os.environ.get("SPV_FUSED_DZ", "1") != "0"  # softmax fix also produc
 FUSED_PACK = os.environ.get("SPV_FUSED_PACK", "1") != "0"  # latent / trunk kernels also write the decoder's bf16 operand images
 DEFER_WM = os.environ.get("SPV_DEFER_WM", "1") != "0"  # mixture-weight gradient GEMMs on the late side stream
 DEFER_BC = os.environ.get("SPV_DEFER_BC", "1") != "0"  # regressor weight-gradient GEMMs beside the trunk backward (side stream)
+DZ_ONLY = os.environ.get("SPV_DZ_ONLY", "1") != "0"  # critical chain runs the read-only latent-gradient pass; the in-place softmax fix moves beside it
 _PENDING: list = []
 _PENDING_KEEP: list = []
 
@@ -136,6 +137,26 @@ def defer(stream, keep=()) -> None:
     if stream not in _PENDING:
         _PENDING.append(stream)
     _PENDING_KEEP.extend(keep)
+
+
+def join_all_side_streams(device) -> None:
+    """Make the current stream wait for every side stream of this device.  Called at the end of a backward pass: autograd runs a
+    node's backward on the stream its forward ran on (group g > 0: a side stream) and joins such a stream back only through the
+    parameters' cached gradient-accumulator nodes, whose stream is whatever was current the FIRST time the parameter took part
+    in a graph.  If that first step ran single-stream (bench.py's per-kernel event pass, SERIAL_STREAMS), nothing joins the
+    side stream any more, and a later hipGraph capture ends with "capturing stream has unjoined work".  Joining explicitly makes
+    the step independent of that history."""
+    dev = torch.device(device)
+    cur = torch.cuda.current_stream(dev)
+    capturing = torch.cuda.is_current_stream_capturing()
+    for (idx, _i), st in _SIDE_STREAMS.items():
+        if idx != dev.index or st is cur:
+            continue
+        if capturing:   # only streams that have been forked into this capture may be waited for
+            with torch.cuda.stream(st):
+                if not torch.cuda.is_current_stream_capturing():
+                    continue
+        cur.wait_stream(st)
 
 
 def join_pending(device=None) -> None:

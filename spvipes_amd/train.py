@@ -163,6 +163,7 @@ class Trainer:
             nn_ops.GRAD_SINK = False
             ops.DEFER_JOIN = False
             ops.join_pending()
+            ops.join_all_side_streams(self.device)
         return lo
 
     def _backward_encoders(self):
@@ -179,6 +180,7 @@ class Trainer:
             nn_ops.GRAD_SINK = False
             ops.DEFER_JOIN = False
             ops.join_pending()
+            ops.join_all_side_streams(self.device)
         self.module._cut = None
 
     def capture(self, rows: Sequence[torch.Tensor], warmup: int = 3) -> None:
