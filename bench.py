@@ -174,12 +174,11 @@ def synthetic_plan(n0, n1, k=8, seed=2000):
     return m
 
 
-def elbo_delta(trainer, module, groups, rows, args, plan):
-    """|loss_build - loss_oracle| / |loss_oracle| at kl_weight = 1 for ONE training-mode step of this run's workload, same
-    parameters, minibatch and noise (SURVEY.md 8d "ELBO delta"; module/spVIPESmodule.py:809-899).  Dropout is switched
-    off for this one comparison step (the two implementations cannot share a dropout RNG stream); no optimiser step."""
-    from oracle import spvipes_oracle as O
-
+def elbo_delta_gpu(trainer, module, groups, rows, args):
+    """First half of the ELBO comparison (SURVEY.md 8d "ELBO delta"; module/spVIPESmodule.py:809-899): ONE eager training-mode
+    step of this run's workload with injected noise, dropout off (the two implementations cannot share a dropout RNG stream),
+    kl_weight 1, no optimiser step.  Returns what the CPU oracle needs to repeat it (run AFTER the timed region: its thread
+    pool would otherwise still be spinning on the host cores while the timed steps are launched)."""
     B, n_p, n_s = args.batch_size, args.n_private, args.n_shared
     gen = torch.Generator().manual_seed(12345)
     noise = {f"enc_{g}_{k}": torch.randn(B, n, generator=gen) for g in range(2) for k, n in (("private", n_p), ("shared", n_s))}
@@ -196,19 +195,27 @@ def elbo_delta(trainer, module, groups, rows, args, plan):
     for g in range(2):
         X = groups[g].counts.X[rows[g].long()].cpu()
         counts.append(torch.from_numpy(X.numpy().view(np.uint16).astype(np.float32)) if X.dtype == torch.int16 else X)
+    return {"got": got, "sd": sd, "noise": noise, "counts": counts, "rows": [r.cpu().numpy() for r in rows],
+            "labels": [groups[g].labels[rows[g].long()].cpu() for g in range(2)]}
+
+
+def elbo_delta_oracle(st, args, plan):
+    """Second half: the CPU oracle on the same parameters, minibatch and noise; |loss_build - loss_oracle| / |loss_oracle|."""
+    from oracle import spvipes_oracle as O
+
     kw = {}
     if args.poe == "label":
-        kw["labels"] = [groups[g].labels[rows[g].long()].cpu() for g in range(2)]
+        kw["labels"] = st["labels"]
     else:
-        r0, r1 = rows[0].cpu().numpy(), rows[1].cpu().numpy()
-        kw["plan_block"] = torch.from_numpy(plan[r0][:, r1].toarray().astype(np.float32))
+        kw["plan_block"] = torch.from_numpy(plan[st["rows"][0]][:, st["rows"][1]].toarray().astype(np.float32))
         if args.poe == "cluster":
-            kw["components"] = [groups[g].labels[rows[g].long()].cpu() for g in range(2)]
+            kw["components"] = st["labels"]
     with torch.no_grad():
-        want = float(O.forward_loss(sd, counts, n_dimensions_shared=n_s, n_dimensions_private=n_p, noise=noise, mode=args.poe,
-                                    training=True, kl_weight=1.0, **kw)["loss"])
+        want = float(O.forward_loss(st["sd"], st["counts"], n_dimensions_shared=args.n_shared, n_dimensions_private=args.n_private, noise=st["noise"],
+                                    mode=args.poe, training=True, kl_weight=1.0, **kw)["loss"])
+    got = st["got"]
     return {"value": abs(got - want) / abs(want), "loss_build": got, "loss_oracle": want,
-            "what": f"one training-mode step of this workload (B {B} x G {args.genes}, {args.poe} PoE, {args.precision}), same parameters / rows / noise, dropout off, kl_weight 1"}
+            "what": f"one training-mode step of this workload (B {args.batch_size} x G {args.genes}, {args.poe} PoE, {args.precision}), same parameters / rows / noise, dropout off, kl_weight 1"}
 
 
 def main():
@@ -264,10 +271,10 @@ def main():
     prof_names = ["spv_dec_nb_fwd", "spv_dec_logits", "spv_enc_fc1_fwd", "spv_enc_fc1_wgrad", "spv_dec_lse", "spv_dec_softmax_bwd",
                   "spv_gemm_bf16", "spv_adam_step"]
     use_graph = not args.no_graph
-    delta = None
+    delta = delta_state = None
     if rank == 0 and world == 1 and NG == 2 and not args.no_elbo_delta:
         try:
-            delta = elbo_delta(trainer, module, groups, next(it), args, plan)
+            delta_state = elbo_delta_gpu(trainer, module, groups, next(it), args)
         except Exception as e:  # a reported extra; never lose the throughput number over it
             delta = {"value": None, "what": f"failed: {e!r}"}
     prof = {}
@@ -332,6 +339,11 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         exposed = float(tt)
 
+    if rank == 0 and delta_state is not None:
+        try:
+            delta = elbo_delta_oracle(delta_state, args, plan)
+        except Exception as e:
+            delta = {"value": None, "what": f"failed: {e!r}"}
     if rank == 0:
         B, G, H = args.batch_size, args.genes, args.n_hidden
         n_s, n_p = args.n_shared, args.n_private

@@ -156,6 +156,7 @@ typedef struct spv_dec_params {
   void* dL; void* tP; void* tS; int32_t grads_f32;              /* tiled like logits; bf16 [Bp][Gp], or (grads_f32) a bf16 hi plane
                                                                   followed by a bf16 lo plane, [2][Bp][Gp]: value = hi + lo */
   int32_t nb_splits; int32_t nb_genes_per_split;               /* gene splits of spv_dec_nb_fwd: multiple of 32, <= SPV_NB_GSPL_MAX */
+  int32_t nb_cell_tiles;   /* 64-cell tiles one likelihood workgroup walks (0 = 1); dtheta_part then holds ceil(Bp / 64 / nb_cell_tiles) rows */
 } spv_dec_params;
 
 /* theta = exp(px_r) and the per-(count, gene) lgamma / digamma table (module/spVIPESmodule.py:758

@@ -35,7 +35,7 @@ class SpvDecParams(C.Structure):
         ("part_max_p", C.c_void_p), ("part_sum_p", C.c_void_p), ("part_max_s", C.c_void_p), ("part_sum_s", C.c_void_p),
         ("rec_part", C.c_void_p), ("tp_part", C.c_void_p), ("ts_part", C.c_void_p), ("dtheta_part", C.c_void_p),
         ("dL", C.c_void_p), ("tP", C.c_void_p), ("tS", C.c_void_p), ("grads_f32", C.c_int32),
-        ("nb_splits", C.c_int32), ("nb_genes_per_split", C.c_int32),
+        ("nb_splits", C.c_int32), ("nb_genes_per_split", C.c_int32), ("nb_cell_tiles", C.c_int32),
     ]
 
 

@@ -308,7 +308,7 @@ static int to_dec(const spv_dec_params* q, DecParams& p) {
   p.part_max_p = q->part_max_p; p.part_sum_p = q->part_sum_p; p.part_max_s = q->part_max_s; p.part_sum_s = q->part_sum_s;
   p.rec_part = q->rec_part; p.tp_part = q->tp_part; p.ts_part = q->ts_part; p.dtheta_part = q->dtheta_part;
   p.dL = q->dL; p.tP = q->tP; p.tS = q->tS; p.grads_f32 = q->grads_f32;
-  p.nb_splits = q->nb_splits; p.nb_genes_per_split = q->nb_genes_per_split;
+  p.nb_splits = q->nb_splits; p.nb_genes_per_split = q->nb_genes_per_split; p.nb_cell_tiles = q->nb_cell_tiles > 0 ? q->nb_cell_tiles : 1;
   if (p.B <= 0 || p.G <= 0 || p.Bp < p.B || p.Gp < p.G || (p.Bp % DEC_CELLS_PER_WG) || (p.Gp % 32))
     return fail(SPV_ERR_ARG, "decoder: Bp must be a multiple of 128 and Gp of 32%s");
   if ((long)p.Bp * p.Gp * (p.grads_f32 ? 2 : 1) >= (1L << 30) || p.Gp >= (1 << 24))   // the likelihood kernel addresses its [Bp][Gp] arrays (two planes with grads_f32) with 32-bit byte offsets
@@ -342,7 +342,8 @@ extern "C" int spv_dec_lse(const spv_dec_params* q, const float* library, void* 
 
 template <bool TRAIN, typename GT, int CM>
 static void nb_launch_mode(const DecParams& p, hipStream_t s) {
-  dim3 grid((p.Bp + NB_CELLS_PER_WG - 1) / NB_CELLS_PER_WG, p.nb_splits);
+  const int ctiles = (p.Bp + NB_CELLS_PER_WG - 1) / NB_CELLS_PER_WG;
+  dim3 grid((ctiles + p.nb_cell_tiles - 1) / p.nb_cell_tiles, p.nb_splits);
   if (p.logits_f32) hipLaunchKernelGGL((dec_nb_kernel<TRAIN, GT, float, CM>), grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL((dec_nb_kernel<TRAIN, GT, _Float16, CM>), grid, dim3(256), 0, s, p);
 }

@@ -57,6 +57,7 @@ struct DecParams {
   float* dtheta_part;           // [Bp/64][Gp]  one partial row per 64-cell workgroup
   void* dL; void* tP; void* tS; int grads_f32;                                 // tiled like logits; bf16 or f32
   int nb_splits; int nb_genes_per_split;     // gene splits of the likelihood kernel (multiple of 32, <= NB_GSPL_MAX)
+  int nb_cell_tiles;                         // 64-cell tiles a likelihood workgroup walks with ONE staged weight slice (>= 1)
 };
 
 // ---- per-gene tables ----------------------------------------------------------
@@ -395,12 +396,15 @@ __global__ __launch_bounds__(256, SPV_NB_OCC) void dec_nb_kernel(DecParams p) {
   if (gend > ((p.G + 15) & ~15)) gend = (p.G + 15) & ~15;
   const int ng = gend - gbeg;
   NB_STAMP(0);
+  const int nct = p.nb_cell_tiles;   // cell tiles of this workgroup: blockIdx.x * nct .. + nct - 1
   if (ng <= 0) {  // a split made of padding genes only: its partials are zeros
-    const int cell = blockIdx.x * NB_CELLS_PER_WG + tid;
-    if (cell < p.Bp) {
-      const long o = (long)split * p.Bp + cell;
-      p.rec_part[o] = 0.f;
-      if constexpr (TRAIN) { p.tp_part[o] = 0.f; p.ts_part[o] = 0.f; }
+    for (int ct = 0; ct < nct; ++ct) {
+      const int cell = (blockIdx.x * nct + ct) * NB_CELLS_PER_WG + tid;
+      if (cell < p.Bp) {
+        const long o = (long)split * p.Bp + cell;
+        p.rec_part[o] = 0.f;
+        if constexpr (TRAIN) { p.tp_part[o] = 0.f; p.ts_part[o] = 0.f; }
+      }
     }
     return;
   }
@@ -415,8 +419,11 @@ __global__ __launch_bounds__(256, SPV_NB_OCC) void dec_nb_kernel(DecParams p) {
   NB_STAMP(1);
   const int nchunks = ng >> 4;
 
-  {
-    const int tile16 = blockIdx.x * (NB_CELLS_PER_WG / 16) + wave;   // 16-cell tile of this wave (Bp % 64 == 0: always inside)
+  // The staged weight slice serves nct consecutive 64-cell tiles (the staging + its barrier is ~15 % of a one-tile workgroup's
+  // lifetime: tools/probes/nb_bench.hip, phase stamps); the per-gene d-theta sums of the tiles add up in s_dth.
+  for (int ct = 0; ct < nct; ++ct) {
+    const int tile16 = (blockIdx.x * nct + ct) * (NB_CELLS_PER_WG / 16) + wave;   // 16-cell tile of this wave
+    if (tile16 * 16 >= p.Bp) break;   // (wave-uniform: a trailing workgroup with fewer tiles)
     const int cell = tile16 * 16 + c16;
     const int cell_tile = tile16 >> 1, chh = tile16 & 1;   // 32-cell storage tile and which half of it
     const bool cell_ok = cell < p.B;
@@ -580,7 +587,10 @@ __global__ __launch_bounds__(256, SPV_NB_OCC) void dec_nb_kernel(DecParams p) {
         float s = (u2 ? a1 : a0) + __shfl_xor(u2 ? a0 : a1, 4, 64);
         s += __shfl_xor(s, 2, 64);
         s += __shfl_xor(s, 1, 64);
-        if ((lane & 3) == 0) s_dth[wave][16 * c + 4 * gq + 2 * ((lane >> 3) & 1) + ((lane >> 2) & 1)] = s;
+        if ((lane & 3) == 0) {   // (each entry belongs to exactly one lane of this wave: no race across the cell tiles)
+          float* slot = &s_dth[wave][16 * c + 4 * gq + 2 * ((lane >> 3) & 1) + ((lane >> 2) & 1)];
+          *slot = (ct == 0) ? s : *slot + s;
+        }
         }
       }
 

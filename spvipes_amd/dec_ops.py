@@ -21,7 +21,7 @@ from ._abi import (DEC_CELLS_PER_WG, DEC_KP, DEC_KPS, DEC_KS, NB_CMAX, SpvBnBatc
                    ptr, round_up, stream_ptr)
 from .nn_ops import _add_lin, _fptr, _lin_batch, _wgrad, grad_out
 from . import ops as _ops
-from .ops import N_HIDDEN_MIX, GroupCounts, Workspace, _bf16_image, _gemm_slabs, _gene_splits, _nb_splits, _pack, fork, group_streams, join
+from .ops import N_HIDDEN_MIX, GroupCounts, Workspace, _bf16_image, _gemm_slabs, _gene_splits, _nb_cell_tiles, _nb_splits, _pack, fork, group_streams, join
 
 N_DEC_PARAMS = 13  # Wp, gamma_p, beta_p, Ws, gamma_s, beta_s, Wa, ba, gamma_a, beta_a, Wm, bm, px_r
 KMP = 320
@@ -278,6 +278,7 @@ class DecoderFused(torch.autograd.Function):
                   part_max_p=ptr(part("dec_pmp")), part_sum_p=ptr(part("dec_psp")), part_max_s=ptr(part("dec_pms")), part_sum_s=ptr(part("dec_pss")),
                   rec_part=ptr(nbpart("dec_rec")), tp_part=ptr(nbpart("dec_tp")), ts_part=ptr(nbpart("dec_ts")),
                   dtheta_part=ptr(dth), dL=ptr(dL), tP=ptr(tP), tS=ptr(tS), grads_f32=int(grads_f32), nb_splits=nbs, nb_genes_per_split=nbper,
+                  nb_cell_tiles=_nb_cell_tiles(Bp, Gp),
               )
               _abi.call("spv_dec_lse", C.byref(p), ptr(cont(library[g].flatten())), stream_ptr())
               if lse_first:
@@ -378,7 +379,7 @@ class DecoderFused(torch.autograd.Function):
                 _add_red(red2, ef_slabs[g][0], st.ksp_n, B * DEC_KP, DEC_KP, B, n_p, d_zcat[g], nt, accumulate=True, alpha=al)
                 _add_red(red2, ef_slabs[g][1], st.ksp_n, B * DEC_KS, DEC_KS, B, n_s, d_zcat[g], nt, dst_col=n_p, accumulate=True, alpha=al)
             # d px_r = exp(px_r) * d theta (theta = exp(px_r): module/spVIPESmodule.py:758)
-            _add_red(red, ctx.saved_g[g]["dth"], Bp // 64, Gp, Gp, 1, G, pg[g][12][0], G, alpha=al, exp_scale=par[g][12])
+            _add_red(red, ctx.saved_g[g]["dth"], -(-(Bp // 64) // _nb_cell_tiles(Bp, Gp)), Gp, Gp, 1, G, pg[g][12][0], G, alpha=al, exp_scale=par[g][12])
         gk = None
         if ctx.n_kl:  # d loss / d kl_i[b] = g * kl_weight / B for every KL vector: rides in the second reduction launch
             gk = new(B)

@@ -127,7 +127,10 @@ FUSED_DZ = os.environ.get("SPV_FUSED_DZ", "1") != "0"  # softmax fix also produc
 FUSED_PACK = os.environ.get("SPV_FUSED_PACK", "1") != "0"  # latent / trunk kernels also write the decoder's bf16 operand images
 DEFER_WM = os.environ.get("SPV_DEFER_WM", "1") != "0"  # mixture-weight gradient GEMMs on the late side stream
 DEFER_BC = os.environ.get("SPV_DEFER_BC", "1") != "0"  # regressor weight-gradient GEMMs beside the trunk backward (side stream)
-DZ_ONLY = os.environ.get("SPV_DZ_ONLY", "1") != "0"  # critical chain runs the read-only latent-gradient pass; the in-place softmax fix moves beside it
+# critical chain runs the read-only latent-gradient pass (spv_dec_dz), the in-place softmax fix moves beside it on the side stream.
+# Measured at C2, same box, alternating (round 2): OFF 1.690 / 1.690 ms per step, ON 1.745 / 1.737 ms -- the second pass over the two
+# gradient arrays (2 x 168 MB more HBM reads per step) costs more than the shorter critical chain gains.  Kept as a switch, off.
+DZ_ONLY = os.environ.get("SPV_DZ_ONLY", "0") != "0"
 _PENDING: list = []
 _PENDING_KEEP: list = []
 
@@ -279,6 +282,13 @@ NB_GSPL_MAX = 160  # genes per likelihood split (their regressor weights sit in 
 def _nb_splits(Gp: int) -> Tuple[int, int]:
     per = min(NB_GSPL_MAX, Gp)
     return -(-Gp // per), per
+
+
+def _nb_cell_tiles(Bp: int, Gp: int) -> int:
+    """64-cell tiles one likelihood workgroup walks with one staged weight slice (spv_dec_params.nb_cell_tiles).  Measured at C2
+    (tools/probes/nb_bench.hip, alternating): 1 tile 183.8 / 179.7 us, 2 tiles 179.8 / 184.7 us, 4 tiles 188.3 us -- the other
+    resident workgroups already cover a workgroup's staging phase, so one tile per workgroup (the finest work split) stays."""
+    return 1
 
 
 def _gemm_slabs(a_kmajor: bool, A_hi, A_lo, lda, B_hi, B_lo, ldb, M, N, K, nsplit, splits, ws: Workspace, name: str,

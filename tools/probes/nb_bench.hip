@@ -72,13 +72,14 @@ int main(int argc, char** argv) {
   p.a_p = upload(ap); p.a_s = upload(as); p.lse_p = p.a_p; p.lse_s = p.a_s; p.w_row = upload(w);
   const int per = Gp < NB_GSPL_MAX ? Gp : NB_GSPL_MAX, nbs = (Gp + per - 1) / per;
   p.nb_splits = nbs; p.nb_genes_per_split = per; p.gene_splits = 1; p.genes_per_split = Gp;
+  p.nb_cell_tiles = getenv("NB_CELL_TILES") ? atoi(getenv("NB_CELL_TILES")) : 1;
   p.rec_part = dalloc<float>((size_t)nbs * Bp); p.tp_part = dalloc<float>((size_t)nbs * Bp); p.ts_part = dalloc<float>((size_t)nbs * Bp);
   p.dtheta_part = dalloc<float>((size_t)(Bp / 64) * Gp);
   p.dL = dalloc<unsigned short>((size_t)Bp * Gp); p.tP = dalloc<unsigned short>((size_t)Bp * Gp); p.tS = dalloc<unsigned short>((size_t)Bp * Gp);
   p.grads_f32 = 0;
   CK(hipDeviceSynchronize());
 
-  dim3 grid((Bp + NB_CELLS_PER_WG - 1) / NB_CELLS_PER_WG, nbs);
+  dim3 grid(((Bp + NB_CELLS_PER_WG - 1) / NB_CELLS_PER_WG + p.nb_cell_tiles - 1) / p.nb_cell_tiles, nbs);
 #ifdef SPV_NB_STAMPS
   unsigned long long* d_st = dalloc<unsigned long long>((size_t)grid.x * grid.y * 8);   // set BEFORE the first launch: every launch of this build stamps
   CK(hipMemcpyToSymbol(HIP_SYMBOL(g_nb_stamps), &d_st, sizeof(d_st)));
