@@ -350,11 +350,17 @@ class DecoderFused(torch.autograd.Function):
         fork(streams)
         for g in range(NG):
             with torch.cuda.stream(streams[g]):
+                # group 1 issues its (MFMA / LDS-bound) d A_m GEMM BEFORE its (HBM-bound) softmax fix, group 0 the other way round: the two
+                # streams then pair a bandwidth-bound kernel with a compute-bound one instead of two of a kind (ops.STAGGER_BWD)
+                gemm_first = bool(_ops.STAGGER_BWD and g % 2 == 1)
+                if gemm_first:
+                    d_slabs[g] = stages[g].gemm_d()
                 if split_fix:
                     stages[g].dz_only()
                 else:
                     stages[g].softmax()
-                d_slabs[g] = stages[g].gemm_d()
+                if not gemm_first:
+                    d_slabs[g] = stages[g].gemm_d()
                 if not _ops.DEFER_BC:
                     bc_slabs[g] = stages[g].gemm_bc()
                 if not stages[g].fused_dz:
