@@ -118,6 +118,12 @@ int spv_enc_fc1_bwd_prep(const float* dh1, const float* h1, int32_t B, int32_t N
  * produced it (genes on MFMA rows, register 4 qq + j), register-group major, so one wave
  * instruction moves 512 contiguous bytes.  n_gene_tiles = Gp / 32. */
 
+/* 1 when spv_gemm_bf16 will take its LDS-DMA kernel (spvipes_amd/csrc/spv_dec_gemm.h) for these arguments: nsplit 1, a tile-ordered
+ * A operand, 32 < N <= 320, ldb == 320.  It works on 128-row x 320-column workgroup tiles, so the caller should pick `splits`
+ * with ceil(M / 128) * splits close to (a multiple of) the 256 CUs, and the tiled array must cover round_up(M, 128) rows /
+ * round_up(K, 64) contraction indices (the decoder's Bp / Gp paddings do). */
+int spv_gemm_bf16_uses_dma(int32_t a_kmajor, int32_t M, int32_t N, int32_t K, int32_t nsplit, int32_t a_tiles, int64_t ldb);
+
 /* Plain bf16 MFMA GEMM, fp32 out:  C[M][N] (+)= sum_k A(m,k) B(k,n).
  *   a_kmajor == 0: A is mem[m][k] (k contiguous); a_kmajor == 1: A is mem[k][m];
  *   a_tiles > 0: A is a tiled [cells][genes] array (above) with a_tiles gene tiles per cell tile;

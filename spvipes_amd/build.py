@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "_lib")
 LIB = os.path.join(LIBDIR, "libspvipes_hip.so")
 SOURCES = ["spv_abi.hip"]
-HEADERS = ["spv_common.h", "spv_gemm.h", "spv_fc1.h", "spv_decoder.h", "spv_small.h", "spv_poe_n.h", os.path.join("..", "..", "include", "spvipes_hip.h")]
+HEADERS = ["spv_common.h", "spv_gemm.h", "spv_fc1.h", "spv_dec_gemm.h", "spv_decoder.h", "spv_small.h", "spv_poe_n.h", os.path.join("..", "..", "include", "spvipes_hip.h")]
 
 
 FLAGS = [

@@ -3,6 +3,7 @@
 #include "spv_common.h"
 #include "spv_gemm.h"
 #include "spv_fc1.h"
+#include "spv_dec_gemm.h"
 #include "spv_decoder.h"
 #include "spv_small.h"
 #include "spv_poe_n.h"
@@ -264,6 +265,16 @@ static int gemm_dispatch(const GemmParams& p, int splits, hipStream_t s) {
   return launch_gemm<GemmCfg<64, 320, 2, 2, A_KMAJ, true, A_SRC, SRC_PLAIN, unsigned short, NSPLIT, 64, 1, (NSPLIT == 1 ? 2 : 1)>>(p, splits, s);
 }
 
+// Shapes the LDS-DMA 320-column kernels (spv_dec_gemm.h) take: bf16 mode, a tile-ordered [cells][genes] A operand, a 320-wide
+// k-major B image.  The tiled array must cover round_up(M, 128) x round_up(K, 64) (cells x genes, a_kmajor 0) or
+// round_up(K, 64) x round_up(M, 128) (a_kmajor 1): the decoder's Bp / Gp paddings (multiples of 128 / 256) do.
+extern "C" int spv_gemm_bf16_uses_dma(int32_t a_kmajor, int32_t M, int32_t N, int32_t K, int32_t nsplit, int32_t a_tiles, int64_t ldb) {
+  if (nsplit != 1 || a_tiles <= 0 || N <= 32 || N > DG_BN || ldb != DG_BN || M <= 0 || K <= 0) return 0;
+  const long genes_needed = a_kmajor ? ((long)M + DG_BM - 1) / DG_BM * DG_BM : ((long)K + DG_BK - 1) / DG_BK * DG_BK;
+  if ((long)a_tiles * 32 < genes_needed) return 0;
+  return 1;
+}
+
 extern "C" int spv_gemm_bf16(int32_t a_kmajor, const uint16_t* A_hi, const uint16_t* A_lo, int64_t lda, const uint16_t* B_hi,
                              const uint16_t* B_lo, int64_t ldb, float* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
                              int32_t nsplit, int32_t splits, int64_t slab_stride, int32_t a_tiles, void* stream) {
@@ -283,6 +294,21 @@ extern "C" int spv_gemm_bf16(int32_t a_kmajor, const uint16_t* A_hi, const uint1
   p.epi = EPI_STORE;
   p.tiles_inner = a_tiles;
   hipStream_t s = (hipStream_t)stream;
+  if (spv_gemm_bf16_uses_dma(a_kmajor, M, N, K, nsplit, a_tiles, ldb) && ((reinterpret_cast<uintptr_t>(A_hi) | reinterpret_cast<uintptr_t>(B_hi)) & 15) == 0) {
+    // LDS-DMA kernels (spv_dec_gemm.h): 128 x 320 workgroup tiles, `splits` K ranges (measured at C2, tools/probes/dec_gemm_bench.hip:
+    // d A_m 37.7 us, d W_m 41.0 us against 76.5 / 84.8 us for the register-staged 64 x 320 kernel below)
+    const int mtiles = (M + DG_BM - 1) / DG_BM;
+    p.c_split_row = splits;
+    static bool raised = false;
+    if (!raised) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm320_dma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, DG_LDS_BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm320_dma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, DG_LDS_BYTES);
+      raised = true;
+    }
+    if (a_kmajor) hipLaunchKernelGGL(dec_gemm320_dma_kernel<true>, dim3(mtiles * splits), dim3(512), DG_LDS_BYTES, s, p);
+    else hipLaunchKernelGGL(dec_gemm320_dma_kernel<false>, dim3(mtiles * splits), dim3(512), DG_LDS_BYTES, s, p);
+    return launch_status("spv_gemm_bf16 dma");
+  }
   if (a_tiles) {
     if (a_kmajor) { if (nsplit == 3) gemm_dispatch<true, 3, SRC_TILED>(p, splits, s); else gemm_dispatch<true, 1, SRC_TILED>(p, splits, s); }
     else { if (nsplit == 3) gemm_dispatch<false, 3, SRC_TILED>(p, splits, s); else gemm_dispatch<false, 1, SRC_TILED>(p, splits, s); }

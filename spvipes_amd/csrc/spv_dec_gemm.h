@@ -1,0 +1,165 @@
+// The two 320-column GEMMs of the decoder backward in bf16 mode, LDS-DMA staged (same skeleton as spv_fc1.h):
+//
+//   d A_m[cell][n] = sum_gene dL[cell][gene] * W_m[gene][n]      (backward of the mixing head, nn/networks.py:322-325, wrt its input)
+//   d W_m[gene][n] = sum_cell dL[cell][gene] * A_m[cell][n]      (... wrt its weight; n runs over the 320-column padded image
+//                                                                 [hidden trunk 256 | z_private | z_shared | 1 | 0...])
+//
+// dL is the likelihood kernel's gradient wrt the mixing logits, bf16 in accumulator-tile order
+// T[cell / 32][gene / 32][qq][lane][j] (gene % 32 = 8 qq + 4 h + j, lane = cell % 32 + 32 h; spv_decoder.h): a 32 x 32 tile is 2 KiB
+// of contiguous memory, so the LDS-DMA moves whole tiles and the fragment reads pick 8-byte pieces ((cell, 4 genes)) out of them.
+// The other operand (W_m image [Gp][320] or A_m image [Bp][320], bf16 row-major) has the contraction index on its rows in both
+// GEMMs: "k-major", fragments by transposed LDS reads (ds_read_b64_tr_b16).
+//
+// Workgroup = 8 waves as 4 (M) x 2 (N): 128 rows x 320 columns, wave tile 32 x 160 = 1 x 5 MFMA 32x32x16 tiles (6 fragments
+// for 5 MFMAs per k step -- the register-staged 64 x 320 kernel of spv_gemm.h reads 2 + 5 for 2 x 2.5).  K tile = 64, two 56 KiB
+// LDS stages (16 KiB of dL tiles + 40 KiB of the k-major operand), tile t + 1 in flight while tile t is multiplied, one
+// s_waitcnt vmcnt(0) + one barrier per tile.  Split-K over workgroups, fp32 slabs [split][M][320] for spv_reduce_slabs.
+//
+// LDS images and bank conflicts:
+//   * k-major operand: lane-linear copy of 64 rows x 640 bytes.  The four k rows of a transposed read are 640 bytes apart =
+//     128 bytes modulo the 256-byte bank period, rows r and r + 2 would collide: the 64-byte granule (32 columns) index inside a
+//     row is XOR-ed with (row >> 1) & 1 on the DMA's source address and again on the read;
+//   * dL, d A_m (cells on M): tiles copied as they are; a fragment is two 8-byte reads 256 bytes apart (h = 0, 1) per lane;
+//   * dL, d W_m (cells on K, transposed reads): inside a tile the 16-byte DMA chunks ((2 cells) x (4 genes)) are re-ordered to
+//     [cell / 4][gene / 4][cell % 4][4 genes], so that the 4 cells x 4 gene-pieces of a 16-lane transposed read cover 128
+//     contiguous bytes (in tile order the gene pieces are 256 / 512 bytes apart: the same banks, a 4-way conflict).
+#pragma once
+#include "spv_common.h"
+#include "spv_gemm.h"
+#include "spv_fc1.h"
+
+namespace spv {
+
+constexpr int DG_BM = 128, DG_BN = 320, DG_BK = 64;
+constexpr int DG_A_BYTES = DG_BM * DG_BK * 2, DG_B_ROW = DG_BN * 2, DG_B_BYTES = DG_BK * DG_B_ROW, DG_STAGE = DG_A_BYTES + DG_B_BYTES;
+constexpr int DG_LDS_BYTES = 2 * DG_STAGE;                       // 114 688 B: one workgroup per CU
+constexpr int DG_A_PIECES = DG_A_BYTES / 1024 / 8, DG_B_PIECES = DG_B_BYTES / 1024 / 8;   // 2 + 5 LDS-DMA pieces (1 KiB) per wave and tile
+
+__device__ __forceinline__ void lds_read8(s4v& d, unsigned addr) { asm volatile("ds_read_b64 %0, %1" : "=v"(d) : "v"(addr)); }
+
+// A_CELLS_ON_K = false: d A_m (M = cells, K = genes);  true: d W_m (M = genes, K = cells).
+// p.A = dL tiles (bf16), p.tiles_inner = gene tiles per cell tile; p.B = k-major image [K rows][320] bf16 (ldb == 320);
+// p.C = slabs [split][M][ldc] fp32, p.slab_stride; p.M, p.N (<= 320 columns stored), p.K; p.k_per_split multiple of 64;
+// p.c_split_row = number of K splits.  grid = ceil(M / 128) * splits (1-D, split fastest: one K range per XCD), 512 threads.
+template <bool A_CELLS_ON_K>
+__global__ __launch_bounds__(512) void dec_gemm320_dma_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dg_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uniform_wave_id();
+  const int wm = wave >> 1, wn = wave & 1;
+  const int split = blockIdx.x % p.c_split_row, mtile = blockIdx.x / p.c_split_row;
+  const int m0 = mtile * DG_BM;
+  const int kbeg = split * p.k_per_split;
+  const int Kpad = (p.K + DG_BK - 1) / DG_BK * DG_BK;
+  int kend = kbeg + p.k_per_split;
+  if (kend > Kpad) kend = Kpad;
+  const int ntiles = (kend - kbeg) / DG_BK;   // may be <= 0 for a trailing split: its slab is zeros
+
+  lds_byte* const lds = (lds_byte*)(dg_smem);
+  // ---- DMA sources ---------------------------------------------------------------------------------------------------------
+  // A: 8 tiles of 2 KiB per stage = 16 pieces; wave w owns pieces 2w, 2w + 1 = the two halves of stage tile w.
+  //    d A_m: stage tile w = (cell tile w >> 1, gene tile w & 1);  d W_m: stage tile w = (cell tile w >> 2, gene tile w & 3)
+  const glb_byte* srcA[DG_A_PIECES];
+  long a_step;   // byte advance of the A sources per K tile
+  {
+    const long T = p.tiles_inner;
+    long tile0;
+    if constexpr (!A_CELLS_ON_K) { tile0 = ((long)(m0 / 32) + (wave >> 1)) * T + (kbeg / 32) + (wave & 1); a_step = 2 * 2048; }
+    else { tile0 = ((long)(kbeg / 32) + (wave >> 2)) * T + (m0 / 32) + (wave & 3); a_step = 2 * T * 2048; }
+#pragma unroll
+    for (int i = 0; i < DG_A_PIECES; ++i) {
+      int chunk = i * 64 + lane;   // 16-byte chunk of the LDS tile image this lane fills
+      if constexpr (A_CELLS_ON_K) {  // LDS chunk (cq, gp, cpair) <- tile-order chunk qq * 32 + hh * 16 + c / 2, gp = 2 qq + hh, c = 4 cq + 2 cpair
+        const int cq = chunk >> 4, gp = (chunk >> 1) & 7, cpair = chunk & 1;
+        chunk = (gp >> 1) * 32 + (gp & 1) * 16 + 2 * cq + cpair;
+      }
+      srcA[i] = (glb_byte*)(p.A) + tile0 * 2048 + chunk * 16;
+    }
+  }
+  // B: 64 rows x 640 bytes = 40 pieces; wave w owns pieces 5w .. 5w + 4
+  const glb_byte* srcB[DG_B_PIECES];
+#pragma unroll
+  for (int i = 0; i < DG_B_PIECES; ++i) {
+    const int o = (DG_B_PIECES * wave + i) * 1024 + lane * 16;     // byte offset inside the stage's B image
+    const int row = o / DG_B_ROW, w = o % DG_B_ROW;
+    const int gran = (w >> 6) ^ ((row >> 1) & 1);
+    srcB[i] = (glb_byte*)(p.B) + ((long)(kbeg + row) * DG_B_ROW) + gran * 64 + (w & 63);
+  }
+  auto issue = [&](int t) {
+    const int stage = (t & 1) * DG_STAGE;
+#pragma unroll
+    for (int i = 0; i < DG_A_PIECES; ++i) dma16(srcA[i] + (long)t * a_step, lds + stage + (DG_A_PIECES * wave + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < DG_B_PIECES; ++i) dma16(srcB[i] + (long)t * DG_B_BYTES, lds + stage + DG_A_BYTES + (DG_B_PIECES * wave + i) * 1024);
+  };
+
+  f16v acc[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+
+  if (ntiles > 0) issue(0);
+  const int gi = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3, h = lane >> 5, r = lane & 31;
+  const int in_gran = 32 * (gi & 1) + 8 * p4;   // byte offset inside the 64-byte granule (32 columns of one k row)
+  const int fB = (q4 >> 1) & 1;                 // (row >> 1) & 1 of every k row this lane reads (rows 16 ks + 8 h + q4 [+ 4])
+  const unsigned lds0 = lds_addr_of(dg_smem);
+  for (int t = 0; t < ntiles; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile t have landed ...
+    raw_barrier();                                     // ... everybody's have, and everybody is done reading the other buffer
+    if (t + 1 < ntiles) issue(t + 1);
+    const unsigned stA = lds0 + (t & 1) * DG_STAGE, stB = stA + DG_A_BYTES;
+    s4v ra[2][2], rb[2][5][2];
+    auto reads = [&](int ks, int set) {
+      if constexpr (!A_CELLS_ON_K) {   // stage tile (wm, ks >> 1): genes 16 (ks & 1) + 8 h .. + 7 of cell r = two 8-byte pieces
+        const unsigned ad = stA + (wm * 2 + (ks >> 1)) * 2048 + (2 * (ks & 1) + h) * 512 + r * 8;
+        lds_read8(ra[set][0], ad);
+        lds_read8(ra[set][1], ad + 256);
+      } else {                         // stage tile (ks >> 1, wm): cells 16 (ks & 1) + 8 h + q4 (+ 4), gene piece 4 (gi & 1) + p4
+        const unsigned ad = stA + ((ks >> 1) * 4 + wm) * 2048 + (4 * (ks & 1) + 2 * h) * 256 + (4 * (gi & 1) + p4) * 32 + q4 * 8;
+        tr_issue(ra[set][0], ad);
+        tr_issue(ra[set][1], ad + 256);
+      }
+      const unsigned rowB = stB + (16 * ks + 8 * h + q4) * DG_B_ROW + in_gran;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const unsigned ad = rowB + (((wn * 5 + j) ^ fB) * 64);
+        tr_issue(rb[set][j][0], ad);
+        tr_issue(rb[set][j][1], ad + 4 * DG_B_ROW);
+      }
+    };
+    reads(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < DG_BK / 16; ++ks) {
+      const int set = ks & 1;
+      if (ks + 1 < DG_BK / 16) {
+        reads(ks + 1, set ^ 1);
+        // all but the newest 12 reads (k-step ks + 1's) are back
+        asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(ra[set][0]), "+v"(ra[set][1]), "+v"(rb[set][0][0]), "+v"(rb[set][0][1]), "+v"(rb[set][1][0]), "+v"(rb[set][1][1]),
+                     "+v"(rb[set][2][0]), "+v"(rb[set][2][1]), "+v"(rb[set][3][0]), "+v"(rb[set][3][1]), "+v"(rb[set][4][0]), "+v"(rb[set][4][1]));
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[set][0]), "+v"(ra[set][1]), "+v"(rb[set][0][0]), "+v"(rb[set][0][1]), "+v"(rb[set][1][0]), "+v"(rb[set][1][1]),
+                     "+v"(rb[set][2][0]), "+v"(rb[set][2][1]), "+v"(rb[set][3][0]), "+v"(rb[set][3][1]), "+v"(rb[set][4][0]), "+v"(rb[set][4][1]));
+      }
+      const s8v a = join8(ra[set][0], ra[set][1]);
+#pragma unroll
+      for (int j = 0; j < 5; ++j) acc[j] = mfma32(a, join8(rb[set][j][0], rb[set][j][1]), acc[j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // ---- fp32 partial slab [M][ldc] of this split ---------------------------------------------------------------------------------
+  float* slab = p.C + (long)split * p.slab_stride;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int col = wn * 160 + 32 * j + r;
+    if (col >= p.N) continue;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = m0 + wm * 32 + crow(q, h);
+      if (row < p.M) slab[(long)row * p.ldc + col] = acc[j][q];
+    }
+  }
+}
+
+}  // namespace spv

@@ -71,6 +71,8 @@ class _DecoderBwd:
         # -0.05 ms per step, same-box A/B); the narrow ones (16 / 32 columns) stream their [B,G] operand with ~2 per CU
         self.ksp_m, self.ksp_n = max(1, min(T // 8, -(-256 // max(Bp // 64, 1)))), max(1, min(T // 8, -(-512 // max(Bp // 128, 1))))
         self.csp_m, self.csp_n = max(1, min(bt // 8, -(-256 // max(Gp // 64, 1)))), max(1, min(bt // 8, -(-512 // max(Gp // 128, 1))))
+        # bf16 mode: the two 320-column GEMMs run the LDS-DMA 128 x 320 kernels, which want their own split counts
+        self.ksp_m, self.csp_m = self._splits(False, B, G, self.ksp_m), self._splits(True, G, Bp, self.csp_m)
 
     def _operand(self, key: str):
         """(hi, lo) operand image of dL / tP / tS: the bf16 tile array itself, or its hi / lo planes in fp32 mode"""
@@ -90,9 +92,29 @@ class _DecoderBwd:
         """the in-place correction of tP / tS alone (what gemm_bc consumes)"""
         _abi.call("spv_dec_softmax_bwd", C.byref(self.P), ptr(self.S["Tp"]), ptr(self.S["Ts"]), None, stream_ptr())
 
+    @staticmethod
+    def _dma_splits(M: int, K: int) -> int:
+        """K splits for the LDS-DMA 128 x 320 kernels (csrc/spv_dec_gemm.h): the count that minimises
+        rounds-of-256-workgroups x (64-deep steps per split + ~4 steps of prologue / slab store)."""
+        mt, kt = -(-M // 128), -(-K // 64)
+        best, best_cost = 1, None
+        for s_ in range(1, 17):
+            if s_ > 1 and kt // s_ < 4:
+                break
+            cost = -(-(mt * s_) // 256) * (-(-kt // s_) + 4)
+            if best_cost is None or cost < best_cost:
+                best, best_cost = s_, cost
+        return best
+
+    def _splits(self, a_kmajor: bool, M: int, K: int, default: int) -> int:
+        if _abi.load().spv_gemm_bf16_uses_dma(int(a_kmajor), M, KMP, K, self.nsplit, self.T, KMP):
+            return self._dma_splits(M, K)
+        return default
+
     def gemm_d(self):
         (Wm_hi, Wm_lo), (dL_hi, dL_lo) = self.S["Wm"], self._operand("dL")
-        return _gemm_slabs(False, dL_hi, dL_lo, self.Gp, Wm_hi, Wm_lo, KMP, self.B, KMP, self.G, self.nsplit, self.ksp_m, self.wsg, "dec_dAm", a_tiles=self.T)
+        return _gemm_slabs(False, dL_hi, dL_lo, self.Gp, Wm_hi, Wm_lo, KMP, self.B, KMP, self.G, self.nsplit,
+                           self.ksp_m, self.wsg, "dec_dAm", a_tiles=self.T)
 
     def gemm_bc(self):
         (Aps_hi, Aps_lo), (tP_hi, tP_lo), (tS_hi, tS_lo) = self.S["Aps"], self._operand("tP"), self._operand("tS")
@@ -103,7 +125,8 @@ class _DecoderBwd:
 
     def gemm_a(self):
         (Am_hi, Am_lo), (dL_hi, dL_lo) = self.S["Am"], self._operand("dL")
-        return _gemm_slabs(True, dL_hi, dL_lo, self.Gp, Am_hi, Am_lo, KMP, self.G, KMP, self.Bp, self.nsplit, self.csp_m, self.wsg, "dec_dWm", a_tiles=self.T)
+        return _gemm_slabs(True, dL_hi, dL_lo, self.Gp, Am_hi, Am_lo, KMP, self.G, KMP, self.Bp, self.nsplit,
+                           self.csp_m, self.wsg, "dec_dWm", a_tiles=self.T)
 
     def gemm_ef(self):
         (tP_hi, tP_lo), (tS_hi, tS_lo) = self._operand("tP"), self._operand("tS")
