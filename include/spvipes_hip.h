@@ -136,6 +136,14 @@ int spv_gemm_bf16(int32_t a_kmajor, const uint16_t* A_hi, const uint16_t* A_lo, 
                   float* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
                   int32_t nsplit, int32_t splits, int64_t slab_stride, int32_t a_tiles, void* stream);
 
+/* Weight gradients of both rate heads' regressors (BatchNorm folded) in one streaming pass, bf16 mode:
+ *   slabP[split][g][0..15] = sum_{cells of the split} tP(cell, g) * Aps[cell][0..15]
+ *   slabS[split][g][0..31] = sum_{cells of the split} tS(cell, g) * Aps[cell][16..47]        (backward of nn/networks.py:314-320)
+ * tP / tS: bf16 [Bp][Gp] in accumulator-tile order (a_tiles = Gp / 32 >= round_up(G, 256) / 32), already softmax-corrected
+ * (spv_dec_softmax_bwd); Aps: bf16 [Bp][48] latent operand image; Bp % 64 == 0.  Sum the slabs with spv_reduce_slabs. */
+int spv_dec_heads_wgrad(const uint16_t* tP, const uint16_t* tS, int32_t a_tiles, const uint16_t* Aps, int32_t G, int32_t Bp,
+                        int32_t splits, float* slabP, float* slabS, void* stream);
+
 /* Mixing logits of the decoder (nn/networks.py:322-325 with the bias folded into a ones column):
  *   out(b, g) = sum_k Am[b][k] * Wm[g][k],  Am bf16 [Bp][K], Wm bf16 [Gp][K], K % 32 == 0,
  *   Bp, Gp multiples of 128; out is f16 (out_f32 == 0) or f32 in accumulator-tile order. */

@@ -319,6 +319,22 @@ extern "C" int spv_gemm_bf16(int32_t a_kmajor, const uint16_t* A_hi, const uint1
   return launch_status("spv_gemm_bf16");
 }
 
+extern "C" int spv_dec_heads_wgrad(const uint16_t* tP, const uint16_t* tS, int32_t a_tiles, const uint16_t* Aps, int32_t G, int32_t Bp,
+                                   int32_t splits, float* slabP, float* slabS, void* stream) {
+  if (!tP || !tS || !Aps || !slabP || !slabS) return fail(SPV_ERR_ARG, "spv_dec_heads_wgrad: null pointer%s");
+  if (G <= 0 || Bp <= 0 || (Bp % DH_BK) != 0 || splits <= 0 || (long)a_tiles * 32 < ((long)G + DH_BM - 1) / DH_BM * DH_BM)
+    return fail(SPV_ERR_ARG, "spv_dec_heads_wgrad: Bp must be a multiple of 64 and the tile arrays must cover round_up(G, 256) genes%s");
+  if (((reinterpret_cast<uintptr_t>(tP) | reinterpret_cast<uintptr_t>(tS) | reinterpret_cast<uintptr_t>(Aps)) & 15) != 0)
+    return fail(SPV_ERR_ARG, "spv_dec_heads_wgrad: operands must be 16-byte aligned%s");
+  static bool raised = false;
+  if (!raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_heads_wgrad_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DH_LDS_BYTES); raised = true; }
+  const int mtiles = (G + DH_BM - 1) / DH_BM, ktiles = Bp / DH_BK;
+  const int k_per_split = (ktiles + splits - 1) / splits * DH_BK;
+  hipLaunchKernelGGL(dec_heads_wgrad_dma_kernel, dim3(mtiles * splits), dim3(512), DH_LDS_BYTES, (hipStream_t)stream, (const bf16_t*)tP, (const bf16_t*)tS, a_tiles,
+                     (const bf16_t*)Aps, G, Bp, k_per_split, splits, slabP, slabS);
+  return launch_status("spv_dec_heads_wgrad");
+}
+
 // ---------------------------------------------------------------------------------------------
 // decoder / likelihood
 // ---------------------------------------------------------------------------------------------

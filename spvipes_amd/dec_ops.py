@@ -71,6 +71,11 @@ class _DecoderBwd:
         # -0.05 ms per step, same-box A/B); the narrow ones (16 / 32 columns) stream their [B,G] operand with ~2 per CU
         self.ksp_m, self.ksp_n = max(1, min(T // 8, -(-256 // max(Bp // 64, 1)))), max(1, min(T // 8, -(-512 // max(Bp // 128, 1))))
         self.csp_m, self.csp_n = max(1, min(bt // 8, -(-256 // max(Gp // 64, 1)))), max(1, min(bt // 8, -(-512 // max(Gp // 128, 1))))
+        # bf16 mode: one streaming kernel for both regressor weight gradients, 256-gene workgroup tiles, ~one workgroup per CU
+        self.heads_dma = bool(_ops.HEADS_DMA and nsplit == 1 and not grads_f32 and Bp % 64 == 0)
+        if self.heads_dma:
+            mt, kt = -(-G // 256), Bp // 64
+            self.csp_n = max(1, min(256 // mt if mt <= 256 else 1, max(kt // 4, 1)))
         # bf16 mode: the two 320-column GEMMs run the LDS-DMA 128 x 320 kernels, which want their own split counts
         self.ksp_m, self.csp_m = self._splits(False, B, G, self.ksp_m), self._splits(True, G, Bp, self.csp_m)
 
@@ -118,6 +123,11 @@ class _DecoderBwd:
 
     def gemm_bc(self):
         (Aps_hi, Aps_lo), (tP_hi, tP_lo), (tS_hi, tS_lo) = self.S["Aps"], self._operand("tP"), self._operand("tS")
+        if self.heads_dma:   # bf16 mode: both heads in one LDS-DMA streaming pass (csrc/spv_dec_gemm.h)
+            b = self.wsg.get("dec_dWp", (self.csp_n, self.G, DEC_KP), torch.float32)
+            c = self.wsg.get("dec_dWs", (self.csp_n, self.G, DEC_KS), torch.float32)
+            _abi.call("spv_dec_heads_wgrad", ptr(tP_hi), ptr(tS_hi), self.T, ptr(Aps_hi), self.G, self.Bp, self.csp_n, ptr(b), ptr(c), stream_ptr())
+            return b, c
         b = _gemm_slabs(True, tP_hi, tP_lo, self.Gp, Aps_hi, Aps_lo, DEC_KPS, self.G, DEC_KP, self.Bp, self.nsplit, self.csp_n, self.wsg, "dec_dWp", a_tiles=self.T)
         c = _gemm_slabs(True, tS_hi, tS_lo, self.Gp, Aps_hi, Aps_lo, DEC_KPS, self.G, DEC_KS, self.Bp, self.nsplit, self.csp_n, self.wsg, "dec_dWs",
                         b_col_off=DEC_KP, a_tiles=self.T)
@@ -370,8 +380,19 @@ class DecoderFused(torch.autograd.Function):
         # the READ-ONLY pass spv_dec_dz gives (168 MB read per group instead of 336 MB read + written); the in-place fix of
         # tP / tS runs on the side stream right before the GEMMs that consume it
         split_fix = bool(_ops.DZ_ONLY and _ops.DEFER_BC and _ops.DEFER_WM and all(st.fused_dz for st in stages))
+        # DA_FIRST: the critical chain (trunk / fold / PoE / encoder backward) only needs d A_m up to the point where the latent
+        # gradient of the rate heads joins (red2) -- so the two d A_m GEMMs go first and the HBM-bound softmax fixes move to the
+        # side stream, ahead of the regressor and mixture weight-gradient GEMMs they feed
+        da_first = int(_ops.DA_FIRST) if (_ops.DEFER_BC and _ops.DEFER_WM and side is not cur and not split_fix and all(st.fused_dz for st in stages)) else 0
+        sm_done = None
+        if da_first == 2:
+            side.wait_stream(cur)
         fork(streams)
         for g in range(NG):
+            if da_first:
+                with torch.cuda.stream(streams[g]):
+                    d_slabs[g] = stages[g].gemm_d()
+                continue
             with torch.cuda.stream(streams[g]):
                 # group 1 issues its (MFMA / LDS-bound) d A_m GEMM BEFORE its (HBM-bound) softmax fix, group 0 the other way round: the two
                 # streams then pair a bandwidth-bound kernel with a compute-bound one instead of two of a kind (ops.STAGGER_BWD)
@@ -389,8 +410,14 @@ class DecoderFused(torch.autograd.Function):
                 if not stages[g].fused_dz:
                     ef_slabs[g] = stages[g].gemm_ef()
         join(streams)
-        if _ops.DEFER_WM:
+        if _ops.DEFER_WM and da_first != 2:
             side.wait_stream(cur)   # (before the reductions: the side work needs none of them)
+        if da_first:
+            with torch.cuda.stream(side):
+                for g in range(NG):
+                    stages[g].softmax()
+                sm_done = torch.cuda.Event()
+                sm_done.record(side)
         # slab sums, scaled by the upstream gradient, straight into their consumers' buffers
         al = g_loss
         for g in range(NG):
@@ -414,7 +441,8 @@ class DecoderFused(torch.autograd.Function):
             gk = new(B)
             _add_red(red2, ctx.gkl, 1, B, B, 1, B, gk, B, alpha=g_loss)
         _run_red(red)
-        _run_red(red2)
+        if not da_first:
+            _run_red(red2)
         # side stream: the regressor weight gradients (the main stream picks them up with an event before
         # spv_bn_fold_bwd), then the mixture-weight gradients (2 x [G, K_M] from dL^T A_m, the largest GEMMs of the backward
         # pass, which feed nothing but the optimiser)
@@ -482,6 +510,9 @@ class DecoderFused(torch.autograd.Function):
                 q.red_part = ptr(ws[g].get(f"fold_red_{k}", (-(-Gs[g] // 256) + 1, n + n * n), torch.float32))
                 q.dz, q.lddz = _fptr(d_zcat[g], zoff), nt
                 i += 1
+        if da_first:   # the rate heads' latent gradient (softmax fix on the side stream) joins d_zcat here
+            cur.wait_event(sm_done)
+            _run_red(red2)
         if bc_done is not None:
             cur.wait_event(bc_done)
         _abi.call("spv_bn_fold_bwd", C.byref(fb), stream_ptr())
