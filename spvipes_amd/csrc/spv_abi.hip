@@ -9,6 +9,7 @@
 #include "spv_poe_n.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 using namespace spv;
@@ -235,10 +236,15 @@ extern "C" int spv_enc_fc1_wgrad(const spv_counts* x, int32_t B, int32_t G, cons
         ((reinterpret_cast<uintptr_t>(xb) | reinterpret_cast<uintptr_t>(dh_hi)) & 15) == 0) {
       // LDS-DMA kernel (spv_fc1.h): all 256 rows x 64 genes per workgroup over the whole batch, results straight into dW / dW2
       // (measured at C2, tools/probes/fc1w_bench.hip: 51 us alone against 75 us for the register-staged kernel below)
-      void (*kfn)(GemmParams) = fc1_wgrad_dma_kernel<64>;
-      const int lds = fw_lds_bytes(64, Kpad);
+      // 96-gene tiles when they put TWO groups' launches (two streams, one workgroup per CU) into one round of the 256 CUs and
+      // 64-gene tiles do not (C2: 2 x 105 against 2 x 157 workgroups; alone the 64-gene tile is the faster one)
+      const int nb64 = (G + 63) / 64, nb96 = (G + 95) / 96;
+      static const int force_bn = getenv("SPV_FC1W_BN") ? atoi(getenv("SPV_FC1W_BN")) : 0;   // (A/B switch)
+      const bool use96 = force_bn ? force_bn == 96 : (2 * nb96 <= 256 && 2 * nb64 > 256 && fw_lds_bytes(96, Kpad) <= 160 * 1024);
+      void (*kfn)(GemmParams) = use96 ? fc1_wgrad_dma_kernel<96> : fc1_wgrad_dma_kernel<64>;
+      const int lds = fw_lds_bytes(use96 ? 96 : 64, Kpad);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipLaunchKernelGGL(kfn, dim3((G + 63) / 64), dim3(512), lds, s, p);
+      hipLaunchKernelGGL(kfn, dim3(use96 ? nb96 : nb64), dim3(512), lds, s, p);
       return launch_status("spv_enc_fc1_wgrad dma");
     }
     // 96-gene tiles when the image rows are padded that far: at G = 10 000 that is 2 x 105 workgroups per group, so the two

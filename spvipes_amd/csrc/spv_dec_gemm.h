@@ -169,22 +169,25 @@ __global__ __launch_bounds__(512) void dec_gemm320_dma_kernel(GemmParams p) {
 //                                                                                     nn/networks.py:314-320, BatchNorm folded)
 // tP / tS: the (softmax-corrected) gradients wrt the two heads' pre-softmax outputs, bf16 tile order; Aps: the latent operand
 // image [Bp][48] bf16 = [z_private | 1 | 0.. | z_shared | 1 | 0..].  Pure streaming (168 MB per group for 0.8 GFLOP): what matters
-// is that every byte of tP / tS crosses a CU once and with enough in flight -- 256 genes x 64 cells x both arrays per stage
-// (64 KiB of tiles + 8 KiB of latents), two stages, LDS-DMA.  8 waves, wave w owns gene tile w of the workgroup's eight; per
-// 16-cell step two MFMA 32x32x16 (the private head multiplies against columns 0..31 and keeps 0..15).
+// is that every byte of tP / tS crosses a CU once and with enough in flight.  Workgroup = 128 genes x both arrays, K tile = 64 cells:
+// 32 KiB of tiles + 8 KiB of latents per stage, two stages = 80 KiB, so TWO workgroups share a CU (two tiles in flight per CU and
+// one workgroup's fill overlaps the other's multiply; the first version -- 256 genes, one workgroup per CU -- ran at 42 us, 4.0 TB/s).
+// 8 waves: wave w owns gene tile w & 3 of array w >> 2 (0: tP / private head, 1: tS / shared head): one MFMA 32x32x16 per 16-cell step
+// (the private head multiplies against latent columns 0..31 and keeps 0..15).
 // The latent rows are staged as TWO 64-byte-pitch images (columns 0..31 and 16..47): four consecutive k rows then cover the 256-byte
 // bank period exactly and the transposed reads need no swizzle.
-constexpr int DH_BM = 256, DH_BK = 64;
-constexpr int DH_T_BYTES = DH_BM * DH_BK * 2, DH_L_BYTES = 2 * DH_BK * 64, DH_STAGE = 2 * DH_T_BYTES + DH_L_BYTES;   // 32 K + 32 K + 8 K
-constexpr int DH_LDS_BYTES = 2 * DH_STAGE;   // 147 456 B
+constexpr int DH_BM = 128, DH_BK = 64;
+constexpr int DH_T_BYTES = DH_BM * DH_BK * 2, DH_L_BYTES = 2 * DH_BK * 64, DH_STAGE = 2 * DH_T_BYTES + DH_L_BYTES;   // 16 K + 16 K + 8 K
+constexpr int DH_LDS_BYTES = 2 * DH_STAGE;   // 81 920 B: two workgroups per CU
 
-// tP, tS: tiles, T = gene tiles per cell tile; Aps [>= Kpad cells][48]; slabP [splits][G][16], slabS [splits][G][32];
-// K = cells (multiple of 64), k_per_split multiple of 64.  grid = ceil(G / 256) * splits (split fastest), 512 threads.
-__global__ __launch_bounds__(512) void dec_heads_wgrad_dma_kernel(const bf16_t* tP, const bf16_t* tS, int T, const bf16_t* Aps, int G, int K, int k_per_split,
-                                                                  int splits, float* slabP, float* slabS) {
+// tP, tS: tiles, T = gene tiles per cell tile; Aps [>= K cells][48]; slabP [splits][G][16], slabS [splits][G][32];
+// K = cells (multiple of 64), k_per_split multiple of 64.  grid = ceil(G / 128) * splits (split fastest), 512 threads.
+__global__ __launch_bounds__(512, 2) void dec_heads_wgrad_dma_kernel(const bf16_t* tP, const bf16_t* tS, int T, const bf16_t* Aps, int G, int K, int k_per_split,
+                                                                     int splits, float* slabP, float* slabS) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dh_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = uniform_wave_id();
+  const int arr = wave >> 2, gt = wave & 3;
   const int split = blockIdx.x % splits, mtile = blockIdx.x / splits;
   const int m0 = mtile * DH_BM;
   const int kbeg = split * k_per_split;
@@ -193,34 +196,34 @@ __global__ __launch_bounds__(512) void dec_heads_wgrad_dma_kernel(const bf16_t* 
   const int ntiles = (kend - kbeg) / DH_BK;
 
   lds_byte* const lds = (lds_byte*)(dh_smem);
-  // A pieces: stage image [array 2][cell tile 2][gene tile 8][2 KiB]; wave w copies gene tile w of both cell tiles of both arrays
-  // (4 tiles = 8 pieces), each re-ordered to [cell / 4][gene / 4][cell % 4][4 genes] (see dec_gemm320_dma_kernel)
-  const glb_byte* srcT[8];
+  // stage image [array 2][cell tile 2][gene tile 4][2 KiB]; wave w copies ITS gene tile of ITS array for both cell tiles (4 pieces),
+  // each tile re-ordered to [cell / 4][gene / 4][cell % 4][4 genes] (see dec_gemm320_dma_kernel)
+  const glb_byte* srcT[4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int arr = i >> 2, ct = (i >> 1) & 1, half = i & 1;
+  for (int i = 0; i < 4; ++i) {
+    const int ct = i >> 1, half = i & 1;
     const int lc = half * 64 + lane, cq = lc >> 4, gp = (lc >> 1) & 7, cpair = lc & 1;
     const int chunk = (gp >> 1) * 32 + (gp & 1) * 16 + 2 * cq + cpair;
-    const long tile = ((long)(kbeg / 32) + ct) * T + (m0 / 32) + wave;
+    const long tile = ((long)(kbeg / 32) + ct) * T + (m0 / 32) + gt;
     srcT[i] = (glb_byte*)(arr ? tS : tP) + tile * 2048 + chunk * 16;
   }
   const long t_step = 2L * T * 2048;
   // latent piece of this wave: waves 0..3 rows 16 w .. of the private image (source columns 0..31), waves 4..7 of the shared one (16..47)
-  const int lrow = 16 * (wave & 3) + (lane >> 2);
-  const glb_byte* srcL = (glb_byte*)(Aps) + ((long)(kbeg + lrow) * DEC_KPS + (wave >> 2) * 16) * 2 + (lane & 3) * 16;
+  const int lrow = 16 * gt + (lane >> 2);
+  const glb_byte* srcL = (glb_byte*)(Aps) + ((long)(kbeg + lrow) * DEC_KPS + arr * 16) * 2 + (lane & 3) * 16;
   auto issue = [&](int t) {
     const int stage = (t & 1) * DH_STAGE;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int arr = i >> 2, ct = (i >> 1) & 1, half = i & 1;
-      dma16(srcT[i] + (long)t * t_step, lds + stage + arr * DH_T_BYTES + ((ct * 8 + wave) * 2 + half) * 1024);
+    for (int i = 0; i < 4; ++i) {
+      const int ct = i >> 1, half = i & 1;
+      dma16(srcT[i] + (long)t * t_step, lds + stage + arr * DH_T_BYTES + ((ct * 4 + gt) * 2 + half) * 1024);
     }
     dma16(srcL + (long)t * (DH_BK * DEC_KPS * 2), lds + stage + 2 * DH_T_BYTES + wave * 1024);
   };
 
-  f16v accP, accS;
+  f16v acc;
 #pragma unroll
-  for (int q = 0; q < 16; ++q) { accP[q] = 0.f; accS[q] = 0.f; }
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
   if (ntiles > 0) issue(0);
   const int gi = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3, h = lane >> 5, r = lane & 31;
   const int in_gran = 32 * (gi & 1) + 8 * p4;
@@ -229,29 +232,26 @@ __global__ __launch_bounds__(512) void dec_heads_wgrad_dma_kernel(const bf16_t* 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     raw_barrier();
     if (t + 1 < ntiles) issue(t + 1);
-    const unsigned st = lds0 + (t & 1) * DH_STAGE, stL = st + 2 * DH_T_BYTES;
+    const unsigned st = lds0 + (t & 1) * DH_STAGE, stT = st + arr * DH_T_BYTES, stL = st + 2 * DH_T_BYTES + arr * (DH_BK * 64);
+    s4v a[4][2], b[4][2];
 #pragma unroll
     for (int ks = 0; ks < DH_BK / 16; ++ks) {
-      s4v ap[2], as[2], bp[2], bs[2];
-      const unsigned adT = st + ((ks >> 1) * 8 + wave) * 2048 + (4 * (ks & 1) + 2 * h) * 256 + (4 * (gi & 1) + p4) * 32 + q4 * 8;
-      tr_issue(ap[0], adT); tr_issue(ap[1], adT + 256);
-      tr_issue(as[0], adT + DH_T_BYTES); tr_issue(as[1], adT + DH_T_BYTES + 256);
+      const unsigned adT = stT + ((ks >> 1) * 4 + gt) * 2048 + (4 * (ks & 1) + 2 * h) * 256 + (4 * (gi & 1) + p4) * 32 + q4 * 8;
+      tr_issue(a[ks][0], adT); tr_issue(a[ks][1], adT + 256);
       const unsigned adL = stL + (16 * ks + 8 * h + q4) * 64 + in_gran;
-      tr_issue(bp[0], adL); tr_issue(bp[1], adL + 256);
-      tr_issue(bs[0], adL + DH_BK * 64); tr_issue(bs[1], adL + DH_BK * 64 + 256);
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ap[0]), "+v"(ap[1]), "+v"(as[0]), "+v"(as[1]), "+v"(bp[0]), "+v"(bp[1]), "+v"(bs[0]), "+v"(bs[1]));
-      accP = mfma32(join8(ap[0], ap[1]), join8(bp[0], bp[1]), accP);
-      accS = mfma32(join8(as[0], as[1]), join8(bs[0], bs[1]), accS);
+      tr_issue(b[ks][0], adL); tr_issue(b[ks][1], adL + 256);
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[2][0]), "+v"(a[2][1]), "+v"(a[3][0]), "+v"(a[3][1]),
+                 "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[2][0]), "+v"(b[2][1]), "+v"(b[3][0]), "+v"(b[3][1]));
+#pragma unroll
+    for (int ks = 0; ks < DH_BK / 16; ++ks) acc = mfma32(join8(a[ks][0], a[ks][1]), join8(b[ks][0], b[ks][1]), acc);
   }
-  float* oP = slabP + (long)split * G * DEC_KP;
-  float* oS = slabS + (long)split * G * DEC_KS;
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
-    const int gene = m0 + wave * 32 + crow(q, h);
+    const int gene = m0 + gt * 32 + crow(q, h);
     if (gene < G) {
-      if (r < DEC_KP) oP[(long)gene * DEC_KP + r] = accP[q];
-      oS[(long)gene * DEC_KS + r] = accS[q];
+      if (arr == 0) { if (r < DEC_KP) slabP[((long)split * G + gene) * DEC_KP + r] = acc[q]; }
+      else slabS[((long)split * G + gene) * DEC_KS + r] = acc[q];
     }
   }
 }

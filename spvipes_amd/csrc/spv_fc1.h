@@ -222,15 +222,22 @@ __global__ __launch_bounds__(256) void fc1_epilogue_tiled_kernel(const float* sl
 // drain the DMA queue with vmcnt(0) at its first use).
 //   LDS images are lane-linear copies of the global rows (512-byte dh rows, 2 WG_BN-byte gene rows); the four k rows a
 //   transposed read touches would fall on the same banks, so the 64-byte granule index inside a row is XOR-ed with
-//   (row & 3) (128-byte rows: (row >> 1) & 1) on the DMA's source address and again on the read.
+//   (row & 3) (128-byte rows: (row >> 1) & 1) on the DMA's source address and again on the read.  192-byte rows (96 genes)
+//   need no swizzle: four consecutive rows start 0 / 192 / 128 / 64 bytes into the 256-byte bank period.
+//   WG_BN = 96 exists for the chip's round structure: at G = 10 000 it makes 105 workgroups per group, so the two groups' launches
+//   (two streams, one workgroup per CU) are resident TOGETHER in one round of 256 CUs, where 2 x 157 workgroups of 64 genes take two.
 constexpr int FW_BM = 256, FW_BK = 64, FW_NBUF = 3;
 template <int WG_BN>
 struct FwCfg {
   static constexpr int A_BYTES = FW_BK * FW_BM * 2, B_ROW = WG_BN * 2, B_BYTES = FW_BK * B_ROW, STAGE = A_BYTES + B_BYTES;
-  static constexpr int A_PIECES = A_BYTES / 1024 / 8, B_PIECES = B_BYTES / 1024 / 8, PIECES = A_PIECES + B_PIECES;   // per wave
-  static constexpr int TN = WG_BN / 2 / 32;   // 32-gene MFMA tiles per wave (2 wave columns)
-  static constexpr int ROWS_PER_BPIECE = 1024 / B_ROW;   // 4 (WG_BN 128) or 8 (WG_BN 64)
-  static_assert(WG_BN == 64 || WG_BN == 128, "gene tile");
+  static constexpr int A_PIECES = A_BYTES / 1024 / 8;                 // per wave
+  static constexpr int B_PIECES_ALL = B_BYTES / 1024;                 // 8 (64 genes), 12 (96), 16 (128) per stage
+  static constexpr int B_PIECES = (B_PIECES_ALL + 7) / 8;             // per wave; 96 genes: waves 0..3 issue two, waves 4..7 one
+  static constexpr int PIECES = A_PIECES + B_PIECES;
+  // 8 waves as 4 (M) x 2 (N); the 96-gene tile (three 32-gene MFMA tiles) as 8 (M) x 1 (N)
+  static constexpr int WAVES_N = (WG_BN == 96) ? 1 : 2, WAVES_M = 8 / WAVES_N;
+  static constexpr int TM = FW_BM / WAVES_M / 32, TN = WG_BN / WAVES_N / 32;
+  static_assert(WG_BN == 64 || WG_BN == 96 || WG_BN == 128, "gene tile");
 };
 __host__ __device__ constexpr int fw_lds_bytes(int wg_bn, int kpad) { return (FW_BK * FW_BM * 2 + FW_BK * wg_bn * 2) * FW_NBUF + kpad * 4; }
 
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(512) void fc1_wgrad_dma_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fw_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = uniform_wave_id();
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
   const int n0 = blockIdx.x * WG_BN;
   const int Kpad = (p.n_cells + FW_BK - 1) / FW_BK * FW_BK, ntiles = Kpad / FW_BK;
   int* rowtab = reinterpret_cast<int*>(fw_smem + Cfg::STAGE * FW_NBUF);
@@ -267,7 +274,13 @@ __global__ __launch_bounds__(512) void fc1_wgrad_dma_kernel(GemmParams p) {
 #pragma unroll
   for (int i = 0; i < Cfg::B_PIECES; ++i) {
     const int piece = Cfg::B_PIECES * wave + i;
-    if constexpr (WG_BN == 128) {
+    if constexpr (WG_BN == 96) {   // piece = wave + 8 i (the second one only exists for waves 0..3); pieces cross rows
+      const int o = (wave + 8 * i) * 1024 + lane * 16;
+      browB[i] = (o / Cfg::B_ROW) & (FW_BK - 1);
+      int cb = o % Cfg::B_ROW;
+      if ((long)n0 + cb / 2 + 8 > p.ldb) cb = 0;   // the last workgroup's columns beyond the image row: any in-bounds bytes do (never stored)
+      bcolB[i] = cb;
+    } else if constexpr (WG_BN == 128) {
       const int row = 4 * piece + (lane >> 4), ch = lane & 15;
       browB[i] = row; bcolB[i] = ((((ch >> 2) ^ (row & 3)) << 2) | (ch & 3)) * 16;
     } else {
@@ -282,8 +295,10 @@ __global__ __launch_bounds__(512) void fc1_wgrad_dma_kernel(GemmParams p) {
   auto issueB = [&](int t) {          // all B pieces of tile t (their row indices come out of the LDS table)
 #pragma unroll
     for (int i = 0; i < Cfg::B_PIECES; ++i) {
+      if (WG_BN == 96 && i == 1 && wave >= 4) break;   // (wave-uniform)
       const long ridx = rowtab[t * FW_BK + browB[i]];
-      dma16(Bbase + ridx * p.ldb * 2 + bcolB[i], lds + (t % FW_NBUF) * Cfg::STAGE + Cfg::A_BYTES + (Cfg::B_PIECES * wave + i) * 1024);
+      const int piece = (WG_BN == 96) ? wave + 8 * i : Cfg::B_PIECES * wave + i;
+      dma16(Bbase + ridx * p.ldb * 2 + bcolB[i], lds + (t % FW_NBUF) * Cfg::STAGE + Cfg::A_BYTES + piece * 1024);
     }
   };
   auto issue = [&](int t) {
@@ -292,9 +307,9 @@ __global__ __launch_bounds__(512) void fc1_wgrad_dma_kernel(GemmParams p) {
     issueB(t);
   };
 
-  f16v acc[2][Cfg::TN];
+  f16v acc[Cfg::TM][Cfg::TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
     for (int j = 0; j < Cfg::TN; ++j)
 #pragma unroll
@@ -306,26 +321,30 @@ __global__ __launch_bounds__(512) void fc1_wgrad_dma_kernel(GemmParams p) {
   const int in_gran = 32 * (gi & 1) + 8 * p4;   // byte offset inside the 64-byte granule (32 columns of one k row)
   const unsigned lds0 = lds_addr_of(fw_smem);
   for (int t = 0; t < ntiles; ++t) {
-    if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::PIECES) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (t + 1 < ntiles) {   // all but this wave's youngest tile (t + 1) have landed
+      if constexpr (WG_BN == 96) {
+        if (wave < 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      } else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::PIECES) : "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     raw_barrier();
     const bool more = t + 2 < ntiles;
     if (more) issueB(t + 2);   // (first: its LDS-table reads are compiler-visible and must not sit between the asm reads below and their waits)
     const unsigned stA = lds0 + (t % FW_NBUF) * Cfg::STAGE, stB = stA + Cfg::A_BYTES;
     // fragments of k-step ks + 1 are requested before the MFMAs of k-step ks (two register sets); one A piece of tile
     // t + 2 goes out behind each k-step's MFMAs
-    s4v ra[2][2][2], rb[2][Cfg::TN][2];
+    s4v ra[2][Cfg::TM][2], rb[2][Cfg::TN][2];
     auto reads = [&](int ks, int set) {
       const int row = 16 * ks + 8 * h + q4;   // (row & 3) == q4
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const unsigned ad = stA + row * 512 + (((wm * 2 + i) ^ q4) * 64) + in_gran;
+      for (int i = 0; i < Cfg::TM; ++i) {
+        const unsigned ad = stA + row * 512 + (((wm * Cfg::TM + i) ^ q4) * 64) + in_gran;
         tr_issue(ra[set][i][0], ad);
         tr_issue(ra[set][i][1], ad + 4 * 512);
       }
 #pragma unroll
       for (int j = 0; j < Cfg::TN; ++j) {
-        const int f = (WG_BN == 128) ? q4 : ((row >> 1) & 1);
+        const int f = (WG_BN == 128) ? q4 : (WG_BN == 96 ? 0 : ((row >> 1) & 1));
         const unsigned ad = stB + row * Cfg::B_ROW + (((wn * Cfg::TN + j) ^ f) * 64) + in_gran;
         tr_issue(rb[set][j][0], ad);
         tr_issue(rb[set][j][1], ad + 4 * Cfg::B_ROW);
@@ -337,19 +356,23 @@ __global__ __launch_bounds__(512) void fc1_wgrad_dma_kernel(GemmParams p) {
       const int set = ks & 1;
       if (ks + 1 < FW_BK / 16) {
         reads(ks + 1, set ^ 1);
-        // all but the newest 4 + 2 TN reads (k-step ks + 1's) are back
-        if constexpr (Cfg::TN == 2)
+        // all but the newest 2 TM + 2 TN reads (k-step ks + 1's) are back
+        if constexpr (Cfg::TN == 3)
+          asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(ra[set][0][0]), "+v"(ra[set][0][1]), "+v"(rb[set][0][0]), "+v"(rb[set][0][1]), "+v"(rb[set][1][0]), "+v"(rb[set][1][1]), "+v"(rb[set][2][0]), "+v"(rb[set][2][1]));
+        else if constexpr (Cfg::TN == 2)
           asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(ra[set][0][0]), "+v"(ra[set][0][1]), "+v"(ra[set][1][0]), "+v"(ra[set][1][1]), "+v"(rb[set][0][0]), "+v"(rb[set][0][1]), "+v"(rb[set][1][0]), "+v"(rb[set][1][1]));
         else
           asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(ra[set][0][0]), "+v"(ra[set][0][1]), "+v"(ra[set][1][0]), "+v"(ra[set][1][1]), "+v"(rb[set][0][0]), "+v"(rb[set][0][1]));
       } else {
-        if constexpr (Cfg::TN == 2)
+        if constexpr (Cfg::TN == 3)
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[set][0][0]), "+v"(ra[set][0][1]), "+v"(rb[set][0][0]), "+v"(rb[set][0][1]), "+v"(rb[set][1][0]), "+v"(rb[set][1][1]), "+v"(rb[set][2][0]), "+v"(rb[set][2][1]));
+        else if constexpr (Cfg::TN == 2)
           asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[set][0][0]), "+v"(ra[set][0][1]), "+v"(ra[set][1][0]), "+v"(ra[set][1][1]), "+v"(rb[set][0][0]), "+v"(rb[set][0][1]), "+v"(rb[set][1][0]), "+v"(rb[set][1][1]));
         else
           asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[set][0][0]), "+v"(ra[set][0][1]), "+v"(ra[set][1][0]), "+v"(ra[set][1][1]), "+v"(rb[set][0][0]), "+v"(rb[set][0][1]));
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
         for (int j = 0; j < Cfg::TN; ++j) acc[i][j] = mfma32(join8(ra[set][i][0], ra[set][i][1]), join8(rb[set][j][0], rb[set][j][1]), acc[i][j]);
       if (more) issueA(t + 2, ks);   // A_PIECES == 4 == k-steps per tile
@@ -359,14 +382,14 @@ __global__ __launch_bounds__(512) void fc1_wgrad_dma_kernel(GemmParams p) {
   // ---- dW rows 0 .. 127 -> p.C, rows 128 .. 255 -> p.C2 (the two encoders' weight gradients), fp32 [128][ldc] ----------------------
   const int r = lane & 31;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
     for (int j = 0; j < Cfg::TN; ++j) {
-      const int col = n0 + wn * (WG_BN / 2) + 32 * j + r;
+      const int col = n0 + wn * (WG_BN / Cfg::WAVES_N) + 32 * j + r;
       if (col >= p.N) continue;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const int row = wm * 64 + 32 * i + crow(q, h);
+        const int row = wm * (FW_BM / Cfg::WAVES_M) + 32 * i + crow(q, h);
         float* dst = (row >= p.c_split_row) ? p.C2 + (long)(row - p.c_split_row) * p.ldc + col : p.C + (long)row * p.ldc + col;
         *dst = acc[i][j][q];
       }

@@ -71,11 +71,11 @@ class _DecoderBwd:
         # -0.05 ms per step, same-box A/B); the narrow ones (16 / 32 columns) stream their [B,G] operand with ~2 per CU
         self.ksp_m, self.ksp_n = max(1, min(T // 8, -(-256 // max(Bp // 64, 1)))), max(1, min(T // 8, -(-512 // max(Bp // 128, 1))))
         self.csp_m, self.csp_n = max(1, min(bt // 8, -(-256 // max(Gp // 64, 1)))), max(1, min(bt // 8, -(-512 // max(Gp // 128, 1))))
-        # bf16 mode: one streaming kernel for both regressor weight gradients, 256-gene workgroup tiles, ~one workgroup per CU
+        # bf16 mode: one streaming kernel for both regressor weight gradients (csrc/spv_dec_gemm.h)
         self.heads_dma = bool(_ops.HEADS_DMA and nsplit == 1 and not grads_f32 and Bp % 64 == 0)
         if self.heads_dma:
-            mt, kt = -(-G // 256), Bp // 64
-            self.csp_n = max(1, min(256 // mt if mt <= 256 else 1, max(kt // 4, 1)))
+            mt, kt = -(-G // 128), Bp // 64   # 128-gene workgroup tiles, two workgroups per CU
+            self.csp_n = max(1, min(512 // mt if mt <= 512 else 1, max(kt // 4, 1)))
         # bf16 mode: the two 320-column GEMMs run the LDS-DMA 128 x 320 kernels, which want their own split counts
         self.ksp_m, self.csp_m = self._splits(False, B, G, self.ksp_m), self._splits(True, G, Bp, self.csp_m)
 

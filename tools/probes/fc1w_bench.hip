@@ -67,7 +67,7 @@ static void run(const GemmParams& p, int G, int Kpad, const std::vector<float>& 
 int main(int argc, char** argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 4096, G = argc > 2 ? atoi(argv[2]) : 10000;
   const int NCELLS = 30000;
-  const long lda = ((G + 95) / 96 * 96 + 127) / 128 * 128;
+  const long lda = (G + 127) / 128 * 128;   // (the 96-gene tile's last workgroup reads past this: the kernel clamps)
   const int Kpad = (B + 63) / 64 * 64;
   std::mt19937 rng(5);
   std::uniform_real_distribution<float> uni(0.f, 1.f);
@@ -80,6 +80,7 @@ int main(int argc, char** argv) {
   std::vector<int> rows(B);
   for (auto& r : rows) r = (int)(uni(rng) * (NCELLS - 1));
   unsigned short* dA = upload(A); unsigned short* ddh = upload(dh); int* drows = upload(rows);
+  unsigned short* dA2 = upload(A);   // the second group's image: the pair must not share cache lines
   float* dW = dalloc<float>((size_t)256 * G); float* dW_b = dalloc<float>((size_t)256 * G); float* dref = dalloc<float>((size_t)256 * G);
   hipLaunchKernelGGL(naive_kernel, dim3((G + 255) / 256, 256), dim3(256), 0, 0, ddh, dA, lda, drows, B, G, dref);
   CK(hipDeviceSynchronize());
@@ -88,10 +89,11 @@ int main(int argc, char** argv) {
   GemmParams p{};
   p.A = ddh; p.lda = 256; p.B = dA; p.ldb = lda; p.rows = drows; p.n_cells = B; p.N = G; p.M = 256; p.K = B;
   p.C = dW; p.C2 = dW + (size_t)128 * G; p.c_split_row = 128; p.ldc = G;
-  GemmParams p2 = p; p2.C = dW_b; p2.C2 = dW_b + (size_t)128 * G;
+  GemmParams p2 = p; p2.C = dW_b; p2.C2 = dW_b + (size_t)128 * G; p2.B = dA2;
   hipStream_t s2; CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
   printf("fc1_wgrad_dma B=%d G=%d (Kpad %d)\n", B, G, Kpad);
   run<128>(p, G, Kpad, ref, dW, s2, p2);
+  run<96>(p, G, Kpad, ref, dW, s2, p2);
   run<64>(p, G, Kpad, ref, dW, s2, p2);
   return 0;
 }
