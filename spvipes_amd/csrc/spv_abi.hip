@@ -440,6 +440,14 @@ extern "C" int spv_dec_logits(const uint16_t* Am_hi, const uint16_t* Am_lo, cons
   p.epi = out_f32 ? EPI_TILED_F32 : EPI_TILED_F16;
   p.tiles_inner = Gp / 32;
   hipStream_t s = (hipStream_t)stream;
+  static const int logits_dma = getenv("SPV_LOGITS_DMA") ? atoi(getenv("SPV_LOGITS_DMA")) : 1;   // (A/B switch)
+  if (logits_dma && nsplit == 1 && !out_f32 && Gp % DL_BM == 0 && Bp % DL_BN == 0 && ((reinterpret_cast<uintptr_t>(Am_hi) | reinterpret_cast<uintptr_t>(Wm_hi)) & 15) == 0) {
+    // LDS-DMA kernel (spv_dec_gemm.h): 256 x 128 tiles, two workgroups per CU
+    static bool raised = false;
+    if (!raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_logits_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DL_LDS_BYTES); raised = true; }
+    hipLaunchKernelGGL(dec_logits_dma_kernel, dim3(Gp / DL_BM, Bp / DL_BN), dim3(512), DL_LDS_BYTES, s, (const bf16_t*)Wm_hi, (const bf16_t*)Am_hi, K, Gp / 32, (_Float16*)out);
+    return launch_status("spv_dec_logits dma");
+  }
   if (nsplit == 3) launch_gemm<GemmCfg<128, 128, 2, 2, false, false, SRC_PLAIN, SRC_PLAIN, unsigned short, 3, 32, 4>>(p, 1, s);
   else if (Gp % 256 == 0) launch_gemm<GemmCfg<256, 128, 2, 2, false, false, SRC_PLAIN, SRC_PLAIN, unsigned short, 1, 32, 2, 2>>(p, 1, s);  // 128 x 64 wave tiles: 25 % less LDS traffic per MFMA
   else launch_gemm<GemmCfg<128, 128, 2, 2, false, false, SRC_PLAIN, SRC_PLAIN, unsigned short, 1, 32, 4>>(p, 1, s);
