@@ -259,6 +259,7 @@ def main():
                       overlap_allreduce=None if args.allreduce == "auto" else args.allreduce == "overlap")
     if world > 1:  # identical initial weights on every rank
         dist.broadcast(trainer.fp.flat, src=0)
+        trainer.parameters_changed()
     sampler = MinibatchSampler([args.cells] * NG, args.batch_size, dev, seed=rank)
     module.train()
 

@@ -203,6 +203,24 @@ int spv_dec_dz(const spv_dec_params* p, const float* Tp, const float* Ts, float*
  * (sum the slabs with spv_reduce_slabs): replaces the two [B,G] x [G,K] GEMMs over tP and tS. */
 int spv_dec_softmax_bwd(const spv_dec_params* p, const float* Tp, const float* Ts, float* dz_part, void* stream);
 
+/* One bf16 operand image kept in step with a parameter by spv_adam_step_images: the `count` fp32 values at flat offset `begin`
+ * (a multiple of 4) are a row-major matrix with `cols` columns; element (r, c) is also written, rounded to bf16, to
+ * dst[(r + row_off) * ld + c + col_off].  A vector that forms one column of an image is cols = 1. */
+#define SPV_ADAM_MAX_IMAGES 16
+typedef struct spv_adam_image {
+  int64_t begin, count;
+  int32_t cols, row_off, col_off, _pad;
+  int64_t ld;
+  uint16_t* dst;
+} spv_adam_image;
+
+/* spv_adam_step that also rewrites the bf16 images of the matrices it updates (the packed operands spv_pack_bf16 would otherwise
+ * rebuild at the start of the next step: fc1 weights, [W_m | b_m]).  Image padding (rows / columns outside the matrix) is not
+ * touched: the image must have been produced by spv_pack_bf16 once. */
+int spv_adam_step_images(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, float bc1, float bc2, float grad_scale, const spv_adam_image* images, int32_t n_images,
+                         void* stream);
+
 /* One Adam step (torch.optim.Adam semantics, L2 weight decay folded into the gradient) over a
  * flat fp32 parameter buffer; grad_scale multiplies g first (1/world for data-parallel means).
  * bc1 = 1 - beta1^t, bc2 = 1 - beta2^t.  Replaces scvi TrainingPlan's optimiser step

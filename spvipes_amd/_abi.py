@@ -102,6 +102,14 @@ class SpvPoeArgs(C.Structure):
 SPV_POE_MAXG, POE_COMP_SEG, POE_COMP_CMAX = 4, 16, 64
 
 
+ADAM_MAX_IMAGES = 16
+
+
+class SpvAdamImage(C.Structure):
+    _fields_ = [("begin", C.c_int64), ("count", C.c_int64), ("cols", C.c_int32), ("row_off", C.c_int32), ("col_off", C.c_int32), ("_pad", C.c_int32),
+                ("ld", C.c_int64), ("dst", C.c_void_p)]
+
+
 class SpvPoeCompArgs(C.Structure):
     _fields_ = ([("ngroups", C.c_int32), ("n", C.c_int32), ("ncomp", C.c_int32), ("pad_", C.c_int32), ("B", C.c_int32 * SPV_POE_MAXG),
                  ("stats", C.c_void_p * SPV_POE_MAXG), ("ld", C.c_int64 * SPV_POE_MAXG), ("comp", C.c_void_p * SPV_POE_MAXG),
@@ -193,6 +201,8 @@ _SIGNATURES = {
     "spv_reduce_slabs": (C.c_int, [C.POINTER(SpvReduceBatch), C.c_void_p]),
     "spv_loss_assemble": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
+    "spv_adam_step_images": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
+                                       C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]),
     "spv_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float,
                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
 }

@@ -526,6 +526,86 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   }
 }
 
+// Adam that also refreshes the bf16 operand images of the matrices it has just updated (the fc1 weights of both encoders, the
+// mixing head's [W_m | b_m]): the step that follows then starts without its spv_pack_bf16 launches.  Same arithmetic as
+// adam_kernel; per 4-element chunk one range test per image (<= SPV_ADAM_MAX_IMAGES, all warp-uniform but at range borders).
+struct AdamImages { int n; spv_adam_image img[SPV_ADAM_MAX_IMAGES]; };
+
+__global__ void adam_images_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                   long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2, float gscale, AdamImages im) {
+  const long stride = (long)gridDim.x * blockDim.x * 4;
+  const float step = lr / bc1, isq = rsqrtf(bc2);
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    float out[4];
+    const int cnt = (i + 4 <= n) ? 4 : (int)(n - i);
+    if (cnt == 4) {
+      f4v pp = *reinterpret_cast<f4v*>(p + i), gg = *reinterpret_cast<const f4v*>(g + i);
+      f4v mm = *reinterpret_cast<f4v*>(m + i), vv = *reinterpret_cast<f4v*>(v + i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float gr = gg[j] * gscale + wd * pp[j];
+        mm[j] = b1 * mm[j] + (1.f - b1) * gr;
+        vv[j] = b2 * vv[j] + (1.f - b2) * gr * gr;
+        pp[j] -= step * mm[j] / (sqrtf(vv[j]) * isq + eps);
+        out[j] = pp[j];
+      }
+      *reinterpret_cast<f4v*>(p + i) = pp; *reinterpret_cast<f4v*>(m + i) = mm; *reinterpret_cast<f4v*>(v + i) = vv;
+    } else {
+      for (int j = 0; j < cnt; ++j) {
+        const long k = i + j;
+        const float gr = g[k] * gscale + wd * p[k];
+        m[k] = b1 * m[k] + (1.f - b1) * gr;
+        v[k] = b2 * v[k] + (1.f - b2) * gr * gr;
+        p[k] -= step * m[k] / (sqrtf(v[k]) * isq + eps);
+        out[j] = p[k];
+      }
+    }
+    for (int d = 0; d < im.n; ++d) {
+      const spv_adam_image& q = im.img[d];
+      const long k0 = i - q.begin;
+      if (k0 + cnt <= 0 || k0 >= q.count) continue;
+      // (parameters start on 4-element boundaries of the flat buffer, so k0 >= 0 here; count need not be a multiple of 4)
+      const unsigned cols = (unsigned)q.cols;
+      unsigned r = (unsigned)k0 / cols, c = (unsigned)k0 - r * cols;
+      uint16_t* dst = q.dst + ((long)r + q.row_off) * q.ld + q.col_off;
+      if (cnt == 4 && k0 + 4 <= q.count && c + 4 <= cols && (((reinterpret_cast<uintptr_t>(dst + c)) & 7) == 0)) {
+        typedef __attribute__((ext_vector_type(4))) unsigned short us4;
+        *reinterpret_cast<us4*>(dst + c) = us4{f2bf(out[0]), f2bf(out[1]), f2bf(out[2]), f2bf(out[3])};
+      } else {
+        for (int j = 0; j < cnt && k0 + j < q.count; ++j) {
+          dst[c] = f2bf(out[j]);
+          if (++c == cols) { c = 0; dst += q.ld; }
+        }
+      }
+      break;   // ranges are disjoint
+    }
+  }
+}
+
+extern "C" int spv_adam_step_images(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                                    float weight_decay, float bc1, float bc2, float grad_scale, const spv_adam_image* images, int32_t n_images,
+                                    void* stream) {
+  if (!p || !g || !m || !v || n < 0 || n_images < 0 || n_images > SPV_ADAM_MAX_IMAGES || (n_images && !images)) return fail(SPV_ERR_ARG, "spv_adam_step_images: bad arguments%s");
+  if (n == 0) return SPV_OK;
+  if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15)
+    return fail(SPV_ERR_ARG, "spv_adam_step_images: buffers must be 16-byte aligned%s");
+  AdamImages im{};
+  im.n = n_images;
+  for (int d = 0; d < n_images; ++d) {
+    const spv_adam_image& q = images[d];
+    if (!q.dst || q.begin < 0 || (q.begin & 3) || q.count <= 0 || q.begin + q.count > n || q.cols <= 0 || q.ld < q.cols + q.col_off || q.row_off < 0 || q.col_off < 0 ||
+        q.count >= (1L << 31))
+      return fail(SPV_ERR_ARG, "spv_adam_step_images: bad image descriptor%s");
+    im.img[d] = q;
+  }
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adam_images_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, lr, beta1, beta2, eps,
+                     weight_decay, bc1, bc2, grad_scale, im);
+  return launch_status("spv_adam_step_images");
+}
+
 extern "C" int spv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                              float eps, float weight_decay, float bc1, float bc2, float grad_scale, void* stream) {
   if (!p || !g || !m || !v || n < 0) return fail(SPV_ERR_ARG, "spv_adam_step: bad arguments%s");

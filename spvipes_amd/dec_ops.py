@@ -232,7 +232,8 @@ class DecoderFused(torch.autograd.Function):
             _abi.call("spv_bn_fold_fwd", C.byref(fb), stream_ptr())
             for g in range(NG):
                 Wm_hi, Wm_lo = _bf16_image(ws[g], "dec_Wm", Gps[g], KMP, mlo)
-                _pack(cont(par[g][10]), Wm_hi, Wm_lo, extra_col=cont(par[g][11]))
+                if Wm_lo is not None or ws[g].fresh.get("dec_Wm") != _ops.image_token(par[g][10], par[g][11]):   # (else: Adam has just rewritten it)
+                    _pack(cont(par[g][10]), Wm_hi, Wm_lo, extra_col=cont(par[g][11]))
                 gene_tab = ws[g].get("dec_gene_tab", (Gps[g], 4), torch.float32)
                 cnt_tab = ws[g].get("dec_cnt_tab", (NB_CMAX, Gps[g], 2), torch.float32)
                 _abi.call("spv_dec_tables", ptr(cont(par[g][12])), Gs[g], Gps[g], ptr(gene_tab), ptr(cnt_tab), stream_ptr())
@@ -462,20 +463,32 @@ class DecoderFused(torch.autograd.Function):
                 if side is not cur:
                     bc_done = torch.cuda.Event()
                     bc_done.record(side)
-            red3 = SpvReduceBatch()
-            red3.nprob = 0
-            for g in range(NG):
-                st, G = stages[g], Gs[g]
-                a = st.gemm_a()
-                _add_red(red3, a, st.csp_m, G * KMP, KMP, G, KM - 1, pg[g][10][0], KM - 1, alpha=g_loss)                 # d W_m
-                _add_red(red3, a, st.csp_m, G * KMP, KMP, G, 1, pg[g][11][0], 1, col_off=KM - 1, alpha=g_loss)           # d b_m
-            _run_red(red3)
-        if not _ops.DEFER_WM:
-            pass
-        elif _ops.DEFER_JOIN:
-            _ops.defer(side, [g_loss])
-        else:
-            cur.wait_stream(side)
+
+        def issue_wm(after=None):
+            with torch.cuda.stream(side):
+                if after is not None:
+                    side.wait_event(after)
+                red3 = SpvReduceBatch()
+                red3.nprob = 0
+                for g in range(NG):
+                    st, G = stages[g], Gs[g]
+                    a = st.gemm_a()
+                    _add_red(red3, a, st.csp_m, G * KMP, KMP, G, KM - 1, pg[g][10][0], KM - 1, alpha=g_loss)                 # d W_m
+                    _add_red(red3, a, st.csp_m, G * KMP, KMP, G, 1, pg[g][11][0], 1, col_off=KM - 1, alpha=g_loss)           # d b_m
+                _run_red(red3)
+            if not _ops.DEFER_WM:
+                pass
+            elif _ops.DEFER_JOIN:
+                _ops.defer(side, [g_loss])
+            else:
+                cur.wait_stream(side)
+
+        # WM_LATE: the mixture-weight GEMMs are held back until the main stream reaches the BatchNorm-fold backward: they then run beside
+        # the ~25 tiny launches of the fold / PoE / encoder-tail backward, where the GPU is otherwise almost idle, instead of beside the
+        # trunk backward, which they slow down
+        wm_late = bool(_ops.WM_LATE and side is not cur)
+        if not wm_late:
+            issue_wm()
         # ---- trunk backward (BatchNorm + relu, Linear) ----------------------------------------------
         nblk = -(-B // _abi.BN_ROWS)
         d_pre = [new(B, n_m) for _ in range(NG)]
@@ -515,6 +528,10 @@ class DecoderFused(torch.autograd.Function):
             _run_red(red2)
         if bc_done is not None:
             cur.wait_event(bc_done)
+        if wm_late:
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            issue_wm(ev)
         _abi.call("spv_bn_fold_bwd", C.byref(fb), stream_ptr())
         # ---- latent slicing backward ------------------------------------------------------------------
         d_priv, d_poe = [new(B, n_p) for _ in range(NG)], [new(B, n_s) for _ in range(NG)]

@@ -154,6 +154,7 @@ class spVIPES:
                           n_steps_kl_warmup=n_steps_kl_warmup)
         if world > 1:
             dist.broadcast(trainer.fp.flat, src=0)
+            trainer.parameters_changed()
         trainer.minibatch = self._minibatch  # labels / components / plan indices of this AnnData
         self.trainer_, self.sampler_ = trainer, sampler
         self.history = trainer.fit(sampler, max_epochs, log_every=trainer_kwargs.get("log_every", 1), use_graph=trainer_kwargs.get("use_graph", True),

@@ -75,6 +75,10 @@ class Workspace:
     def __init__(self, device):
         self.device = device
         self._buf: Dict[Tuple, torch.Tensor] = {}
+        # packed bf16 weight images that are known to equal their fp32 parameters: name -> image_token(parameters).  Only
+        # train.Trainer writes here, after its Adam launch has rewritten the images (spv_adam_step_images) or after an explicit
+        # repack; a forward pass that finds the token of the CURRENT parameters skips its spv_pack_bf16 launches.
+        self.fresh: Dict[str, Tuple] = {}
 
     def get(self, name: str, shape, dtype, zero: bool = False) -> torch.Tensor:
         key = (name, tuple(shape), dtype)
@@ -83,6 +87,12 @@ class Workspace:
             t = (torch.zeros if zero else torch.empty)(tuple(shape), dtype=dtype, device=self.device)
             self._buf[key] = t
         return t
+
+
+def image_token(*tensors) -> Tuple:
+    """identity + in-place version of the parameters an image was built from (any torch-side write to a parameter bumps
+    ``_version``; the HIP Adam kernel does not, and it is the one writer that keeps the images in step itself)"""
+    return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
 
 
 _SIDE_STREAMS: Dict[Tuple, "torch.cuda.Stream"] = {}
@@ -125,6 +135,7 @@ OVERLAP_SMALL = os.environ.get("SPV_OVERLAP_SMALL", "1") != "0"  # side-stream o
 STAGGER = os.environ.get("SPV_STAGGER", "1") != "0"  # group 1 orders its independent kernels differently from group 0
 STAGGER_BWD = os.environ.get("SPV_STAGGER_BWD", "0") != "0"  # backward: group 1 runs its d A_m GEMM ahead of its softmax fix (A/B on MI355X: 1.703 vs 1.693 ms, noise -> off)
 DA_FIRST = int(os.environ.get("SPV_DA_FIRST", "0"))  # backward: d A_m GEMMs first, softmax fixes on the side stream (1: side starts after them, 2: with them)
+WM_LATE = os.environ.get("SPV_WM_LATE", "0") != "0"  # mixture-weight GEMMs held back until the BatchNorm-fold backward (beside the tiny-kernel tail)
 HEADS_DMA = os.environ.get("SPV_HEADS_DMA", "1") != "0"  # both regressor weight gradients in one LDS-DMA pass (spv_dec_heads_wgrad)
 FUSED_DZ = os.environ.get("SPV_FUSED_DZ", "1") != "0"  # softmax fix also produces the latent gradient of the rate heads
 FUSED_PACK = os.environ.get("SPV_FUSED_PACK", "1") != "0"  # latent / trunk kernels also write the decoder's bf16 operand images
@@ -214,8 +225,9 @@ class EncoderFC1(torch.autograd.Function):
         bn = 32 if N1 <= 32 else (128 if N1 <= 128 else 256)
         N1p, Gp = round_up(N1, bn), round_up(G, 64)
         W_hi, W_lo = _bf16_image(ws, "fc1_W", N1p, Gp, nsplit == 3)
-        _pack(w_priv, W_hi, W_lo, dst_row_off=0, rows_cover=H)
-        _pack(w_sh, W_hi, W_lo, dst_row_off=H, rows_cover=N1p - H)
+        if W_lo is not None or ws.fresh.get("fc1_W") != image_token(w_priv, w_sh):   # (else: Adam has just rewritten the image)
+            _pack(w_priv, W_hi, W_lo, dst_row_off=0, rows_cover=H)
+            _pack(w_sh, W_hi, W_lo, dst_row_off=H, rows_cover=N1p - H)
         f32c = lambda t: t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
         b_priv, b_sh = f32c(b_priv), f32c(b_sh)
         h1 = torch.empty((B, N1), dtype=torch.float32, device=w_priv.device)

@@ -18,6 +18,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Sequence
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -90,9 +92,15 @@ class HipAdam:
         self.v = torch.zeros_like(fp.flat)
         self.t = 0
 
-    def step(self, grad_scale: float = 1.0):
+    def step(self, grad_scale: float = 1.0, images=None):
+        """``images``: optional ctypes array of SpvAdamImage -- bf16 operand images the kernel rewrites from the updated values"""
         self.t += 1
         b1, b2 = self.betas
+        if images is not None and len(images):
+            _abi.call("spv_adam_step_images", _abi.ptr(self.fp.flat), _abi.ptr(self.fp.grad), _abi.ptr(self.m), _abi.ptr(self.v),
+                      self.fp.numel, self.lr, b1, b2, self.eps, self.wd, 1.0 - b1 ** self.t, 1.0 - b2 ** self.t,
+                      grad_scale, images, len(images), _abi.stream_ptr())
+            return
         _abi.call("spv_adam_step", _abi.ptr(self.fp.flat), _abi.ptr(self.fp.grad), _abi.ptr(self.m), _abi.ptr(self.v),
                   self.fp.numel, self.lr, b1, b2, self.eps, self.wd, 1.0 - b1 ** self.t, 1.0 - b2 ** self.t,
                   grad_scale, _abi.stream_ptr())
@@ -124,6 +132,95 @@ class Trainer:
         self.graph = self.graph2 = None
         self.last_outputs = None
         self.history: Dict[str, List[float]] = {"train_loss": [], "elbo_train": [], "reconstruction_loss_train": [], "kl_local_train": []}
+
+    # ---- bf16 weight images kept in step by the optimiser -------------------------------------------------------------------
+    # The step starts by repacking the fc1 weights of every encoder and [W_m | b_m] of every decoder into bf16 operand images
+    # (6 spv_pack_bf16 launches, ~45 us of HBM time at C2, the first 30 us of them ahead of the fc1 GEMMs).  In bf16 mode the Adam
+    # kernel writes those images itself from the values it has just computed (spv_adam_step_images, +29 MB of stores next to its
+    # 330 MB), the workspaces are told so (ops.Workspace.fresh) and the forward pass skips the packs -- also inside the captured
+    # graph, which is captured with the images fresh.  Any torch-side write to one of the parameters (load_state_dict, broadcast)
+    # changes its version counter: the token no longer matches and ``_ensure_images`` repacks before the next step.
+    IMAGES_BY_ADAM = os.environ.get("SPV_ADAM_IMAGES", "1") != "0"
+
+    def _image_specs(self):
+        """[(workspace, key, image tensor, [(parameter, rows_off, col_off)], token parameters)] for every packed weight image"""
+        from . import ops
+        from .dec_ops import KMP
+
+        m = self.module
+        out = []
+        for g in range(m.n_groups):
+            ws = m._workspace(g, self.device)
+            ep, es = m.encoders[g]["private"], m.encoders[g]["shared"]
+            H, G = ep.fc1.weight.shape
+            N1 = 2 * H
+            bn = 32 if N1 <= 32 else (128 if N1 <= 128 else 256)
+            img = ops._bf16_image(ws, "fc1_W", ops.round_up(N1, bn), ops.round_up(G, 64), False)[0]
+            out.append((ws, "fc1_W", img, [(ep.fc1.weight, 0, 0), (es.fc1.weight, H, 0)], (ep.fc1.weight, es.fc1.weight)))
+            dec = m.decoders[g]
+            Wm, bm = dec.mixture.linear.weight, dec.mixture.linear.bias
+            img = ops._bf16_image(ws, "dec_Wm", ops.round_up(G, 256), KMP, False)[0]
+            out.append((ws, "dec_Wm", img, [(Wm, 0, 0), (bm, 0, Wm.shape[1])], (Wm, bm)))
+        return out
+
+    def _build_image_plan(self):
+        if not self.IMAGES_BY_ADAM or self.module.nsplit != 1:
+            self._img_specs, self._img_plan = [], None
+            return
+        specs = self._image_specs()
+        offs = {}
+        for p_ in self.fp.params:
+            offs[id(p_)] = (p_.data_ptr() - self.fp.flat.data_ptr()) // 4
+        descs = []
+        for ws, key, img, parts, _tok in specs:
+            for par, row_off, col_off in parts:
+                if id(par) not in offs:   # (a frozen parameter: nothing to keep in step -- the plain pack path stays)
+                    self._img_specs, self._img_plan = [], None
+                    return
+                d = _abi.SpvAdamImage()
+                d.begin, d.count = offs[id(par)], par.numel()
+                d.cols = par.shape[1] if par.dim() == 2 else 1
+                d.row_off, d.col_off, d.ld, d.dst = row_off, col_off, img.shape[1], _abi.ptr(img)
+                descs.append(d)
+        if not descs or len(descs) > _abi.ADAM_MAX_IMAGES:
+            self._img_specs, self._img_plan = [], None
+            return
+        self._img_specs, self._img_plan = specs, (_abi.SpvAdamImage * len(descs))(*descs)
+
+    def _images_are_fresh(self) -> bool:
+        from .ops import image_token
+        if getattr(self, "_flat_version", None) != self.fp.flat._version:   # a torch-side write to the flat buffer itself
+            return False
+        return all(ws.fresh.get(key) == image_token(*tok) for ws, key, _img, _parts, tok in self._img_specs)
+
+    def _mark_images_fresh(self) -> None:
+        from .ops import image_token
+        for ws, key, _img, _parts, tok in self._img_specs:
+            ws.fresh[key] = image_token(*tok)
+        self._flat_version = self.fp.flat._version
+
+    def parameters_changed(self) -> None:
+        """Tell the trainer that parameter values were written behind torch's back (a collective into ``fp.flat``, a raw kernel):
+        the packed bf16 weight images are rebuilt before the next step."""
+        for ws, key, _img, _parts, _tok in getattr(self, "_img_specs", []):
+            ws.fresh.pop(key, None)
+
+    def _ensure_images(self) -> None:
+        """(re)pack every image from the current parameters unless the workspaces already hold them"""
+        from . import ops
+        if getattr(self, "_img_plan", "unset") == "unset":
+            self._build_image_plan()
+        if self._img_plan is None or self._images_are_fresh():
+            return
+        for ws, key, img, parts, _tok in self._img_specs:
+            if key == "fc1_W":
+                (wp, _, _), (wsh, H, _) = parts
+                ops._pack(wp, img, None, dst_row_off=0, rows_cover=H)
+                ops._pack(wsh, img, None, dst_row_off=H, rows_cover=img.shape[0] - H)
+            else:
+                (Wm, _, _), (bm, _, _) = parts
+                ops._pack(Wm, img, None, extra_col=bm)
+        self._mark_images_fresh()
 
     def minibatch(self, rows: Sequence[torch.Tensor]):
         """tensors_by_group in the resident layout for the given per-group row indices."""
@@ -192,6 +289,7 @@ class Trainer:
         memory pool) so that the first gradient bucket is on the wire while the second graph runs."""
         if self.graph is not None:
             return
+        self._ensure_images()   # the graph is captured WITHOUT the weight-image packs (see IMAGES_BY_ADAM)
         self._static_rows = [r.clone() for r in rows]
         self._klw = torch.ones((), dtype=torch.float32, device=self.device)
         self._klw_host = 1.0
@@ -228,6 +326,7 @@ class Trainer:
             raise ValueError("injected noise needs an eager step (the captured graph draws its own)")
         if kl_weight is None:
             kl_weight = kl_weight_at(self.epoch, self.global_step, self.n_epochs_kl_warmup, self.n_steps_kl_warmup)
+        self._ensure_images()
         if self.graph is not None:
             for s, r in zip(self._static_rows, rows):
                 s.copy_(r)
@@ -261,7 +360,10 @@ class Trainer:
             dist.all_reduce(self.fp.grad, op=dist.ReduceOp.SUM)  # ONE collective for the whole flat buffer (the north_star form)
             self._ev_ar[1].record()
         if optimizer_step:
-            self.opt.step(grad_scale=1.0 / self.world)
+            plan = getattr(self, "_img_plan", None)
+            if plan is not None and not self._images_are_fresh():
+                plan = None   # (somebody wrote to a parameter since the images were made: plain Adam, _ensure_images repacks next step)
+            self.opt.step(grad_scale=1.0 / self.world, images=plan)
             self.global_step += 1
         return lo
 

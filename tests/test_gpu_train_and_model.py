@@ -305,3 +305,62 @@ def test_five_optimiser_steps_follow_the_oracle_trajectory(dev):
     torch.cuda.synchronize()
     for k, p in module.named_parameters():
         torch.testing.assert_close(p.detach().cpu(), leaves[k].detach(), rtol=2e-3, atol=2e-5, msg=lambda m: f"{k} after {steps} steps: {m}")
+
+
+def test_adam_written_weight_images_are_bit_identical_to_repacking(dev):
+    """bf16 mode: the optimiser rewrites the packed bf16 weight images itself (spv_adam_step_images) and the next forward pass
+    skips its spv_pack_bf16 launches.  Same minibatches and noise, feature on / off: every loss, every parameter and the images
+    themselves must agree BITWISE (same rounding), eagerly and under hipGraph replay; a torch-side write to a parameter must be
+    noticed (version counter) and repacked."""
+    from spvipes_amd.data import MinibatchSampler, make_synthetic_group
+    from spvipes_amd.module import spVIPESmodule
+    from spvipes_amd.train import Trainer
+    groups = [make_synthetic_group(g, 2048, 777, dev) for g in range(2)]
+
+    def run(by_adam, use_graph, poke):
+        torch.manual_seed(0)
+        module = spVIPESmodule({0: 777, 1: 777}, use_labels=True, n_hidden=128, n_dimensions_shared=10, n_dimensions_private=5,
+                               dropout_rate=0.0, precision="bf16").to(dev)
+        Trainer.IMAGES_BY_ADAM = by_adam
+        try:
+            trainer = Trainer(module, [g.counts for g in groups], labels=[g.labels for g in groups], lr=5e-3)
+            sampler = MinibatchSampler([2048, 2048], 256, dev, seed=0)
+            module.train()
+            batches = [rows for _ in range(2) for rows in sampler.epoch()]
+            if use_graph:
+                trainer.capture(batches[0], warmup=1)
+            torch.manual_seed(123)
+            losses = []
+            for i, rows in enumerate(batches):
+                if poke and i == 5:   # somebody writes to parameters between two steps
+                    with torch.no_grad():
+                        module.encoders[0]["shared"].fc1.weight.mul_(1.25)
+                        module.decoders[1].mixture.linear.bias.add_(0.5)
+                losses.append(float(trainer.step(rows, kl_weight=1.0).loss.detach()))
+            imgs = [img.clone() for _ws, _k, img, _p, _t in trainer._image_specs()]
+            assert (trainer._img_plan is not None) == bool(by_adam)
+            if by_adam:
+                assert trainer._images_are_fresh()
+            return losses, trainer.fp.flat.clone(), imgs
+        finally:
+            Trainer.IMAGES_BY_ADAM = True
+
+    for use_graph in (False, True):
+        for poke in (False, True):
+            a, b = run(True, use_graph, poke), run(False, use_graph, poke)
+            assert a[0] == b[0], (use_graph, poke, a[0][:8], b[0][:8])
+            assert torch.equal(a[1], b[1])
+    # images == pack(parameters) after an Adam-with-images step
+    torch.manual_seed(0)
+    module = spVIPESmodule({0: 777, 1: 777}, use_labels=True, n_hidden=128, n_dimensions_shared=10, n_dimensions_private=5, dropout_rate=0.0).to(dev)
+    trainer = Trainer(module, [g.counts for g in groups], labels=[g.labels for g in groups], lr=5e-3)
+    sampler = MinibatchSampler([2048, 2048], 256, dev, seed=0)
+    module.train()
+    for rows in list(sampler.epoch())[:3]:
+        trainer.step(rows, kl_weight=1.0)
+    by_adam = [img.clone() for _ws, _k, img, _p, _t in trainer._img_specs]
+    trainer.parameters_changed()
+    assert not trainer._images_are_fresh()
+    trainer._ensure_images()    # explicit repack from the same parameters
+    for x, (_ws, key, img, _p, _t) in zip(by_adam, trainer._img_specs):
+        assert torch.equal(x, img), key
