@@ -301,18 +301,19 @@ extern "C" int spv_gemm_bf16(int32_t a_kmajor, const uint16_t* A_hi, const uint1
   p.tiles_inner = a_tiles;
   hipStream_t s = (hipStream_t)stream;
   if (spv_gemm_bf16_uses_dma(a_kmajor, M, N, K, nsplit, a_tiles, ldb) && ((reinterpret_cast<uintptr_t>(A_hi) | reinterpret_cast<uintptr_t>(B_hi)) & 15) == 0) {
-    // LDS-DMA kernels (spv_dec_gemm.h): 128 x 320 workgroup tiles, `splits` K ranges (measured at C2, tools/probes/dec_gemm_bench.hip:
-    // d A_m 37.7 us, d W_m 41.0 us against 76.5 / 84.8 us for the register-staged 64 x 320 kernel below)
+    // LDS-DMA kernels (spv_dec_gemm.h): 128 x 320 workgroup tiles, `splits` K ranges, four 28 KiB stages (measured at C2,
+    // tools/probes/dec_gemm_bench.hip: d A_m 37.5 us, d W_m 38.9 us against 76.5 / 84.8 us for the register-staged 64 x 320 kernel below;
+    // the two-stage x 64-deep version of the same kernel: 38.2 / 41.5 us)
     const int mtiles = (M + DG_BM - 1) / DG_BM;
     p.c_split_row = splits;
     static bool raised = false;
     if (!raised) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm320_dma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, DG_LDS_BYTES);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm320_dma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, DG_LDS_BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm320_dma4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, D4_LDS_BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm320_dma4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, D4_LDS_BYTES);
       raised = true;
     }
-    if (a_kmajor) hipLaunchKernelGGL(dec_gemm320_dma_kernel<true>, dim3(mtiles * splits), dim3(512), DG_LDS_BYTES, s, p);
-    else hipLaunchKernelGGL(dec_gemm320_dma_kernel<false>, dim3(mtiles * splits), dim3(512), DG_LDS_BYTES, s, p);
+    if (a_kmajor) hipLaunchKernelGGL(dec_gemm320_dma4_kernel<true>, dim3(mtiles * splits), dim3(512), D4_LDS_BYTES, s, p);
+    else hipLaunchKernelGGL(dec_gemm320_dma4_kernel<false>, dim3(mtiles * splits), dim3(512), D4_LDS_BYTES, s, p);
     return launch_status("spv_gemm_bf16 dma");
   }
   if (a_tiles) {

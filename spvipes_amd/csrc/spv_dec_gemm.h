@@ -163,6 +163,133 @@ __global__ __launch_bounds__(512) void dec_gemm320_dma_kernel(GemmParams p) {
   }
 }
 
+// ---- the same two GEMMs with K tiles of 32 and FOUR LDS stages (three tiles = 84 KiB in flight per CU instead of one of 56 KiB) ------
+// The two-stage kernel above waits for a whole tile's fill between two multiplies: it runs at the LATENCY of one 56 KiB fill per tile
+// (~1.4 us) rather than at the CU's fill rate.  Here a tile is 8 KiB of dL (4 tiles' halves: one 32 x 32 tile per wave pair) + 20 KiB
+// of the k-major operand (32 rows x 640 B = 20 pieces: waves 0..3 issue three, waves 4..7 two), and the wait at the top of tile t is
+// the counted one: everything but this wave's pieces of the three younger tiles (12 / 9) must have landed.
+constexpr int D4_BK = 32, D4_NBUF = 4;
+constexpr int D4_A_BYTES = DG_BM * D4_BK * 2, D4_B_BYTES = D4_BK * DG_B_ROW, D4_STAGE = D4_A_BYTES + D4_B_BYTES;   // 8 K + 20 K
+constexpr int D4_LDS_BYTES = D4_NBUF * D4_STAGE;   // 114 688 B
+
+template <bool A_CELLS_ON_K>
+__global__ __launch_bounds__(512) void dec_gemm320_dma4_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char d4_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uniform_wave_id();
+  const int wm = wave >> 1, wn = wave & 1;
+  const int split = blockIdx.x % p.c_split_row, mtile = blockIdx.x / p.c_split_row;
+  const int m0 = mtile * DG_BM;
+  const int kbeg = split * p.k_per_split;
+  const int Kpad = (p.K + DG_BK - 1) / DG_BK * DG_BK;   // (the operands are padded to multiples of 64 along K)
+  int kend = kbeg + p.k_per_split;
+  if (kend > Kpad) kend = Kpad;
+  const int ntiles = (kend - kbeg) / D4_BK;
+
+  lds_byte* const lds = (lds_byte*)(d4_smem);
+  // A: 4 tiles of 2 KiB per stage = 8 pieces, one per wave: the half (wave & 1) of stage tile (wave >> 1).
+  //    d A_m: stage tile = cell tile (one gene tile per K tile);  d W_m: stage tile = gene tile (one cell tile per K tile)
+  const glb_byte* srcA;
+  long a_step;
+  {
+    const long T = p.tiles_inner;
+    long tile0;
+    if constexpr (!A_CELLS_ON_K) { tile0 = ((long)(m0 / 32) + (wave >> 1)) * T + (kbeg / 32); a_step = 2048; }
+    else { tile0 = (long)(kbeg / 32) * T + (m0 / 32) + (wave >> 1); a_step = T * 2048; }
+    int chunk = (wave & 1) * 64 + lane;
+    if constexpr (A_CELLS_ON_K) {
+      const int cq = chunk >> 4, gp = (chunk >> 1) & 7, cpair = chunk & 1;
+      chunk = (gp >> 1) * 32 + (gp & 1) * 16 + 2 * cq + cpair;
+    }
+    srcA = (glb_byte*)(p.A) + tile0 * 2048 + chunk * 16;
+  }
+  // B: 20 pieces: piece = wave + 8 i, i = 0..2 (the third only for waves 0..3)
+  const glb_byte* srcB[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int o = ((wave + 8 * i) * 1024 + lane * 16) % D4_B_BYTES;   // (% only tames the non-existent third piece of waves 4..7)
+    const int row = o / DG_B_ROW, w = o % DG_B_ROW;
+    const int gran = (w >> 6) ^ ((row >> 1) & 1);
+    srcB[i] = (glb_byte*)(p.B) + ((long)(kbeg + row) * DG_B_ROW) + gran * 64 + (w & 63);
+  }
+  auto issue = [&](int t) {
+    const int stage = (t % D4_NBUF) * D4_STAGE;
+    dma16(srcA + (long)t * a_step, lds + stage + wave * 1024);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (i == 2 && wave >= 4) break;   // (wave-uniform)
+      dma16(srcB[i] + (long)t * D4_B_BYTES, lds + stage + D4_A_BYTES + (wave + 8 * i) * 1024);
+    }
+  };
+
+  f16v acc[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+
+  for (int t = 0; t < D4_NBUF - 1 && t < ntiles; ++t) issue(t);
+  const int gi = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3, h = lane >> 5, r = lane & 31;
+  const int in_gran = 32 * (gi & 1) + 8 * p4;
+  const int fB = (q4 >> 1) & 1;
+  const unsigned lds0 = lds_addr_of(d4_smem);
+  for (int t = 0; t < ntiles; ++t) {
+    // tile t has landed once all but this wave's pieces of the younger tiles in flight are done
+    const int younger = min(ntiles - 1 - t, D4_NBUF - 2);
+    if (younger == 2) { if (wave < 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+    else if (younger == 1) { if (wave < 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    raw_barrier();   // ... everybody's pieces have, and everybody is done reading buffer (t - 1) % 4, which tile t + 3 now overwrites
+    if (t + D4_NBUF - 1 < ntiles) issue(t + D4_NBUF - 1);
+    const unsigned stA = lds0 + (t % D4_NBUF) * D4_STAGE, stB = stA + D4_A_BYTES;
+    s4v ra[2][2], rb[2][5][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if constexpr (!A_CELLS_ON_K) {
+        const unsigned ad = stA + wm * 2048 + (2 * ks + h) * 512 + r * 8;
+        lds_read8(ra[ks][0], ad);
+        lds_read8(ra[ks][1], ad + 256);
+      } else {
+        const unsigned ad = stA + wm * 2048 + (4 * ks + 2 * h) * 256 + (4 * (gi & 1) + p4) * 32 + q4 * 8;
+        tr_issue(ra[ks][0], ad);
+        tr_issue(ra[ks][1], ad + 256);
+      }
+      const unsigned rowB = stB + (16 * ks + 8 * h + q4) * DG_B_ROW + in_gran;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const unsigned ad = rowB + (((wn * 5 + j) ^ fB) * 64);
+        tr_issue(rb[ks][j][0], ad);
+        tr_issue(rb[ks][j][1], ad + 4 * DG_B_ROW);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (ks == 0)
+        asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(rb[0][0][0]), "+v"(rb[0][0][1]), "+v"(rb[0][1][0]), "+v"(rb[0][1][1]),
+                     "+v"(rb[0][2][0]), "+v"(rb[0][2][1]), "+v"(rb[0][3][0]), "+v"(rb[0][3][1]), "+v"(rb[0][4][0]), "+v"(rb[0][4][1]));
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[1][0]), "+v"(ra[1][1]), "+v"(rb[1][0][0]), "+v"(rb[1][0][1]), "+v"(rb[1][1][0]), "+v"(rb[1][1][1]),
+                     "+v"(rb[1][2][0]), "+v"(rb[1][2][1]), "+v"(rb[1][3][0]), "+v"(rb[1][3][1]), "+v"(rb[1][4][0]), "+v"(rb[1][4][1]));
+      const s8v a = join8(ra[ks][0], ra[ks][1]);
+#pragma unroll
+      for (int j = 0; j < 5; ++j) acc[j] = mfma32(a, join8(rb[ks][j][0], rb[ks][j][1]), acc[j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  float* slab = p.C + (long)split * p.slab_stride;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int col = wn * 160 + 32 * j + r;
+    if (col >= p.N) continue;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = m0 + wm * 32 + crow(q, h);
+      if (row < p.M) slab[(long)row * p.ldc + col] = acc[j][q];
+    }
+  }
+}
+
 // ---- regressor weight gradients of both rate heads in one pass --------------------------------------------------------------------
 //   d [W'_p | c_p][gene][0..15] = sum_cell tP[cell][gene] * Aps[cell][0..15]
 //   d [W'_s | c_s][gene][0..31] = sum_cell tS[cell][gene] * Aps[cell][16..47]        (backward of the two factor regressors,

@@ -45,7 +45,7 @@ __global__ void sum_slabs(const float* slabs, int splits, size_t n, float* out) 
   out[i] = s;
 }
 
-template <bool KM>
+template <bool KM, bool FOUR>
 static void run(const char* name, GemmParams p, int M, int K, const float* dref) {
   const int mtiles = (M + DG_BM - 1) / DG_BM, ktiles = (K + DG_BK - 1) / DG_BK;
   const int splits = std::max(1, std::min(256 / std::max(mtiles, 1), std::max(ktiles / 4, 1)));
@@ -55,10 +55,11 @@ static void run(const char* name, GemmParams p, int M, int K, const float* dref)
   float* slabs = dalloc<float>((size_t)splits * M * 320);
   float* out = dalloc<float>((size_t)M * 320);
   p.C = slabs;
-  void (*kfn)(GemmParams) = dec_gemm320_dma_kernel<KM>;
-  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, DG_LDS_BYTES));
+  void (*kfn)(GemmParams) = FOUR ? dec_gemm320_dma4_kernel<KM> : dec_gemm320_dma_kernel<KM>;
+  const int DG_LDS = FOUR ? D4_LDS_BYTES : DG_LDS_BYTES;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, DG_LDS));
   CK(hipMemset(slabs, 0xFF, (size_t)splits * M * 320 * 4));
-  hipLaunchKernelGGL(kfn, dim3(mtiles * splits), dim3(512), DG_LDS_BYTES, 0, p);
+  hipLaunchKernelGGL(kfn, dim3(mtiles * splits), dim3(512), DG_LDS, 0, p);
   CK(hipDeviceSynchronize());
   hipLaunchKernelGGL(sum_slabs, dim3((unsigned)(((size_t)M * 320 + 255) / 256)), dim3(256), 0, 0, slabs, splits, (size_t)M * 320, out);
   CK(hipDeviceSynchronize());
@@ -69,9 +70,9 @@ static void run(const char* name, GemmParams p, int M, int K, const float* dref)
   for (size_t i = 0; i < h.size(); ++i) { const double e = fabs((double)h[i] - ref[i]); maxerr = std::max(maxerr, e); maxref = std::max(maxref, (double)fabs(ref[i])); if (!(e <= 2e-3 + 1e-3 * fabs(ref[i]))) ++bad; }
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int reps = 30;
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kfn, dim3(mtiles * splits), dim3(512), DG_LDS_BYTES, 0, p);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kfn, dim3(mtiles * splits), dim3(512), DG_LDS, 0, p);
   CK(hipEventRecord(e0));
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kfn, dim3(mtiles * splits), dim3(512), DG_LDS_BYTES, 0, p);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kfn, dim3(mtiles * splits), dim3(512), DG_LDS, 0, p);
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   const double us = ms * 1e3 / reps, fl = 2.0 * M * (double)K * 320;
@@ -101,7 +102,7 @@ int main(int argc, char** argv) {
   printf("dec_gemm320_dma B=%d G=%d (Bp %d, Gp %d)\n", B, G, Bp, Gp);
   GemmParams p{};
   p.A = ddL; p.tiles_inner = T; p.ldb = 320; p.ldc = 320; p.N = 320;
-  { GemmParams q = p; q.B = dW; q.M = B; q.K = G; run<false>("d A_m (cells x 320, K = genes)", q, B, G, refA); }
-  { GemmParams q = p; q.B = dA; q.M = G; q.K = Bp; run<true>("d W_m (genes x 320, K = cells)", q, G, Bp, refW); }
+  { GemmParams q = p; q.B = dW; q.M = B; q.K = G; run<false, false>("d A_m 2 stages x 64", q, B, G, refA); run<false, true>("d A_m 4 stages x 32", q, B, G, refA); }
+  { GemmParams q = p; q.B = dA; q.M = G; q.K = Bp; run<true, false>("d W_m 2 stages x 64", q, G, Bp, refW); run<true, true>("d W_m 4 stages x 32", q, G, Bp, refW); }
   return 0;
 }
