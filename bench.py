@@ -270,7 +270,7 @@ def main():
 
     it = batches()
     prof_names = ["spv_dec_nb_fwd", "spv_dec_logits", "spv_enc_fc1_fwd", "spv_enc_fc1_wgrad", "spv_dec_lse", "spv_dec_softmax_bwd",
-                  "spv_gemm_bf16", "spv_adam_step"]
+                  "spv_gemm_bf16", "spv_dec_heads_wgrad", "spv_adam_step", "spv_adam_step_images"]
     use_graph = not args.no_graph
     delta = delta_state = None
     if rank == 0 and world == 1 and NG == 2 and not args.no_elbo_delta:

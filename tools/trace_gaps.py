@@ -3,7 +3,7 @@
 import csv, sys, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-adam = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
+adam = [i for i, r in enumerate(rows) if ("adam_kernel" in r["Kernel_Name"] or "adam_images_kernel" in r["Kernel_Name"])]
 a, b = adam[-3], adam[-2]          # one full step between two optimiser launches
 seg = rows[a + 1:b + 1]
 t0, t1 = int(seg[0]["Start_Timestamp"]), int(seg[-1]["End_Timestamp"])

@@ -4,7 +4,7 @@ import csv, sys, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 lo = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
-adam = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
+adam = [i for i, r in enumerate(rows) if ("adam_kernel" in r["Kernel_Name"] or "adam_images_kernel" in r["Kernel_Name"])]
 seg = rows[adam[-3] + 1:adam[-2] + 1]
 t0 = int(seg[0]["Start_Timestamp"])
 def short(n):
