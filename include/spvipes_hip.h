@@ -112,6 +112,29 @@ int spv_enc_fc1_wgrad(const spv_counts* x, int32_t B, int32_t G,
 int spv_enc_fc1_bwd_prep(const float* dh1, const float* h1, int32_t B, int32_t N1, uint16_t* img_hi, uint16_t* img_lo,
                          int64_t ld_img, int32_t Bp, float* part, float* db, float* db2, int32_t n_first, void* stream);
 
+/* Grouped forms of the three fc1 entry points above: one argument block per group (same meaning as the parameters of
+ * spv_enc_fc1_fwd / spv_enc_fc1_bwd_prep + spv_enc_fc1_wgrad).  Pairs of groups whose shapes take the LDS-DMA kernels run as ONE launch
+ * per kernel (both groups' tiles in one grid: the 2 x 256 one-per-CU workgroups of two separate launches can only run one after the
+ * other anyway, and a single stream needs no fork / join); anything else falls back to the per-group entry points in order. */
+typedef struct spv_fc1_fwd_args {
+  const spv_counts* x; int32_t B, G;
+  const uint16_t* W1_hi; const uint16_t* W1_lo; int64_t ldw; int32_t N1;
+  const float* bias; const float* bias2; int32_t n_first, nsplit, splits;
+  float* slabs; float* rowsum_ws; float* h1; float* library;
+  const uint16_t* xb_all; int64_t ld_xb; const float* library_all;
+} spv_fc1_fwd_args;
+int spv_enc_fc1_fwd_grouped(const spv_fc1_fwd_args* groups, int32_t n_groups, void* stream);
+
+typedef struct spv_fc1_bwd_args {
+  const float* dh1; const float* h1; const spv_counts* x;
+  int32_t B, G, N1, n_first, nsplit, Bp;
+  uint16_t* dh_hi; uint16_t* dh_lo; int64_t ld_dh;      /* workspace: packed bf16 image of relu'(h1) * dh1, [Bp][ld_dh] */
+  float* part;                                          /* workspace: [Bp / 16][N1] column partial sums */
+  float* db; float* db2; float* dW; float* dW2; int64_t ldc;
+  const uint16_t* xb; int64_t ld_xb;
+} spv_fc1_bwd_args;
+int spv_enc_fc1_bwd_grouped(const spv_fc1_bwd_args* groups, int32_t n_groups, void* stream);
+
 /* "Accumulator-tile" order of the [cells][genes] arrays exchanged between the decoder kernels
  * (mixing logits, dL, tP, tS):  T[cell/32][gene/32][qq][lane][j], lane = cell%32 + 32 h,
  * gene%32 = 8 qq + 4 h + j, qq, j = 0..3 -- each 32x32 tile is stored as the MFMA accumulator that

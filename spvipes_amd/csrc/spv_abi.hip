@@ -950,6 +950,46 @@ __global__ __launch_bounds__(256) void fc1_bwd_bias_kernel(const float* part, in
   else db[col] = v;
 }
 
+struct Fc1PrepArgs { const float* dh1; const float* h1; int B, N1; bf16_t* img_hi; bf16_t* img_lo; long ld_img; float* part; int nblk; float* db; float* db2; int n_first; };
+__global__ __launch_bounds__(256) void fc1_bwd_prep_pair_kernel(Fc1PrepArgs a0, Fc1PrepArgs a1) {   // blockIdx.y = group
+  const Fc1PrepArgs a = blockIdx.y ? a1 : a0;
+  if ((int)blockIdx.x >= a.nblk) return;
+  const int r0 = blockIdx.x * 16;
+  for (int col = threadIdx.x; col < (int)a.ld_img; col += 256) {
+    float sum = 0.f;
+#pragma unroll 4
+    for (int r = r0; r < r0 + 16; ++r) {
+      float v = 0.f;
+      if (r < a.B && col < a.N1) {
+        const long i = (long)r * a.N1 + col;
+        v = (a.h1[i] > 0.f) ? a.dh1[i] : 0.f;
+      }
+      bf16_t hi, lo;
+      split_bf16(v, hi, lo);
+      a.img_hi[(long)r * a.ld_img + col] = hi;
+      if (a.img_lo) a.img_lo[(long)r * a.ld_img + col] = lo;
+      sum += v;
+    }
+    if (col < a.N1) a.part[(long)blockIdx.x * a.N1 + col] = sum;
+  }
+}
+__global__ __launch_bounds__(256) void fc1_bwd_bias_pair_kernel(Fc1PrepArgs a0, Fc1PrepArgs a1) {   // blockIdx.y = group
+  const Fc1PrepArgs a = blockIdx.y ? a1 : a0;
+  __shared__ float s_p[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + tx;
+  float v = 0.f;
+  if (col < a.N1)
+#pragma unroll 8
+    for (int k = ty; k < a.nblk; k += 4) v += a.part[(long)k * a.N1 + col];
+  s_p[ty][tx] = v;
+  __syncthreads();
+  if (ty != 0 || col >= a.N1) return;
+  v = ((s_p[0][tx] + s_p[1][tx]) + s_p[2][tx]) + s_p[3][tx];
+  if (a.db2 != nullptr && col >= a.n_first) a.db2[col - a.n_first] = v;
+  else a.db[col] = v;
+}
+
 extern "C" int spv_enc_fc1_bwd_prep(const float* dh1, const float* h1, int32_t B, int32_t N1, uint16_t* img_hi, uint16_t* img_lo,
                                     int64_t ld_img, int32_t Bp, float* part, float* db, float* db2, int32_t n_first, void* stream) {
   if (!dh1 || !h1 || !img_hi || !part || !db) return fail(SPV_ERR_ARG, "spv_enc_fc1_bwd_prep: null pointer%s");
@@ -958,6 +998,101 @@ extern "C" int spv_enc_fc1_bwd_prep(const float* dh1, const float* h1, int32_t B
   hipLaunchKernelGGL(fc1_bwd_prep_kernel, dim3(Bp / 16), dim3(256), 0, s, dh1, h1, B, N1, img_hi, img_lo, (long)ld_img, part);
   hipLaunchKernelGGL(fc1_bwd_bias_kernel, dim3((N1 + 63) / 64), dim3(256), 0, s, part, Bp / 16, N1, db, db2, n_first);
   return launch_status("spv_enc_fc1_bwd_prep");
+}
+
+// ---- both groups of a step in one launch per kernel (csrc/spv_fc1.h: *_pair_kernel) ---------------------------------------------------
+static bool fc1_fwd_dma_ok(const spv_fc1_fwd_args& a) {
+  return a.x && a.x->X && a.W1_hi && a.bias && a.slabs && a.h1 && a.library && a.xb_all && a.library_all && a.B > 0 && a.G > 0 && a.splits > 0 &&
+         spv_enc_fc1_fwd_uses_dma(a.B, a.G, a.N1, a.nsplit, 1, a.ldw, a.ld_xb) &&
+         ((reinterpret_cast<uintptr_t>(a.xb_all) | reinterpret_cast<uintptr_t>(a.W1_hi)) & 15) == 0;
+}
+static GemmParams fc1_fwd_dma_params(const spv_fc1_fwd_args& a) {
+  GemmParams p{};
+  p.A = a.xb_all; p.lda = a.ld_xb; p.B = a.W1_hi; p.ldb = a.ldw; p.rows = a.x->rows;
+  p.n_cells = a.B; p.n_genes = a.G; p.C = a.slabs; p.ldc = a.N1; p.M = a.B; p.N = a.N1; p.K = a.G;
+  const int kt = (a.G + F1_BK - 1) / F1_BK;
+  p.k_per_split = ((kt + a.splits - 1) / a.splits) * F1_BK;
+  p.c_split_row = a.splits;
+  return p;
+}
+
+extern "C" int spv_enc_fc1_fwd_grouped(const spv_fc1_fwd_args* g, int32_t n_groups, void* stream) {
+  if (!g || n_groups <= 0) return fail(SPV_ERR_ARG, "spv_enc_fc1_fwd_grouped: bad arguments%s");
+  hipStream_t s = (hipStream_t)stream;
+  int i = 0;
+  for (; i + 1 < n_groups; i += 2) {
+    const spv_fc1_fwd_args &a = g[i], &b = g[i + 1];
+    if (!(fc1_fwd_dma_ok(a) && fc1_fwd_dma_ok(b))) break;
+    const GemmParams p0 = fc1_fwd_dma_params(a), p1 = fc1_fwd_dma_params(b);
+    const int mt0 = (a.B + F1_BM - 1) / F1_BM, mt1 = (b.B + F1_BM - 1) / F1_BM;
+    static bool raised = false;
+    if (!raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fc1_fwd_dma_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F1_LDS_BYTES); raised = true; }
+    hipLaunchKernelGGL(fc1_fwd_dma_pair_kernel, dim3(mt0 * a.splits + mt1 * b.splits), dim3(512), F1_LDS_BYTES, s, p0, p1, mt0 * a.splits);
+    if (hipGetLastError() != hipSuccess) return launch_status("spv_enc_fc1_fwd_grouped gemm");
+    const long se0 = (long)mt0 * F1_BM * F1_BN, se1 = (long)mt1 * F1_BM * F1_BN;
+    const Fc1EpiArgs e0{a.slabs, a.splits, se0, a.B, a.bias, a.bias2, a.n_first, a.h1, a.library, a.library_all, a.x->rows};
+    const Fc1EpiArgs e1{b.slabs, b.splits, se1, b.B, b.bias, b.bias2, b.n_first, b.h1, b.library, b.library_all, b.x->rows};
+    const long sem = se0 > se1 ? se0 : se1;
+    hipLaunchKernelGGL(fc1_epilogue_tiled_pair_kernel, dim3((unsigned)((sem / 4 + 255) / 256), 2), dim3(256), 0, s, e0, e1);
+    if (hipGetLastError() != hipSuccess) return launch_status("spv_enc_fc1_fwd_grouped epilogue");
+  }
+  for (; i < n_groups; ++i) {   // a leftover group, or shapes the LDS-DMA kernel does not take: the per-group entry point
+    const spv_fc1_fwd_args& a = g[i];
+    const int rc = spv_enc_fc1_fwd(a.x, a.B, a.G, a.W1_hi, a.W1_lo, a.ldw, a.N1, a.bias, a.bias2, a.n_first, a.nsplit, a.splits, a.slabs, a.rowsum_ws, a.h1,
+                                   a.library, a.xb_all, a.ld_xb, a.library_all, stream);
+    if (rc != SPV_OK) return rc;
+  }
+  return SPV_OK;
+}
+
+static bool fc1_bwd_dma_ok(const spv_fc1_bwd_args& a) {
+  if (!a.x || !a.x->X || !a.dh1 || !a.h1 || !a.dh_hi || !a.part || !a.db || !a.dW || !a.dW2 || !a.xb || a.B <= 0 || a.G <= 0) return false;
+  const int Kpad = (a.B + FW_BK - 1) / FW_BK * FW_BK;
+  return a.nsplit == 1 && a.N1 == FW_BM && a.ld_dh == FW_BM && a.n_first == FW_BM / 2 && a.Bp >= Kpad && (a.Bp % 64) == 0 && a.ldc >= a.G &&
+         a.ld_xb >= ((a.G + 63) & ~63) && (a.ld_xb % 8) == 0 && fw_lds_bytes(96, Kpad) <= 160 * 1024 &&
+         ((reinterpret_cast<uintptr_t>(a.xb) | reinterpret_cast<uintptr_t>(a.dh_hi)) & 15) == 0;
+}
+
+extern "C" int spv_enc_fc1_bwd_grouped(const spv_fc1_bwd_args* g, int32_t n_groups, void* stream) {
+  if (!g || n_groups <= 0) return fail(SPV_ERR_ARG, "spv_enc_fc1_bwd_grouped: bad arguments%s");
+  hipStream_t s = (hipStream_t)stream;
+  int i = 0;
+  for (; i + 1 < n_groups; i += 2) {
+    const spv_fc1_bwd_args &a = g[i], &b = g[i + 1];
+    if (!(fc1_bwd_dma_ok(a) && fc1_bwd_dma_ok(b))) break;
+    const Fc1PrepArgs q0{a.dh1, a.h1, a.B, a.N1, (bf16_t*)a.dh_hi, (bf16_t*)a.dh_lo, (long)a.ld_dh, a.part, a.Bp / 16, a.db, a.db2, a.n_first};
+    const Fc1PrepArgs q1{b.dh1, b.h1, b.B, b.N1, (bf16_t*)b.dh_hi, (bf16_t*)b.dh_lo, (long)b.ld_dh, b.part, b.Bp / 16, b.db, b.db2, b.n_first};
+    const int nb = q0.nblk > q1.nblk ? q0.nblk : q1.nblk;
+    hipLaunchKernelGGL(fc1_bwd_prep_pair_kernel, dim3(nb, 2), dim3(256), 0, s, q0, q1);
+    hipLaunchKernelGGL(fc1_bwd_bias_pair_kernel, dim3((FW_BM + 63) / 64, 2), dim3(256), 0, s, q0, q1);
+    if (hipGetLastError() != hipSuccess) return launch_status("spv_enc_fc1_bwd_grouped prep");
+    GemmParams p[2];
+    for (int k = 0; k < 2; ++k) {
+      const spv_fc1_bwd_args& c = k ? b : a;
+      GemmParams& w = p[k];
+      w = GemmParams{};
+      w.A = c.dh_hi; w.lda = c.ld_dh; w.B = c.xb; w.ldb = c.ld_xb; w.rows = c.x->rows; w.n_cells = c.B; w.n_genes = c.G;
+      w.C = c.dW; w.ldc = c.ldc; w.C2 = c.dW2; w.c_split_row = c.n_first; w.M = c.N1; w.N = c.G; w.K = c.B;
+    }
+    // tile: the one that gets BOTH groups into the fewest rounds of 256 one-per-CU workgroups (64-gene tiles are the faster ones alone)
+    const int n64 = (a.G + 63) / 64 + (b.G + 63) / 64, n96 = (a.G + 95) / 96 + (b.G + 95) / 96;
+    const bool use96 = (n96 + 255) / 256 < (n64 + 255) / 256;
+    const int Kp0 = (a.B + FW_BK - 1) / FW_BK * FW_BK, Kp1 = (b.B + FW_BK - 1) / FW_BK * FW_BK;
+    const int lds = fw_lds_bytes(use96 ? 96 : 64, Kp0 > Kp1 ? Kp0 : Kp1);
+    void (*kfn)(GemmParams, GemmParams, int) = use96 ? fc1_wgrad_dma_pair_kernel<96> : fc1_wgrad_dma_pair_kernel<64>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const int t = use96 ? 96 : 64, nA = (a.G + t - 1) / t, nB = (b.G + t - 1) / t;
+    hipLaunchKernelGGL(kfn, dim3(nA + nB), dim3(512), lds, s, p[0], p[1], nA);
+    if (hipGetLastError() != hipSuccess) return launch_status("spv_enc_fc1_bwd_grouped wgrad");
+  }
+  for (; i < n_groups; ++i) {
+    const spv_fc1_bwd_args& a = g[i];
+    int rc = spv_enc_fc1_bwd_prep(a.dh1, a.h1, a.B, a.N1, a.dh_hi, a.dh_lo, a.ld_dh, a.Bp, a.part, a.db, a.db2, a.n_first, stream);
+    if (rc != SPV_OK) return rc;
+    rc = spv_enc_fc1_wgrad(a.x, a.B, a.G, a.dh_hi, a.dh_lo, a.ld_dh, a.N1, a.nsplit, a.dW, a.dW2, a.n_first, a.ldc, a.xb, a.ld_xb, stream);
+    if (rc != SPV_OK) return rc;
+  }
+  return SPV_OK;
 }
 
 extern "C" int spv_plan_invmap(const int32_t* idx0, int32_t B0, const int32_t* idx1, int32_t B1, int32_t* inv0, int32_t n0, int32_t* inv1,

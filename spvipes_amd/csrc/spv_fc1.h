@@ -53,14 +53,13 @@ __device__ __forceinline__ s8v join8(const s4v& v0, const s4v& v1) { return s8v{
 // p.A = bf16 image [n_cells_total][lda] (zero padded to a multiple of 64 genes), p.rows = minibatch row index (nullable),
 // p.B = W bf16 [256][ldb] (zero padded likewise), p.C = slabs in tile order, p.M = cells in the minibatch, p.K = genes,
 // p.k_per_split multiple of 64, p.c_split_row = number of K splits.  grid = ceil(M / 128) * splits (1-D), 512 threads.
-__global__ __launch_bounds__(512) void fc1_fwd_dma_kernel(GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char f1_smem[];
+__device__ __forceinline__ void fc1_fwd_dma_body(const GemmParams& p, const int blk, unsigned char* f1_smem) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: the LDS-DMA destination must be
   const int wm = wave >> 2, wn = wave & 3;
   // 1-D grid, split fastest: workgroups are dealt round-robin over the 8 XCDs (MI355X_MICROARCH.md), so with 8 splits every
   // XCD works on ONE K range and its slice of W (256 x k_per_split bf16 = 640 KB at C2) stays resident in that XCD's L2
-  const int split = blockIdx.x % p.c_split_row, mtile = blockIdx.x / p.c_split_row;   // (c_split_row carries the split count)
+  const int split = blk % p.c_split_row, mtile = blk / p.c_split_row;   // (c_split_row carries the split count)
   const int m0 = mtile * F1_BM;
   const int kbeg = split * p.k_per_split;
   const int Kpad = (p.K + F1_BK - 1) / F1_BK * F1_BK;
@@ -172,7 +171,7 @@ __global__ __launch_bounds__(512) void fc1_fwd_dma_kernel(GemmParams p) {
   }
 
   // ---- partial slab in accumulator-tile order: S[split][row / 32][col / 32][qq][lane][4] ------------------------------------
-  const long mtiles = (long)(gridDim.x / p.c_split_row) * (F1_BM / 32);
+  const long mtiles = (long)((p.M + F1_BM - 1) / F1_BM) * (F1_BM / 32);
   float* slab = p.C + (long)split * mtiles * (F1_BN / 32) * 1024;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -186,11 +185,26 @@ __global__ __launch_bounds__(512) void fc1_fwd_dma_kernel(GemmParams p) {
     }
 }
 
+__global__ __launch_bounds__(512) void fc1_fwd_dma_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char f1_smem_[];
+  fc1_fwd_dma_body(p, blockIdx.x, f1_smem_);
+}
+// both groups of a step in ONE grid (workgroups 0 .. n0 - 1: the first group's): one launch instead of two launches on two streams
+// whose 2 x 256 one-per-CU workgroups can only run one after the other anyway -- without the fork / join of the graph branches
+__global__ __launch_bounds__(512) void fc1_fwd_dma_pair_kernel(GemmParams p0, GemmParams p1, int n0) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char f1_smem_[];
+  const bool first = (int)blockIdx.x < n0;   // (workgroup-uniform)
+  const GemmParams p = first ? p0 : p1;
+  fc1_fwd_dma_body(p, first ? (int)blockIdx.x : (int)blockIdx.x - n0, f1_smem_);
+}
+
 // h1[cell][col] = relu(bias[col] + sum_splits S[split][...]), library from the data set's table (spv_prepare_log1p).
 // One thread per (tile, qq, lane): 16 bytes of every split's slab in, four floats (rows jj + 8 qq + 4 h of the tile) out.
-__global__ __launch_bounds__(256) void fc1_epilogue_tiled_kernel(const float* slabs, int splits, long slab_elems, int M, const float* bias,
-                                                                 const float* bias2, int n_first, float* h1, float* library,
-                                                                 const float* library_all, const int* rows) {
+struct Fc1EpiArgs { const float* slabs; int splits; long slab_elems; int M; const float* bias; const float* bias2; int n_first; float* h1; float* library;
+                    const float* library_all; const int* rows; };
+__device__ __forceinline__ void fc1_epilogue_tiled_body(const float* slabs, int splits, long slab_elems, int M, const float* bias,
+                                                        const float* bias2, int n_first, float* h1, float* library,
+                                                        const float* library_all, const int* rows) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // float4 index inside one slab
   if (idx * 4 < slab_elems) {
     const long tile = idx >> 8;
@@ -210,6 +224,15 @@ __global__ __launch_bounds__(256) void fc1_epilogue_tiled_kernel(const float* sl
       if (row0 + jj < M) h1[(row0 + jj) * F1_BN + col] = fmaxf(s[jj] + bv, 0.f);   // relu(fc1(x)), nn/networks.py:119
   }
   if (idx < M) library[idx] = library_all[rows ? rows[idx] : (int)idx];   // log(sum_g log1p(x)), module/spVIPESmodule.py:435
+}
+__global__ __launch_bounds__(256) void fc1_epilogue_tiled_kernel(const float* slabs, int splits, long slab_elems, int M, const float* bias,
+                                                                 const float* bias2, int n_first, float* h1, float* library,
+                                                                 const float* library_all, const int* rows) {
+  fc1_epilogue_tiled_body(slabs, splits, slab_elems, M, bias, bias2, n_first, h1, library, library_all, rows);
+}
+__global__ __launch_bounds__(256) void fc1_epilogue_tiled_pair_kernel(Fc1EpiArgs a0, Fc1EpiArgs a1) {   // blockIdx.y = group
+  const Fc1EpiArgs a = blockIdx.y ? a1 : a0;
+  fc1_epilogue_tiled_body(a.slabs, a.splits, a.slab_elems, a.M, a.bias, a.bias2, a.n_first, a.h1, a.library, a.library_all, a.rows);
 }
 
 // ---- fc1 weight gradient:  dW[n1][gene] = sum_cell dh[cell][n1] * log1p(X)[rows[cell]][gene]   (backward of nn/networks.py:119) -------
@@ -245,13 +268,12 @@ __host__ __device__ constexpr int fw_lds_bytes(int wg_bn, int kpad) { return (FW
 // minibatch, p.N = genes, p.C / p.C2 = dW of the first / second 128 rows, p.ldc.  grid = ceil(N / WG_BN), 512 threads,
 // dynamic LDS = fw_lds_bytes(WG_BN, Kpad).
 template <int WG_BN>
-__global__ __launch_bounds__(512) void fc1_wgrad_dma_kernel(GemmParams p) {
+__device__ __forceinline__ void fc1_wgrad_dma_body(const GemmParams& p, const int blk, unsigned char* fw_smem) {
   typedef FwCfg<WG_BN> Cfg;
-  extern __shared__ __attribute__((aligned(16))) unsigned char fw_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = uniform_wave_id();
   const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
-  const int n0 = blockIdx.x * WG_BN;
+  const int n0 = blk * WG_BN;
   const int Kpad = (p.n_cells + FW_BK - 1) / FW_BK * FW_BK, ntiles = Kpad / FW_BK;
   int* rowtab = reinterpret_cast<int*>(fw_smem + Cfg::STAGE * FW_NBUF);
   for (int k = tid; k < Kpad; k += 512) {
@@ -394,6 +416,20 @@ __global__ __launch_bounds__(512) void fc1_wgrad_dma_kernel(GemmParams p) {
         *dst = acc[i][j][q];
       }
     }
+}
+
+template <int WG_BN>
+__global__ __launch_bounds__(512) void fc1_wgrad_dma_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fw_smem_[];
+  fc1_wgrad_dma_body<WG_BN>(p, blockIdx.x, fw_smem_);
+}
+// both groups in one grid (see fc1_fwd_dma_pair_kernel); dynamic LDS = the larger of the two groups' needs
+template <int WG_BN>
+__global__ __launch_bounds__(512) void fc1_wgrad_dma_pair_kernel(GemmParams p0, GemmParams p1, int n0) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fw_smem_[];
+  const bool first = (int)blockIdx.x < n0;
+  const GemmParams p = first ? p0 : p1;
+  fc1_wgrad_dma_body<WG_BN>(p, first ? (int)blockIdx.x : (int)blockIdx.x - n0, fw_smem_);
 }
 
 }  // namespace spv

@@ -350,7 +350,20 @@ class spVIPESmodule(nn.Module):
             self._seed_dev.add_(1)
         label_pre = None  # (measured: hoisting the label pairing up here as well, on this or on a third stream, gains nothing)
         streams = None
-        for g in groups_:
+        from . import ops as _ops_mod
+        grouped = bool(_ops_mod.FC1_GROUPED and len(groups_) >= 2)
+        if grouped:   # one autograd node, one launch per kernel for every pair of groups (ops.EncoderFC1Grouped)
+            cl, rl, bl, wl, pl = [], [], [], [], []
+            for g in groups_:
+                counts, rows, B = self._step_inputs[g]
+                ep, es = self.encoders[g]["private"], self.encoders[g]["shared"]
+                cl.append(counts); rl.append(rows); bl.append(B); wl.append(self._workspace(g, counts.X.device))
+                pl += [ep.fc1.weight, ep.fc1.bias, es.fc1.weight, es.fc1.bias]
+            outs_fc1 = _ops_mod.EncoderFC1Grouped.apply(cl, rl, bl, self.nsplit, wl, *pl)
+            for i, g in enumerate(groups_):
+                h1s[g] = outs_fc1[2 * i]
+                library[g] = outs_fc1[2 * i + 1].unsqueeze(1)
+        for g in ([] if grouped else groups_):
             counts, rows, B = self._step_inputs[g]
             ep, es = self.encoders[g]["private"], self.encoders[g]["shared"]
             ws = self._workspace(g, counts.X.device)

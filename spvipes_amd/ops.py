@@ -136,6 +136,7 @@ STAGGER = os.environ.get("SPV_STAGGER", "1") != "0"  # group 1 orders its indepe
 STAGGER_BWD = os.environ.get("SPV_STAGGER_BWD", "0") != "0"  # backward: group 1 runs its d A_m GEMM ahead of its softmax fix (A/B on MI355X: 1.703 vs 1.693 ms, noise -> off)
 DA_FIRST = int(os.environ.get("SPV_DA_FIRST", "0"))  # backward: d A_m GEMMs first, softmax fixes on the side stream (1: side starts after them, 2: with them)
 WM_LATE = os.environ.get("SPV_WM_LATE", "0") != "0"  # mixture-weight GEMMs held back until the BatchNorm-fold backward (beside the tiny-kernel tail)
+FC1_GROUPED = os.environ.get("SPV_FC1_GROUPED", "1") != "0"  # both groups' fc1 GEMMs as one launch per kernel (EncoderFC1Grouped) instead of two streams
 HEADS_DMA = os.environ.get("SPV_HEADS_DMA", "1") != "0"  # both regressor weight gradients in one LDS-DMA pass (spv_dec_heads_wgrad)
 FUSED_DZ = os.environ.get("SPV_FUSED_DZ", "1") != "0"  # softmax fix also produces the latent gradient of the rate heads
 FUSED_PACK = os.environ.get("SPV_FUSED_PACK", "1") != "0"  # latent / trunk kernels also write the decoder's bf16 operand images
@@ -276,6 +277,98 @@ class EncoderFC1(torch.autograd.Function):
         _abi.call("spv_enc_fc1_wgrad", C.byref(cs), B, G, ptr(dh_hi), ptr(dh_lo), N1p, N1, nsplit, ptr(dWp), ptr(dWs), H, G,
                   ptr(ctx.xb), ctx.ld_xb, stream_ptr())
         return None, None, None, rWp, rbp, rWs, rbs, None, None
+
+
+class EncoderFC1Grouped(torch.autograd.Function):
+    """``EncoderFC1`` for several groups in one autograd node and -- for pairs of groups whose shapes take the LDS-DMA kernels -- ONE
+    launch per kernel (spv_enc_fc1_fwd_grouped / spv_enc_fc1_bwd_grouped: both groups' tiles in one grid).  Two separate launches
+    on two streams cannot overlap (each fills the chip with one-per-CU workgroups) and pay the fork / join of the graph branches.
+    inputs : per-group lists counts, rows, B, workspaces; then 4 parameters per group (w_priv, b_priv, w_sh, b_sh)
+    outputs: (h1_0, library_0, h1_1, library_1, ...)"""
+
+    @staticmethod
+    def forward(ctx, counts, rows, Bs, nsplit: int, wss, *params):
+        ctx.set_materialize_grads(False)
+        NG = len(counts)
+        args = (_abi.SpvFc1FwdArgs * NG)()
+        keep, outs, saved, meta = [], [], [], []
+        f32c = lambda t: t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+        lib = _abi.load()
+        for g in range(NG):
+            w_priv, b_priv, w_sh, b_sh = params[4 * g: 4 * g + 4]
+            ws, B = wss[g], Bs[g]
+            H, G = w_priv.shape
+            N1 = 2 * H
+            bn = 32 if N1 <= 32 else (128 if N1 <= 128 else 256)
+            N1p, Gp = round_up(N1, bn), round_up(G, 64)
+            W_hi, W_lo = _bf16_image(ws, "fc1_W", N1p, Gp, nsplit == 3)
+            if W_lo is not None or ws.fresh.get("fc1_W") != image_token(w_priv, w_sh):   # (else: Adam has just rewritten the image)
+                _pack(w_priv, W_hi, W_lo, dst_row_off=0, rows_cover=H)
+                _pack(w_sh, W_hi, W_lo, dst_row_off=H, rows_cover=N1p - H)
+            b_priv, b_sh = f32c(b_priv), f32c(b_sh)
+            h1 = torch.empty((B, N1), dtype=torch.float32, device=w_priv.device)
+            library = torch.empty((B,), dtype=torch.float32, device=w_priv.device)
+            cs = counts[g].c_struct(rows[g])
+            xb, ld_xb, lib_all = None, 0, None
+            if nsplit == 1 and counts[g].resident:
+                xb, lib_all = counts[g].log1p_image()
+                ld_xb = xb.shape[1]
+            if lib.spv_enc_fc1_fwd_uses_dma(B, G, N1, nsplit, int(xb is not None), Gp, ld_xb):
+                mt = -(-B // 128)
+                splits = max(1, min(16, 256 // mt, (-(-G // 64)) // 4))
+                slabs = ws.get("fc1_slabs_tiled", (splits, mt * 128, N1), torch.float32)
+            else:
+                splits = _fc1_splits(B, G, N1)
+                slabs = ws.get("fc1_slabs", (splits, B, N1), torch.float32)
+            rowsum = ws.get("fc1_rowsum", (splits, B), torch.float32)
+            a = args[g]
+            a.x, a.B, a.G = C.pointer(cs), B, G
+            a.W1_hi, a.W1_lo, a.ldw, a.N1 = ptr(W_hi), ptr(W_lo), Gp, N1
+            a.bias, a.bias2, a.n_first, a.nsplit, a.splits = ptr(b_priv), ptr(b_sh), H, nsplit, splits
+            a.slabs, a.rowsum_ws, a.h1, a.library = ptr(slabs), ptr(rowsum), ptr(h1), ptr(library)
+            a.xb_all, a.ld_xb, a.library_all = ptr(xb), ld_xb, ptr(lib_all)
+            keep += [cs, b_priv, b_sh, W_hi, W_lo, slabs, rowsum, xb, lib_all]
+            outs += [h1, library]
+            saved += [h1, w_priv, b_priv, w_sh, b_sh]
+            meta.append((counts[g], rows[g], B, H, G, ws, xb, ld_xb))
+        _abi.call("spv_enc_fc1_fwd_grouped", args, NG, stream_ptr())
+        ctx.meta, ctx.nsplit, ctx.NG = meta, nsplit, NG
+        ctx.save_for_backward(*saved)
+        ctx.mark_non_differentiable(*outs[1::2])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        from .nn_ops import grad_out
+
+        NG, nsplit = ctx.NG, ctx.nsplit
+        saved = ctx.saved_tensors
+        live = [g for g in range(NG) if grads[2 * g] is not None]
+        rets = [None] * (4 * NG)
+        if live:
+            args = (_abi.SpvFc1BwdArgs * len(live))()
+            keep = []
+            for k, g in enumerate(live):
+                h1, w_priv, b_priv, w_sh, b_sh = saved[5 * g: 5 * g + 5]
+                counts, rows, B, H, G, ws, xb, ld_xb = ctx.meta[g]
+                N1 = 2 * H
+                Bp, N1p = round_up(B, 64), round_up(N1, 128)
+                dh1 = grads[2 * g]
+                dh1 = dh1 if (dh1.dtype == torch.float32 and dh1.is_contiguous()) else dh1.float().contiguous()
+                dh_hi, dh_lo = _bf16_image(ws, "fc1_dh", Bp, N1p, nsplit == 3)
+                part = ws.get("fc1_db_part", (Bp // 16, N1), torch.float32)
+                (dWp, rWp), (dbp, rbp), (dWs, rWs), (dbs, rbs) = grad_out(w_priv), grad_out(b_priv), grad_out(w_sh), grad_out(b_sh)
+                cs = counts.c_struct(rows)
+                a = args[k]
+                a.dh1, a.h1, a.x = ptr(dh1), ptr(h1), C.pointer(cs)
+                a.B, a.G, a.N1, a.n_first, a.nsplit, a.Bp = B, G, N1, H, nsplit, Bp
+                a.dh_hi, a.dh_lo, a.ld_dh, a.part = ptr(dh_hi), ptr(dh_lo), N1p, ptr(part)
+                a.db, a.db2, a.dW, a.dW2, a.ldc = ptr(dbp), ptr(dbs), ptr(dWp), ptr(dWs), G
+                a.xb, a.ld_xb = ptr(xb), ld_xb
+                keep += [cs, dh1, dh_hi, dh_lo, part, dWp, dbp, dWs, dbs]
+                rets[4 * g: 4 * g + 4] = [rWp, rbp, rWs, rbs]
+            _abi.call("spv_enc_fc1_bwd_grouped", args, len(live), stream_ptr())
+        return (None,) * 5 + tuple(rets)
 
 
 # ------------------------------------------------------------------------------------------------
