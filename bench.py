@@ -270,7 +270,7 @@ def main():
 
     it = batches()
     prof_names = ["spv_dec_nb_fwd", "spv_dec_logits", "spv_enc_fc1_fwd", "spv_enc_fc1_wgrad", "spv_dec_lse", "spv_dec_softmax_bwd",
-                  "spv_gemm_bf16", "spv_dec_heads_wgrad", "spv_adam_step", "spv_adam_step_images"]
+                  "spv_gemm_bf16", "spv_dec_heads_wgrad", "spv_adam_step", "spv_adam_step_images", "spv_enc_fc1_fwd_grouped", "spv_enc_fc1_bwd_grouped"]
     use_graph = not args.no_graph
     delta = delta_state = None
     if rank == 0 and world == 1 and NG == 2 and not args.no_elbo_delta:
@@ -371,6 +371,8 @@ def main():
                               "frac": nb_flops / (nb_avg * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS},
                 "per_entry_point": per_kernel}
         fc1_ms = prof.get("spv_enc_fc1_fwd", [])
+        if not fc1_ms and prof.get("spv_enc_fc1_fwd_grouped"):   # one launch per kernel for all groups: per-group share of the entry point
+            fc1_ms = [v / NG for v in prof["spv_enc_fc1_fwd_grouped"]]
         if fc1_ms:   # the encoder contraction SURVEY 8d prices against the MFMA roofline (whole entry point, epilogue included)
             fc1_avg, fc1_flops, fc1_bytes = float(np.mean(fc1_ms)), 2.0 * B * G * 2 * H, B * G * 2 + 2 * H * G * 2
             roof["encoder_fc1_view"] = {"bound": "mfma", "achieved": fc1_flops / (fc1_avg * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",

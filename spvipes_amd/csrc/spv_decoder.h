@@ -148,6 +148,7 @@ __device__ __forceinline__ void load_ps_w(const DecParams& p, int g0, int lane, 
   }
 }
 
+constexpr float NB_LOG2E_C = 1.4426950408889634f;
 // ---- pass 1: per-cell log-sum-exp over genes of y_p and y_s (softmax denominators) ------------
 __global__ __launch_bounds__(256) void dec_lse_kernel(DecParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
@@ -173,24 +174,32 @@ __global__ __launch_bounds__(256) void dec_lse_kernel(DecParams p) {
     ys = mfma32_split<3>(wA.hi[2], wA.lo[2], cf.hi[2], cf.lo[2], ys);
     PsW wB;
     load_ps_w(p, gbeg + 32 * min(t + 1, ntile - 1), lane, wB);  // next tile's fragments fly under this tile's exps
-    float tmp = -INFINITY, tms = -INFINITY;
+    // 2 exp per element is the kernel's arithmetic; everything around it is kept to one fma and half a max per element: the gene-validity
+    // masks only exist in a tile that crosses G (wave-uniform test), the maxima go through v_max3, and exp(y - m) is exp2(fma(y, log2 e, -m log2 e))
+    if (g0 + 32 > p.G) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const bool ok = g0 + crow(q, h) < p.G;
-      yp[q] = ok ? yp[q] : -INFINITY;
-      ys[q] = ok ? ys[q] : -INFINITY;
-      tmp = fmaxf(tmp, yp[q]);
-      tms = fmaxf(tms, ys[q]);
+      for (int q = 0; q < 16; ++q) {
+        const bool ok = g0 + crow(q, h) < p.G;
+        yp[q] = ok ? yp[q] : -INFINITY;
+        ys[q] = ok ? ys[q] : -INFINITY;
+      }
+    }
+    float tmp = fmaxf(yp[0], yp[1]), tms = fmaxf(ys[0], ys[1]);
+#pragma unroll
+    for (int q = 2; q < 16; q += 2) {
+      tmp = __builtin_fmaxf(__builtin_fmaxf(tmp, yp[q]), yp[q + 1]);   // (pairs fold into v_max3_f32)
+      tms = __builtin_fmaxf(__builtin_fmaxf(tms, ys[q]), ys[q + 1]);
     }
     const float nmp = fmaxf(mp, tmp), nms = fmaxf(ms, tms);
     // a half-wave can see only masked genes in the last tile: keep exp() away from (-inf) - (-inf)
     const float smp = (nmp == -INFINITY) ? 0.f : nmp, sms = (nms == -INFINITY) ? 0.f : nms;
     sp *= fast_exp(mp - smp);
     ss *= fast_exp(ms - sms);
+    const float np2 = -smp * NB_LOG2E_C, ns2 = -sms * NB_LOG2E_C;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      sp += fast_exp(yp[q] - smp);
-      ss += fast_exp(ys[q] - sms);
+      sp += __builtin_amdgcn_exp2f(fmaf(yp[q], NB_LOG2E_C, np2));
+      ss += __builtin_amdgcn_exp2f(fmaf(ys[q], NB_LOG2E_C, ns2));
     }
     mp = nmp; ms = nms;
     wA = wB;
@@ -714,7 +723,8 @@ __device__ __forceinline__ void decode4(const u4v& x, float (&v)[4]) {   // hi +
 // over the split's genes and written as one partial slab per split -- the two [B,G] x [G,16|32] GEMMs of the backward
 // pass and their re-read of t'_P / t'_S disappear.
 constexpr int SMB_SUB = 320;            // genes of the transposed slice resident in LDS at a time
-constexpr int SMB_PITCH = SMB_SUB + 8;  // bf16 per row: 656 B = 164 dwords, rows 16 / 32 lanes apart fall on different banks
+constexpr int SMB_PITCH = SMB_SUB + 4;  // bf16 per row: 648 B = 162 dwords = 2 x 81: the 32 rows an 8-byte fragment read touches start on 32 distinct even banks
+                                        // (the first choice, 656 B = 4 x 41 dwords, put rows r and r + 16 on the same banks: SQ_LDS_BANK_CONFLICT 3.7 M per launch)
 
 // WRITE = false: read-only variant (FUSE only): the latent gradient alone, t_P / t_S stay uncorrected.  The backward pass's
 // critical chain (latent gradient -> trunk / PoE / encoder backward) then waits for a pass that only READS the two gradient
