@@ -141,6 +141,11 @@ class Trainer:
     # graph, which is captured with the images fresh.  Any torch-side write to one of the parameters (load_state_dict, broadcast)
     # changes its version counter: the token no longer matches and ``_ensure_images`` repacks before the next step.
     IMAGES_BY_ADAM = os.environ.get("SPV_ADAM_IMAGES", "1") != "0"
+    # Every kernel that produces a parameter gradient OVERWRITES its slice of the flat gradient buffer (the "gradient sink": one
+    # contribution per parameter per step, slab sums written with accumulate off), so the 47 MB fill at the start of a step (9 us at
+    # C2, at the head of the critical path) is not needed; the buffer is zero from construction, alignment padding stays zero.
+    # tests/test_gpu_train_and_model.py::test_every_gradient_element_is_overwritten_by_a_step pins that property (NaN-filled buffer).
+    ZERO_GRADS_EACH_STEP = os.environ.get("SPV_ZERO_GRADS", "0") != "0"
 
     def _image_specs(self):
         """[(workspace, key, image tensor, [(parameter, rows_off, col_off)], token parameters)] for every packed weight image"""
@@ -244,7 +249,8 @@ class Trainer:
         ``noise``: injected standard-normal draws (parity tests; see spVIPESmodule.inference)."""
         from . import nn_ops, ops
 
-        self.fp.grad.zero_()
+        if self.ZERO_GRADS_EACH_STEP:
+            self.fp.grad.zero_()
         self.module.split_backward = self.overlap   # (only for this call: a plain module(...) elsewhere keeps one backward pass)
         try:
             inf, gen, lo = self.module(self.minibatch(rows), inference_kwargs=({"noise": noise} if noise is not None else None),

@@ -364,3 +364,35 @@ def test_adam_written_weight_images_are_bit_identical_to_repacking(dev):
     trainer._ensure_images()    # explicit repack from the same parameters
     for x, (_ws, key, img, _p, _t) in zip(by_adam, trainer._img_specs):
         assert torch.equal(x, img), key
+
+
+@pytest.mark.parametrize("mode,precision", [("label", "bf16"), ("label", "fp32"), ("cluster", "bf16"), ("paired", "fp32")])
+def test_every_gradient_element_is_overwritten_by_a_step(dev, mode, precision):
+    """train.Trainer does not zero the flat gradient buffer at the start of a step (ZERO_GRADS_EACH_STEP off): that is only right
+    while every gradient kernel overwrites.  Fill the buffer with NaN, run forward + backward, and no parameter may hold a NaN."""
+    import scipy.sparse as sp
+    from spvipes_amd.data import MinibatchSampler, make_synthetic_group
+    from spvipes_amd.module import spVIPESmodule
+    from spvipes_amd.train import Trainer
+    groups = [make_synthetic_group(g, 1024, 300, dev) for g in range(2)]
+    torch.manual_seed(0)
+    kw = dict(n_hidden=128, n_dimensions_shared=10, n_dimensions_private=5, precision=precision)
+    if mode == "label":
+        module = spVIPESmodule({0: 300, 1: 300}, use_labels=True, **kw).to(dev)
+        trainer = Trainer(module, [g.counts for g in groups], labels=[g.labels for g in groups])
+    else:
+        rng = np.random.default_rng(0)
+        n = 1024
+        i, j, v = np.repeat(np.arange(n), 3), rng.integers(0, n, size=3 * n), rng.random(3 * n).astype(np.float32) + 0.1
+        P = sp.coo_matrix((v, (i, j)), shape=(n, n)).tocsr()
+        module = spVIPESmodule({0: 300, 1: 300}, use_labels=False, transport_plan=P, pair_data=(mode == "paired"), **kw).to(dev)
+        trainer = Trainer(module, [g.counts for g in groups], components=[g.labels for g in groups] if mode == "cluster" else None)
+    assert not trainer.ZERO_GRADS_EACH_STEP
+    sampler = MinibatchSampler([1024, 1024], 256, dev, seed=0)
+    module.train()
+    rows = next(iter(sampler.epoch()))
+    trainer.step(rows, kl_weight=1.0)
+    trainer.fp.grad.fill_(float("nan"))
+    trainer.step(rows, kl_weight=1.0, optimizer_step=False)
+    bad = [(n_, int(torch.isnan(p.grad).sum())) for n_, p in module.named_parameters() if p.grad is not None and bool(torch.isnan(p.grad).any())]
+    assert not bad, bad
