@@ -239,10 +239,16 @@ typedef struct spv_adam_image {
 
 /* spv_adam_step that also rewrites the bf16 images of the matrices it updates (the packed operands spv_pack_bf16 would otherwise
  * rebuild at the start of the next step: fc1 weights, [W_m | b_m]).  Image padding (rows / columns outside the matrix) is not
- * touched: the image must have been produced by spv_pack_bf16 once. */
+ * touched: the image must have been produced by spv_pack_bf16 once.  n_images may be 0. */
 int spv_adam_step_images(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                          float weight_decay, float bc1, float bc2, float grad_scale, const spv_adam_image* images, int32_t n_images,
-                         void* stream);
+                         int64_t* step_counter, void* stream);   /* step_counter (nullable): device int64 incremented by one per call */
+
+/* n standard-normal draws (the reparameterisation noise of a step: nn/networks.py:128-134, spVIPESmodule.py:346-349 sample with
+ * torch's generator) from a counter-based generator: Philox 4x32-10 on (element index / 4, *counter) keyed by `key`, Box-Muller.
+ * `counter` (nullable = 0) is read on the device when the kernel runs -- pass the step counter spv_adam_step_images increments and
+ * a captured graph draws fresh noise at every replay without any host-side generator state. */
+int spv_randn(float* out, int64_t n, const int64_t* counter, uint64_t key, void* stream);
 
 /* One Adam step (torch.optim.Adam semantics, L2 weight decay folded into the gradient) over a
  * flat fp32 parameter buffer; grad_scale multiplies g first (1/world for data-parallel means).

@@ -527,13 +527,55 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// standard-normal draws from a counter-based generator (Philox 4x32-10 + Box-Muller), keyed by (key, *counter): the step's noise
+// comes out of ONE launch that reads a device-resident step counter, so a captured hipGraph needs no generator state from the host
+// (torch's graph-safe generator costs two fill launches per replay + its own kernel, at the head of the step's critical path).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(unsigned (&c)[4], unsigned k0, unsigned k1) {
+  const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0], p1 = (unsigned long long)0xCD9E8D57u * c[2];
+  const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, long n, const long long* __restrict__ counter, unsigned long long key) {
+  const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  const unsigned long long step = counter ? (unsigned long long)*counter : 0ull;
+  unsigned c[4] = {(unsigned)(i4 >> 2), (unsigned)((unsigned long long)(i4 >> 2) >> 32), (unsigned)step, (unsigned)(step >> 32)};
+  unsigned k0 = (unsigned)key, k1 = (unsigned)(key >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+  float z[4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float u1 = ((float)(c[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);      // (0, 1)
+    const float u2 = ((float)(c[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float rad = sqrtf(-2.0f * __logf(u1));
+    float sn, cs;
+    __sincosf(6.283185307179586f * u2, &sn, &cs);
+    z[2 * h] = rad * cs; z[2 * h + 1] = rad * sn;
+  }
+  if (i4 + 4 <= n && ((reinterpret_cast<uintptr_t>(out + i4) & 15) == 0)) *reinterpret_cast<f4v*>(out + i4) = f4v{z[0], z[1], z[2], z[3]};
+  else for (int j = 0; j < 4 && i4 + j < n; ++j) out[i4 + j] = z[j];
+}
+__global__ void counter_bump_kernel(long long* counter) { if (threadIdx.x == 0 && blockIdx.x == 0) *counter += 1; }
+
+extern "C" int spv_randn(float* out, int64_t n, const int64_t* counter, uint64_t key, void* stream) {
+  if (!out || n < 0) return fail(SPV_ERR_ARG, "spv_randn: bad arguments%s");
+  if (n == 0) return SPV_OK;
+  hipLaunchKernelGGL(randn_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, out, (long)n, (const long long*)counter, (unsigned long long)key);
+  return launch_status("spv_randn");
+}
+
 // Adam that also refreshes the bf16 operand images of the matrices it has just updated (the fc1 weights of both encoders, the
 // mixing head's [W_m | b_m]): the step that follows then starts without its spv_pack_bf16 launches.  Same arithmetic as
 // adam_kernel; per 4-element chunk one range test per image (<= SPV_ADAM_MAX_IMAGES, all warp-uniform but at range borders).
 struct AdamImages { int n; spv_adam_image img[SPV_ADAM_MAX_IMAGES]; };
 
 __global__ void adam_images_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                   long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2, float gscale, AdamImages im) {
+                                   long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2, float gscale, AdamImages im,
+                                   long long* step_counter) {
+  if (step_counter && blockIdx.x == 0 && threadIdx.x == 0) *step_counter += 1;   // (read by the NEXT step's spv_randn / dropout: stream order)
   const long stride = (long)gridDim.x * blockDim.x * 4;
   const float step = lr / bc1, isq = rsqrtf(bc2);
   for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
@@ -585,7 +627,7 @@ __global__ void adam_images_kernel(float* __restrict__ p, const float* __restric
 
 extern "C" int spv_adam_step_images(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                                     float weight_decay, float bc1, float bc2, float grad_scale, const spv_adam_image* images, int32_t n_images,
-                                    void* stream) {
+                                    int64_t* step_counter, void* stream) {
   if (!p || !g || !m || !v || n < 0 || n_images < 0 || n_images > SPV_ADAM_MAX_IMAGES || (n_images && !images)) return fail(SPV_ERR_ARG, "spv_adam_step_images: bad arguments%s");
   if (n == 0) return SPV_OK;
   if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15)
@@ -603,7 +645,7 @@ extern "C" int spv_adam_step_images(float* p, const float* g, float* m, float* v
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adam_images_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, lr, beta1, beta2, eps,
-                     weight_decay, bc1, bc2, grad_scale, im);
+                     weight_decay, bc1, bc2, grad_scale, im, (long long*)step_counter);
   return launch_status("spv_adam_step_images");
 }
 

@@ -257,6 +257,14 @@ class spVIPESmodule(nn.Module):
     def nsplit(self) -> int:
         return 3 if self.precision == "fp32" else 1
 
+    def enable_device_rng(self, device, key: int, counter0: int = 0) -> None:
+        """Draw the step's standard-normal noise with ``spv_randn`` (counter-based, keyed by ``key`` and a device-resident step counter
+        that the optimiser's Adam launch increments) instead of torch's generator; the dropout masks use the same counter as seed.
+        The noise is a function of (key, counter) alone: forward passes between two optimiser steps (validation batches) see the same
+        draws on different cells, and setting ``_rng_counter`` reproduces a step."""
+        self._rng_counter = torch.full((), int(counter0), dtype=torch.int64, device=device)
+        self._rng_key = int(key) & 0xFFFFFFFFFFFFFFFF
+
     def _workspace(self, g: int, device) -> Workspace:
         ws = self._ws.get(g)
         if ws is None or ws.device != device:
@@ -334,7 +342,13 @@ class spVIPESmodule(nn.Module):
         missing = [k for k in want if noise.get(k) is None]
         draws = {}
         if missing:
-            flat = torch.randn(sum(want[k][0] * want[k][1] for k in missing), device=dev0)
+            total = sum(want[k][0] * want[k][1] for k in missing)
+            ctr = getattr(self, "_rng_counter", None)
+            if ctr is not None and ctr.device == dev0:   # counter-based device generator (train.Trainer.DEVICE_RNG, spv_randn)
+                flat = torch.empty(total, dtype=torch.float32, device=dev0)
+                _abi.call("spv_randn", _abi.ptr(flat), total, _abi.ptr(ctr), self._rng_key, _abi.stream_ptr())
+            else:
+                flat = torch.randn(total, device=dev0)
             off = 0
             for k in missing:
                 n = want[k][0] * want[k][1]
@@ -344,10 +358,14 @@ class spVIPESmodule(nn.Module):
         for g in groups_:
             eps_enc[g] = (draw(f"enc_{g}_private"), draw(f"enc_{g}_shared"))
         # (2) the dropout seed of this step,
-        if getattr(self, "_seed_dev", None) is None or self._seed_dev.device != dev0:
-            self._seed_dev = torch.zeros((), dtype=torch.int64, device=dev0)  # device-resident: survives hipGraph replay
-        if self.training and self.dropout_rate > 0:
-            self._seed_dev.add_(1)
+        ctr = getattr(self, "_rng_counter", None)
+        if ctr is not None and ctr.device == dev0:
+            self._seed_dev = ctr   # the dropout masks are keyed by the same device-resident step counter (incremented by the Adam launch)
+        else:
+            if getattr(self, "_seed_dev", None) is None or self._seed_dev.device != dev0 or self._seed_dev is getattr(self, "_rng_counter", None):
+                self._seed_dev = torch.zeros((), dtype=torch.int64, device=dev0)  # device-resident: survives hipGraph replay
+            if self.training and self.dropout_rate > 0:
+                self._seed_dev.add_(1)
         label_pre = None  # (measured: hoisting the label pairing up here as well, on this or on a third stream, gains nothing)
         streams = None
         from . import ops as _ops_mod

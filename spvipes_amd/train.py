@@ -92,14 +92,16 @@ class HipAdam:
         self.v = torch.zeros_like(fp.flat)
         self.t = 0
 
-    def step(self, grad_scale: float = 1.0, images=None):
-        """``images``: optional ctypes array of SpvAdamImage -- bf16 operand images the kernel rewrites from the updated values"""
+    def step(self, grad_scale: float = 1.0, images=None, counter=None):
+        """``images``: optional ctypes array of SpvAdamImage -- bf16 operand images the kernel rewrites from the updated values;
+        ``counter``: optional 0-dim int64 device tensor the kernel increments (the step counter the module's noise is keyed by)"""
         self.t += 1
         b1, b2 = self.betas
-        if images is not None and len(images):
+        if (images is not None and len(images)) or counter is not None:
+            n_img = len(images) if images is not None else 0
             _abi.call("spv_adam_step_images", _abi.ptr(self.fp.flat), _abi.ptr(self.fp.grad), _abi.ptr(self.m), _abi.ptr(self.v),
                       self.fp.numel, self.lr, b1, b2, self.eps, self.wd, 1.0 - b1 ** self.t, 1.0 - b2 ** self.t,
-                      grad_scale, images, len(images), _abi.stream_ptr())
+                      grad_scale, images if n_img else None, n_img, _abi.ptr(counter), _abi.stream_ptr())
             return
         _abi.call("spv_adam_step", _abi.ptr(self.fp.flat), _abi.ptr(self.fp.grad), _abi.ptr(self.m), _abi.ptr(self.v),
                   self.fp.numel, self.lr, b1, b2, self.eps, self.wd, 1.0 - b1 ** self.t, 1.0 - b2 ** self.t,
@@ -129,6 +131,11 @@ class Trainer:
         # two gradient buckets with the backward pass split between them (default: whenever there is more than one rank)
         self.overlap = (self.world > 1) if overlap_allreduce is None else bool(overlap_allreduce)
         self.global_step, self.epoch = 0, 0
+        if self.DEVICE_RNG:
+            # the module draws its noise (and keys its dropout masks) from a counter-based generator on the device: key from torch's
+            # seed + rank, counter incremented by the Adam launch -- see spv_randn; a replayed graph then needs no host generator state
+            rank = dist.get_rank() if self.world > 1 else 0   # ranks share the key and start their counters 2^40 apart
+            module.enable_device_rng(self.device, key=(int(torch.initial_seed()) * 0x9E3779B97F4A7C15 + 1) & 0xFFFFFFFFFFFFFFFF, counter0=rank << 40)
         self.graph = self.graph2 = None
         self.last_outputs = None
         self.history: Dict[str, List[float]] = {"train_loss": [], "elbo_train": [], "reconstruction_loss_train": [], "kl_local_train": []}
@@ -146,6 +153,7 @@ class Trainer:
     # C2, at the head of the critical path) is not needed; the buffer is zero from construction, alignment padding stays zero.
     # tests/test_gpu_train_and_model.py::test_every_gradient_element_is_overwritten_by_a_step pins that property (NaN-filled buffer).
     ZERO_GRADS_EACH_STEP = os.environ.get("SPV_ZERO_GRADS", "0") != "0"
+    DEVICE_RNG = os.environ.get("SPV_DEVICE_RNG", "1") != "0"
 
     def _image_specs(self):
         """[(workspace, key, image tensor, [(parameter, rows_off, col_off)], token parameters)] for every packed weight image"""
@@ -369,7 +377,7 @@ class Trainer:
             plan = getattr(self, "_img_plan", None)
             if plan is not None and not self._images_are_fresh():
                 plan = None   # (somebody wrote to a parameter since the images were made: plain Adam, _ensure_images repacks next step)
-            self.opt.step(grad_scale=1.0 / self.world, images=plan)
+            self.opt.step(grad_scale=1.0 / self.world, images=plan, counter=getattr(self.module, "_rng_counter", None))
             self.global_step += 1
         return lo
 

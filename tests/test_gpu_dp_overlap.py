@@ -36,7 +36,11 @@ def _setup(dev, overlap, G=(600, 500), n_cells=1024, precision="bf16"):
 
 
 def _set_dropout_seed(module, dev, value):
-    """the device-resident dropout seed counter is created by the first forward pass (and captured by address)"""
+    """the device-resident dropout seed counter is created by the first forward pass (and captured by address); with the trainer's
+    counter-based device generator the same counter also keys the step's noise"""
+    if getattr(module, "_rng_counter", None) is not None:
+        module._rng_counter.fill_(value)
+        return
     if getattr(module, "_seed_dev", None) is None:
         module._seed_dev = torch.zeros((), dtype=torch.int64, device=dev)
     module._seed_dev.fill_(value)

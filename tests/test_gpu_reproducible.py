@@ -32,9 +32,12 @@ def test_repeated_step_is_bit_identical(precision, overlap):
     first = None
     for rep in range(REPS):
         torch.manual_seed(1000)
-        if getattr(module, "_seed_dev", None) is None:
-            module._seed_dev = torch.zeros((), dtype=torch.int64, device=dev)
-        module._seed_dev.fill_(50)
+        if getattr(module, "_rng_counter", None) is not None:   # the trainer's device generator: noise + dropout keyed by this counter
+            module._rng_counter.fill_(50)
+        else:
+            if getattr(module, "_seed_dev", None) is None:
+                module._seed_dev = torch.zeros((), dtype=torch.int64, device=dev)
+            module._seed_dev.fill_(50)
         lo = tr._forward_backward(rows, 1.0)
         if overlap:
             tr._backward_encoders()

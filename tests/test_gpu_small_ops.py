@@ -85,3 +85,36 @@ def test_dropout_mask_is_reproducible_and_has_the_right_rate(dev):
     # drop rate: compare kept fraction of the positive fc2 activations through a backward pass
     a[3].sum().backward()
     assert torch.isfinite(h1.grad).all()
+
+
+def test_spv_randn_is_standard_normal_and_keyed_by_the_device_counter():
+    """spv_randn (Philox 4x32-10 + Box-Muller): moments of a large draw, independence of draws under different counters / keys,
+    determinism for the same (key, counter), odd lengths and unaligned outputs."""
+    import torch
+    from spvipes_amd import _abi
+    dev = torch.device("cuda:0")
+    n = 1 << 22
+    ctr = torch.zeros((), dtype=torch.int64, device=dev)
+    def draw(n_, key, out=None):
+        out = torch.empty(n_, dtype=torch.float32, device=dev) if out is None else out
+        _abi.call("spv_randn", _abi.ptr(out), n_, _abi.ptr(ctr), key, _abi.stream_ptr())
+        return out
+    a = draw(n, 1234)
+    assert abs(float(a.mean())) < 3e-3 and abs(float(a.std()) - 1.0) < 3e-3
+    assert abs(float((a ** 3).mean())) < 1e-2 and abs(float((a ** 4).mean()) - 3.0) < 3e-2
+    assert float(a.abs().max()) < 7.0 and bool(torch.isfinite(a).all())
+    # fraction inside one sigma
+    assert abs(float((a.abs() < 1).float().mean()) - 0.682689) < 2e-3
+    b = draw(n, 1234)
+    assert torch.equal(a, b)                      # same key, same counter
+    ctr.add_(1)
+    c = draw(n, 1234)
+    d = draw(n, 1235)
+    for x, y in ((a, c), (a, d), (c, d)):
+        assert abs(float((x * y).mean())) < 3e-3  # uncorrelated streams
+    # neighbouring elements uncorrelated, odd length, unaligned start
+    assert abs(float((a[:-1] * a[1:]).mean())) < 3e-3
+    buf = torch.full((1003,), 7.0, device=dev)
+    draw(1001, 99, out=buf[1:1002])
+    assert float(buf[0]) == 7.0 and float(buf[1002]) == 7.0 and bool((buf[1:1002] != 7.0).all())
+    assert torch.equal(buf[1:1002], draw(1001, 99))
