@@ -366,9 +366,17 @@ class spVIPESmodule(nn.Module):
                 self._seed_dev = torch.zeros((), dtype=torch.int64, device=dev0)  # device-resident: survives hipGraph replay
             if self.training and self.dropout_rate > 0:
                 self._seed_dev.add_(1)
-        label_pre = None  # (measured: hoisting the label pairing up here as well, on this or on a third stream, gains nothing)
-        streams = None
         from . import ops as _ops_mod
+        # the label pairing (rank within label + partner lookup, ~28 us of two tiny launches) depends on the labels alone: with
+        # LABEL_PRE it runs on a side stream beside the fc1 GEMMs instead of on the chain between the encoder tails and the fusion
+        label_pre, pre_stream = None, None
+        if (_ops_mod.LABEL_PRE and self.n_groups == 2 and self.use_labels and kwargs.get("labels") is not None and not _ops_mod.SERIAL_STREAMS):
+            from .nn_ops import label_partners
+            pre_stream = group_streams(dev0, 3)[2]
+            pre_stream.wait_stream(torch.cuda.current_stream(dev0))
+            with torch.cuda.stream(pre_stream):
+                label_pre = label_partners([kwargs["labels"][0], kwargs["labels"][1]], self._workspace(0, dev0))
+        streams = None
         grouped = bool(_ops_mod.FC1_GROUPED and len(groups_) >= 2)
         if grouped:   # one autograd node, one launch per kernel for every pair of groups (ops.EncoderFC1Grouped)
             cl, rl, bl, wl, pl = [], [], [], [], []
@@ -426,12 +434,18 @@ class spVIPESmodule(nn.Module):
             labels = dict(enumerate(kwargs["labels"]))
         if self.use_transport_plan and not self.pair_data:
             processed_labels = kwargs.get("processed_labels")
+        if pre_stream is not None and not (self.n_groups == 2 and self.use_labels and labels is not None):
+            torch.cuda.current_stream(dev0).wait_stream(pre_stream)
+            pre_stream = None
         if self.n_groups > 2:
             poe_stats = self._components_poe_hip(shared_stats, processed_labels if processed_labels is not None else (list(labels.values()) if labels else None), noise)
         elif self.use_labels and labels is not None:
             # label-based PoE (priority as spVIPESmodule.py:492-493): pairing + fusion + draw + KL in HIP
             dev = shared_stats[0]["logtheta_loc"].device
             e = [draw(f"poe_{g}") for g in (0, 1)]
+            if pre_stream is not None:
+                torch.cuda.current_stream(dev).wait_stream(pre_stream)
+                pre_stream = None
             o = PoELabel.apply([labels[0], labels[1]], e, self._workspace(0, dev), label_pre, shared_stats[0]["logtheta_loc"], shared_stats[0]["logtheta_logvar"],
                                shared_stats[1]["logtheta_loc"], shared_stats[1]["logtheta_logvar"])
             poe_stats = {}

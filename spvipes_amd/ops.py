@@ -137,6 +137,7 @@ STAGGER_BWD = os.environ.get("SPV_STAGGER_BWD", "0") != "0"  # backward: group 1
 DA_FIRST = int(os.environ.get("SPV_DA_FIRST", "0"))  # backward: d A_m GEMMs first, softmax fixes on the side stream (1: side starts after them, 2: with them)
 WM_LATE = os.environ.get("SPV_WM_LATE", "0") != "0"  # mixture-weight GEMMs held back until the BatchNorm-fold backward (beside the tiny-kernel tail)
 FC1_GROUPED = os.environ.get("SPV_FC1_GROUPED", "1") != "0"  # both groups' fc1 GEMMs as one launch per kernel (EncoderFC1Grouped) instead of two streams
+LABEL_PRE = os.environ.get("SPV_LABEL_PRE", "0") != "0"  # label pairing on a side stream beside the fc1 GEMMs
 HEADS_DMA = os.environ.get("SPV_HEADS_DMA", "1") != "0"  # both regressor weight gradients in one LDS-DMA pass (spv_dec_heads_wgrad)
 FUSED_DZ = os.environ.get("SPV_FUSED_DZ", "1") != "0"  # softmax fix also produces the latent gradient of the rate heads
 FUSED_PACK = os.environ.get("SPV_FUSED_PACK", "1") != "0"  # latent / trunk kernels also write the decoder's bf16 operand images
