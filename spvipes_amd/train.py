@@ -297,8 +297,8 @@ class Trainer:
     def capture(self, rows: Sequence[torch.Tensor], warmup: int = 3) -> None:
         """Capture forward + loss + backward of one step into a hipGraph (``torch.cuda.CUDAGraph``): the ~100
         launches of a step replay as one submission.  Everything that changes between steps lives in device
-        memory: the row indices (copied into static buffers), the KL weight (0-dim tensor), the dropout seed
-        (module._seed_dev), the noise (graph-safe generator).  The all-reduce and Adam stay outside; in a
+        memory: the row indices (copied into static buffers), the KL weight (0-dim tensor) and the step counter that keys the
+        dropout masks and the noise (module._rng_counter; torch's graph-safe generator when DEVICE_RNG is off).  The all-reduce and Adam stay outside; in a
         data-parallel job the step is captured as TWO graphs (decoder half / encoder half of the backward pass, same
         memory pool) so that the first gradient bucket is on the wire while the second graph runs."""
         if self.graph is not None:

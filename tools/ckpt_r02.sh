@@ -24,12 +24,12 @@ done
 unset SPV_SERIAL_STREAMS
 cd $R
 { echo "# workload: c2 bf16 u16 B4096 G10000"; for d in fetch write valu wave mfma; do f=$(find $O/${T}_pmc_$d -name "*counter_collection.csv" | head -1); echo "== --pmc pass: $d"; [ -n "$f" ] && python tools/pmc_summary.py $f dec_nb_kernel; done; } > $O/${T}_pmc_dec_nb_kernel.txt
-{ echo "# workload: c2 bf16 u16 B4096 G10000"; for d in fetch write valu wave mfma; do f=$(find $O/${T}_pmc_$d -name "*counter_collection.csv" | head -1); echo "== --pmc pass: $d"; [ -n "$f" ] && python tools/pmc_summary.py $f fc1_fwd_dma_kernel; done; } > $O/${T}_pmc_fc1_fwd_dma_kernel.txt
-{ echo "# workload: c2 bf16 u16 B4096 G10000"; for d in fetch write valu wave mfma; do f=$(find $O/${T}_pmc_$d -name "*counter_collection.csv" | head -1); echo "== --pmc pass: $d"; [ -n "$f" ] && python tools/pmc_summary.py $f fc1_wgrad_dma_kernel; done; } > $O/${T}_pmc_fc1_wgrad_dma_kernel.txt
+{ echo "# workload: c2 bf16 u16 B4096 G10000"; for d in fetch write valu wave mfma; do f=$(find $O/${T}_pmc_$d -name "*counter_collection.csv" | head -1); echo "== --pmc pass: $d"; [ -n "$f" ] && python tools/pmc_summary.py $f fc1_fwd_dma_pair_kernel; done; } > $O/${T}_pmc_fc1_fwd_dma_pair_kernel.txt
+{ echo "# workload: c2 bf16 u16 B4096 G10000"; for d in fetch write valu wave mfma; do f=$(find $O/${T}_pmc_$d -name "*counter_collection.csv" | head -1); echo "== --pmc pass: $d"; [ -n "$f" ] && python tools/pmc_summary.py $f fc1_wgrad_dma_pair_kernel; done; } > $O/${T}_pmc_fc1_wgrad_dma_pair_kernel.txt
 for k in dec_gemm320_dma4_kernel dec_heads_wgrad_dma_kernel dec_logits_dma_kernel dec_softmax_bwd_kernel; do
   { echo "# workload: c2 bf16 u16 B4096 G10000"; for d in fetch write valu wave mfma; do f=$(find $O/${T}_pmc_$d -name "*counter_collection.csv" | head -1); echo "== --pmc pass: $d"; [ -n "$f" ] && python tools/pmc_summary.py $f $k; done; } > $O/${T}_pmc_$k.txt
 done
-cat $O/${T}_pmc_fc1_fwd_dma_kernel.txt
+cat $O/${T}_pmc_fc1_fwd_dma_pair_kernel.txt
 f=$(find $O/${T}_prof_serial -name "*kernel_stats.csv" | head -1); cp $f $O/${T}_serial_rocprofv3_kernel_stats.csv; python tools/prof_summary.py $f 38 40 > $O/${T}_serial_rocprofv3_kernel_stats_summary.txt; head -24 $O/${T}_serial_rocprofv3_kernel_stats_summary.txt
 f=$(find $O/${T}_prof -name "*kernel_stats.csv" | head -1); cp $f $O/${T}_rocprofv3_kernel_stats.csv; python tools/prof_summary.py $f 38 40 > $O/${T}_rocprofv3_kernel_stats_summary.txt
 bash tools/timeline.sh $T > /dev/null 2>&1 || true
