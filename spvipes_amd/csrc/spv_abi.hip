@@ -147,7 +147,7 @@ static int fc1_fwd_dispatch(const GemmParams& p, int N1, int splits, hipStream_t
 // because the path fixes the slab workspace: [splits][round_up(B, 128)][256] fp32 in accumulator-tile order.
 extern "C" int spv_enc_fc1_fwd_uses_dma(int32_t B, int32_t G, int32_t N1, int32_t nsplit, int32_t have_xb, int64_t ldw, int64_t ld_xb) {
   const long G64 = (G + 63) & ~63L;
-  return have_xb && nsplit == 1 && N1 == F1_BN && B > 0 && G > 0 && ldw >= G64 && ld_xb >= G64 && (ldw % 8) == 0 && (ld_xb % 8) == 0;
+  return have_xb && nsplit == 1 && (N1 == F1_BN || N1 == 2 * F1_BN) && B > 0 && G > 0 && ldw >= G64 && ld_xb >= G64 && (ldw % 8) == 0 && (ld_xb % 8) == 0;
 }
 
 static int fc1_bn(int N1) { return N1 <= 32 ? 32 : (N1 <= 128 ? 128 : 256); }
@@ -189,10 +189,10 @@ extern "C" int spv_enc_fc1_fwd(const spv_counts* x, int32_t B, int32_t G, const 
     p.c_split_row = splits;
     static bool raised = false;
     if (!raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fc1_fwd_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F1_LDS_BYTES); raised = true; }
-    hipLaunchKernelGGL(fc1_fwd_dma_kernel, dim3(mtiles * splits), dim3(512), F1_LDS_BYTES, s, p);
+    hipLaunchKernelGGL(fc1_fwd_dma_kernel, dim3(mtiles * splits, N1 / F1_BN), dim3(512), F1_LDS_BYTES, s, p);
     if (hipGetLastError() != hipSuccess) return launch_status("spv_enc_fc1_fwd dma gemm");
-    const long slab_elems = (long)mtiles * F1_BM * F1_BN;
-    hipLaunchKernelGGL(fc1_epilogue_tiled_kernel, dim3((unsigned)((slab_elems / 4 + 255) / 256)), dim3(256), 0, s, slabs, splits, slab_elems, B, bias, bias2, n_first, h1, library,
+    const long slab_elems = (long)mtiles * F1_BM * N1;
+    hipLaunchKernelGGL(fc1_epilogue_tiled_kernel, dim3((unsigned)((slab_elems / 4 + 255) / 256)), dim3(256), 0, s, slabs, splits, slab_elems, B, N1, bias, bias2, n_first, h1, library,
                        library_all, x->rows);
     return launch_status("spv_enc_fc1_fwd dma epilogue");
   }
@@ -232,7 +232,7 @@ extern "C" int spv_enc_fc1_wgrad(const spv_counts* x, int32_t B, int32_t G, cons
     if (nsplit != 1 || ld_xb < ((G + 63) & ~63) || (ld_xb % 8)) return fail(SPV_ERR_ARG, "spv_enc_fc1_wgrad: xb needs nsplit 1 and ld_xb >= round_up(G, 64)%s");
     p.B = xb; p.ldb = ld_xb;
     const int Kpad = (B + FW_BK - 1) / FW_BK * FW_BK;
-    if (N1 == FW_BM && ld_dh == FW_BM && rows_first == FW_BM / 2 && dW2 != nullptr && fw_lds_bytes(64, Kpad) <= 160 * 1024 &&
+    if ((N1 == FW_BM || N1 == 2 * FW_BM) && ld_dh == N1 && rows_first == N1 / 2 && dW2 != nullptr && fw_lds_bytes(64, Kpad) <= 160 * 1024 &&
         ((reinterpret_cast<uintptr_t>(xb) | reinterpret_cast<uintptr_t>(dh_hi)) & 15) == 0) {
       // LDS-DMA kernel (spv_fc1.h): all 256 rows x 64 genes per workgroup over the whole batch, results straight into dW / dW2
       // (measured at C2, tools/probes/fc1w_bench.hip: 51 us alone against 75 us for the register-staged kernel below)
@@ -244,7 +244,7 @@ extern "C" int spv_enc_fc1_wgrad(const spv_counts* x, int32_t B, int32_t G, cons
       void (*kfn)(GemmParams) = use96 ? fc1_wgrad_dma_kernel<96> : fc1_wgrad_dma_kernel<64>;
       const int lds = fw_lds_bytes(use96 ? 96 : 64, Kpad);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipLaunchKernelGGL(kfn, dim3(use96 ? nb96 : nb64), dim3(512), lds, s, p);
+      hipLaunchKernelGGL(kfn, dim3(use96 ? nb96 : nb64, N1 / FW_BM), dim3(512), lds, s, p);
       return launch_status("spv_enc_fc1_wgrad dma");
     }
     // 96-gene tiles when the image rows are padded that far: at G = 10 000 that is 2 x 105 workgroups per group, so the two
@@ -1064,16 +1064,16 @@ extern "C" int spv_enc_fc1_fwd_grouped(const spv_fc1_fwd_args* g, int32_t n_grou
   int i = 0;
   for (; i + 1 < n_groups; i += 2) {
     const spv_fc1_fwd_args &a = g[i], &b = g[i + 1];
-    if (!(fc1_fwd_dma_ok(a) && fc1_fwd_dma_ok(b))) break;
+    if (!(fc1_fwd_dma_ok(a) && fc1_fwd_dma_ok(b) && a.N1 == b.N1)) break;
     const GemmParams p0 = fc1_fwd_dma_params(a), p1 = fc1_fwd_dma_params(b);
     const int mt0 = (a.B + F1_BM - 1) / F1_BM, mt1 = (b.B + F1_BM - 1) / F1_BM;
     static bool raised = false;
     if (!raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fc1_fwd_dma_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F1_LDS_BYTES); raised = true; }
-    hipLaunchKernelGGL(fc1_fwd_dma_pair_kernel, dim3(mt0 * a.splits + mt1 * b.splits), dim3(512), F1_LDS_BYTES, s, p0, p1, mt0 * a.splits);
+    hipLaunchKernelGGL(fc1_fwd_dma_pair_kernel, dim3(mt0 * a.splits + mt1 * b.splits, a.N1 / F1_BN), dim3(512), F1_LDS_BYTES, s, p0, p1, mt0 * a.splits);
     if (hipGetLastError() != hipSuccess) return launch_status("spv_enc_fc1_fwd_grouped gemm");
-    const long se0 = (long)mt0 * F1_BM * F1_BN, se1 = (long)mt1 * F1_BM * F1_BN;
-    const Fc1EpiArgs e0{a.slabs, a.splits, se0, a.B, a.bias, a.bias2, a.n_first, a.h1, a.library, a.library_all, a.x->rows};
-    const Fc1EpiArgs e1{b.slabs, b.splits, se1, b.B, b.bias, b.bias2, b.n_first, b.h1, b.library, b.library_all, b.x->rows};
+    const long se0 = (long)mt0 * F1_BM * a.N1, se1 = (long)mt1 * F1_BM * b.N1;
+    const Fc1EpiArgs e0{a.slabs, a.splits, se0, a.B, a.N1, a.bias, a.bias2, a.n_first, a.h1, a.library, a.library_all, a.x->rows};
+    const Fc1EpiArgs e1{b.slabs, b.splits, se1, b.B, b.N1, b.bias, b.bias2, b.n_first, b.h1, b.library, b.library_all, b.x->rows};
     const long sem = se0 > se1 ? se0 : se1;
     hipLaunchKernelGGL(fc1_epilogue_tiled_pair_kernel, dim3((unsigned)((sem / 4 + 255) / 256), 2), dim3(256), 0, s, e0, e1);
     if (hipGetLastError() != hipSuccess) return launch_status("spv_enc_fc1_fwd_grouped epilogue");
@@ -1090,7 +1090,7 @@ extern "C" int spv_enc_fc1_fwd_grouped(const spv_fc1_fwd_args* g, int32_t n_grou
 static bool fc1_bwd_dma_ok(const spv_fc1_bwd_args& a) {
   if (!a.x || !a.x->X || !a.dh1 || !a.h1 || !a.dh_hi || !a.part || !a.db || !a.dW || !a.dW2 || !a.xb || a.B <= 0 || a.G <= 0) return false;
   const int Kpad = (a.B + FW_BK - 1) / FW_BK * FW_BK;
-  return a.nsplit == 1 && a.N1 == FW_BM && a.ld_dh == FW_BM && a.n_first == FW_BM / 2 && a.Bp >= Kpad && (a.Bp % 64) == 0 && a.ldc >= a.G &&
+  return a.nsplit == 1 && (a.N1 == FW_BM || a.N1 == 2 * FW_BM) && a.ld_dh == a.N1 && a.n_first == a.N1 / 2 && a.Bp >= Kpad && (a.Bp % 64) == 0 && a.ldc >= a.G &&
          a.ld_xb >= ((a.G + 63) & ~63) && (a.ld_xb % 8) == 0 && fw_lds_bytes(96, Kpad) <= 160 * 1024 &&
          ((reinterpret_cast<uintptr_t>(a.xb) | reinterpret_cast<uintptr_t>(a.dh_hi)) & 15) == 0;
 }
@@ -1101,12 +1101,12 @@ extern "C" int spv_enc_fc1_bwd_grouped(const spv_fc1_bwd_args* g, int32_t n_grou
   int i = 0;
   for (; i + 1 < n_groups; i += 2) {
     const spv_fc1_bwd_args &a = g[i], &b = g[i + 1];
-    if (!(fc1_bwd_dma_ok(a) && fc1_bwd_dma_ok(b))) break;
+    if (!(fc1_bwd_dma_ok(a) && fc1_bwd_dma_ok(b) && a.N1 == b.N1)) break;
     const Fc1PrepArgs q0{a.dh1, a.h1, a.B, a.N1, (bf16_t*)a.dh_hi, (bf16_t*)a.dh_lo, (long)a.ld_dh, a.part, a.Bp / 16, a.db, a.db2, a.n_first};
     const Fc1PrepArgs q1{b.dh1, b.h1, b.B, b.N1, (bf16_t*)b.dh_hi, (bf16_t*)b.dh_lo, (long)b.ld_dh, b.part, b.Bp / 16, b.db, b.db2, b.n_first};
     const int nb = q0.nblk > q1.nblk ? q0.nblk : q1.nblk;
     hipLaunchKernelGGL(fc1_bwd_prep_pair_kernel, dim3(nb, 2), dim3(256), 0, s, q0, q1);
-    hipLaunchKernelGGL(fc1_bwd_bias_pair_kernel, dim3((FW_BM + 63) / 64, 2), dim3(256), 0, s, q0, q1);
+    hipLaunchKernelGGL(fc1_bwd_bias_pair_kernel, dim3((a.N1 + 63) / 64, 2), dim3(256), 0, s, q0, q1);
     if (hipGetLastError() != hipSuccess) return launch_status("spv_enc_fc1_bwd_grouped prep");
     GemmParams p[2];
     for (int k = 0; k < 2; ++k) {
@@ -1118,13 +1118,14 @@ extern "C" int spv_enc_fc1_bwd_grouped(const spv_fc1_bwd_args* g, int32_t n_grou
     }
     // tile: the one that gets BOTH groups into the fewest rounds of 256 one-per-CU workgroups (64-gene tiles are the faster ones alone)
     const int n64 = (a.G + 63) / 64 + (b.G + 63) / 64, n96 = (a.G + 95) / 96 + (b.G + 95) / 96;
-    const bool use96 = (n96 + 255) / 256 < (n64 + 255) / 256;
+    const int mth = a.N1 / FW_BM;   // 256-unit halves of the dh image (H = 256: one per encoder)
+    const bool use96 = (n96 * mth + 255) / 256 < (n64 * mth + 255) / 256;
     const int Kp0 = (a.B + FW_BK - 1) / FW_BK * FW_BK, Kp1 = (b.B + FW_BK - 1) / FW_BK * FW_BK;
     const int lds = fw_lds_bytes(use96 ? 96 : 64, Kp0 > Kp1 ? Kp0 : Kp1);
     void (*kfn)(GemmParams, GemmParams, int) = use96 ? fc1_wgrad_dma_pair_kernel<96> : fc1_wgrad_dma_pair_kernel<64>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     const int t = use96 ? 96 : 64, nA = (a.G + t - 1) / t, nB = (b.G + t - 1) / t;
-    hipLaunchKernelGGL(kfn, dim3(nA + nB), dim3(512), lds, s, p[0], p[1], nA);
+    hipLaunchKernelGGL(kfn, dim3(nA + nB, mth), dim3(512), lds, s, p[0], p[1], nA);
     if (hipGetLastError() != hipSuccess) return launch_status("spv_enc_fc1_bwd_grouped wgrad");
   }
   for (; i < n_groups; ++i) {

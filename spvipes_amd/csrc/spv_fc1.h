@@ -53,7 +53,7 @@ __device__ __forceinline__ s8v join8(const s4v& v0, const s4v& v1) { return s8v{
 // p.A = bf16 image [n_cells_total][lda] (zero padded to a multiple of 64 genes), p.rows = minibatch row index (nullable),
 // p.B = W bf16 [256][ldb] (zero padded likewise), p.C = slabs in tile order, p.M = cells in the minibatch, p.K = genes,
 // p.k_per_split multiple of 64, p.c_split_row = number of K splits.  grid = ceil(M / 128) * splits (1-D), 512 threads.
-__device__ __forceinline__ void fc1_fwd_dma_body(const GemmParams& p, const int blk, unsigned char* f1_smem) {
+__device__ __forceinline__ void fc1_fwd_dma_body(const GemmParams& p, const int blk, const int ntile, unsigned char* f1_smem) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: the LDS-DMA destination must be
   const int wm = wave >> 2, wn = wave & 3;
@@ -83,7 +83,7 @@ __device__ __forceinline__ void fc1_fwd_dma_body(const GemmParams& p, const int 
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {   // B pieces 4 wave + i: rows (output columns) 8 (4 wave + i) + lr of W
-    const int piece = 4 * wave + i, n = 8 * piece + lr;
+    const int piece = 4 * wave + i, n = 8 * piece + lr + ntile * F1_BN;   // (ntile: which 256 of the N1 = 256 or 512 output columns)
     const int c = pos ^ ((n >> 1) & 7);
     src[2 + i] = (glb_byte*)(p.B) + ((long)n * p.ldb + kbeg + 8 * c) * 2;
     dst_off[2 + i] = F1_A_BYTES + piece * 1024;
@@ -172,13 +172,14 @@ __device__ __forceinline__ void fc1_fwd_dma_body(const GemmParams& p, const int 
 
   // ---- partial slab in accumulator-tile order: S[split][row / 32][col / 32][qq][lane][4] ------------------------------------
   const long mtiles = (long)((p.M + F1_BM - 1) / F1_BM) * (F1_BM / 32);
-  float* slab = p.C + (long)split * mtiles * (F1_BN / 32) * 1024;
+  const int NT = p.N / 32;   // column tiles of a slab row
+  float* slab = p.C + (long)split * mtiles * NT * 1024;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const long tm = (long)mtile * (F1_BM / 32) + wm * 2 + i, tn = wn * 2 + j;
-      float* o = slab + (tm * (F1_BN / 32) + tn) * 1024 + lane * 4;
+      const long tm = (long)mtile * (F1_BM / 32) + wm * 2 + i, tn = ntile * (F1_BN / 32) + wn * 2 + j;
+      float* o = slab + (tm * NT + tn) * 1024 + lane * 4;
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq)
         *reinterpret_cast<f4v*>(o + qq * 256) = f4v{acc[i][j][4 * qq], acc[i][j][4 * qq + 1], acc[i][j][4 * qq + 2], acc[i][j][4 * qq + 3]};
@@ -187,7 +188,7 @@ __device__ __forceinline__ void fc1_fwd_dma_body(const GemmParams& p, const int 
 
 __global__ __launch_bounds__(512) void fc1_fwd_dma_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char f1_smem_[];
-  fc1_fwd_dma_body(p, blockIdx.x, f1_smem_);
+  fc1_fwd_dma_body(p, blockIdx.x, blockIdx.y, f1_smem_);
 }
 // both groups of a step in ONE grid (workgroups 0 .. n0 - 1: the first group's): one launch instead of two launches on two streams
 // whose 2 x 256 one-per-CU workgroups can only run one after the other anyway -- without the fork / join of the graph branches
@@ -195,22 +196,22 @@ __global__ __launch_bounds__(512) void fc1_fwd_dma_pair_kernel(GemmParams p0, Ge
   extern __shared__ __attribute__((aligned(16))) unsigned char f1_smem_[];
   const bool first = (int)blockIdx.x < n0;   // (workgroup-uniform)
   const GemmParams p = first ? p0 : p1;
-  fc1_fwd_dma_body(p, first ? (int)blockIdx.x : (int)blockIdx.x - n0, f1_smem_);
+  fc1_fwd_dma_body(p, first ? (int)blockIdx.x : (int)blockIdx.x - n0, blockIdx.y, f1_smem_);
 }
 
 // h1[cell][col] = relu(bias[col] + sum_splits S[split][...]), library from the data set's table (spv_prepare_log1p).
 // One thread per (tile, qq, lane): 16 bytes of every split's slab in, four floats (rows jj + 8 qq + 4 h of the tile) out.
-struct Fc1EpiArgs { const float* slabs; int splits; long slab_elems; int M; const float* bias; const float* bias2; int n_first; float* h1; float* library;
+struct Fc1EpiArgs { const float* slabs; int splits; long slab_elems; int M; int N1; const float* bias; const float* bias2; int n_first; float* h1; float* library;
                     const float* library_all; const int* rows; };
-__device__ __forceinline__ void fc1_epilogue_tiled_body(const float* slabs, int splits, long slab_elems, int M, const float* bias,
+__device__ __forceinline__ void fc1_epilogue_tiled_body(const float* slabs, int splits, long slab_elems, int M, const int N1, const float* bias,
                                                         const float* bias2, int n_first, float* h1, float* library,
                                                         const float* library_all, const int* rows) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // float4 index inside one slab
   if (idx * 4 < slab_elems) {
     const long tile = idx >> 8;
     const int qq = (int)(idx >> 6) & 3, lane = (int)idx & 63, r = lane & 31, h = lane >> 5;
-    const long tm = tile / (F1_BN / 32);
-    const int tn = (int)(tile % (F1_BN / 32));
+    const long tm = tile / (N1 / 32);
+    const int tn = (int)(tile % (N1 / 32));
     f4v s = *reinterpret_cast<const f4v*>(slabs + idx * 4);
     for (int k = 1; k < splits; ++k) {
       const f4v v = *reinterpret_cast<const f4v*>(slabs + (long)k * slab_elems + idx * 4);
@@ -221,18 +222,18 @@ __device__ __forceinline__ void fc1_epilogue_tiled_body(const float* slabs, int 
     const long row0 = tm * 32 + 8 * qq + 4 * h;
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj)
-      if (row0 + jj < M) h1[(row0 + jj) * F1_BN + col] = fmaxf(s[jj] + bv, 0.f);   // relu(fc1(x)), nn/networks.py:119
+      if (row0 + jj < M) h1[(row0 + jj) * N1 + col] = fmaxf(s[jj] + bv, 0.f);   // relu(fc1(x)), nn/networks.py:119
   }
   if (idx < M) library[idx] = library_all[rows ? rows[idx] : (int)idx];   // log(sum_g log1p(x)), module/spVIPESmodule.py:435
 }
-__global__ __launch_bounds__(256) void fc1_epilogue_tiled_kernel(const float* slabs, int splits, long slab_elems, int M, const float* bias,
+__global__ __launch_bounds__(256) void fc1_epilogue_tiled_kernel(const float* slabs, int splits, long slab_elems, int M, int N1, const float* bias,
                                                                  const float* bias2, int n_first, float* h1, float* library,
                                                                  const float* library_all, const int* rows) {
-  fc1_epilogue_tiled_body(slabs, splits, slab_elems, M, bias, bias2, n_first, h1, library, library_all, rows);
+  fc1_epilogue_tiled_body(slabs, splits, slab_elems, M, N1, bias, bias2, n_first, h1, library, library_all, rows);
 }
 __global__ __launch_bounds__(256) void fc1_epilogue_tiled_pair_kernel(Fc1EpiArgs a0, Fc1EpiArgs a1) {   // blockIdx.y = group
   const Fc1EpiArgs a = blockIdx.y ? a1 : a0;
-  fc1_epilogue_tiled_body(a.slabs, a.splits, a.slab_elems, a.M, a.bias, a.bias2, a.n_first, a.h1, a.library, a.library_all, a.rows);
+  fc1_epilogue_tiled_body(a.slabs, a.splits, a.slab_elems, a.M, a.N1, a.bias, a.bias2, a.n_first, a.h1, a.library, a.library_all, a.rows);
 }
 
 // ---- fc1 weight gradient:  dW[n1][gene] = sum_cell dh[cell][n1] * log1p(X)[rows[cell]][gene]   (backward of nn/networks.py:119) -------
@@ -268,7 +269,7 @@ __host__ __device__ constexpr int fw_lds_bytes(int wg_bn, int kpad) { return (FW
 // minibatch, p.N = genes, p.C / p.C2 = dW of the first / second 128 rows, p.ldc.  grid = ceil(N / WG_BN), 512 threads,
 // dynamic LDS = fw_lds_bytes(WG_BN, Kpad).
 template <int WG_BN>
-__device__ __forceinline__ void fc1_wgrad_dma_body(const GemmParams& p, const int blk, unsigned char* fw_smem) {
+__device__ __forceinline__ void fc1_wgrad_dma_body(const GemmParams& p, const int blk, const int mtile, unsigned char* fw_smem) {
   typedef FwCfg<WG_BN> Cfg;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = uniform_wave_id();
@@ -289,7 +290,7 @@ __device__ __forceinline__ void fc1_wgrad_dma_body(const GemmParams& p, const in
   for (int i = 0; i < Cfg::A_PIECES; ++i) {
     const int piece = Cfg::A_PIECES * wave + i, row = 2 * piece + (lane >> 5), ch = lane & 31;
     const int chs = (((ch >> 2) ^ (row & 3)) << 2) | (ch & 3);
-    srcA[i] = (glb_byte*)(p.A) + ((long)row * FW_BM) * 2 + chs * 16;
+    srcA[i] = (glb_byte*)(p.A) + ((long)row * p.lda + mtile * FW_BM) * 2 + chs * 16;   // (mtile: which 256 of the N1 = 256 or 512 units; lda = N1)
   }
   // B pieces: rows of 2 WG_BN bytes; wave w owns rows 8w .. 8w + 7 as well
   int browB[Cfg::B_PIECES], bcolB[Cfg::B_PIECES];
@@ -312,7 +313,7 @@ __device__ __forceinline__ void fc1_wgrad_dma_body(const GemmParams& p, const in
   }
   const glb_byte* const Bbase = (glb_byte*)(p.B) + (long)n0 * 2;
   auto issueA = [&](int t, int i) {   // A piece i of tile t
-    dma16(srcA[i] + (long)t * (FW_BK * FW_BM * 2), lds + (t % FW_NBUF) * Cfg::STAGE + (Cfg::A_PIECES * wave + i) * 1024);
+    dma16(srcA[i] + (long)t * (FW_BK * p.lda * 2), lds + (t % FW_NBUF) * Cfg::STAGE + (Cfg::A_PIECES * wave + i) * 1024);
   };
   auto issueB = [&](int t) {          // all B pieces of tile t (their row indices come out of the LDS table)
 #pragma unroll
@@ -411,7 +412,7 @@ __device__ __forceinline__ void fc1_wgrad_dma_body(const GemmParams& p, const in
       if (col >= p.N) continue;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const int row = wm * (FW_BM / Cfg::WAVES_M) + 32 * i + crow(q, h);
+        const int row = mtile * FW_BM + wm * (FW_BM / Cfg::WAVES_M) + 32 * i + crow(q, h);
         float* dst = (row >= p.c_split_row) ? p.C2 + (long)(row - p.c_split_row) * p.ldc + col : p.C + (long)row * p.ldc + col;
         *dst = acc[i][j][q];
       }
@@ -421,7 +422,7 @@ __device__ __forceinline__ void fc1_wgrad_dma_body(const GemmParams& p, const in
 template <int WG_BN>
 __global__ __launch_bounds__(512) void fc1_wgrad_dma_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fw_smem_[];
-  fc1_wgrad_dma_body<WG_BN>(p, blockIdx.x, fw_smem_);
+  fc1_wgrad_dma_body<WG_BN>(p, blockIdx.x, blockIdx.y, fw_smem_);
 }
 // both groups in one grid (see fc1_fwd_dma_pair_kernel); dynamic LDS = the larger of the two groups' needs
 template <int WG_BN>
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(512) void fc1_wgrad_dma_pair_kernel(GemmParams p0, 
   extern __shared__ __attribute__((aligned(16))) unsigned char fw_smem_[];
   const bool first = (int)blockIdx.x < n0;
   const GemmParams p = first ? p0 : p1;
-  fc1_wgrad_dma_body<WG_BN>(p, first ? (int)blockIdx.x : (int)blockIdx.x - n0, fw_smem_);
+  fc1_wgrad_dma_body<WG_BN>(p, first ? (int)blockIdx.x : (int)blockIdx.x - n0, blockIdx.y, fw_smem_);
 }
 
 }  // namespace spv

@@ -109,13 +109,15 @@ def test_encoder_fc1_forward_backward(dev, dtype, nsplit, B, G, H, gather):
     torch.testing.assert_close(db, b.grad, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("B,G,gather", [(100, 333, True), (257, 1000, True), (128, 64, False), (1000, 3001, True), (4096, 2050, True)])
-def test_encoder_fc1_resident_image_dma_path(dev, B, G, gather):
-    """bf16 mode on a RESIDENT count matrix with the default n_hidden = 128 (2H = 256 columns): the forward pass runs the
+@pytest.mark.parametrize("grouped", [False, True])
+@pytest.mark.parametrize("B,G,gather,H", [(100, 333, True, 128), (257, 1000, True, 128), (128, 64, False, 128), (1000, 3001, True, 128),
+                                          (4096, 2050, True, 128), (300, 777, True, 256), (1030, 2050, True, 256)])
+def test_encoder_fc1_resident_image_dma_path(dev, B, G, gather, H, grouped):
+    """bf16 mode on a RESIDENT count matrix with n_hidden = 128 or 256 (2H = 256 / 512 columns): the forward pass runs the
     LDS-DMA kernel (csrc/spv_fc1.h) on the data set's bf16 log1p image, the weight gradient its DMA counterpart.  Checked
-    against fp64 on the same bf16-rounded operands (module/spVIPESmodule.py:428-435, nn/networks.py:119), ragged B and G."""
+    against fp64 on the same bf16-rounded operands (module/spVIPESmodule.py:428-435, nn/networks.py:119), ragged B and G;
+    ``grouped``: through EncoderFC1Grouped with a second, differently shaped group in the same launches."""
     from spvipes_amd import _abi, ops
-    H = 128
     rng = np.random.default_rng(B + G)
     n_cells = B + 37
     Xh = (rng.poisson(2.0, size=(n_cells, G)) * (rng.random((n_cells, G)) < 0.3)).astype(np.float32)
@@ -130,9 +132,21 @@ def test_encoder_fc1_resident_image_dma_path(dev, B, G, gather):
     ws = ops.Workspace(dev)
     xb, _ = counts.log1p_image()
     assert _abi.load().spv_enc_fc1_fwd_uses_dma(B, G, 2 * H, 1, 1, _abi.round_up(G, 64), xb.shape[1]) == 1
-    h1, lib = ops.EncoderFC1.apply(counts, rows, B, *params, 1, ws)
     dh = torch.randn(B, 2 * H, generator=g)
-    (h1 * dh.to(dev)).sum().backward()
+    if grouped:   # the other group: other shape, other data; only group 0 is checked below (group 1 is its own parametrisation elsewhere)
+        B2, G2 = 200, 500
+        X2 = (rng.poisson(2.0, size=(B2 + 5, G2)) * (rng.random((B2 + 5, G2)) < 0.3)).astype(np.float32)
+        counts2 = ops.GroupCounts(torch.tensor(X2.astype(np.uint16).view(np.int16)).to(dev), G2, 0, resident=True)
+        rows2 = torch.tensor(rng.permutation(B2 + 5)[:B2], dtype=torch.int32, device=dev)
+        params2 = [t.clone().to(dev).requires_grad_(True) for t in (mk(H, G2), mk(H), mk(H, G2), mk(H))]
+        outs = ops.EncoderFC1Grouped.apply([counts, counts2], [rows, rows2], [B, B2], 1, [ws, ops.Workspace(dev)], *params, *params2)
+        h1, lib, h1b = outs[0], outs[1], outs[2]
+        ((h1 * dh.to(dev)).sum() + h1b.sum()).backward()
+        single = ops.EncoderFC1.apply(counts2, rows2, B2, *[p_.detach().clone().requires_grad_(True) for p_ in params2], 1, ops.Workspace(dev))[0]
+        assert torch.equal(single.detach(), h1b.detach())   # the pair launch and the single launch run the same arithmetic
+    else:
+        h1, lib = ops.EncoderFC1.apply(counts, rows, B, *params, 1, ws)
+        (h1 * dh.to(dev)).sum().backward()
     torch.cuda.synchronize()
     x = torch.log1p(torch.tensor(Xh[rows_h]).double())
     xr = _bf16_round(torch.log1p(torch.tensor(Xh[rows_h])).float()).double()   # the image holds bf16(fp32 log1p)

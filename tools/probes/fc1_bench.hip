@@ -56,7 +56,7 @@ int main(int argc, char** argv) {
   p.k_per_split = ((ktiles + splits - 1) / splits) * F1_BK; p.c_split_row = splits;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(fc1_fwd_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F1_LDS_BYTES));
   auto gemm = [&]() { hipLaunchKernelGGL(fc1_fwd_dma_kernel, dim3(mtiles * splits), dim3(512), F1_LDS_BYTES, 0, p); };
-  auto epi = [&]() { hipLaunchKernelGGL(fc1_epilogue_tiled_kernel, dim3((unsigned)((slab_elems / 4 + 255) / 256)), dim3(256), 0, 0, slabs, splits, slab_elems, B, dbias, (const float*)nullptr, 0, h1, lib, dlib, drows); };
+  auto epi = [&]() { hipLaunchKernelGGL(fc1_epilogue_tiled_kernel, dim3((unsigned)((slab_elems / 4 + 255) / 256)), dim3(256), 0, 0, slabs, splits, slab_elems, B, 256, dbias, (const float*)nullptr, 0, h1, lib, dlib, drows); };
   gemm(); epi();
   CK(hipDeviceSynchronize());
   hipLaunchKernelGGL(naive_kernel, dim3((N1 + 255) / 256, B), dim3(256), 0, 0, dA, lda, drows, dW, ldw, B, N1, G, ref);
