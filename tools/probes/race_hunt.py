@@ -40,9 +40,12 @@ time.sleep(8)   # (the noise makers have to import torch first)
 first, nbad = None, 0
 for it in range(reps):
     torch.manual_seed(1000)
-    if getattr(module, "_seed_dev", None) is None:
-        module._seed_dev = torch.zeros((), dtype=torch.int64, device=dev)
-    module._seed_dev.fill_(50)
+    if getattr(module, "_rng_counter", None) is not None:   # the trainer's device generator: noise + dropout keyed by this counter
+        module._rng_counter.fill_(50)
+    else:
+        if getattr(module, "_seed_dev", None) is None:
+            module._seed_dev = torch.zeros((), dtype=torch.int64, device=dev)
+        module._seed_dev.fill_(50)
     if os.environ.get("RACE_FWD_ONLY"):
         tr.fp.grad.zero_()
         _, _, lo = module(tr.minibatch(rows), loss_kwargs={"kl_weight": 1.0})
