@@ -138,6 +138,7 @@ DA_FIRST = int(os.environ.get("SPV_DA_FIRST", "0"))  # backward: d A_m GEMMs fir
 WM_LATE = os.environ.get("SPV_WM_LATE", "0") != "0"  # mixture-weight GEMMs held back until the BatchNorm-fold backward (beside the tiny-kernel tail)
 FC1_GROUPED = os.environ.get("SPV_FC1_GROUPED", "1") != "0"  # both groups' fc1 GEMMs as one launch per kernel (EncoderFC1Grouped) instead of two streams
 LABEL_PRE = os.environ.get("SPV_LABEL_PRE", "0") != "0"  # label pairing on a side stream beside the fc1 GEMMs
+FC1_PAIR_SPLITS = os.environ.get("SPV_FC1_PAIR_SPLITS", "1") != "0"  # grouped fc1 forward: K splits sized for the pair's shared grid
 HEADS_DMA = os.environ.get("SPV_HEADS_DMA", "1") != "0"  # both regressor weight gradients in one LDS-DMA pass (spv_dec_heads_wgrad)
 FUSED_DZ = os.environ.get("SPV_FUSED_DZ", "1") != "0"  # softmax fix also produces the latent gradient of the rate heads
 FUSED_PACK = os.environ.get("SPV_FUSED_PACK", "1") != "0"  # latent / trunk kernels also write the decoder's bf16 operand images
@@ -316,7 +317,10 @@ class EncoderFC1Grouped(torch.autograd.Function):
                 ld_xb = xb.shape[1]
             if lib.spv_enc_fc1_fwd_uses_dma(B, G, N1, nsplit, int(xb is not None), Gp, ld_xb):
                 mt = -(-B // 128)
-                splits = max(1, min(16, 256 // mt, (-(-G // 64)) // 4))
+                # K splits: the groups of a pair share one grid, so the 256 CUs are divided by the PAIR's workgroup count (FC1_PAIR_SPLITS:
+                # half the splits of a single launch = one round of workgroups with twice the K range, half the slab traffic)
+                mt_all = mt * (2 if (FC1_PAIR_SPLITS and NG >= 2) else 1) * (N1 // 256 if N1 >= 256 else 1)
+                splits = max(1, min(16, 256 // mt_all, (-(-G // 64)) // 4))
                 slabs = ws.get("fc1_slabs_tiled", (splits, mt * 128, N1), torch.float32)
             else:
                 splits = _fc1_splits(B, G, N1)
