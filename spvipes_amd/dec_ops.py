@@ -59,7 +59,7 @@ class _DecoderBwd:
     (Measured: issuing these from the forward pass right after the group's likelihood kernel, staggered so that the other
     group's VALU-bound likelihood kernel runs beside these memory-bound kernels, changes nothing.)"""
 
-    def __init__(self, g: int, P, S, Wps_g, wsg, B: int, Bp: int, G: int, Gp: int, nsplit: int, grads_f32: bool):
+    def __init__(self, g: int, P, S, Wps_g, wsg, B: int, Bp: int, G: int, Gp: int, nsplit: int, grads_f32: bool, pair: bool = False):
         self.g, self.P, self.S, self.Wps_g, self.wsg = g, P, S, Wps_g, wsg
         self.B, self.Bp, self.G, self.Gp, self.nsplit, self.grads_f32 = B, Bp, G, Gp, nsplit, grads_f32
         self.fused_dz = bool(_ops.FUSED_DZ and not grads_f32)
@@ -77,7 +77,9 @@ class _DecoderBwd:
             mt, kt = -(-G // 128), Bp // 64   # 128-gene workgroup tiles, two workgroups per CU
             self.csp_n = max(1, min(512 // mt if mt <= 512 else 1, max(kt // 4, 1)))
         # bf16 mode: the two 320-column GEMMs run the LDS-DMA 128 x 320 kernels, which want their own split counts
-        self.ksp_m, self.csp_m = self._splits(False, B, G, self.ksp_m), self._splits(True, G, Bp, self.csp_m)
+        # (d A_m of the two groups run side by side on the group streams; d W_m one after the other on the side stream)
+        self.ksp_m = self._splits(False, B, G, self.ksp_m, 128 if (pair and _ops.DEC_PAIR_SPLITS) else 256)
+        self.csp_m = self._splits(True, G, Bp, self.csp_m)
 
     def _operand(self, key: str):
         """(hi, lo) operand image of dL / tP / tS: the bf16 tile array itself, or its hi / lo planes in fp32 mode"""
@@ -98,22 +100,23 @@ class _DecoderBwd:
         _abi.call("spv_dec_softmax_bwd", C.byref(self.P), ptr(self.S["Tp"]), ptr(self.S["Ts"]), None, stream_ptr())
 
     @staticmethod
-    def _dma_splits(M: int, K: int) -> int:
+    def _dma_splits(M: int, K: int, cus: int = 256) -> int:
         """K splits for the LDS-DMA 128 x 320 kernels (csrc/spv_dec_gemm.h): the count that minimises
-        rounds-of-256-workgroups x (64-deep steps per split + ~4 steps of prologue / slab store)."""
+        rounds-of-``cus``-workgroups x (64-deep steps per split + ~4 steps of prologue / slab store).  ``cus`` = 128 for a launch that
+        runs beside its twin of the other group on a second stream (one workgroup per CU: the pair then shares ONE round)."""
         mt, kt = -(-M // 128), -(-K // 64)
         best, best_cost = 1, None
         for s_ in range(1, 17):
             if s_ > 1 and kt // s_ < 4:
                 break
-            cost = -(-(mt * s_) // 256) * (-(-kt // s_) + 4)
+            cost = -(-(mt * s_) // cus) * (-(-kt // s_) + 4)
             if best_cost is None or cost < best_cost:
                 best, best_cost = s_, cost
         return best
 
-    def _splits(self, a_kmajor: bool, M: int, K: int, default: int) -> int:
+    def _splits(self, a_kmajor: bool, M: int, K: int, default: int, cus: int = 256) -> int:
         if _abi.load().spv_gemm_bf16_uses_dma(int(a_kmajor), M, KMP, K, self.nsplit, self.T, KMP):
-            return self._dma_splits(M, K)
+            return self._dma_splits(M, K, cus)
         return default
 
     def gemm_d(self):
@@ -375,7 +378,7 @@ class DecoderFused(torch.autograd.Function):
         cur = torch.cuda.current_stream(dev)
         streams = group_streams(dev, NG)
         side = group_streams(dev, 3)[2] if _ops.DEFER_WM else cur
-        stages = [_DecoderBwd(g, ctx.P[g], ctx.saved_g[g], ctx.Wps[g], ws[g], B, Bp, Gs[g], Gps[g], nsplit, ctx.grads_f32) for g in range(NG)]
+        stages = [_DecoderBwd(g, ctx.P[g], ctx.saved_g[g], ctx.Wps[g], ws[g], B, Bp, Gs[g], Gps[g], nsplit, ctx.grads_f32, pair=(NG == 2)) for g in range(NG)]
         d_slabs, bc_slabs, ef_slabs = [None] * NG, [None] * NG, [None] * NG
         # bf16 mode with the regressor GEMMs deferred to the side stream: the critical chain only needs the latent gradient, which
         # the READ-ONLY pass spv_dec_dz gives (168 MB read per group instead of 336 MB read + written); the in-place fix of

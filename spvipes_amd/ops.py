@@ -139,6 +139,7 @@ WM_LATE = os.environ.get("SPV_WM_LATE", "0") != "0"  # mixture-weight GEMMs held
 FC1_GROUPED = os.environ.get("SPV_FC1_GROUPED", "1") != "0"  # both groups' fc1 GEMMs as one launch per kernel (EncoderFC1Grouped) instead of two streams
 LABEL_PRE = os.environ.get("SPV_LABEL_PRE", "0") != "0"  # label pairing on a side stream beside the fc1 GEMMs
 FC1_PAIR_SPLITS = os.environ.get("SPV_FC1_PAIR_SPLITS", "1") != "0"  # grouped fc1 forward: K splits sized for the pair's shared grid
+DEC_PAIR_SPLITS = os.environ.get("SPV_DEC_PAIR_SPLITS", "1") != "0"  # d A_m GEMMs of the two groups: K splits sized so that the pair shares one round
 HEADS_DMA = os.environ.get("SPV_HEADS_DMA", "1") != "0"  # both regressor weight gradients in one LDS-DMA pass (spv_dec_heads_wgrad)
 FUSED_DZ = os.environ.get("SPV_FUSED_DZ", "1") != "0"  # softmax fix also produces the latent gradient of the rate heads
 FUSED_PACK = os.environ.get("SPV_FUSED_PACK", "1") != "0"  # latent / trunk kernels also write the decoder's bf16 operand images
