@@ -142,6 +142,11 @@ def _pmc_fields(args):
     widths the gfx950 FETCH_SIZE correction is calibrated for, so the raw counter is reported."""
     import glob, re
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_dec_nb_kernel.txt")))
+    latest = os.path.join(ROOT, "profiles", "LATEST")   # tag of the newest evidence set (file names do not sort by time)
+    if os.path.exists(latest):
+        want = os.path.join(ROOT, "profiles", open(latest).read().strip() + "_pmc_dec_nb_kernel.txt")
+        if os.path.exists(want):
+            files = [want]
     if not files:
         return None, None, None
     txt = open(files[-1]).read()
