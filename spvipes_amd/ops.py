@@ -134,7 +134,7 @@ DEFER_JOIN = False
 OVERLAP_SMALL = os.environ.get("SPV_OVERLAP_SMALL", "1") != "0"  # side-stream overlap of independent small-kernel groups
 STAGGER = os.environ.get("SPV_STAGGER", "1") != "0"  # group 1 orders its independent kernels differently from group 0
 STAGGER_BWD = os.environ.get("SPV_STAGGER_BWD", "0") != "0"  # backward: group 1 runs its d A_m GEMM ahead of its softmax fix (A/B on MI355X: 1.703 vs 1.693 ms, noise -> off)
-DA_FIRST = int(os.environ.get("SPV_DA_FIRST", "0"))  # backward: d A_m GEMMs first, softmax fixes on the side stream (1: side starts after them, 2: with them)
+DA_FIRST = int(os.environ.get("SPV_DA_FIRST", "1"))  # backward: d A_m GEMMs first, softmax fixes on the side stream (1: side starts after them, 2: with them); A/B with the half-chip d A_m launches: -9 / -3 us on two boxes
 WM_LATE = os.environ.get("SPV_WM_LATE", "0") != "0"  # mixture-weight GEMMs held back until the BatchNorm-fold backward (beside the tiny-kernel tail)
 FC1_GROUPED = os.environ.get("SPV_FC1_GROUPED", "1") != "0"  # both groups' fc1 GEMMs as one launch per kernel (EncoderFC1Grouped) instead of two streams
 LABEL_PRE = os.environ.get("SPV_LABEL_PRE", "0") != "0"  # label pairing on a side stream beside the fc1 GEMMs
