@@ -244,6 +244,12 @@ int spv_adam_step_images(float* p, const float* g, float* m, float* v, int64_t n
                          float weight_decay, float bc1, float bc2, float grad_scale, const spv_adam_image* images, int32_t n_images,
                          int64_t* step_counter, void* stream);   /* step_counter (nullable): device int64 incremented by one per call */
 
+/* Up to SPV_MAXP gathers / copies of 4-byte words in one launch: dst[i] = src[idx ? idx[i] : i], i < count (the minibatch's label
+ * gathers, labels[rows] of every group -- the reference's loader does this on the host: data/_multi_datasplitter.py:65-98 -- and the
+ * copies of the row indices into the buffers a captured graph reads). */
+typedef struct spv_gather_prob { const uint32_t* src; const int32_t* idx; uint32_t* dst; int64_t count; } spv_gather_prob;
+int spv_gather_u32(const spv_gather_prob* probs, int32_t nprob, void* stream);
+
 /* n standard-normal draws (the reparameterisation noise of a step: nn/networks.py:128-134, spVIPESmodule.py:346-349 sample with
  * torch's generator) from a counter-based generator: Philox 4x32-10 on (element index / 4, *counter) keyed by `key`, Box-Muller.
  * `counter` (nullable = 0) is read on the device when the kernel runs -- pass the step counter spv_adam_step_images increments and

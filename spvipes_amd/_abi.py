@@ -116,6 +116,18 @@ class SpvFc1BwdArgs(C.Structure):
                 ("xb", C.c_void_p), ("ld_xb", C.c_int64)]
 
 
+class SpvGatherProb(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("idx", C.c_void_p), ("dst", C.c_void_p), ("count", C.c_int64)]
+
+
+def gather_u32(probs) -> None:
+    """[(src, idx or None, dst)] -> dst[i] = src[idx[i]] (or src[i]) on 4-byte words, one launch for all problems (spv_gather_u32)"""
+    arr = (SpvGatherProb * len(probs))()
+    for a, (src, idx, dst) in zip(arr, probs):
+        a.src, a.idx, a.dst, a.count = ptr(src), ptr(idx), ptr(dst), dst.numel()
+    call("spv_gather_u32", arr, len(probs), stream_ptr())
+
+
 ADAM_MAX_IMAGES = 16
 
 
@@ -219,6 +231,7 @@ _SIGNATURES = {
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "spv_adam_step_images": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                        C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "spv_gather_u32": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "spv_randn": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_uint64, C.c_void_p]),
     "spv_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float,
                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),

@@ -528,6 +528,31 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// several small gathers / copies of 4-byte words in one launch: dst[i] = src[idx ? idx[i] : i].  The step's prologue (two row-index
+// copies into the graph's static buffers, two label gathers) is a chain of 5-us launches at the head of the critical path.
+// ---------------------------------------------------------------------------------------------
+struct GatherBatch { int n; spv_gather_prob p[SPV_MAXP]; };
+__global__ __launch_bounds__(256) void gather_u32_kernel(GatherBatch a) {
+  const spv_gather_prob& q = a.p[blockIdx.y];
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < q.count) q.dst[i] = q.src[q.idx ? (long)q.idx[i] : i];
+}
+extern "C" int spv_gather_u32(const spv_gather_prob* probs, int32_t nprob, void* stream) {
+  if (!probs || nprob <= 0 || nprob > SPV_MAXP) return fail(SPV_ERR_ARG, "spv_gather_u32: bad arguments%s");
+  GatherBatch a{};
+  a.n = nprob;
+  long nmax = 0;
+  for (int i = 0; i < nprob; ++i) {
+    if (!probs[i].src || !probs[i].dst || probs[i].count < 0) return fail(SPV_ERR_ARG, "spv_gather_u32: bad problem%s");
+    a.p[i] = probs[i];
+    nmax = probs[i].count > nmax ? probs[i].count : nmax;
+  }
+  if (nmax == 0) return SPV_OK;
+  hipLaunchKernelGGL(gather_u32_kernel, dim3((unsigned)((nmax + 255) / 256), nprob), dim3(256), 0, (hipStream_t)stream, a);
+  return launch_status("spv_gather_u32");
+}
+
+// ---------------------------------------------------------------------------------------------
 // standard-normal draws from a counter-based generator (Philox 4x32-10 + Box-Muller), keyed by (key, *counter): the step's noise
 // comes out of ONE launch that reads a device-resident step counter, so a captured hipGraph needs no generator state from the host
 // (torch's graph-safe generator costs two fill launches per replay + its own kernel, at the head of the step's critical path).

@@ -154,6 +154,7 @@ class Trainer:
     # tests/test_gpu_train_and_model.py::test_every_gradient_element_is_overwritten_by_a_step pins that property (NaN-filled buffer).
     ZERO_GRADS_EACH_STEP = os.environ.get("SPV_ZERO_GRADS", "0") != "0"
     DEVICE_RNG = os.environ.get("SPV_DEVICE_RNG", "1") != "0"
+    MULTI_GATHER = os.environ.get("SPV_MULTI_GATHER", "1") != "0"   # the groups' label gathers / row-index copies as one launch each (spv_gather_u32)
 
     def _image_specs(self):
         """[(workspace, key, image tensor, [(parameter, rows_off, col_off)], token parameters)] for every packed weight image"""
@@ -241,11 +242,18 @@ class Trainer:
         need_idx = bool(getattr(self.module, "use_transport_plan", False))
         if self.labels is not None and getattr(self, "_labels_f32", None) is None:
             self._labels_f32 = [l.flatten().to(torch.float32).contiguous() for l in self.labels]  # once: the PoE kernel reads fp32 codes
+        lab = None
+        if self.labels is not None:   # labels[rows] of every group in ONE launch (spv_gather_u32) when the indices are int32 device tensors
+            if self.MULTI_GATHER and all(r.dtype == torch.int32 and r.is_cuda and r.is_contiguous() for r in rows):
+                lab = [torch.empty(r.numel(), dtype=torch.float32, device=r.device) for r in rows]
+                _abi.gather_u32([(self._labels_f32[g], r, lab[g]) for g, r in enumerate(rows)])
+            else:
+                lab = [self._labels_f32[g].index_select(0, r) for g, r in enumerate(rows)]
         for g, r in enumerate(rows):
             d = {"counts": self.counts[g], "rows": r, "groups": None, "batch": None}
             d["indices"] = r.to(torch.float32).unsqueeze(1) if need_idx else None
-            if self.labels is not None:
-                d["labels"] = self._labels_f32[g].index_select(0, r).unsqueeze(1)  # one gather launch per group
+            if lab is not None:
+                d["labels"] = lab[g].unsqueeze(1)
             if self.components is not None:
                 d["processed_transport_labels"] = self.components[g][r.long()].unsqueeze(1)
             out.append(d)
@@ -342,8 +350,11 @@ class Trainer:
             kl_weight = kl_weight_at(self.epoch, self.global_step, self.n_epochs_kl_warmup, self.n_steps_kl_warmup)
         self._ensure_images()
         if self.graph is not None:
-            for s, r in zip(self._static_rows, rows):
-                s.copy_(r)
+            if self.MULTI_GATHER and all(r.dtype == torch.int32 and r.is_cuda and r.is_contiguous() and r.numel() == s.numel() for s, r in zip(self._static_rows, rows)):
+                _abi.gather_u32([(r, None, s) for s, r in zip(self._static_rows, rows)])   # one launch for all groups' row indices
+            else:
+                for s, r in zip(self._static_rows, rows):
+                    s.copy_(r)
             if float(kl_weight) != self._klw_host:  # (changes once per epoch during the warm-up, then never)
                 self._klw.fill_(float(kl_weight))
                 self._klw_host = float(kl_weight)
