@@ -21,9 +21,15 @@ __device__ __forceinline__ unsigned hash_u32(unsigned long long x) {
   return (unsigned)x;
 }
 // keep-probability test of inverted dropout, counter-based (seed, problem, element) -> reproducible
+// (32-bit PCG-style mixing: the 64-bit finaliser above costs ~3 us in the epilogue of the four-encoder fc2 launch, 16 draws per lane)
 __device__ __forceinline__ bool dropout_keep(unsigned long long seed, int prob, long idx, float p) {
-  const unsigned u = hash_u32(seed + 0x9E3779B97F4A7C15ULL * (unsigned long long)(idx * SPV_MAXP + prob + 1));
-  return (float)(u >> 8) * (1.0f / 16777216.0f) >= p;
+  const unsigned key = ((unsigned)seed ^ ((unsigned)(seed >> 32) * 0x9E3779B9u)) + (unsigned)(prob + 1) * 0x85EBCA6Bu;
+  unsigned x = (unsigned)idx * 747796405u + key;
+  x = ((x >> ((x >> 28) + 4u)) ^ x) * 277803737u;
+  x ^= x >> 22;
+  x = x * 0x2C1B3C6Du + key;
+  x ^= x >> 15;
+  return (float)(x >> 8) * (1.0f / 16777216.0f) >= p;
 }
 
 // ---- small dense layers on the fp32 matrix pipe ------------------------------------------------------
@@ -35,8 +41,12 @@ __device__ __forceinline__ f16v mfma_f32(float x, float w, const f16v& c) { retu
 
 // v[j] = p[j] for j < lim, else 0 (lim may be <= 0).  vec: p is 16-byte aligned and lim is >= 8 or <= 0.
 // Branch-free: out-of-range elements are read from `safe` (any valid aligned address) and zeroed afterwards.
-__device__ __forceinline__ void load8(const float* p, const float* safe, int lim, bool vec, float (&v)[8]) {
-  if (vec) {
+// (VEC is a template parameter on purpose: with a run-time flag the two forms sit in the arms of a branch, and hipcc then waits for
+// every load INSIDE its arm -- s_waitcnt vmcnt(0) right behind the load -- so that nothing is in flight under the MFMAs of the step:
+// tools/probes/linear_probe.py measured 0.5 us per 16-deep step, twice the eight MFMAs' time.)
+template <bool VEC>
+__device__ __forceinline__ void load8(const float* p, const float* safe, int lim, float (&v)[8]) {
+  if constexpr (VEC) {
     const float* s = (lim >= 8) ? p : safe;
     const f4v a = *reinterpret_cast<const f4v*>(s), b = *reinterpret_cast<const f4v*>(s + 4);
 #pragma unroll
@@ -54,7 +64,8 @@ __device__ __forceinline__ void load8_strided(const float* p, long ld, int c0, i
 __device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // Y = act(X W^T + b): workgroup = 2 x 2 waves = 64 rows x 64 columns
-__global__ __launch_bounds__(256) void linear_fwd_kernel(LinearBatch a) {
+template <bool VX, bool VW>
+__device__ __forceinline__ void linear_fwd_body(const LinearBatch& a) {
   const LinearProb& q = a.p[blockIdx.z];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
   const int b0 = blockIdx.x * 64 + 32 * (wave >> 1), n0 = blockIdx.y * 64 + 32 * (wave & 1);
@@ -62,19 +73,17 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(LinearBatch a) {
   const int row = b0 + r, col = n0 + r;
   const float* xr = q.X + (long)min(row, a.B - 1) * q.ldx;   // rows / columns beyond the problem only feed outputs never stored
   const float* wr = q.W + (long)min(col, q.N - 1) * q.K;
-  const bool vx = ((q.ldx & 3) == 0) && aligned16(q.X) && ((q.K & 7) == 0);
-  const bool vw = aligned16(q.W) && ((q.K & 7) == 0);
   f16v acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   float xa[8], wb[8];
-  load8(xr + 8 * h, xr, q.K - 8 * h, vx, xa);
-  load8(wr + 8 * h, wr, q.K - 8 * h, vw, wb);
+  load8<VX>(xr + 8 * h, xr, q.K - 8 * h, xa);
+  load8<VW>(wr + 8 * h, wr, q.K - 8 * h, wb);
   for (int k0 = 0; k0 < q.K; k0 += 16) {
     float xn[8], wn[8];
     const int kn = k0 + 16 + 8 * h;   // next step's elements fly under this step's eight MFMAs
-    load8(xr + kn, xr, q.K - kn, vx, xn);
-    load8(wr + kn, wr, q.K - kn, vw, wn);
+    load8<VX>(xr + kn, xr, q.K - kn, xn);
+    load8<VW>(wr + kn, wr, q.K - kn, wn);
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc = mfma_f32(xa[j], wb[j], acc);
 #pragma unroll
@@ -96,6 +105,15 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(LinearBatch a) {
     q.Y[(long)b * q.ldy + col] = v;
   }
 }
+__global__ __launch_bounds__(256) void linear_fwd_kernel(LinearBatch a) {
+  const LinearProb& q = a.p[blockIdx.z];
+  const bool vx = ((q.ldx & 3) == 0) && aligned16(q.X) && ((q.K & 7) == 0);   // (block-uniform)
+  const bool vw = aligned16(q.W) && ((q.K & 7) == 0);
+  if (vx && vw) linear_fwd_body<true, true>(a);
+  else if (vw) linear_fwd_body<false, true>(a);
+  else if (vx) linear_fwd_body<true, false>(a);
+  else linear_fwd_body<false, false>(a);
+}
 
 __device__ __forceinline__ float masked_dy(const LinearBatch& a, const LinearProb& q, int b, int n) {
   float g = q.dY[(long)b * q.lddy + n];
@@ -110,25 +128,23 @@ __device__ __forceinline__ void apply_mask8(const LinearBatch& a, float (&g)[8],
 }
 
 // dX (+)= mask(dY) W : rows = cells, columns = k, contraction over the N outputs of the layer
-__global__ __launch_bounds__(256) void linear_dgrad_kernel(LinearBatch a) {
+template <bool VEC, bool MASKED>   // (compile-time for the same reason as load8's VEC: no load may sit in the arm of a run-time branch)
+__device__ __forceinline__ void linear_dgrad_body(const LinearBatch& a) {
   const LinearProb& q = a.p[blockIdx.z];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
   const int b0 = blockIdx.x * 64 + 32 * (wave >> 1), k0 = blockIdx.y * 64 + 32 * (wave & 1);
   if (k0 >= q.K || b0 >= a.B) return;
   const int row = b0 + r, col = k0 + r;
-  const bool masked = a.relu || a.drop_p > 0.f;
   const float* gr = q.dY + (long)min(row, a.B - 1) * q.lddy;
-  const float* yr = masked ? q.Y + (long)min(row, a.B - 1) * q.ldy : gr;
+  const float* yr = MASKED ? q.Y + (long)min(row, a.B - 1) * q.ldy : gr;
   const float* wc = q.W + min(col, q.K - 1);
-  const bool vg = ((q.lddy & 3) == 0) && aligned16(q.dY) && ((q.N & 7) == 0);
-  const bool vy = masked && ((q.ldy & 3) == 0) && aligned16(q.Y) && ((q.N & 7) == 0);
   f16v acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   float ga[8], wb[8];
   auto fetch = [&](int n, float (&g)[8], float (&w)[8]) {
-    load8(gr + n, gr, q.N - n, vg, g);
-    if (masked) { float y[8]; load8(yr + n, yr, q.N - n, vy, y); apply_mask8(a, g, y); }
+    load8<VEC>(gr + n, gr, q.N - n, g);
+    if constexpr (MASKED) { float y[8]; load8<VEC>(yr + n, yr, q.N - n, y); apply_mask8(a, g, y); }
     load8_strided(wc, q.K, n, q.N, w);
   };
   fetch(8 * h, ga, wb);
@@ -149,20 +165,28 @@ __global__ __launch_bounds__(256) void linear_dgrad_kernel(LinearBatch a) {
     *dst = a.accumulate ? *dst + acc[i] : acc[i];
   }
 }
+__global__ __launch_bounds__(256) void linear_dgrad_kernel(LinearBatch a) {
+  const LinearProb& q = a.p[blockIdx.z];
+  const bool masked = a.relu || a.drop_p > 0.f;
+  const bool vec = ((q.lddy & 3) == 0) && aligned16(q.dY) && ((q.N & 7) == 0) && (!masked || (((q.ldy & 3) == 0) && aligned16(q.Y)));
+  if (masked) { if (vec) linear_dgrad_body<true, true>(a); else linear_dgrad_body<false, true>(a); }
+  else { if (vec) linear_dgrad_body<true, false>(a); else linear_dgrad_body<false, false>(a); }
+}
 
 // dW = mask(dY)^T X, db = colsum(mask(dY)): rows = n, columns = k, contraction over the batch.  The batch is cut into
 // WG_SLICES slices (one workgroup each; its four waves take a quarter each and are added in wave order); partial
 // tiles go to `wpart` and are summed in slice order by linear_wgrad_reduce_kernel.
 constexpr int WG_SLICES = 16;
 
-__global__ __launch_bounds__(256) void linear_wgrad_kernel(LinearBatch a, float* wpart, long prob_stride) {
+template <bool MASKED>
+__device__ __forceinline__ void linear_wgrad_body(const LinearBatch& a, float* wpart, long prob_stride) {
   const int prob = blockIdx.z / WG_SLICES, slice = blockIdx.z % WG_SLICES;
   const LinearProb& q = a.p[prob];
   const int n0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
   if (n0 >= q.N || k0 >= q.K) return;  // block-uniform
   __shared__ float s_acc[3][16][64], s_b[3][32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
-  const bool masked = a.relu || a.drop_p > 0.f;
+  constexpr bool masked = MASKED;
   const int per = ((a.B + WG_SLICES * 64 - 1) / (WG_SLICES * 64)) * 64;   // rows per slice, a multiple of 64 (16 per wave and step)
   const int bbeg = slice * per + wave * (per / 4), bend = min(bbeg + per / 4, a.B);
   const float* gc = q.dY + min(n0 + r, q.N - 1);
@@ -175,7 +199,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(LinearBatch a, float*
   float ga[8], xb[8];
   auto fetch = [&](int b, float (&g)[8], float (&x)[8]) {
     load8_strided(gc, q.lddy, b, bend, g);
-    if (masked) { float y[8]; load8_strided(yc, q.ldy, b, bend, y); apply_mask8(a, g, y); }
+    if constexpr (MASKED) { float y[8]; load8_strided(yc, q.ldy, b, bend, y); apply_mask8(a, g, y); }
     load8_strided(xc, q.ldx, b, bend, x);
   };
   fetch(bbeg + 8 * h, ga, xb);
@@ -207,6 +231,10 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(LinearBatch a, float*
     if (n < q.N && k < q.K) base[(long)n * (q.K + 1) + k] = acc[i];
   }
   if (blockIdx.y == 0 && h == 0 && n0 + r < q.N) base[(long)(n0 + r) * (q.K + 1) + q.K] = bsum;
+}
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(LinearBatch a, float* wpart, long prob_stride) {
+  if (a.relu || a.drop_p > 0.f) linear_wgrad_body<true>(a, wpart, prob_stride);
+  else linear_wgrad_body<false>(a, wpart, prob_stride);
 }
 
 __global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(LinearBatch a, const float* wpart, long prob_stride) {
