@@ -348,12 +348,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnBatch a) {
   const float mean = q.stats[2 * c], sc = q.stats[2 * c + 1] * q.gamma[c], be = q.beta[c];
 #pragma unroll 4
   for (int b = b0 + slot; b < b1; b += RS) {
-    float v = 0.f;
-    if (b < a.B) {
-      v = (q.X[(long)b * q.ldx + c] - mean) * sc + be;
-      if (a.relu) v = fmaxf(v, 0.f);
-      q.Y[(long)b * q.ldy + c] = v;
-    }
+    // (the load is unconditional -- rows of the image padding re-read the last batch row -- so that the unrolled iterations' loads
+    // are all issued before the first use: see load8)
+    float v = (q.X[(long)min(b, a.B - 1) * q.ldx + c] - mean) * sc + be;
+    if (a.relu) v = fmaxf(v, 0.f);
+    if (b < a.B) q.Y[(long)b * q.ldy + c] = v;
+    else v = 0.f;
     if (q.img_hi != nullptr) {
       bf16_t hi, lo;
       split_bf16(v, hi, lo);
@@ -363,12 +363,17 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnBatch a) {
   }
 }
 
-__device__ __forceinline__ float bn_masked_dy(const BnBatch& a, const BnProb& q, int b, int j) {
+// (RELU / TRAINING are template parameters: a load in the arm of a run-time branch is waited for inside that arm, and the unrolled row
+// loops below then pay one dependent L2 round trip per row -- see load8)
+template <bool RELU>
+__device__ __forceinline__ float bn_masked_dy(const BnProb& q, int b, int j) {
   const float g = q.dY[(long)b * q.lddy + j];
-  return (a.relu && !(q.Y[(long)b * q.ldy + j] > 0.f)) ? 0.f : g;
+  if constexpr (RELU) return (q.Y[(long)b * q.ldy + j] > 0.f) ? g : 0.f;
+  else return g;
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBatch a) {
+template <bool RELU>
+__device__ __forceinline__ void bn_bwd_reduce_body(const BnBatch& a) {
   const BnProb& q = a.p[blockIdx.y];
   __shared__ float s_g[256], s_gx[256];
   const int NC = pow2_at_least(q.N), RS = 256 / NC;
@@ -379,7 +384,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBatch a) {
     const float mean = q.stats[2 * c], inv = q.stats[2 * c + 1];
 #pragma unroll 4
     for (int b = b0 + slot; b < b1; b += RS) {
-      const float g = bn_masked_dy(a, q, b, c);
+      const float g = bn_masked_dy<RELU>(q, b, c);
       sg += g;
       sgx += g * (q.X[(long)b * q.ldx + c] - mean) * inv;
     }
@@ -392,6 +397,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBatch a) {
     q.part[((long)blockIdx.x * q.N + threadIdx.x) * 2] = t0;
     q.part[((long)blockIdx.x * q.N + threadIdx.x) * 2 + 1] = t1;
   }
+}
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBatch a) {
+  if (a.relu) bn_bwd_reduce_body<true>(a); else bn_bwd_reduce_body<false>(a);
 }
 
 // d gamma = sum_b g * xhat, d beta = sum_b g: the per-block partials added in block order within four interleaved groups
@@ -413,7 +421,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBatch a) {
   }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBatch a) {
+template <bool RELU, bool TRAINING>
+__device__ __forceinline__ void bn_bwd_apply_body(const BnBatch& a) {
   const BnProb& q = a.p[blockIdx.y];
   const int b0 = blockIdx.x * BN_ROWS, b1 = min(b0 + BN_ROWS, a.B);
   const float invB = 1.0f / (float)a.B;
@@ -424,9 +433,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBatch a) {
   const float msg = q.dbeta[c] * invB, msgx = q.dgamma[c] * invB;  // written by bn_bwd_finalize_kernel
 #pragma unroll 4
   for (int b = b0 + slot; b < b1; b += RS) {
-    const float g = bn_masked_dy(a, q, b, c);
+    const float g = bn_masked_dy<RELU>(q, b, c);
     float dx;
-    if (a.training) {
+    if constexpr (TRAINING) {
       const float xhat = (q.X[(long)b * q.ldx + c] - mean) * inv;
       dx = gi * (g - msg - xhat * msgx);
     } else {
@@ -434,6 +443,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBatch a) {
     }
     q.dX[(long)b * q.lddx + c] = dx;
   }
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBatch a) {
+  if (a.relu) { if (a.training) bn_bwd_apply_body<true, true>(a); else bn_bwd_apply_body<true, false>(a); }
+  else { if (a.training) bn_bwd_apply_body<false, true>(a); else bn_bwd_apply_body<false, false>(a); }
 }
 
 // ---------------------------------------------------------------------------------------------
