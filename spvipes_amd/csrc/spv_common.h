@@ -93,6 +93,11 @@ __device__ __forceinline__ f16v mfma32_split(const s8v& a_hi, const s8v& a_lo, c
 // C/D row owned by accumulator register q of lane-half h
 __device__ __forceinline__ int crow(int q, int h) { return (q & 3) + 8 * (q >> 2) + 4 * h; }
 
+// p ? p[i] : 0 as an UNCONDITIONAL load (the address is selected, not the load skipped): a load behind a null test is waited for inside
+// that branch, and a kernel that reads five optional gradients pays five dependent round trips instead of one
+__device__ const float g_spv_zero = 0.f;
+__device__ __forceinline__ float ld_or_zero(const float* p, long i) { return *(p ? p + i : &g_spv_zero); }
+
 // ---- fragment reads from LDS -----------------------------------------------
 // natural image: [rows][pitch] bf16, k contiguous.  Fragment of the 32-row tile starting at
 // row0, k-step kbase (multiple of 16): lane reads 16 B at (row0 + r, kbase + 8h).

@@ -223,10 +223,12 @@ __global__ __launch_bounds__(256) void dec_lse_kernel(DecParams p) {
 // lse_k[b] = log sum_splits ...;  a_k[b] = library[b] - lse_k[b]   (log of exp(library) * softmax)
 // block = 64 cells x 4 split groups: group y merges splits y, y+4, ... in order (online log-sum-exp), the four group
 // results are merged in order
+// (branch-free: with data-dependent branches between them the loads of the unrolled merge loop cannot be issued ahead of the chain)
 __device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2) {
-  if (m2 == -INFINITY) return;
-  if (m2 > m) { s = s * __expf(m - m2) + s2; m = m2; }
-  else s += s2 * __expf(m2 - m);
+  const float mn = fmaxf(m, m2);
+  const float base = (mn == -INFINITY) ? 0.f : mn;   // both empty: keep exp() away from (-inf) - (-inf)
+  s = s * __expf(m - base) + s2 * __expf(m2 - base);
+  m = mn;
 }
 __global__ __launch_bounds__(256) void dec_lse_combine_kernel(const float* pmp, const float* psp, const float* pms, const float* pss, int splits,
                                                               int Bp, int B, const float* library, float* lse_p, float* lse_s, float* a_p,

@@ -108,10 +108,10 @@ __global__ __launch_bounds__(256) void pn_cell_bwd_kernel(PoeN a) {
   const float jl = a.loc[g][i], sc = a.scale[g][i];
   const bool live = sc >= 1e-6f;
   const float sq = fmaxf(sc, 1e-6f);
-  const float gk = a.g_kl[g] ? a.g_kl[g][b] : 0.f, gz = a.g_logz[g] ? a.g_logz[g][i] : 0.f;
-  const float Gl = (a.g_loc[g] ? a.g_loc[g][i] : 0.f) + gz + gk * jl;
-  const float Gs = (a.g_scale[g] ? a.g_scale[g][i] : 0.f) + (live ? gz * a.eps[g][i] + gk * (sq - 1.0f / sq) : 0.f);
-  const float Gv = (a.g_logvar[g] ? a.g_logvar[g][i] : 0.f) + 0.5f * sc * Gs;
+  const float gk = ld_or_zero(a.g_kl[g], b), gz = ld_or_zero(a.g_logz[g], i);
+  const float Gl = ld_or_zero(a.g_loc[g], i) + gz + gk * jl;
+  const float Gs = ld_or_zero(a.g_scale[g], i) + (live ? gz * a.eps[g][i] + gk * (sq - 1.0f / sq) : 0.f);
+  const float Gv = ld_or_zero(a.g_logvar[g], i) + 0.5f * sc * Gs;
   const float J = sc * sc;                       // 1 / prec
   const float dN = Gl * J, dP = -J * (Gl * jl + Gv);   // d / d num,  d / d prec
   a.dpn[g][(long)b * 2 * n + d] = dP;

@@ -496,13 +496,13 @@ __global__ __launch_bounds__(256) void enc_sample_bwd_kernel(SampleBatch a) {
   const int n = q.n;
   if (b >= a.B || d >= n) return;
   const long i = (long)b * n + d;
-  const float gk = q.g_kl ? q.g_kl[b] : 0.f;
+  const float gk = ld_or_zero(q.g_kl, b);
   const float loc = q.post[(long)b * 2 * n + d], sc = q.scale[i];
-  const float gz = q.g_logz ? q.g_logz[i] : 0.f;
+  const float gz = ld_or_zero(q.g_logz, i);
   const long ig = q.g_ld ? (long)b * q.g_ld + d : i;
-  const float gl = (q.g_loc ? q.g_loc[ig] : 0.f) + gz + gk * loc;
-  const float gs = (q.g_scale ? q.g_scale[i] : 0.f) + gz * q.eps[i] + gk * sc;
-  const float gv = (q.g_logvar ? q.g_logvar[ig] : 0.f) + 0.5f * sc * gs - 0.5f * gk;
+  const float gl = ld_or_zero(q.g_loc, ig) + gz + gk * loc;
+  const float gs = ld_or_zero(q.g_scale, i) + gz * q.eps[i] + gk * sc;
+  const float gv = ld_or_zero(q.g_logvar, ig) + 0.5f * sc * gs - 0.5f * gk;
   q.d_post[(long)b * 2 * n + d] = gl;
   q.d_post[(long)b * 2 * n + n + d] = gv;
 }
@@ -666,15 +666,15 @@ __global__ __launch_bounds__(256) void poe_fuse_bwd_kernel(PoeArgs a) {
   float* d_own = a.d_stats[g] + (long)b * a.ld[g];
   float* d_self = a.expert[g] ? a.d_expert[g] + (long)b * a.ld_expert[g] : d_own;
   float* d_oth = a.expert[o] ? a.d_expert[o] + prc * a.ld_expert[o] : a.d_stats[o] + prc * a.ld[o];
-  const float gk = a.g_kl[g] ? a.g_kl[g][b] : 0.f;
+  const float gk = ld_or_zero(a.g_kl[g], b);
   const long i = (long)b * n + d;
   const float jl = a.loc[g][i], sc = a.scale[g][i];
   const bool live = !a.clamp_scale || sc >= 1e-6f;   // below the clamp the draw and the KL do not depend on the scale
   const float sq = a.clamp_scale ? fmaxf(sc, 1e-6f) : sc;
-  const float gz = a.g_logz[g] ? a.g_logz[g][i] : 0.f;
-  const float Gl = (a.g_loc[g] ? a.g_loc[g][i] : 0.f) + gz + gk * jl;
-  const float Gs = (a.g_scale[g] ? a.g_scale[g][i] : 0.f) + (live ? gz * a.eps[g][i] + gk * (sq - 1.0f / sq) : 0.f);
-  const float Gv = (a.g_logvar[g] ? a.g_logvar[g][i] : 0.f) + 0.5f * sc * Gs;
+  const float gz = ld_or_zero(a.g_logz[g], i);
+  const float Gl = ld_or_zero(a.g_loc[g], i) + gz + gk * jl;
+  const float Gs = ld_or_zero(a.g_scale[g], i) + (live ? gz * a.eps[g][i] + gk * (sq - 1.0f / sq) : 0.f);
+  const float Gv = ld_or_zero(a.g_logvar[g], i) + 0.5f * sc * Gs;
   if (m == 2 && a.lone_passthrough) {  // loc* = loc, logvar* = logvar, scale* = exp(logvar / 2)
     atomicAdd(&d_own[d], Gl);
     atomicAdd(&d_own[n + d], Gv);
@@ -1054,22 +1054,37 @@ __device__ __forceinline__ void reduce_finish(const spv_reduce_prob& q, int r, i
   float* d = q.dst + (long)r * q.ld_dst + c;
   *d = q.accumulate ? *d + v : v;
 }
+// NS slabs, NS known at compile time: NS independent loads per element, then an ordered sum (with a run-time count every load sits
+// behind its own `k < nslabs` branch and is waited for there: NS dependent round trips per element instead of one)
+template <int NS>
+__device__ __forceinline__ void reduce_few_slabs(const spv_reduce_prob& q, long total, float alpha) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int r = (int)(i / q.cols), c = (int)(i - (long)r * q.cols);
+    const float* s = q.src + (long)r * q.ld_src + q.col_off + c;
+    float v[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) v[k] = s[(long)k * q.slab_stride];
+    float acc = v[0];
+#pragma unroll
+    for (int k = 1; k < NS; ++k) acc += v[k];
+    reduce_finish(q, r, c, acc, alpha);
+  }
+}
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(spv_reduce_batch b) {
   __shared__ float s_part[4][64];
   const spv_reduce_prob& q = b.p[blockIdx.y];
   const long total = (long)q.rows * q.cols;
   const float alpha = q.alpha ? *q.alpha : 1.f;
   if (q.nslabs <= 8) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-      const int r = (int)(i / q.cols), c = (int)(i - (long)r * q.cols);
-      const float* s = q.src + (long)r * q.ld_src + q.col_off + c;
-      float v[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = (k < q.nslabs) ? s[(long)k * q.slab_stride] : 0.f;  // independent loads, then an ordered sum
-      float acc = v[0];
-#pragma unroll
-      for (int k = 1; k < 8; ++k) acc += v[k];
-      reduce_finish(q, r, c, acc, alpha);
+    switch (q.nslabs) {   // (block-uniform)
+      case 1: reduce_few_slabs<1>(q, total, alpha); break;
+      case 2: reduce_few_slabs<2>(q, total, alpha); break;
+      case 3: reduce_few_slabs<3>(q, total, alpha); break;
+      case 4: reduce_few_slabs<4>(q, total, alpha); break;
+      case 5: reduce_few_slabs<5>(q, total, alpha); break;
+      case 6: reduce_few_slabs<6>(q, total, alpha); break;
+      case 7: reduce_few_slabs<7>(q, total, alpha); break;
+      default: reduce_few_slabs<8>(q, total, alpha); break;
     }
     return;
   }
