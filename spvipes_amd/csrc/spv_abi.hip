@@ -987,11 +987,10 @@ __global__ __launch_bounds__(256) void fc1_bwd_prep_kernel(const float* dh1, con
     float sum = 0.f;
 #pragma unroll 4
     for (int r = r0; r < r0 + 16; ++r) {
-      float v = 0.f;
-      if (r < B && col < N1) {
-        const long i = (long)r * N1 + col;
-        v = (h1[i] > 0.f) ? dh1[i] : 0.f;
-      }
+      // (unconditional loads from a clamped address, then a select: a load behind the bounds test is waited for inside that branch)
+      const long i = (long)min(r, B - 1) * N1 + min(col, N1 - 1);
+      const float hv = h1[i], gv = dh1[i];
+      const float v = (r < B && col < N1 && hv > 0.f) ? gv : 0.f;
       bf16_t hi, lo;
       split_bf16(v, hi, lo);
       img_hi[(long)r * ld_img + col] = hi;
@@ -1026,11 +1025,9 @@ __global__ __launch_bounds__(256) void fc1_bwd_prep_pair_kernel(Fc1PrepArgs a0, 
     float sum = 0.f;
 #pragma unroll 4
     for (int r = r0; r < r0 + 16; ++r) {
-      float v = 0.f;
-      if (r < a.B && col < a.N1) {
-        const long i = (long)r * a.N1 + col;
-        v = (a.h1[i] > 0.f) ? a.dh1[i] : 0.f;
-      }
+      const long i = (long)min(r, a.B - 1) * a.N1 + min(col, a.N1 - 1);   // (unconditional loads: see fc1_bwd_prep_kernel)
+      const float hv = a.h1[i], gv = a.dh1[i];
+      const float v = (r < a.B && col < a.N1 && hv > 0.f) ? gv : 0.f;
       bf16_t hi, lo;
       split_bf16(v, hi, lo);
       a.img_hi[(long)r * a.ld_img + col] = hi;

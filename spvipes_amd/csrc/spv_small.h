@@ -1117,14 +1117,14 @@ __global__ __launch_bounds__(1024) void loss_assemble_kernel(const float* rec0, 
   const float klw = kl_weight ? *kl_weight : 1.f;
   const float gk = klw / (float)B;
   for (int i = t; i < B; i += 1024) {
-    const float wi = w[i];
+    const float wi = w[i];   // (optional inputs through ld_or_zero: seven loads in flight at once instead of seven dependent round trips)
     ar += wi * rec0[i];
-    if (rec1) ar += wi * rec1[i];
+    ar += wi * ld_or_zero(rec1, i);
     float k = 0.f;
-    if (kl0) k += kl0[i];
-    if (kl1) k += kl1[i];
-    if (kl2) k += kl2[i];
-    if (kl3) k += kl3[i];
+    k += ld_or_zero(kl0, i);
+    k += ld_or_zero(kl1, i);
+    k += ld_or_zero(kl2, i);
+    k += ld_or_zero(kl3, i);
     ak += k;
     if (gkl) gkl[i] = gk;
   }
