@@ -118,3 +118,37 @@ def test_spv_randn_is_standard_normal_and_keyed_by_the_device_counter():
     draw(1001, 99, out=buf[1:1002])
     assert float(buf[0]) == 7.0 and float(buf[1002]) == 7.0 and bool((buf[1:1002] != 7.0).all())
     assert torch.equal(buf[1:1002], draw(1001, 99))
+
+
+@pytest.mark.parametrize("B0,B1,nlab", [(64, 64, 3), (1000, 777, 10), (4096, 4096, 10), (5000, 9000, 37), (4096, 300, 1)])
+def test_label_pairing_matches_the_reference_rule(B0, B1, nlab):
+    """spv_poe_partner (rank within label + partner lookup) against a plain Python restatement of the reference's pairing rule
+    (module/spVIPESmodule.py:685-701): cell i with label L and rank k among the same-label cells of its minibatch (batch order) gets the
+    k-th cell of label L of the other minibatch (mode 0), the padding expert if L occurs there fewer than k + 1 times (mode 1), the
+    dummy expert if L does not occur there (mode 2).  Includes minibatches beyond the 4096 cells whose chunks stay in registers."""
+    import numpy as np
+    import torch
+    from spvipes_amd import ops
+    from spvipes_amd.nn_ops import label_partners
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(B0 + B1 + nlab)
+    labs = [rng.integers(0, nlab, size=B0), rng.integers(0, nlab + 2, size=B1)]   # group 1 also has labels group 0 never sees
+    t = [torch.tensor(l, dtype=torch.float32, device=dev).unsqueeze(1) for l in labs]
+    partner, mode, _ = label_partners(t, ops.Workspace(dev))
+    torch.cuda.synchronize()
+    for g in (0, 1):
+        o = 1 - g
+        where = {}
+        for j, L in enumerate(labs[o]):
+            where.setdefault(int(L), []).append(j)
+        seen, want_p, want_m = {}, [], []
+        for L in labs[g]:
+            k = seen.get(int(L), 0)
+            seen[int(L)] = k + 1
+            cells = where.get(int(L), [])
+            if k < len(cells):
+                want_p.append(cells[k]); want_m.append(0)
+            else:
+                want_p.append(-1); want_m.append(1 if cells else 2)
+        assert mode[g].cpu().tolist() == want_m
+        assert partner[g].cpu().tolist() == want_p
