@@ -826,6 +826,24 @@ extern "C" int spv_poe_fuse_fwd(const spv_poe_args* a, void* stream) {
   hipLaunchKernelGGL(poe_fuse_fwd_kernel, dim3((Bm + 7) / 8, 2), dim3(256), 0, (hipStream_t)stream, *a);
   return launch_status("spv_poe_fuse_fwd");
 }
+// zero fill as an ordinary kernel launch.  (hipMemsetAsync inside a captured graph becomes a memset node; with two processes sharing the
+// GPU the two-rank hipGraph test intermittently -- ~1 run in 10 -- showed NaN gradients in exactly the tensors fed by the buffers these
+// memsets clear, as if the fill had not happened before the kernel that accumulates into them; a kernel node has not shown it.)
+__global__ void zero_fill_kernel(float* p, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+__global__ void fill_i32_kernel(int32_t* p, long n, int32_t v) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+static int zero_fill(void* p, size_t bytes, hipStream_t s) {
+  const long n = (long)(bytes / 4);
+  if (n <= 0) return SPV_OK;
+  hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (float*)p, n);
+  return hipGetLastError() == hipSuccess ? SPV_OK : SPV_ERR_LAUNCH;
+}
+
 extern "C" int spv_poe_fuse_bwd(const spv_poe_args* a, void* stream) {
   int rc = check_poe(a, "spv_poe_fuse_bwd");
   if (rc) return rc;
@@ -836,12 +854,12 @@ extern "C" int spv_poe_fuse_bwd(const spv_poe_args* a, void* stream) {
   for (int g = 0; g < 2; ++g) {  // the kernel accumulates (own expert + partner's): start from zero
     const size_t bytes = (size_t)a->B[g] * a->ld[g] * sizeof(float);
     if (g == 1 && adjacent) {
-    } else if (hipMemsetAsync(a->d_stats[g], 0, (g == 0 && adjacent) ? bytes0 + (size_t)a->B[1] * a->ld[1] * sizeof(float) : bytes, (hipStream_t)stream) != hipSuccess)
-      return fail(SPV_ERR_LAUNCH, "spv_poe_fuse_bwd: memset failed%s");
+    } else if (zero_fill(a->d_stats[g], (g == 0 && adjacent) ? bytes0 + (size_t)a->B[1] * a->ld[1] * sizeof(float) : bytes, (hipStream_t)stream) != SPV_OK)
+      return fail(SPV_ERR_LAUNCH, "spv_poe_fuse_bwd: fill failed%s");
     if (a->expert[g]) {
       if (!a->d_expert[g]) return fail(SPV_ERR_ARG, "spv_poe_fuse_bwd: d_expert missing%s");
-      if (hipMemsetAsync(a->d_expert[g], 0, (size_t)a->B[g] * a->ld_expert[g] * sizeof(float), (hipStream_t)stream) != hipSuccess)
-        return fail(SPV_ERR_LAUNCH, "spv_poe_fuse_bwd: memset failed%s");
+      if (zero_fill(a->d_expert[g], (size_t)a->B[g] * a->ld_expert[g] * sizeof(float), (hipStream_t)stream) != SPV_OK)
+        return fail(SPV_ERR_LAUNCH, "spv_poe_fuse_bwd: fill failed%s");
     }
   }
   hipLaunchKernelGGL(poe_fuse_bwd_kernel, dim3((Bm + 7) / 8, 2), dim3(256), 0, (hipStream_t)stream, *a);
@@ -1164,8 +1182,10 @@ extern "C" int spv_plan_invmap(const int32_t* idx0, int32_t B0, const int32_t* i
                                int32_t n1, void* stream) {
   if (!idx0 || !idx1 || !inv0 || !inv1 || B0 <= 0 || B1 <= 0 || n0 <= 0 || n1 <= 0) return fail(SPV_ERR_ARG, "spv_plan_invmap: bad arguments%s");
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(inv0, 0xFF, (size_t)n0 * sizeof(int32_t), s) != hipSuccess || hipMemsetAsync(inv1, 0xFF, (size_t)n1 * sizeof(int32_t), s) != hipSuccess)
-    return fail(SPV_ERR_LAUNCH, "spv_plan_invmap: memset failed%s");
+  // (fill kernels, not hipMemsetAsync: see zero_fill)
+  hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, s, inv0, (long)n0, -1);
+  hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, inv1, (long)n1, -1);
+  if (hipGetLastError() != hipSuccess) return fail(SPV_ERR_LAUNCH, "spv_plan_invmap: fill failed%s");
   const int Bm = B0 > B1 ? B0 : B1;
   hipLaunchKernelGGL(plan_invmap_kernel, dim3((Bm + 255) / 256, 2), dim3(256), 0, s, idx0, B0, idx1, B1, inv0, n0, inv1, n1);
   return launch_status("spv_plan_invmap");

@@ -387,7 +387,8 @@ class Trainer:
         if optimizer_step:
             plan = getattr(self, "_img_plan", None)
             if plan is not None and not self._images_are_fresh():
-                plan = None   # (somebody wrote to a parameter since the images were made: plain Adam, _ensure_images repacks next step)
+                plan = None   # (somebody wrote to a parameter since the images were made: plain Adam, and the images are rebuilt next step)
+                self.parameters_changed()
             self.opt.step(grad_scale=1.0 / self.world, images=plan, counter=getattr(self.module, "_rng_counter", None))
             self.global_step += 1
         return lo
