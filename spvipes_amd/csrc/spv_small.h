@@ -523,10 +523,11 @@ constexpr int POE_WAVES = 8;
 // stage 1 (one workgroup of 8 waves per group): stable rank of every cell within its label, label counts and
 // first slots, and the cells of each label listed in batch order.  Wave w owns a contiguous segment of the
 // minibatch and counts into its own histogram row; an exclusive prefix over the waves makes the ranks global.
+constexpr int PR_CH = 8;   // 64-cell chunks of a wave whose labels / ranks stay in registers (B <= 4096: all of them)
 __global__ __launch_bounds__(512) void poe_rank_kernel(const float* lab0, const float* lab1, int B0, int B1, int* order0, int* order1,
                                                        int* rank0, int* rank1, int* tables /*[2][2][POE_LMAX]: cnt, start*/, int* err) {
   __shared__ int hist[POE_WAVES][POE_LMAX];
-  __shared__ int s_scan[512];
+  __shared__ int s_scan[512], s_start[POE_LMAX];
   const int g = blockIdx.x;
   const float* lab = g ? lab1 : lab0;
   const int B = g ? B1 : B0;
@@ -535,15 +536,22 @@ __global__ __launch_bounds__(512) void poe_rank_kernel(const float* lab0, const 
   int* cnt = tables + (g * 2 + 0) * POE_LMAX;
   int* start = tables + (g * 2 + 1) * POE_LMAX;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  for (int l = tid; l < POE_WAVES * POE_LMAX; l += 512) (&hist[0][0])[l] = 0;
-  __syncthreads();
   const int seg = ((B + POE_WAVES * 64 - 1) / (POE_WAVES * 64)) * 64;
   const int cbeg = w * seg, cend = min(cbeg + seg, B);
-  for (int c0 = cbeg; c0 < cend; c0 += 64) {
-    const int i = c0 + lane;
-    const bool act = i < cend;
-    int L = act ? (int)lab[i] : -1;
+  // the first PR_CH chunks' labels are requested up front, all at once (one load per chunk in the loop below is one dependent
+  // round trip per chunk), and their ranks stay in registers for the last phase
+  int Lc[PR_CH], Rk[PR_CH];
+#pragma unroll
+  for (int c = 0; c < PR_CH; ++c) {
+    const int i = cbeg + 64 * c + lane;
+    Lc[c] = (int)lab[min(i, B - 1)];
+    Rk[c] = 0;
+  }
+  for (int l = tid; l < POE_WAVES * POE_LMAX; l += 512) (&hist[0][0])[l] = 0;
+  __syncthreads();
+  auto rank_chunk = [&](int i, bool act, int L) {   // stable rank of the chunk's cells within their labels, wave-local running counts in hist[w]
     if (act && (L < 0 || L >= POE_LMAX)) { *err = 1; L = 0; }
+    if (!act) L = -1;
     unsigned long long todo = __ballot(act);
     int my_rank = 0;
     while (todo) {
@@ -555,7 +563,18 @@ __global__ __launch_bounds__(512) void poe_rank_kernel(const float* lab0, const 
       if (lane == src) hist[w][cur] = base + __popcll(same);
       todo &= ~same;
     }
-    if (act) rank[i] = my_rank;
+    return my_rank;
+  };
+#pragma unroll
+  for (int c = 0; c < PR_CH; ++c) {
+    const int i = cbeg + 64 * c + lane;
+    if (cbeg + 64 * c < cend) Rk[c] = rank_chunk(i, i < cend, Lc[c]);   // (wave-uniform test)
+  }
+  for (int c0 = cbeg + 64 * PR_CH; c0 < cend; c0 += 64) {   // B > 4096: the remaining chunks through memory
+    const int i = c0 + lane;
+    const bool act = i < cend;
+    const int r = rank_chunk(i, act, act ? (int)lab[i] : -1);
+    if (act) rank[i] = r;
   }
   __syncthreads();
   // exclusive prefix over the waves (per label) and the label totals; two labels per thread
@@ -580,15 +599,26 @@ __global__ __launch_bounds__(512) void poe_rank_kernel(const float* lab0, const 
   const int excl = s_scan[tid] - (tot[0] + tot[1]);
   start[2 * tid] = excl;
   start[2 * tid + 1] = excl + tot[0];
-  __threadfence();
+  s_start[2 * tid] = excl;
+  s_start[2 * tid + 1] = excl + tot[0];
   __syncthreads();
-  for (int c0 = cbeg; c0 < cend; c0 += 64) {
+#pragma unroll
+  for (int c = 0; c < PR_CH; ++c) {
+    const int i = cbeg + 64 * c + lane;
+    if (i < cend) {
+      const int L = min(max(Lc[c], 0), POE_LMAX - 1);
+      const int r = hist[w][L] + Rk[c];
+      rank[i] = r;
+      order[s_start[L] + r] = i;
+    }
+  }
+  for (int c0 = cbeg + 64 * PR_CH; c0 < cend; c0 += 64) {
     const int i = c0 + lane;
     if (i < cend) {
       const int L = min(max((int)lab[i], 0), POE_LMAX - 1);
       const int r = hist[w][L] + rank[i];
       rank[i] = r;
-      order[start[L] + r] = i;
+      order[s_start[L] + r] = i;
     }
   }
 }

@@ -460,7 +460,10 @@ class PoECluster(torch.autograd.Function):
             a.kl[g] = ptr(kl[g])
         _abi.call("spv_poe_fuse_fwd", C.byref(a), stream_ptr())
         # the inverse maps of the plan are rebuilt by the next minibatch: keep what the backward needs of them
-        ctx.plan, ctx.idx, ctx.comp, ctx.inv = plan, idx, comp, [plan.inv0.clone(), plan.inv1.clone()]
+        # (copied by a kernel: a tensor .clone() would put a memcpy node into the captured step, DESIGN.md §4 "memset node")
+        kept = [torch.empty_like(plan.inv0), torch.empty_like(plan.inv1)]
+        _abi.gather_u32([(plan.inv0, None, kept[0]), (plan.inv1, None, kept[1])])
+        ctx.plan, ctx.idx, ctx.comp, ctx.inv = plan, idx, comp, kept
         ctx.blocks, ctx.eps, ctx.partner, ctx.mode, ctx.n, ctx.B = blocks, eps, partner, mode, n, B
         ctx.expert, ctx.rowsum = expert, rowsum
         ctx.save_for_backward(out["loc"][0], out["loc"][1], out["scale"][0], out["scale"][1])
