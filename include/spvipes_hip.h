@@ -462,7 +462,8 @@ int spv_bn_fold_bwd(const spv_fold_batch* a, void* stream);   /* fold backward +
 /* ---------------------------------------------------------------------------------------------
  * Deterministic slab reduction (the tail of every split-K GEMM and of the per-wave partials):
  *   dst[r][c] (+)= alpha * escale(c) * sum_s src[s * slab_stride + r * ld_src + col_off + c]
- * slabs are added in index order inside four fixed interleaved groups.  alpha: optional device scalar
+ * up to 8 slabs are added in index order; more than 8 in index order inside four fixed interleaved groups
+ * (s = y, y + 4, ...; then ((p0 + p1) + p2) + p3).  rows * cols < 2^31.  alpha: optional device scalar
  * (the upstream gradient of the loss); exp_scale: optional per-column log-scale, multiplies by
  * exp(exp_scale[c]) (d px_r = exp(px_r) * d theta, module/spVIPESmodule.py:758).
  * ------------------------------------------------------------------------------------------- */

@@ -972,15 +972,15 @@ extern "C" int spv_bn_fold_bwd(const spv_fold_batch* a, void* stream) {
 
 extern "C" int spv_reduce_slabs(const spv_reduce_batch* b, void* stream) {
   if (!b || b->nprob <= 0 || b->nprob > SPV_MAXR) return fail(SPV_ERR_ARG, "spv_reduce_slabs: bad batch%s");
-  long most = 0;
+  long blocks = 1;
   for (int i = 0; i < b->nprob; ++i) {
     const spv_reduce_prob& q = b->p[i];
-    if (!q.src || !q.dst || q.nslabs <= 0 || q.rows <= 0 || q.cols <= 0 || q.ld_src < q.col_off + q.cols || q.ld_dst < q.cols || q.col_off < 0)
+    if (!q.src || !q.dst || q.nslabs <= 0 || q.rows <= 0 || q.cols <= 0 || q.ld_src < q.col_off + q.cols || q.ld_dst < q.cols || q.col_off < 0 ||
+        (long)q.rows * q.cols >= (1l << 31))
       return fail(SPV_ERR_ARG, "spv_reduce_slabs: bad problem%s");
-    const long t = (long)q.rows * q.cols;
-    if (t > most) most = t;
+    const long t = reduce_blocks_needed(q);   // the grid covers the neediest problem in one pass (beyond 8192 workgroups: grid-stride loops)
+    if (t > blocks) blocks = t;
   }
-  long blocks = (most + 255) / 256;   // problems with many slabs take 64 elements per block and loop
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)blocks, b->nprob), dim3(256), 0, (hipStream_t)stream, *b);
   return launch_status("spv_reduce_slabs");

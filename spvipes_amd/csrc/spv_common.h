@@ -97,6 +97,8 @@ __device__ __forceinline__ int crow(int q, int h) { return (q & 3) + 8 * (q >> 2
 // that branch, and a kernel that reads five optional gradients pays five dependent round trips instead of one
 __device__ const float g_spv_zero = 0.f;
 __device__ __forceinline__ float ld_or_zero(const float* p, long i) { return *(p ? p + i : &g_spv_zero); }
+__device__ const float g_spv_one = 1.f;
+__device__ const float g_spv_zero4[4] __attribute__((aligned(16))) = {0.f, 0.f, 0.f, 0.f};
 
 // ---- fragment reads from LDS -----------------------------------------------
 // natural image: [rows][pitch] bf16, k contiguous.  Fragment of the 32-row tile starting at

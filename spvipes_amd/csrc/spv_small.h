@@ -1085,37 +1085,90 @@ __device__ __forceinline__ void reduce_finish(const spv_reduce_prob& q, int r, i
   *d = q.accumulate ? *d + v : v;
 }
 // NS slabs, NS known at compile time: NS independent loads per element, then an ordered sum (with a run-time count every load sits
-// behind its own `k < nslabs` branch and is waited for there: NS dependent round trips per element instead of one)
+// behind its own `k < nslabs` branch and is waited for there: NS dependent round trips per element instead of one).  V = 4 elements
+// of a row per thread (16-byte loads and stores) where the problem's columns, offsets, pitches and pointers allow (reduce_vec4).
+constexpr int RED_FEW_MAX = 8;   // (more slabs in registers cost the kernel its occupancy: 16 x 4 elements = 88 VGPRs, and the 3-slab d W_m sum went 22.8 -> 28.9 us)
+template <int V> struct RedVec { float x[V]; };
+template <int V> __device__ __forceinline__ RedVec<V> red_ld(const float* p);
+template <> __device__ __forceinline__ RedVec<1> red_ld<1>(const float* p) { RedVec<1> r; r.x[0] = *p; return r; }
+template <> __device__ __forceinline__ RedVec<4> red_ld<4>(const float* p) {
+  const float4 t = *reinterpret_cast<const float4*>(p);
+  RedVec<4> r; r.x[0] = t.x; r.x[1] = t.y; r.x[2] = t.z; r.x[3] = t.w; return r;
+}
+__device__ __forceinline__ void red_st(float* p, const RedVec<1>& v) { *p = v.x[0]; }
+__device__ __forceinline__ void red_st(float* p, const RedVec<4>& v) { *reinterpret_cast<float4*>(p) = make_float4(v.x[0], v.x[1], v.x[2], v.x[3]); }
+__host__ __device__ inline bool reduce_vec4(const spv_reduce_prob& q) {
+  return !((q.cols | q.col_off) & 3) && !((q.ld_src | q.slab_stride | q.ld_dst) & 3) &&
+         !(((unsigned long long)q.src | (unsigned long long)q.dst | (unsigned long long)q.exp_scale) & 15ull);
+}
+// the sum in slab order
 template <int NS>
-__device__ __forceinline__ void reduce_few_slabs(const spv_reduce_prob& q, long total, float alpha) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int r = (int)(i / q.cols), c = (int)(i - (long)r * q.cols);
+__device__ __forceinline__ float reduce_ordered_sum(const float (&v)[NS]) {
+  float acc = v[0];
+#pragma unroll
+  for (int k = 1; k < NS; ++k) acc += v[k];
+  return acc;
+}
+// EXTRA: the problem has a column scale and / or accumulates
+template <int NS, int V, bool EXTRA>
+__device__ __forceinline__ void reduce_few_slabs(const spv_reduce_prob& q, float alpha) {
+  const unsigned cols_v = (unsigned)q.cols / V, total = (unsigned)q.rows * cols_v;   // (rows * cols < 2^31: spv_reduce_slabs)
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const unsigned r = i / cols_v, c = (i - r * cols_v) * V;
     const float* s = q.src + (long)r * q.ld_src + q.col_off + c;
-    float v[NS];
+    float* d = q.dst + (long)r * q.ld_dst + c;
+    RedVec<V> v[NS];
 #pragma unroll
-    for (int k = 0; k < NS; ++k) v[k] = s[(long)k * q.slab_stride];
-    float acc = v[0];
+    for (int k = 0; k < NS; ++k) v[k] = red_ld<V>(s + (long)k * q.slab_stride);
+    // the optional scale and the accumulation target through selected addresses: in flight together with the slabs
+    RedVec<V> e, prev, out;
+    if constexpr (EXTRA) {
+      e = red_ld<V>(q.exp_scale ? q.exp_scale + c : g_spv_zero4);
+      prev = red_ld<V>(q.accumulate ? d : g_spv_zero4);
+    }
 #pragma unroll
-    for (int k = 1; k < NS; ++k) acc += v[k];
-    reduce_finish(q, r, c, acc, alpha);
+    for (int j = 0; j < V; ++j) {
+      float t[NS];
+#pragma unroll
+      for (int k = 0; k < NS; ++k) t[k] = v[k].x[j];
+      float a = reduce_ordered_sum<NS>(t) * alpha;
+      if constexpr (EXTRA) {
+        if (q.exp_scale) a *= expf(e.x[j]);
+        a = q.accumulate ? prev.x[j] + a : a;
+      }
+      out.x[j] = a;
+    }
+    red_st(d, out);
   }
+}
+template <int V, bool EXTRA>
+__device__ __forceinline__ void reduce_few_dispatch(const spv_reduce_prob& q, float alpha) {
+  switch (q.nslabs) {   // (block-uniform)
+    case 1: reduce_few_slabs<1, V, EXTRA>(q, alpha); break;
+    case 2: reduce_few_slabs<2, V, EXTRA>(q, alpha); break;
+    case 3: reduce_few_slabs<3, V, EXTRA>(q, alpha); break;
+    case 4: reduce_few_slabs<4, V, EXTRA>(q, alpha); break;
+    case 5: reduce_few_slabs<5, V, EXTRA>(q, alpha); break;
+    case 6: reduce_few_slabs<6, V, EXTRA>(q, alpha); break;
+    case 7: reduce_few_slabs<7, V, EXTRA>(q, alpha); break;
+    default: reduce_few_slabs<8, V, EXTRA>(q, alpha); break;
+  }
+}
+// workgroups problem q needs (one pass): 256 threads x 1 or 4 elements on the few-slab path, 64 elements on the many-slab path
+__host__ __device__ inline long reduce_blocks_needed(const spv_reduce_prob& q) {
+  const long total = (long)q.rows * q.cols;
+  if (q.nslabs > RED_FEW_MAX) return (total + 63) / 64;
+  return reduce_vec4(q) ? (total / 4 + 255) / 256 : (total + 255) / 256;
 }
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(spv_reduce_batch b) {
   __shared__ float s_part[4][64];
   const spv_reduce_prob& q = b.p[blockIdx.y];
   const long total = (long)q.rows * q.cols;
-  const float alpha = q.alpha ? *q.alpha : 1.f;
-  if (q.nslabs <= 8) {
-    switch (q.nslabs) {   // (block-uniform)
-      case 1: reduce_few_slabs<1>(q, total, alpha); break;
-      case 2: reduce_few_slabs<2>(q, total, alpha); break;
-      case 3: reduce_few_slabs<3>(q, total, alpha); break;
-      case 4: reduce_few_slabs<4>(q, total, alpha); break;
-      case 5: reduce_few_slabs<5>(q, total, alpha); break;
-      case 6: reduce_few_slabs<6>(q, total, alpha); break;
-      case 7: reduce_few_slabs<7>(q, total, alpha); break;
-      default: reduce_few_slabs<8>(q, total, alpha); break;
-    }
+  const float alpha = *(q.alpha ? q.alpha : &g_spv_one);
+  if (q.nslabs <= RED_FEW_MAX) {
+    const bool extra = q.exp_scale || q.accumulate;
+    if (reduce_vec4(q)) { if (extra) reduce_few_dispatch<4, true>(q, alpha); else reduce_few_dispatch<4, false>(q, alpha); }
+    else { if (extra) reduce_few_dispatch<1, true>(q, alpha); else reduce_few_dispatch<1, false>(q, alpha); }
     return;
   }
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;

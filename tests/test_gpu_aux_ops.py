@@ -16,26 +16,48 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.mark.parametrize("nslabs", [1, 4, 8, 9, 64])
-def test_reduce_slabs_matches_torch(dev, nslabs):
+def _slab_sum_in_kernel_order(x: torch.Tensor) -> torch.Tensor:
+    """fp32 sum over dim 0 in the order spv_reduce_slabs documents: slab order up to 8 slabs, beyond that four interleaved groups
+    (y, y + 4, ...) summed in order and then ((p0 + p1) + p2) + p3"""
+    n = x.shape[0]
+    if n <= 8:
+        acc = x[0].clone()
+        for k in range(1, n):
+            acc = acc + x[k]
+        return acc
+    part = []
+    for y in range(4):
+        acc = torch.zeros_like(x[0])
+        for k in range(y, n, 4):
+            acc = acc + x[k]
+        part.append(acc)
+    return ((part[0] + part[1]) + part[2]) + part[3]
+
+
+# (37, 50, 21, 7): nothing 16-byte aligned, one element per thread; (37, 52, 24, 8): the four-elements-per-thread form
+@pytest.mark.parametrize("shape", [(37, 50, 21, 7), (37, 52, 24, 8), (1, 64, 64, 0)])
+@pytest.mark.parametrize("nslabs", [1, 4, 8, 9, 13, 16, 17, 64])
+def test_reduce_slabs_matches_torch(dev, nslabs, shape):
     from spvipes_amd import _abi
     from spvipes_amd._abi import SpvReduceBatch, stream_ptr
     from spvipes_amd.dec_ops import _add_red
     g = torch.Generator(device=dev).manual_seed(nslabs)
-    rows, ld, cols, off = 37, 50, 21, 7
+    rows, ld, cols, off = shape
     src = torch.randn(nslabs, rows, ld, generator=g, device=dev)
     alpha = torch.tensor(0.75, device=dev)
     es = torch.randn(cols, generator=g, device=dev) * 0.3
-    dst0 = torch.randn(rows, 30, generator=g, device=dev)
+    dst0 = torch.randn(rows, 4 + cols + 4, generator=g, device=dev)
     dst = dst0.clone()
     plain = torch.empty(rows, cols, device=dev)
     b = SpvReduceBatch()
     b.nprob = 0
     _add_red(b, src, nslabs, rows * ld, ld, rows, cols, plain, cols, col_off=off)
-    _add_red(b, src, nslabs, rows * ld, ld, rows, cols, dst, 30, col_off=off, dst_col=4, accumulate=True, alpha=alpha, exp_scale=es)
+    _add_red(b, src, nslabs, rows * ld, ld, rows, cols, dst, dst0.shape[1], col_off=off, dst_col=4, accumulate=True, alpha=alpha, exp_scale=es)
     _abi.call("spv_reduce_slabs", C.byref(b), stream_ptr())
     want = src[:, :, off:off + cols].double().sum(0)
     torch.testing.assert_close(plain.double(), want, rtol=1e-6, atol=1e-5)
+    assert torch.equal(plain, _slab_sum_in_kernel_order(src[:, :, off:off + cols])), "the documented summation order, bit for bit"
+    assert torch.equal(dst[:, :4], dst0[:, :4]) and torch.equal(dst[:, 4 + cols:], dst0[:, 4 + cols:]), "columns beside the target"
     want2 = dst0.double().clone()
     want2[:, 4:4 + cols] += 0.75 * torch.exp(es.double()) * want
     torch.testing.assert_close(dst.double(), want2, rtol=1e-5, atol=1e-5)
