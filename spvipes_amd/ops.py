@@ -141,6 +141,10 @@ LABEL_PRE = os.environ.get("SPV_LABEL_PRE", "0") != "0"  # label pairing on a si
 FC1_PAIR_SPLITS = os.environ.get("SPV_FC1_PAIR_SPLITS", "1") != "0"  # grouped fc1 forward: K splits sized for the pair's shared grid
 DEC_PAIR_SPLITS = os.environ.get("SPV_DEC_PAIR_SPLITS", "1") != "0"  # d A_m GEMMs of the two groups: K splits sized so that the pair shares one round
 HEADS_DMA = os.environ.get("SPV_HEADS_DMA", "1") != "0"  # both regressor weight gradients in one LDS-DMA pass (spv_dec_heads_wgrad)
+# workgroups the softmax-statistics / softmax-fix kernels are split into (cell blocks x gene splits).  512 = ONE round of two workgroups per CU, and half the
+# per-split partials (statistics, latent gradient) to write and re-read.  Same-box A/B 1024 / 768 / 512 / 384 / 256 at C2: 1.440 / 1.438 / 1.412 / 1.417 / 1.426 ms;
+# C3 2.39 -> 2.36, C4 3.90 -> 3.88, C5 8.29 -> 8.18, C1 unchanged
+GSPLIT_WANT = int(os.environ.get("SPV_GSPLIT_WANT", "512"))
 FUSED_DZ = os.environ.get("SPV_FUSED_DZ", "1") != "0"  # softmax fix also produces the latent gradient of the rate heads
 FUSED_PACK = os.environ.get("SPV_FUSED_PACK", "1") != "0"  # latent / trunk kernels also write the decoder's bf16 operand images
 DEFER_WM = os.environ.get("SPV_DEFER_WM", "1") != "0"  # mixture-weight gradient GEMMs on the late side stream
@@ -382,7 +386,7 @@ class EncoderFC1Grouped(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 def _gene_splits(Bp: int, Gp: int) -> Tuple[int, int]:
     cell_blocks = Bp // DEC_CELLS_PER_WG
-    want = max(1, -(-1024 // cell_blocks))  # ~4 workgroups per CU
+    want = max(1, -(-GSPLIT_WANT // cell_blocks))  # ~2 workgroups per CU
     tiles = Gp // 32
     splits = max(1, min(want, tiles))
     per = -(-tiles // splits) * 32
