@@ -948,7 +948,7 @@ extern "C" int spv_bn_fold_fwd(const spv_fold_batch* a, void* stream) {
       return fail(SPV_ERR_ARG, "spv_bn_fold_fwd: slot, col_off, ld_img must be multiples of 8 elements and the images 16-byte aligned%s");
     gmax = q.Gp > gmax ? q.Gp : gmax;
   }
-  hipLaunchKernelGGL(bn_fold_fwd_kernel, dim3((gmax + 255) / 256, a->nprob), dim3(256), 0, (hipStream_t)stream, *a);
+  hipLaunchKernelGGL(bn_fold_fwd_kernel, dim3((gmax + FOLD_FWD_GENES - 1) / FOLD_FWD_GENES, a->nprob), dim3(256), 0, (hipStream_t)stream, *a);
   return launch_status("spv_bn_fold_fwd");
 }
 extern "C" int spv_bn_fold_bwd(const spv_fold_batch* a, void* stream) {

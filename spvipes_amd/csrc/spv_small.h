@@ -885,60 +885,69 @@ constexpr int FOLD_KMAX = 32;
 // per gene: BatchNorm over the batch of the linear map z -> w_g . z folded into W'_g = inv * w_g and
 // c_g = beta_g - inv * mean_g, with mean_g = w_g . zbar, var_g = w_g^T C w_g (biased), inv = gamma_g / sqrt(var_g + eps);
 // written straight into the packed bf16 hi/lo operand image.  zc[0..K) = column sums of z, zc[K..) = z^T z.
+// Four lanes per gene (FOLD_FWD_GENES genes per workgroup): lane `sub` takes rows sub, sub + 4, ... of C and the 8-element chunks sub, sub + 4, ...
+// of the image row; mean and variance are summed over the four lanes.  (One lane per gene was 40 workgroups per problem on 256 CUs, each
+// lane a K x K chain.)
+constexpr int FOLD_FWD_GENES = 64;
 __global__ __launch_bounds__(256) void bn_fold_fwd_kernel(FoldBatch a) {
   const FoldProb& q = a.p[blockIdx.y];
   __shared__ float s_zbar[FOLD_KMAX], s_C[FOLD_KMAX * FOLD_KMAX];
   const int K = q.K;
+  if (blockIdx.x * FOLD_FWD_GENES >= q.Gp) return;   // (the grid is sized for the largest problem)
   if (a.training) {
     const float invB = 1.0f / (float)a.B;
     for (int i = threadIdx.x; i < K; i += 256) s_zbar[i] = q.zsum[i] * invB;
-    __syncthreads();
-    for (int i = threadIdx.x; i < K * K; i += 256) s_C[i] = q.zz[i] * invB - s_zbar[i / K] * s_zbar[i % K];
+    for (int i = threadIdx.x; i < K * K; i += 256) s_C[i] = q.zz[i] * invB - (q.zsum[i / K] * invB) * (q.zsum[i % K] * invB);
     __syncthreads();
   }
-  const int g = blockIdx.x * 256 + threadIdx.x;
-  if (g >= q.Gp) return;
-  bf16_t* hi = q.img_hi + (long)g * q.ld_img + q.col_off;
-  bf16_t* lo = q.img_lo + (long)g * q.ld_img + q.col_off;
-  if (g >= q.G) {
-    for (int k8 = 0; k8 < q.slot; k8 += 8) { *reinterpret_cast<u4v*>(hi + k8) = u4v{0u, 0u, 0u, 0u}; *reinterpret_cast<u4v*>(lo + k8) = u4v{0u, 0u, 0u, 0u}; }
-    return;
-  }
-  const float* w = q.W + (long)g * K;  // K <= 32 floats, L1-resident: re-read instead of a runtime-indexed register array
+  const int sub = threadIdx.x & 3;
+  const int g = blockIdx.x * FOLD_FWD_GENES + (threadIdx.x >> 2);
+  const bool in_img = g < q.Gp, real = g < q.G;
+  const int gi = min(g, q.G - 1);                    // padding rows compute on the last gene and store zeros: no lane leaves before the shuffles
+  const float* w = q.W + (long)gi * K;               // K <= 32 floats, L1-resident: re-read instead of a runtime-indexed register array
   float mean, var;
   if (a.training) {
-    mean = 0.f; var = 0.f;
-    for (int k = 0; k < K; ++k) mean += w[k] * s_zbar[k];
-    for (int k0 = 0; k0 < K; k0 += 4) {   // four rows of C at a time: independent chains, one read of w[l] for the four
+    float pm = 0.f, pv = 0.f;
+    for (int k = sub; k < K; k += 4) pm += w[k] * s_zbar[k];
+    for (int k0 = sub; k0 < K; k0 += 16) {   // this lane's rows k0, k0 + 4, k0 + 8, k0 + 12: independent chains, one read of w[l] for the four
       float v[4] = {0.f, 0.f, 0.f, 0.f};
       int row[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) row[u] = min(k0 + u, K - 1) * K;
+      for (int u = 0; u < 4; ++u) row[u] = min(k0 + 4 * u, K - 1) * K;
       for (int l = 0; l < K; ++l) {
         const float wl = w[l];
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u] += s_C[row[u] + l] * wl;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) var += (k0 + u < K) ? w[k0 + u] * v[u] : 0.f;
+      for (int u = 0; u < 4; ++u) pv += (k0 + 4 * u < K) ? w[k0 + 4 * u] * v[u] : 0.f;
     }
-    var = fmaxf(var, 0.f);
-    q.running_mean[g] = (1.f - a.momentum) * q.running_mean[g] + a.momentum * mean;
-    q.running_var[g] = (1.f - a.momentum) * q.running_var[g] + a.momentum * var * ((float)a.B / fmaxf((float)a.B - 1.f, 1.f));
+    pm += __shfl_xor(pm, 1); pm += __shfl_xor(pm, 2);   // (the same bits on the four lanes: the additions commute)
+    pv += __shfl_xor(pv, 1); pv += __shfl_xor(pv, 2);
+    mean = pm;
+    var = fmaxf(pv, 0.f);
+    if (real && sub == 0) {
+      q.running_mean[g] = (1.f - a.momentum) * q.running_mean[g] + a.momentum * mean;
+      q.running_var[g] = (1.f - a.momentum) * q.running_var[g] + a.momentum * var * ((float)a.B / fmaxf((float)a.B - 1.f, 1.f));
+    }
   } else {
-    mean = q.running_mean[g]; var = q.running_var[g];
+    mean = q.running_mean[gi]; var = q.running_var[gi];
   }
-  const float inv = q.gamma[g] * rsqrtf(var + a.eps);
-  q.stat[2 * g] = mean; q.stat[2 * g + 1] = var;
-  const float cg = q.beta[g] - mean * inv;
-  for (int k8 = 0; k8 < q.slot; k8 += 8) {   // slot, ld_img and col_off are multiples of 8 elements: one 16-byte store per image
+  const float inv = q.gamma[gi] * rsqrtf(var + a.eps);
+  const float cg = q.beta[gi] - mean * inv;
+  if (real && sub == 0) { q.stat[2 * g] = mean; q.stat[2 * g + 1] = var; }
+  if (!in_img) return;
+  bf16_t* hi = q.img_hi + (long)g * q.ld_img + q.col_off;
+  bf16_t* lo = q.img_lo + (long)g * q.ld_img + q.col_off;
+  for (int k8 = 8 * sub; k8 < q.slot; k8 += 32) {   // slot, ld_img and col_off are multiples of 8 elements: one 16-byte store per image
     unsigned hw[4], lw[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       bf16_t h0, l0, h1, l1;
       const int ka = k8 + 2 * j, kb = ka + 1;
-      split_bf16((ka < K) ? w[ka] * inv : (ka == K ? cg : 0.f), h0, l0);
-      split_bf16((kb < K) ? w[kb] * inv : (kb == K ? cg : 0.f), h1, l1);
+      const float va = (ka < K) ? w[min(ka, K - 1)] * inv : (ka == K ? cg : 0.f), vb = (kb < K) ? w[min(kb, K - 1)] * inv : (kb == K ? cg : 0.f);
+      split_bf16(real ? va : 0.f, h0, l0);
+      split_bf16(real ? vb : 0.f, h1, l1);
       hw[j] = (unsigned)h0 | ((unsigned)h1 << 16);
       lw[j] = (unsigned)l0 | ((unsigned)l1 << 16);
     }
