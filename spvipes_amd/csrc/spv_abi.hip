@@ -962,7 +962,7 @@ extern "C" int spv_bn_fold_bwd(const spv_fold_batch* a, void* stream) {
     gmax = q.G > gmax ? q.G : gmax;
   }
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(bn_fold_bwd_kernel, dim3((gmax + 255) / 256, a->nprob), dim3(256), 0, s, *a);
+  hipLaunchKernelGGL(bn_fold_bwd_kernel, dim3((gmax + 255) / 256, a->nprob), dim3(FOLD_BWD_THREADS), 0, s, *a);
   if (a->training) {
     hipLaunchKernelGGL(fold_red_finalize_kernel, dim3((FOLD_KMAX + FOLD_KMAX * FOLD_KMAX + 63) / 64, a->nprob), dim3(256), 0, s, *a);
     hipLaunchKernelGGL(zstats_bwd_kernel, dim3((a->B + 63) / 64, a->nprob), dim3(256), 0, s, *a);

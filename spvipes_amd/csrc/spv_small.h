@@ -958,56 +958,68 @@ __global__ __launch_bounds__(256) void bn_fold_fwd_kernel(FoldBatch a) {
 
 // backward of the fold: from dW' [G][ld_dw] (columns 0..K-1 = d W'_g, column K = d c_g) to dW, d gamma, d beta and
 // per-block partial sums of d zbar [K] and d C [K][K]
-__global__ __launch_bounds__(256) void bn_fold_bwd_kernel(FoldBatch a) {
+// 256 genes per workgroup (the unit of the block partials), four lanes per gene as in the forward kernel: 1024 threads
+constexpr int FOLD_BWD_THREADS = 1024;
+__global__ __launch_bounds__(FOLD_BWD_THREADS) void bn_fold_bwd_kernel(FoldBatch a) {
   const FoldProb& q = a.p[blockIdx.y];
   __shared__ float s_zbar[FOLD_KMAX], s_C[FOLD_KMAX * FOLD_KMAX], s_w[256 * FOLD_KMAX], s_dm[256], s_dv[256], s_acc[3][17][64];
   const int K = q.K;
   const int nred = K + K * K;
   if (blockIdx.x * 256 >= q.G) return;  // (the grid is sized for the largest problem)
+  const int gl = threadIdx.x >> 2, sub = threadIdx.x & 3;   // gene of the block, lane of the gene
+  const int g = blockIdx.x * 256 + gl;
+  const bool real = g < q.G;
+  const int gi = min(g, q.G - 1);   // lanes past the last gene compute on it and store nothing: no lane leaves before the shuffles
+  float* w = s_w + gl * FOLD_KMAX;  // this gene's weight row lives in LDS
+  for (int k = sub; k < K; k += 4) w[k] = real ? q.W[(long)g * K + k] : 0.f;
   if (a.training) {
     const float invB = 1.0f / (float)a.B;
-    for (int i = threadIdx.x; i < K; i += 256) s_zbar[i] = q.zsum[i] * invB;
-    __syncthreads();
-    for (int i = threadIdx.x; i < K * K; i += 256) s_C[i] = q.zz[i] * invB - s_zbar[i / K] * s_zbar[i % K];
+    for (int i = threadIdx.x; i < K; i += FOLD_BWD_THREADS) s_zbar[i] = q.zsum[i] * invB;
+    for (int i = threadIdx.x; i < K * K; i += FOLD_BWD_THREADS) s_C[i] = q.zz[i] * invB - (q.zsum[i / K] * invB) * (q.zsum[i % K] * invB);
   }
   __syncthreads();
-  const int g = blockIdx.x * 256 + threadIdx.x;
   float dmean = 0.f, dvar = 0.f;
-  float* w = s_w + threadIdx.x * FOLD_KMAX;  // this thread's weight row lives in LDS
-  for (int k = 0; k < K; ++k) w[k] = (g < q.G) ? q.W[(long)g * K + k] : 0.f;
-  if (g < q.G) {
-    const float mean = q.stat[2 * g], var = q.stat[2 * g + 1];
-    const float rs = rsqrtf(var + a.eps), gam = q.gamma[g], inv = gam * rs;
-    const float* gW = q.dWeff + (long)g * q.ld_dw;
+  {
+    const float mean = q.stat[2 * gi], var = q.stat[2 * gi + 1];
+    const float rs = rsqrtf(var + a.eps), gam = q.gamma[gi], inv = gam * rs;
+    const float* gW = q.dWeff + (long)gi * q.ld_dw;
     const float gc = gW[K];
-    float dinv = -gc * mean;
-    for (int k = 0; k < K; ++k) dinv += gW[k] * w[k];
-    q.dbeta[g] = gc;
-    q.dgamma[g] = dinv * rs;
+    float dinv = 0.f;
+    for (int k = sub; k < K; k += 4) dinv += gW[k] * w[k];
+    dinv += __shfl_xor(dinv, 1); dinv += __shfl_xor(dinv, 2);   // (the same bits on the four lanes: the additions commute)
+    dinv -= gc * mean;
+    if (real && sub == 0) {
+      q.dbeta[g] = gc;
+      q.dgamma[g] = dinv * rs;
+    }
     if (a.training) {
-      dmean = -gc * inv;
-      dvar = dinv * gam * (-0.5f) * rs * rs * rs;
-      for (int k0 = 0; k0 < K; k0 += 4) {   // four rows of C at a time (independent chains)
+      if (real) {
+        dmean = -gc * inv;
+        dvar = dinv * gam * (-0.5f) * rs * rs * rs;
+      }
+      for (int k0 = sub; k0 < K; k0 += 16) {   // this lane's rows k0, k0 + 4, k0 + 8, k0 + 12 of C (independent chains)
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         int row[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) row[u] = min(k0 + u, K - 1) * K;
+        for (int u = 0; u < 4; ++u) row[u] = min(k0 + 4 * u, K - 1) * K;
         for (int l = 0; l < K; ++l) {
           const float wl = w[l];
 #pragma unroll
           for (int u = 0; u < 4; ++u) v[u] += s_C[row[u] + l] * wl;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (k0 + u < K) q.dW[(long)g * K + k0 + u] = gW[k0 + u] * inv + dmean * s_zbar[k0 + u] + 2.0f * dvar * v[u];
+        for (int u = 0; u < 4; ++u) {
+          const int k = k0 + 4 * u;
+          if (real && k < K) q.dW[(long)g * K + k] = gW[k] * inv + dmean * s_zbar[k] + 2.0f * dvar * v[u];
+        }
       }
-    } else {
-      for (int k = 0; k < K; ++k) q.dW[(long)g * K + k] = gW[k] * inv;
+    } else if (real) {
+      for (int k = sub; k < K; k += 4) q.dW[(long)g * K + k] = gW[k] * inv;
     }
   }
   if (!a.training) return;
   // block partials of d zbar[k] = sum_g dmean_g w_gk and d C[k][l] = sum_g dvar_g w_gk w_gl, summed in gene order
-  s_dm[threadIdx.x] = dmean; s_dv[threadIdx.x] = dvar;
+  if (sub == 0) { s_dm[gl] = dmean; s_dv[gl] = dvar; }
   __syncthreads();
   // One exact-fp32 MFMA tile per wave (v_mfma_f32_32x32x2_f32, two genes per step): dC = (dv . W)^T W is a
   // [K x 256] x [256 x K] product and d zbar rides along as row 0 of a second tile; the four waves' tiles are added in
@@ -1019,12 +1031,13 @@ __global__ __launch_bounds__(256) void bn_fold_bwd_kernel(FoldBatch a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) accC[i] = 0.f;
     f16v accM = accC;
-    for (int t = 64 * wave; t < 64 * wave + 64; t += 2) {
-      const float wv = (r < K) ? s_w[(t + h) * FOLD_KMAX + r] : 0.f;
-      accC = mfma_f32(s_dv[t + h] * wv, wv, accC);
-      accM = mfma_f32((r == 0) ? s_dm[t + h] : 0.f, wv, accM);
-    }
-    if (wave > 0) {
+    if (wave < 4)   // (waves 4..15 only served the per-gene phase)
+      for (int t = 64 * wave; t < 64 * wave + 64; t += 2) {
+        const float wv = (r < K) ? s_w[(t + h) * FOLD_KMAX + r] : 0.f;
+        accC = mfma_f32(s_dv[t + h] * wv, wv, accC);
+        accM = mfma_f32((r == 0) ? s_dm[t + h] : 0.f, wv, accM);
+      }
+    if (wave > 0 && wave < 4) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) s_acc[wave - 1][i][lane] = accC[i];
       s_acc[wave - 1][16][lane] = accM[0];
