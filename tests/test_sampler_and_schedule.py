@@ -1,4 +1,5 @@
 """CPU: host logic of the train loop -- sampler epoch semantics, KL warm-up, epochs heuristic."""
+import pytest
 import numpy as np
 import torch
 
@@ -48,3 +49,17 @@ def test_kl_warmup_and_epoch_heuristic():
     assert kl_weight_at(5, 50, None, 100) == 0.5 and kl_weight_at(5, 150, None, 100) == 1.0  # steps only without an epoch count
     assert kl_weight_at(3, 7, None, None) == 1.0
     assert default_max_epochs(50_000) == 160 and default_max_epochs(1_000) == 400  # training_mixin.py:89-91
+
+
+@pytest.mark.parametrize("B", [64, 128, 500, 4096, 8192])
+@pytest.mark.parametrize("G", [32, 2000, 10000, 20000, 30000])
+def test_launch_splits_cover_every_gene_for_any_shape(B, G):
+    """the host-side split arithmetic the decoder kernels trust (spv_dec_* reject anything else): gene splits are multiples of 32
+    genes that cover the padded gene count, likelihood splits fit their LDS slice"""
+    from spvipes_amd._abi import DEC_CELLS_PER_WG
+    from spvipes_amd.ops import NB_GSPL_MAX, _gene_splits, _nb_splits
+    Bp, Gp = -(-B // DEC_CELLS_PER_WG) * DEC_CELLS_PER_WG, -(-G // 32) * 32
+    splits, per = _gene_splits(Bp, Gp)
+    assert splits >= 1 and per % 32 == 0 and splits * per >= Gp and (splits - 1) * per < Gp
+    nbs, nbper = _nb_splits(Gp)
+    assert nbs >= 1 and nbper % 32 == 0 and nbper <= NB_GSPL_MAX and nbs * nbper >= Gp and (nbs - 1) * nbper < Gp
