@@ -5,6 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
+With N > 1 and no torchrun environment (WORLD_SIZE unset) the first form starts the second one itself as a child process,
+one rank per GPU, forwards rank 0's JSON line and exits with the child's status; a WORLD_SIZE that differs from --gpus is an
+error.  --gpus N > 1 without --config runs c3 (one rank's shard of the 2 x 200 000 x 20 000 configuration the scaling target
+is quoted on).
+
 One "step" = one optimisation step of the hot path on one synthetic minibatch per group
 (forward through both encoders, label-based PoE, decoder + NB-mixture ELBO, backward, one gradient
 all-reduce when N > 1, Adam).  Default workload (--config c2) = BASELINE.json configs[1]: 2 groups x
@@ -57,12 +62,14 @@ CONFIGS = {
 }
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)     # >= 50 timed steps after 10 warm-up
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS), help="BASELINE.json workload preset (see the module docstring)")
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
+                    help="BASELINE.json workload preset (see the module docstring); default: c2 on one GPU, c3 (the shard shape the 1 -> 8 "
+                         "scaling target is quoted on) when --gpus > 1")
     ap.add_argument("--cells", type=int, default=None, help="cells per group per rank")
     ap.add_argument("--genes", type=int, default=None, help="genes per group")
     ap.add_argument("--batch-size", type=int, default=None, help="cells per group per step per rank")
@@ -81,7 +88,9 @@ def parse():
                          "decoder bucket overlapped with the encoder half of the backward pass (auto: overlap when WORLD_SIZE > 1)")
     ap.add_argument("--cpu-batch", type=int, default=1024, help="cells per group of the CPU baseline sample (about 10 s of CPU work at C2)")
     ap.add_argument("--cpu-steps", type=int, default=3)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.config is None:
+        args.config = "c2" if args.gpus <= 1 else "c3"
     preset = CONFIGS[args.config]
     for k, v in preset.items():
         if k != "what" and getattr(args, k) is None:
@@ -223,13 +232,47 @@ def elbo_delta_oracle(st, args, plan):
             "what": f"one training-mode step of this workload (B {args.batch_size} x G {args.genes}, {args.poe} PoE, {args.precision}), same parameters / rows / noise, dropout off, kl_weight 1"}
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+def launcher_command(n: int, argv) -> list:
+    """the one-rank-per-GPU launch of this script (the command the driver uses for N > 1), rendezvous on 127.0.0.1 at a free port"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def launch_ranks(args, argv) -> int:
+    """``python bench.py --gpus N`` (N > 1) outside a torchrun environment: start the N ranks as a CHILD process (never an exec:
+    nothing in this process has touched the GPU, and nothing will), forward the child's output (rank 0 prints the JSON line) and
+    return its exit status -- a plain `--gpus 8` can never end as a silent single-GPU number."""
+    import subprocess
+    cmd = launcher_command(args.gpus, argv)
+    if os.environ.get("SPV_BENCH_LAUNCH_DRYRUN") == "1":   # (tests: show the command, start nothing)
+        print(json.dumps({"launch": cmd}), flush=True)
+        return 0
+    n_dev = torch.cuda.device_count()   # (does not initialise the GPU)
+    if n_dev < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but this node exposes {n_dev} GPU(s)", file=sys.stderr, flush=True)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:   # before anything touches the GPU
+            raise SystemExit(launch_ranks(args, argv))
+        world = 1
+    else:
+        world = int(os.environ["WORLD_SIZE"])
+        if world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (python bench.py --gpus N does it itself)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -345,6 +388,28 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         exposed = float(tt)
 
+    # Weak-scaling reference measured in the same job: rank 0 alone repeats the timed loop on its own shard with the collectives
+    # switched off (same two-graph step, same workload), the other ranks wait at the barrier.  value / this = the speed-up over ONE GPU
+    # on the SAME per-GPU workload (the default N = 1 run of this script is preset c2, a different shape).
+    n1_ref = None
+    if world > 1:
+        torch.cuda.synchronize()
+        dist.barrier()
+        if rank == 0:
+            w_saved, trainer.world = trainer.world, 1
+            try:
+                for _ in range(3):
+                    trainer.step(next(it), kl_weight=1.0)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    trainer.step(next(it), kl_weight=1.0)
+                torch.cuda.synchronize()
+                n1_ref = NG * args.batch_size * args.steps / (time.perf_counter() - t1)
+            finally:
+                trainer.world = w_saved
+        dist.barrier()
+
     if rank == 0 and delta_state is not None:
         try:
             delta = elbo_delta_oracle(delta_state, args, plan)
@@ -393,10 +458,11 @@ def main():
             "config": {"workload": f"{NG} groups x {args.cells} cells x {G} genes per GPU, {poe_txt}, n_shared={n_s} n_private={n_p} "
                                    f"n_hidden={H}, batch {B} cells/group/step/GPU, counts resident as {args.count_dtype} ({CONFIGS[args.config]['what']})",
                        "preset": args.config,
-                       "parallelism": f"dp{world}", "precision": args.precision, "launch": "hipGraph replay, 2 streams" if use_graph else "eager",
+                       "parallelism": f"dp{world}", "rccl_ranks": dist.get_world_size() if world > 1 else 1, "precision": args.precision, "launch": "hipGraph replay, 2 streams" if use_graph else "eager",
                        "allreduce": ("none (1 rank)" if world == 1 else "2 buckets, decoder bucket overlapped with the encoder backward"
                                      if trainer.overlap else "1 bucket after the backward pass (north_star form)"),
-                       "allreduce_exposed_ms_per_step": exposed},
+                       "allreduce_exposed_ms_per_step": exposed,
+                       "one_gpu_same_workload_cells_per_s": n1_ref},   # rank 0 alone, collectives off, same step form (N > 1 runs only)
             "final_loss": loss,
             "elbo_delta": delta,
             "roofline": roof,

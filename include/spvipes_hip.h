@@ -66,6 +66,16 @@ int spv_pack_bf16(const float* src, int64_t ld_src, int32_t R, int32_t C,
                   uint16_t* dst_hi, uint16_t* dst_lo, int64_t ld_dst, int32_t dst_col_off,
                   int32_t Rp, int32_t cslot, void* stream);
 
+/* The encoder's first layer in the nsplit == 1 mode keeps its 16-bit operand images as IEEE f16 words (11 significant bits instead
+ * of bf16's 8, same MFMA rate; a 10 000 .. 30 000-term contraction with bf16 operands left the latent means 5e-3 off the fp32
+ * reference): the weight image W1_hi = f16(W * spv_fc1_w_scale()) (a power of two, undone by the forward epilogue), the resident
+ * log1p image of spv_prepare_log1p, and the dh image of the weight gradient scaled per step by a power of two (spv_enc_fc1_bwd_prep).
+ * spv_pack_f16: fp32 [R][C] * scale -> f16 image dst[Rp][ld_dst] over `cslot` columns, zero filled outside the source, saturating
+ * (cslot and ld_dst multiples of 8, dst 16-byte aligned). */
+float spv_fc1_w_scale(void);
+int spv_pack_f16(const float* src, int64_t ld_src, int32_t R, int32_t C, uint16_t* dst, int64_t ld_dst, int32_t Rp, int32_t cslot,
+                 float scale, void* stream);
+
 /* 1 when spv_enc_fc1_fwd will take its LDS-DMA kernel for these shapes (resident bf16 log1p image, N1 = 256, nsplit 1, operand rows
  * zero padded to multiples of 64 genes).  The caller needs to know because that path wants `slabs` sized
  * [splits][round_up(B, 128)][N1] fp32 (it keeps the partial sums in MFMA accumulator-tile order) and splits chosen as
@@ -75,12 +85,13 @@ int spv_enc_fc1_fwd_uses_dma(int32_t B, int32_t G, int32_t N1, int32_t nsplit, i
 /* A1 + first layer of both encoders of a group (module/spVIPESmodule.py:428-435,
  * nn/networks.py:119):  h1 = relu(log1p(X[rows]) @ W1^T + b1) for the concatenated
  * [private ; shared] fc1 (N1 = 2 * n_hidden output columns), library = log(sum_g log1p(x)).
- *   W1_hi/lo : bf16 [N1p][ldw] (rows = output units, K = genes contiguous, ldw % 32 == 0)
+ *   W1_hi/lo : [N1p][ldw] (rows = output units, K = genes contiguous, ldw % 32 == 0): nsplit 3: bf16 hi / lo of W;
+ *              nsplit 1: W1_hi = f16(W * spv_fc1_w_scale()) from spv_pack_f16 / spv_adam_step_images, W1_lo unused
  *   bias     : fp32 [N1], or the two encoders' biases in place: bias [n_first] and bias2 [N1 - n_first]
  *              (bias2 == NULL: one vector)
  *   slabs    : fp32 workspace [splits][B][N1];  rowsum_ws: fp32 [splits][B]
  *   h1       : fp32 [B][N1];  library: fp32 [B]
- *   xb_all, library_all : optional (nsplit 1 only): bf16(log1p(x)) of the WHOLE resident count matrix [n_cells][ld_xb] (zero
+ *   xb_all, library_all : optional (nsplit 1 only): f16(log1p(x)) of the WHOLE resident count matrix [n_cells][ld_xb] (zero
  *              padded to ld_xb >= round_up(G, 128)) and log(sum_g log1p(x)) per cell, both from spv_prepare_log1p; the GEMM
  *              then gathers plain bf16 rows through x->rows instead of decoding counts, and library is a table lookup */
 int spv_enc_fc1_fwd(const spv_counts* x, int32_t B, int32_t G,
@@ -89,28 +100,32 @@ int spv_enc_fc1_fwd(const spv_counts* x, int32_t B, int32_t G,
                     float* slabs, float* rowsum_ws, float* h1, float* library,
                     const uint16_t* xb_all, int64_t ld_xb, const float* library_all, void* stream);
 
-/* Once per resident count matrix: xb[c][g] = bf16(log1p(X[c][g])) (zero for g >= G, row pitch ld_xb) and
+/* Once per resident count matrix: xb[c][g] = f16(log1p(X[c][g])) (zero for g >= G, row pitch ld_xb) and
  * library[c] = log(sum_g log1p(X[c][g])) (module/spVIPESmodule.py:428-435 evaluated for every cell of the data set).
  * x->rows is ignored.                                                                                               */
 int spv_prepare_log1p(const spv_counts* x, int32_t n_cells, int32_t G, uint16_t* xb, int64_t ld_xb, float* library, void* stream);
 
 /* fc1 weight gradient (autograd of nn/networks.py:119):  dW1[N1][G] = dh^T @ log1p(X[rows]).
- *   dh_hi/lo : bf16 [round_up(B,64)][ld_dh] (ld_dh >= round_up(N1,128), zero padded)
- *   xb       : optional (nsplit 1): the resident bf16 log1p image of spv_prepare_log1p ([n_cells][ld_xb], gathered through
+ *   dh_hi/lo : [round_up(B,64)][ld_dh] (ld_dh >= round_up(N1,128), zero padded) from spv_enc_fc1_bwd_prep: nsplit 3 bf16 hi / lo,
+ *              nsplit 1 f16(dpre * scale) with dh_scale = that call's scale_ws ({scale, 1 / scale}: the result is multiplied by [1])
+ *   xb       : optional (nsplit 1): the resident f16 log1p image of spv_prepare_log1p ([n_cells][ld_xb], gathered through
  *              x->rows); NULL = decode the counts here
  *   dW2      : optional second destination: rows >= rows_first go to dW2[row - rows_first] (the shared
  *              encoder's weight gradient, stored apart from the private encoder's)  */
 int spv_enc_fc1_wgrad(const spv_counts* x, int32_t B, int32_t G,
                       const uint16_t* dh_hi, const uint16_t* dh_lo, int64_t ld_dh, int32_t N1,
                       int32_t nsplit, float* dW, float* dW2, int32_t rows_first, int64_t ldc,
-                      const uint16_t* xb, int64_t ld_xb, void* stream);
+                      const uint16_t* xb, int64_t ld_xb, const float* dh_scale, void* stream);
 
-/* Backward of fc1's ReLU + bias (nn/networks.py:119): dpre = dh1 * (h1 > 0) packed as the bf16 image
- * spv_enc_fc1_wgrad consumes ([Bp][ld_img], zero padded; img_lo optional), and the bias gradients
+/* Backward of fc1's ReLU + bias (nn/networks.py:119): dpre = dh1 * (h1 > 0) packed as the 16-bit image
+ * spv_enc_fc1_wgrad consumes ([Bp][ld_img], zero padded), and the bias gradients
  * db[col] = sum_b dpre[b][col] (cols >= n_first to db2[col - n_first] when db2 != NULL).
- *   part : fp32 workspace [Bp / 16][N1] */
+ *   img_lo != NULL ("fp32" mode): bf16 hi / lo images;  img_lo == NULL: img_hi = f16(dpre * scale), scale = the power of two that
+ *   brings max |dpre| of this call into [4096, 8192) (a pure function of dpre: no state across steps, no atomics)
+ *   part     : fp32 workspace [Bp / 16][N1]
+ *   scale_ws : fp32 [2 + Bp / 16] (required when img_lo == NULL): [0] = scale, [1] = 1 / scale, rest = per-block maxima */
 int spv_enc_fc1_bwd_prep(const float* dh1, const float* h1, int32_t B, int32_t N1, uint16_t* img_hi, uint16_t* img_lo,
-                         int64_t ld_img, int32_t Bp, float* part, float* db, float* db2, int32_t n_first, void* stream);
+                         int64_t ld_img, int32_t Bp, float* part, float* db, float* db2, int32_t n_first, float* scale_ws, void* stream);
 
 /* Grouped forms of the three fc1 entry points above: one argument block per group (same meaning as the parameters of
  * spv_enc_fc1_fwd / spv_enc_fc1_bwd_prep + spv_enc_fc1_wgrad).  Pairs of groups whose shapes take the LDS-DMA kernels run as ONE launch
@@ -128,10 +143,11 @@ int spv_enc_fc1_fwd_grouped(const spv_fc1_fwd_args* groups, int32_t n_groups, vo
 typedef struct spv_fc1_bwd_args {
   const float* dh1; const float* h1; const spv_counts* x;
   int32_t B, G, N1, n_first, nsplit, Bp;
-  uint16_t* dh_hi; uint16_t* dh_lo; int64_t ld_dh;      /* workspace: packed bf16 image of relu'(h1) * dh1, [Bp][ld_dh] */
+  uint16_t* dh_hi; uint16_t* dh_lo; int64_t ld_dh;      /* workspace: packed 16-bit image of relu'(h1) * dh1, [Bp][ld_dh] */
   float* part;                                          /* workspace: [Bp / 16][N1] column partial sums */
   float* db; float* db2; float* dW; float* dW2; int64_t ldc;
   const uint16_t* xb; int64_t ld_xb;
+  float* scale_ws;                                      /* workspace: [2 + Bp / 16] (nsplit 1: scale record of the f16 dh image) */
 } spv_fc1_bwd_args;
 int spv_enc_fc1_bwd_grouped(const spv_fc1_bwd_args* groups, int32_t n_groups, void* stream);
 
@@ -226,15 +242,19 @@ int spv_dec_dz(const spv_dec_params* p, const float* Tp, const float* Ts, float*
  * (sum the slabs with spv_reduce_slabs): replaces the two [B,G] x [G,K] GEMMs over tP and tS. */
 int spv_dec_softmax_bwd(const spv_dec_params* p, const float* Tp, const float* Ts, float* dz_part, void* stream);
 
-/* One bf16 operand image kept in step with a parameter by spv_adam_step_images: the `count` fp32 values at flat offset `begin`
- * (a multiple of 4) are a row-major matrix with `cols` columns; element (r, c) is also written, rounded to bf16, to
- * dst[(r + row_off) * ld + c + col_off].  A vector that forms one column of an image is cols = 1. */
+/* One 16-bit operand image kept in step with a parameter by spv_adam_step_images: the `count` fp32 values at flat offset `begin`
+ * (a multiple of 4) are a row-major matrix with `cols` columns; element (r, c) is also written to
+ * dst[(r + row_off) * ld + c + col_off], rounded to bf16 (fmt SPV_IMAGE_BF16) or as f16(value * scale) (fmt SPV_IMAGE_F16: the fc1
+ * weight images, scale = spv_fc1_w_scale()).  A vector that forms one column of an image is cols = 1. */
 #define SPV_ADAM_MAX_IMAGES 16
+#define SPV_IMAGE_BF16 0
+#define SPV_IMAGE_F16 1
 typedef struct spv_adam_image {
   int64_t begin, count;
-  int32_t cols, row_off, col_off, _pad;
+  int32_t cols, row_off, col_off, fmt;
   int64_t ld;
   uint16_t* dst;
+  float scale; int32_t _pad;
 } spv_adam_image;
 
 /* spv_adam_step that also rewrites the bf16 images of the matrices it updates (the packed operands spv_pack_bf16 would otherwise
@@ -255,6 +275,10 @@ int spv_gather_u32(const spv_gather_prob* probs, int32_t nprob, void* stream);
  * `counter` (nullable = 0) is read on the device when the kernel runs -- pass the step counter spv_adam_step_images increments and
  * a captured graph draws fresh noise at every replay without any host-side generator state. */
 int spv_randn(float* out, int64_t n, const int64_t* counter, uint64_t key, void* stream);
+/* *counter += 1 in stream order.  Forward passes that no optimiser step follows (the reference draws fresh torch.randn noise for
+ * every batch of get_latent_representation, model/spvipes.py:536-538, nn/networks.py:128-134) advance the counter with this, so
+ * that consecutive inference / validation batches do not share one noise matrix. */
+int spv_counter_bump(int64_t* counter, void* stream);
 
 /* One Adam step (torch.optim.Adam semantics, L2 weight decay folded into the gradient) over a
  * flat fp32 parameter buffer; grad_scale multiplies g first (1/world for data-parallel means).

@@ -113,7 +113,7 @@ class SpvFc1BwdArgs(C.Structure):
     _fields_ = [("dh1", C.c_void_p), ("h1", C.c_void_p), ("x", C.POINTER(SpvCounts)), ("B", C.c_int32), ("G", C.c_int32), ("N1", C.c_int32),
                 ("n_first", C.c_int32), ("nsplit", C.c_int32), ("Bp", C.c_int32), ("dh_hi", C.c_void_p), ("dh_lo", C.c_void_p), ("ld_dh", C.c_int64),
                 ("part", C.c_void_p), ("db", C.c_void_p), ("db2", C.c_void_p), ("dW", C.c_void_p), ("dW2", C.c_void_p), ("ldc", C.c_int64),
-                ("xb", C.c_void_p), ("ld_xb", C.c_int64)]
+                ("xb", C.c_void_p), ("ld_xb", C.c_int64), ("scale_ws", C.c_void_p)]
 
 
 class SpvGatherProb(C.Structure):
@@ -129,11 +129,12 @@ def gather_u32(probs) -> None:
 
 
 ADAM_MAX_IMAGES = 16
+IMAGE_BF16, IMAGE_F16 = 0, 1   # spv_adam_image.fmt
 
 
 class SpvAdamImage(C.Structure):
-    _fields_ = [("begin", C.c_int64), ("count", C.c_int64), ("cols", C.c_int32), ("row_off", C.c_int32), ("col_off", C.c_int32), ("_pad", C.c_int32),
-                ("ld", C.c_int64), ("dst", C.c_void_p)]
+    _fields_ = [("begin", C.c_int64), ("count", C.c_int64), ("cols", C.c_int32), ("row_off", C.c_int32), ("col_off", C.c_int32), ("fmt", C.c_int32),
+                ("ld", C.c_int64), ("dst", C.c_void_p), ("scale", C.c_float), ("_pad", C.c_int32)]
 
 
 class SpvPoeCompArgs(C.Structure):
@@ -181,6 +182,8 @@ _SIGNATURES = {
     "spv_build_id": (C.c_char_p, []),
     "spv_pack_bf16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                 C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "spv_fc1_w_scale": (C.c_float, []),
+    "spv_pack_f16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "spv_enc_fc1_fwd_uses_dma": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64]),
     "spv_enc_fc1_fwd": (C.c_int, [C.POINTER(SpvCounts), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                   C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -189,9 +192,9 @@ _SIGNATURES = {
     "spv_enc_fc1_bwd_grouped": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "spv_prepare_log1p": (C.c_int, [C.POINTER(SpvCounts), C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "spv_enc_fc1_wgrad": (C.c_int, [C.POINTER(SpvCounts), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
-                                    C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+                                    C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "spv_enc_fc1_bwd_prep": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
-                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "spv_dec_heads_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "spv_gemm_bf16_uses_dma": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64]),
     "spv_gemm_bf16": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
@@ -233,6 +236,7 @@ _SIGNATURES = {
                                        C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "spv_gather_u32": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "spv_randn": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "spv_counter_bump": (C.c_int, [C.c_void_p, C.c_void_p]),
     "spv_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float,
                                 C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
 }

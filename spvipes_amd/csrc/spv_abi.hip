@@ -101,19 +101,51 @@ extern "C" int spv_pack_bf16(const float* src, int64_t ld_src, int32_t R, int32_
   return launch_status("spv_pack_bf16");
 }
 
+// fp32 [R][C] * scale -> IEEE f16 image dst[Rp][ld_dst] (zero filled outside the source): the fc1 weight operand of the
+// NSPLIT == 1 mode (spv_common.h).  One thread per 8 destination columns.
+__global__ void pack_f16_kernel(const float* src, long ld_src, int R, int C, bf16_t* dst, long ld_dst, int Rp, int cslot8, float scale) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)Rp * cslot8) return;
+  const int r = (int)(idx / cslot8), c0 = (int)(idx % cslot8) * 8;
+  unsigned w[4] = {0u, 0u, 0u, 0u};
+  if (r < R) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c0 + j;
+      const float v = (c < C) ? src[(long)r * ld_src + c] * scale : 0.f;
+      w[j >> 1] |= (unsigned)f2h(v) << (16 * (j & 1));
+    }
+  }
+  *reinterpret_cast<u4v*>(dst + (long)r * ld_dst + c0) = u4v{w[0], w[1], w[2], w[3]};
+}
+
+extern "C" float spv_fc1_w_scale(void) { return SPV_FC1_W_SCALE; }
+
+extern "C" int spv_pack_f16(const float* src, int64_t ld_src, int32_t R, int32_t C, uint16_t* dst, int64_t ld_dst, int32_t Rp, int32_t cslot,
+                            float scale, void* stream) {
+  if (!src || !dst || R < 0 || C < 0 || Rp < R || cslot < C || cslot > ld_dst || (cslot % 8) || (ld_dst % 8) || ((uintptr_t)dst % 16))
+    return fail(SPV_ERR_ARG, "spv_pack_f16: bad shape (cslot, ld_dst multiples of 8, dst 16-byte aligned)%s");
+  const long tot8 = (long)Rp * (cslot / 8);
+  if (tot8 == 0) return SPV_OK;
+  hipLaunchKernelGGL(pack_f16_kernel, dim3((unsigned)((tot8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (long)ld_src, R, C, dst, (long)ld_dst,
+                     Rp, cslot / 8, scale);
+  return launch_status("spv_pack_f16");
+}
+
 // ---------------------------------------------------------------------------------------------
 // encoder fc1
 // ---------------------------------------------------------------------------------------------
 __global__ void fc1_epilogue_kernel(const float* slabs, const float* rowsum_ws, int splits, int B, int N1, const float* bias,
                                     const float* bias2, int n_first, float* h1, float* library, const float* library_all,
-                                    const int* rows) {
+                                    const int* rows, float acc_scale) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)B * N1;
   if (idx < total) {
     const int col = (int)(idx % N1);
-    float v = (bias2 != nullptr && col >= n_first) ? bias2[col - n_first] : bias[col];
+    const float bv = (bias2 != nullptr && col >= n_first) ? bias2[col - n_first] : bias[col];
+    float v = 0.f;
     for (int s = 0; s < splits; ++s) v += slabs[(long)s * total + idx];
-    h1[idx] = fmaxf(v, 0.f);  // relu(fc1(x)), nn/networks.py:119
+    h1[idx] = fmaxf(v * acc_scale + bv, 0.f);  // relu(fc1(x)), nn/networks.py:119
   }
   if (idx < B) {
     if (library_all != nullptr) {  // precomputed per cell of the data set (spv_prepare_log1p)
@@ -134,12 +166,13 @@ static int counts_aligned(const spv_counts* x) {
 
 template <typename CT, int NSPLIT>
 static int fc1_fwd_dispatch(const GemmParams& p, int N1, int splits, hipStream_t s) {
-  if (N1 <= 32) return launch_gemm<GemmCfg<128, 32, 4, 1, false, false, SRC_COUNTS, SRC_PLAIN, CT, NSPLIT, 32, 4>>(p, splits, s);
-  if (N1 <= 128) return launch_gemm<GemmCfg<64, 128, 2, 2, false, false, SRC_COUNTS, SRC_PLAIN, CT, NSPLIT, 32, 4>>(p, splits, s);
+  constexpr bool HF = NSPLIT == 1;   // 16-bit operand words of the one-MFMA mode are f16 (spv_common.h)
+  if (N1 <= 32) return launch_gemm<GemmCfg<128, 32, 4, 1, false, false, SRC_COUNTS, SRC_PLAIN, CT, NSPLIT, 32, 4, 1, HF>>(p, splits, s);
+  if (N1 <= 128) return launch_gemm<GemmCfg<64, 128, 2, 2, false, false, SRC_COUNTS, SRC_PLAIN, CT, NSPLIT, 32, 4, 1, HF>>(p, splits, s);
   if constexpr (NSPLIT == 1) {
-    if (p.M >= 1024) return launch_gemm<GemmCfg<128, 256, 2, 2, false, false, SRC_COUNTS, SRC_PLAIN, CT, NSPLIT, 32, 2, 2>>(p, splits, s);  // 64 x 128 wave tiles
+    if (p.M >= 1024) return launch_gemm<GemmCfg<128, 256, 2, 2, false, false, SRC_COUNTS, SRC_PLAIN, CT, NSPLIT, 32, 2, 2, HF>>(p, splits, s);  // 64 x 128 wave tiles
   }
-  return launch_gemm<GemmCfg<64, 256, 1, 4, false, false, SRC_COUNTS, SRC_PLAIN, CT, NSPLIT, 32, 4>>(p, splits, s);
+  return launch_gemm<GemmCfg<64, 256, 1, 4, false, false, SRC_COUNTS, SRC_PLAIN, CT, NSPLIT, 32, 4, 1, HF>>(p, splits, s);
 }
 
 // Shapes the LDS-DMA fc1 forward kernel (spv_fc1.h) takes: the resident bf16 log1p image, both encoders' 2H = 256 output columns,
@@ -182,6 +215,7 @@ extern "C" int spv_enc_fc1_fwd(const spv_counts* x, int32_t B, int32_t G, const 
   p.epi = EPI_STORE;
   hipStream_t s = (hipStream_t)stream;
   int rc;
+  const float acc_scale = (nsplit == 1) ? 1.0f / SPV_FC1_W_SCALE : 1.0f;   // the f16 weight image holds W * SPV_FC1_W_SCALE (spv_pack_f16)
   if (spv_enc_fc1_fwd_uses_dma(B, G, N1, nsplit, xb_all != nullptr, ldw, ld_xb) && ((reinterpret_cast<uintptr_t>(xb_all) | reinterpret_cast<uintptr_t>(W1_hi)) & 15) == 0) {
     // LDS-DMA kernel (spv_fc1.h): 128-cell tiles, K split `splits` ways, slabs in accumulator-tile order [splits][Mp128][256]
     const int mtiles = (B + F1_BM - 1) / F1_BM, kt = (G + F1_BK - 1) / F1_BK;
@@ -193,26 +227,27 @@ extern "C" int spv_enc_fc1_fwd(const spv_counts* x, int32_t B, int32_t G, const 
     if (hipGetLastError() != hipSuccess) return launch_status("spv_enc_fc1_fwd dma gemm");
     const long slab_elems = (long)mtiles * F1_BM * N1;
     hipLaunchKernelGGL(fc1_epilogue_tiled_kernel, dim3((unsigned)((slab_elems / 4 + 255) / 256)), dim3(256), 0, s, slabs, splits, slab_elems, B, N1, bias, bias2, n_first, h1, library,
-                       library_all, x->rows);
+                       library_all, x->rows, acc_scale);
     return launch_status("spv_enc_fc1_fwd dma epilogue");
   }
   if (xb_all != nullptr) {
-    if (N1 <= 128) rc = launch_gemm<GemmCfg<64, 128, 2, 2, false, false, SRC_GATHER, SRC_PLAIN, unsigned short, 1, 32, 4>>(p, splits, s);
-    else if (wide64) rc = launch_gemm<GemmCfg<128, 256, 2, 2, false, false, SRC_GATHER, SRC_PLAIN, unsigned short, 1, 64, 1, 2>>(p, splits, s);
-    else rc = launch_gemm<GemmCfg<128, 256, 2, 2, false, false, SRC_GATHER, SRC_PLAIN, unsigned short, 1, 32, 2, 2>>(p, splits, s);
+    if (N1 <= 128) rc = launch_gemm<GemmCfg<64, 128, 2, 2, false, false, SRC_GATHER, SRC_PLAIN, unsigned short, 1, 32, 4, 1, true>>(p, splits, s);
+    else if (wide64) rc = launch_gemm<GemmCfg<128, 256, 2, 2, false, false, SRC_GATHER, SRC_PLAIN, unsigned short, 1, 64, 1, 2, true>>(p, splits, s);
+    else rc = launch_gemm<GemmCfg<128, 256, 2, 2, false, false, SRC_GATHER, SRC_PLAIN, unsigned short, 1, 32, 2, 2, true>>(p, splits, s);
   } else if (x->dtype == SPV_COUNT_U16) rc = (nsplit == 3) ? fc1_fwd_dispatch<unsigned short, 3>(p, N1, splits, s) : fc1_fwd_dispatch<unsigned short, 1>(p, N1, splits, s);
   else if (x->dtype == SPV_COUNT_F32) rc = (nsplit == 3) ? fc1_fwd_dispatch<float, 3>(p, N1, splits, s) : fc1_fwd_dispatch<float, 1>(p, N1, splits, s);
   else return fail(SPV_ERR_ARG, "spv_enc_fc1_fwd: unknown count dtype%s");
   if (rc != SPV_OK) return launch_status("spv_enc_fc1_fwd gemm");
   const long total = (long)B * N1;
-  hipLaunchKernelGGL(fc1_epilogue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, slabs, rowsum_ws, splits, B, N1, bias, bias2, n_first, h1, library, xb_all ? library_all : nullptr, x->rows);
+  hipLaunchKernelGGL(fc1_epilogue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, slabs, rowsum_ws, splits, B, N1, bias, bias2, n_first, h1, library, xb_all ? library_all : nullptr, x->rows, acc_scale);
   return launch_status("spv_enc_fc1_fwd epilogue");
 }
 
 extern "C" int spv_enc_fc1_wgrad(const spv_counts* x, int32_t B, int32_t G, const uint16_t* dh_hi, const uint16_t* dh_lo,
                                  int64_t ld_dh, int32_t N1, int32_t nsplit, float* dW, float* dW2, int32_t rows_first, int64_t ldc,
-                                 const uint16_t* xb, int64_t ld_xb, void* stream) {
+                                 const uint16_t* xb, int64_t ld_xb, const float* dh_scale, void* stream) {
   if (!x || !x->X || !dh_hi || !dW) return fail(SPV_ERR_ARG, "spv_enc_fc1_wgrad: null pointer%s");
+  if (nsplit == 1 && !dh_scale) return fail(SPV_ERR_ARG, "spv_enc_fc1_wgrad: nsplit=1 needs the dh image's scale record (spv_enc_fc1_bwd_prep)%s");
   if (B <= 0 || G <= 0 || N1 <= 0 || ld_dh < ((N1 + 127) & ~127) || (ld_dh % 8) != 0 || ldc < G) return fail(SPV_ERR_ARG, "spv_enc_fc1_wgrad: bad shape%s");
   if (nsplit != 1 && nsplit != 3) return fail(SPV_ERR_ARG, "spv_enc_fc1_wgrad: nsplit must be 1 or 3%s");
   if (nsplit == 3 && !dh_lo) return fail(SPV_ERR_ARG, "spv_enc_fc1_wgrad: nsplit=3 needs dh_lo%s");
@@ -223,6 +258,7 @@ extern "C" int spv_enc_fc1_wgrad(const spv_counts* x, int32_t B, int32_t G, cons
   p.rowsum = nullptr;
   p.C = dW; p.ldc = ldc; p.slab_stride = 0;
   p.C2 = dW2; p.c_split_row = rows_first;
+  p.out_scale = (nsplit == 1) ? dh_scale + 1 : nullptr;   // {scale, 1 / scale} of the f16 dh image
   p.M = N1; p.N = G; p.K = B;
   p.k_per_split = (B + 63) & ~63;
   p.epi = EPI_STORE;
@@ -250,14 +286,14 @@ extern "C" int spv_enc_fc1_wgrad(const spv_counts* x, int32_t B, int32_t G, cons
     // 96-gene tiles when the image rows are padded that far: at G = 10 000 that is 2 x 105 workgroups per group, so the two
     // groups' GEMMs (two streams) are resident together in one round instead of 2 x 314 workgroups in two (-0.04 ms per
     // step; alone the 64-gene tile is 4 us faster)
-    if (ld_xb >= (G + 95) / 96 * 96) rc = launch_gemm<GemmCfg<128, 96, 4, 1, true, true, SRC_PLAIN, SRC_GATHER, unsigned short, 1, 64, 4>>(p, 1, s);
-    else rc = launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_GATHER, unsigned short, 1, 64, 4>>(p, 1, s);
+    if (ld_xb >= (G + 95) / 96 * 96) rc = launch_gemm<GemmCfg<128, 96, 4, 1, true, true, SRC_PLAIN, SRC_GATHER, unsigned short, 1, 64, 4, 1, true>>(p, 1, s);
+    else rc = launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_GATHER, unsigned short, 1, 64, 4, 1, true>>(p, 1, s);
   } else if (x->dtype == SPV_COUNT_U16) {
     rc = (nsplit == 3) ? launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_COUNTS, unsigned short, 3, 64, 4>>(p, 1, s)
-                       : launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_COUNTS, unsigned short, 1, 64, 4>>(p, 1, s);
+                       : launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_COUNTS, unsigned short, 1, 64, 4, 1, true>>(p, 1, s);
   } else if (x->dtype == SPV_COUNT_F32) {
     rc = (nsplit == 3) ? launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_COUNTS, float, 3, 64, 4>>(p, 1, s)
-                       : launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_COUNTS, float, 1, 64, 4>>(p, 1, s);
+                       : launch_gemm<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_COUNTS, float, 1, 64, 4, 1, true>>(p, 1, s);
   } else return fail(SPV_ERR_ARG, "spv_enc_fc1_wgrad: unknown count dtype%s");
   (void)rc;
   return launch_status("spv_enc_fc1_wgrad");
@@ -585,6 +621,12 @@ __global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, lon
 }
 __global__ void counter_bump_kernel(long long* counter) { if (threadIdx.x == 0 && blockIdx.x == 0) *counter += 1; }
 
+extern "C" int spv_counter_bump(int64_t* counter, void* stream) {
+  if (!counter) return fail(SPV_ERR_ARG, "spv_counter_bump: null counter%s");
+  hipLaunchKernelGGL(counter_bump_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long*)counter);
+  return launch_status("spv_counter_bump");
+}
+
 extern "C" int spv_randn(float* out, int64_t n, const int64_t* counter, uint64_t key, void* stream) {
   if (!out || n < 0) return fail(SPV_ERR_ARG, "spv_randn: bad arguments%s");
   if (n == 0) return SPV_OK;
@@ -636,12 +678,14 @@ __global__ void adam_images_kernel(float* __restrict__ p, const float* __restric
       const unsigned cols = (unsigned)q.cols;
       unsigned r = (unsigned)k0 / cols, c = (unsigned)k0 - r * cols;
       uint16_t* dst = q.dst + ((long)r + q.row_off) * q.ld + q.col_off;
+      const bool half = q.fmt == SPV_IMAGE_F16;   // (uniform per image: the fc1 weight images are f16 words of W * scale, spv_common.h)
       if (cnt == 4 && k0 + 4 <= q.count && c + 4 <= cols && (((reinterpret_cast<uintptr_t>(dst + c)) & 7) == 0)) {
         typedef __attribute__((ext_vector_type(4))) unsigned short us4;
-        *reinterpret_cast<us4*>(dst + c) = us4{f2bf(out[0]), f2bf(out[1]), f2bf(out[2]), f2bf(out[3])};
+        *reinterpret_cast<us4*>(dst + c) = half ? us4{f2h(out[0] * q.scale), f2h(out[1] * q.scale), f2h(out[2] * q.scale), f2h(out[3] * q.scale)}
+                                                : us4{f2bf(out[0]), f2bf(out[1]), f2bf(out[2]), f2bf(out[3])};
       } else {
         for (int j = 0; j < cnt && k0 + j < q.count; ++j) {
-          dst[c] = f2bf(out[j]);
+          dst[c] = half ? f2h(out[j] * q.scale) : f2bf(out[j]);
           if (++c == cols) { c = 0; dst += q.ld; }
         }
       }
@@ -662,7 +706,7 @@ extern "C" int spv_adam_step_images(float* p, const float* g, float* m, float* v
   for (int d = 0; d < n_images; ++d) {
     const spv_adam_image& q = images[d];
     if (!q.dst || q.begin < 0 || (q.begin & 3) || q.count <= 0 || q.begin + q.count > n || q.cols <= 0 || q.ld < q.cols + q.col_off || q.row_off < 0 || q.col_off < 0 ||
-        q.count >= (1L << 31))
+        q.count >= (1L << 31) || (q.fmt != SPV_IMAGE_BF16 && q.fmt != SPV_IMAGE_F16) || (q.fmt == SPV_IMAGE_F16 && !(q.scale > 0.f)))
       return fail(SPV_ERR_ARG, "spv_adam_step_images: bad image descriptor%s");
     im.img[d] = q;
   }
@@ -996,70 +1040,77 @@ extern "C" int spv_loss_assemble(const float* rec0, const float* rec1, const flo
   return launch_status("spv_loss_assemble");
 }
 
-// relu mask + bf16 (hi/lo) packing of the fc1 output gradient and its column sums (the bias gradients):
-// one workgroup per 64 rows, one thread per column; partial sums reduced in block order by the second kernel.
-__global__ __launch_bounds__(256) void fc1_bwd_prep_kernel(const float* dh1, const float* h1, int B, int N1, bf16_t* img_hi, bf16_t* img_lo,
-                                                           long ld_img, float* part) {
-  const int r0 = blockIdx.x * 16;
-  for (int col = threadIdx.x; col < (int)ld_img; col += 256) {
-    float sum = 0.f;
-#pragma unroll 4
-    for (int r = r0; r < r0 + 16; ++r) {
-      // (unconditional loads from a clamped address, then a select: a load behind the bounds test is waited for inside that branch)
-      const long i = (long)min(r, B - 1) * N1 + min(col, N1 - 1);
-      const float hv = h1[i], gv = dh1[i];
-      const float v = (r < B && col < N1 && hv > 0.f) ? gv : 0.f;
-      bf16_t hi, lo;
-      split_bf16(v, hi, lo);
-      img_hi[(long)r * ld_img + col] = hi;
-      if (img_lo) img_lo[(long)r * ld_img + col] = lo;
-      sum += v;
-    }
-    if (col < N1) part[(long)blockIdx.x * N1 + col] = sum;
-  }
-}
-__global__ __launch_bounds__(256) void fc1_bwd_bias_kernel(const float* part, int nblk, int N1, float* db, float* db2, int n_first) {
-  __shared__ float s_p[4][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + tx;
-  float v = 0.f;
-  if (col < N1)
-#pragma unroll 8
-    for (int k = ty; k < nblk; k += 4) v += part[(long)k * N1 + col];
-  s_p[ty][tx] = v;
+// relu mask + 16-bit packing of the fc1 output gradient and its column sums (the bias gradients), two launches:
+//   fc1_bwd_prep_*: one workgroup per 16 rows, one thread per column: column partial sums of dpre = dh1 * (h1 > 0); split mode
+//     (img_lo != NULL, "fp32" precision) also writes the bf16 hi / lo images here; f16 mode records the block's max |dpre| instead;
+//   fc1_bwd_finish_*: f16 mode: every workgroup reduces the block maxima (fixed order, <= 1024 values) to the step's power-of-two
+//     scale (spv_common.h: pow2_scale_for; the largest element lands in [4096, 8192)), writes f16(dpre * scale) for its 16 rows and
+//     workgroup 0 leaves {scale, 1 / scale} in scale_ws[0..1] for the weight-gradient kernel; the first ceil(N1 / 64) workgroups
+//     (both modes) sum the column partials in block order into the bias gradients.
+// No atomics, no grid synchronisation: the scale is a pure function of dpre, so eager and replayed steps agree bit for bit.
+struct Fc1PrepArgs { const float* dh1; const float* h1; int B, N1; bf16_t* img_hi; bf16_t* img_lo; long ld_img; float* part; int nblk; float* db; float* db2; int n_first;
+                     float* scale_ws; };   // scale_ws: fp32 [2 + nblk] (f16 mode), NULL in split mode
+
+__device__ __forceinline__ float block_max_256(float v, float* s_red) {   // max over the 256 threads of a workgroup, returned to all of them
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
   __syncthreads();
-  if (ty != 0 || col >= N1) return;
-  v = ((s_p[0][tx] + s_p[1][tx]) + s_p[2][tx]) + s_p[3][tx];
-  if (db2 != nullptr && col >= n_first) db2[col - n_first] = v;
-  else db[col] = v;
+  return fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
 }
 
-struct Fc1PrepArgs { const float* dh1; const float* h1; int B, N1; bf16_t* img_hi; bf16_t* img_lo; long ld_img; float* part; int nblk; float* db; float* db2; int n_first; };
-__global__ __launch_bounds__(256) void fc1_bwd_prep_pair_kernel(Fc1PrepArgs a0, Fc1PrepArgs a1) {   // blockIdx.y = group
-  const Fc1PrepArgs a = blockIdx.y ? a1 : a0;
-  if ((int)blockIdx.x >= a.nblk) return;
-  const int r0 = blockIdx.x * 16;
+__device__ __forceinline__ void fc1_bwd_prep_body(const Fc1PrepArgs& a, const int blk, float* s_red) {
+  const int r0 = blk * 16;
+  const bool half = a.img_lo == nullptr;
+  float amax = 0.f;
   for (int col = threadIdx.x; col < (int)a.ld_img; col += 256) {
     float sum = 0.f;
 #pragma unroll 4
     for (int r = r0; r < r0 + 16; ++r) {
-      const long i = (long)min(r, a.B - 1) * a.N1 + min(col, a.N1 - 1);   // (unconditional loads: see fc1_bwd_prep_kernel)
+      // (unconditional loads from a clamped address, then a select: a load behind the bounds test is waited for inside that branch)
+      const long i = (long)min(r, a.B - 1) * a.N1 + min(col, a.N1 - 1);
       const float hv = a.h1[i], gv = a.dh1[i];
       const float v = (r < a.B && col < a.N1 && hv > 0.f) ? gv : 0.f;
-      bf16_t hi, lo;
-      split_bf16(v, hi, lo);
-      a.img_hi[(long)r * a.ld_img + col] = hi;
-      if (a.img_lo) a.img_lo[(long)r * a.ld_img + col] = lo;
+      if (!half) {
+        bf16_t hi, lo;
+        split_bf16(v, hi, lo);
+        a.img_hi[(long)r * a.ld_img + col] = hi;
+        a.img_lo[(long)r * a.ld_img + col] = lo;
+      }
+      amax = fmaxf(amax, fabsf(v));
       sum += v;
     }
-    if (col < a.N1) a.part[(long)blockIdx.x * a.N1 + col] = sum;
+    if (col < a.N1) a.part[(long)blk * a.N1 + col] = sum;
+  }
+  if (half) {
+    amax = block_max_256(amax, s_red);
+    if (threadIdx.x == 0) a.scale_ws[2 + blk] = amax;
   }
 }
-__global__ __launch_bounds__(256) void fc1_bwd_bias_pair_kernel(Fc1PrepArgs a0, Fc1PrepArgs a1) {   // blockIdx.y = group
-  const Fc1PrepArgs a = blockIdx.y ? a1 : a0;
-  __shared__ float s_p[4][64];
+
+__device__ __forceinline__ void fc1_bwd_finish_body(const Fc1PrepArgs& a, const int blk, float* s_red, float (*s_p)[64]) {
+  const bool half = a.img_lo == nullptr;
+  if (half && blk < a.nblk) {
+    float m = 0.f;
+    for (int k = threadIdx.x; k < a.nblk; k += 256) m = fmaxf(m, a.scale_ws[2 + k]);
+    m = block_max_256(m, s_red);
+    float scale, inv;
+    pow2_scale_for(m, scale, inv);
+    if (blk == 0 && threadIdx.x == 0) { a.scale_ws[0] = scale; a.scale_ws[1] = inv; }
+    const int r0 = blk * 16;
+    for (int col = threadIdx.x; col < (int)a.ld_img; col += 256) {
+#pragma unroll 4
+      for (int r = r0; r < r0 + 16; ++r) {
+        const long i = (long)min(r, a.B - 1) * a.N1 + min(col, a.N1 - 1);
+        const float hv = a.h1[i], gv = a.dh1[i];
+        const float v = (r < a.B && col < a.N1 && hv > 0.f) ? gv : 0.f;
+        a.img_hi[(long)r * a.ld_img + col] = f2h(v * scale);
+      }
+    }
+  }
+  if (blk >= (a.N1 + 63) / 64) return;   // (workgroup-uniform)
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + tx;
+  const int col = blk * 64 + tx;
   float v = 0.f;
   if (col < a.N1)
 #pragma unroll 8
@@ -1072,13 +1123,42 @@ __global__ __launch_bounds__(256) void fc1_bwd_bias_pair_kernel(Fc1PrepArgs a0, 
   else a.db[col] = v;
 }
 
+__global__ __launch_bounds__(256) void fc1_bwd_prep_kernel(Fc1PrepArgs a) {
+  __shared__ float s_red[4];
+  fc1_bwd_prep_body(a, blockIdx.x, s_red);
+}
+__global__ __launch_bounds__(256) void fc1_bwd_finish_kernel(Fc1PrepArgs a) {
+  __shared__ float s_red[4];
+  __shared__ float s_p[4][64];
+  fc1_bwd_finish_body(a, blockIdx.x, s_red, s_p);
+}
+__global__ __launch_bounds__(256) void fc1_bwd_prep_pair_kernel(Fc1PrepArgs a0, Fc1PrepArgs a1) {   // blockIdx.y = group
+  __shared__ float s_red[4];
+  const Fc1PrepArgs a = blockIdx.y ? a1 : a0;
+  if ((int)blockIdx.x >= a.nblk) return;
+  fc1_bwd_prep_body(a, blockIdx.x, s_red);
+}
+__global__ __launch_bounds__(256) void fc1_bwd_finish_pair_kernel(Fc1PrepArgs a0, Fc1PrepArgs a1) {   // blockIdx.y = group
+  __shared__ float s_red[4];
+  __shared__ float s_p[4][64];
+  const Fc1PrepArgs a = blockIdx.y ? a1 : a0;
+  fc1_bwd_finish_body(a, blockIdx.x, s_red, s_p);
+}
+static int fc1_finish_blocks(const Fc1PrepArgs& a) {
+  const int nb_bias = (a.N1 + 63) / 64;
+  return (a.img_lo == nullptr && a.nblk > nb_bias) ? a.nblk : nb_bias;
+}
+
 extern "C" int spv_enc_fc1_bwd_prep(const float* dh1, const float* h1, int32_t B, int32_t N1, uint16_t* img_hi, uint16_t* img_lo,
-                                    int64_t ld_img, int32_t Bp, float* part, float* db, float* db2, int32_t n_first, void* stream) {
+                                    int64_t ld_img, int32_t Bp, float* part, float* db, float* db2, int32_t n_first, float* scale_ws, void* stream) {
   if (!dh1 || !h1 || !img_hi || !part || !db) return fail(SPV_ERR_ARG, "spv_enc_fc1_bwd_prep: null pointer%s");
   if (B <= 0 || N1 <= 0 || Bp < B || (Bp % 64) || ld_img < N1) return fail(SPV_ERR_ARG, "spv_enc_fc1_bwd_prep: bad shape (Bp a multiple of 64)%s");
+  if (!img_lo && !scale_ws) return fail(SPV_ERR_ARG, "spv_enc_fc1_bwd_prep: the f16 image (img_lo == NULL) needs scale_ws [2 + Bp / 16]%s");
+  if (Bp / 16 > 65536) return fail(SPV_ERR_ARG, "spv_enc_fc1_bwd_prep: minibatch too large%s");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(fc1_bwd_prep_kernel, dim3(Bp / 16), dim3(256), 0, s, dh1, h1, B, N1, img_hi, img_lo, (long)ld_img, part);
-  hipLaunchKernelGGL(fc1_bwd_bias_kernel, dim3((N1 + 63) / 64), dim3(256), 0, s, part, Bp / 16, N1, db, db2, n_first);
+  const Fc1PrepArgs a{dh1, h1, B, N1, (bf16_t*)img_hi, (bf16_t*)img_lo, (long)ld_img, part, Bp / 16, db, db2, n_first, scale_ws};
+  hipLaunchKernelGGL(fc1_bwd_prep_kernel, dim3(a.nblk), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(fc1_bwd_finish_kernel, dim3(fc1_finish_blocks(a)), dim3(256), 0, s, a);
   return launch_status("spv_enc_fc1_bwd_prep");
 }
 
@@ -1112,8 +1192,8 @@ extern "C" int spv_enc_fc1_fwd_grouped(const spv_fc1_fwd_args* g, int32_t n_grou
     hipLaunchKernelGGL(fc1_fwd_dma_pair_kernel, dim3(mt0 * a.splits + mt1 * b.splits, a.N1 / F1_BN), dim3(512), F1_LDS_BYTES, s, p0, p1, mt0 * a.splits);
     if (hipGetLastError() != hipSuccess) return launch_status("spv_enc_fc1_fwd_grouped gemm");
     const long se0 = (long)mt0 * F1_BM * a.N1, se1 = (long)mt1 * F1_BM * b.N1;
-    const Fc1EpiArgs e0{a.slabs, a.splits, se0, a.B, a.N1, a.bias, a.bias2, a.n_first, a.h1, a.library, a.library_all, a.x->rows};
-    const Fc1EpiArgs e1{b.slabs, b.splits, se1, b.B, b.N1, b.bias, b.bias2, b.n_first, b.h1, b.library, b.library_all, b.x->rows};
+    const Fc1EpiArgs e0{a.slabs, a.splits, se0, a.B, a.N1, a.bias, a.bias2, a.n_first, a.h1, a.library, a.library_all, a.x->rows, 1.0f / SPV_FC1_W_SCALE};
+    const Fc1EpiArgs e1{b.slabs, b.splits, se1, b.B, b.N1, b.bias, b.bias2, b.n_first, b.h1, b.library, b.library_all, b.x->rows, 1.0f / SPV_FC1_W_SCALE};
     const long sem = se0 > se1 ? se0 : se1;
     hipLaunchKernelGGL(fc1_epilogue_tiled_pair_kernel, dim3((unsigned)((sem / 4 + 255) / 256), 2), dim3(256), 0, s, e0, e1);
     if (hipGetLastError() != hipSuccess) return launch_status("spv_enc_fc1_fwd_grouped epilogue");
@@ -1128,7 +1208,7 @@ extern "C" int spv_enc_fc1_fwd_grouped(const spv_fc1_fwd_args* g, int32_t n_grou
 }
 
 static bool fc1_bwd_dma_ok(const spv_fc1_bwd_args& a) {
-  if (!a.x || !a.x->X || !a.dh1 || !a.h1 || !a.dh_hi || !a.part || !a.db || !a.dW || !a.dW2 || !a.xb || a.B <= 0 || a.G <= 0) return false;
+  if (!a.x || !a.x->X || !a.dh1 || !a.h1 || !a.dh_hi || !a.part || !a.db || !a.dW || !a.dW2 || !a.xb || !a.scale_ws || a.B <= 0 || a.G <= 0) return false;
   const int Kpad = (a.B + FW_BK - 1) / FW_BK * FW_BK;
   return a.nsplit == 1 && (a.N1 == FW_BM || a.N1 == 2 * FW_BM) && a.ld_dh == a.N1 && a.n_first == a.N1 / 2 && a.Bp >= Kpad && (a.Bp % 64) == 0 && a.ldc >= a.G &&
          a.ld_xb >= ((a.G + 63) & ~63) && (a.ld_xb % 8) == 0 && fw_lds_bytes(96, Kpad) <= 160 * 1024 &&
@@ -1142,11 +1222,12 @@ extern "C" int spv_enc_fc1_bwd_grouped(const spv_fc1_bwd_args* g, int32_t n_grou
   for (; i + 1 < n_groups; i += 2) {
     const spv_fc1_bwd_args &a = g[i], &b = g[i + 1];
     if (!(fc1_bwd_dma_ok(a) && fc1_bwd_dma_ok(b) && a.N1 == b.N1)) break;
-    const Fc1PrepArgs q0{a.dh1, a.h1, a.B, a.N1, (bf16_t*)a.dh_hi, (bf16_t*)a.dh_lo, (long)a.ld_dh, a.part, a.Bp / 16, a.db, a.db2, a.n_first};
-    const Fc1PrepArgs q1{b.dh1, b.h1, b.B, b.N1, (bf16_t*)b.dh_hi, (bf16_t*)b.dh_lo, (long)b.ld_dh, b.part, b.Bp / 16, b.db, b.db2, b.n_first};
+    const Fc1PrepArgs q0{a.dh1, a.h1, a.B, a.N1, (bf16_t*)a.dh_hi, nullptr, (long)a.ld_dh, a.part, a.Bp / 16, a.db, a.db2, a.n_first, a.scale_ws};
+    const Fc1PrepArgs q1{b.dh1, b.h1, b.B, b.N1, (bf16_t*)b.dh_hi, nullptr, (long)b.ld_dh, b.part, b.Bp / 16, b.db, b.db2, b.n_first, b.scale_ws};
     const int nb = q0.nblk > q1.nblk ? q0.nblk : q1.nblk;
+    const int nf0 = fc1_finish_blocks(q0), nf1 = fc1_finish_blocks(q1);
     hipLaunchKernelGGL(fc1_bwd_prep_pair_kernel, dim3(nb, 2), dim3(256), 0, s, q0, q1);
-    hipLaunchKernelGGL(fc1_bwd_bias_pair_kernel, dim3((a.N1 + 63) / 64, 2), dim3(256), 0, s, q0, q1);
+    hipLaunchKernelGGL(fc1_bwd_finish_pair_kernel, dim3(nf0 > nf1 ? nf0 : nf1, 2), dim3(256), 0, s, q0, q1);
     if (hipGetLastError() != hipSuccess) return launch_status("spv_enc_fc1_bwd_grouped prep");
     GemmParams p[2];
     for (int k = 0; k < 2; ++k) {
@@ -1155,6 +1236,7 @@ extern "C" int spv_enc_fc1_bwd_grouped(const spv_fc1_bwd_args* g, int32_t n_grou
       w = GemmParams{};
       w.A = c.dh_hi; w.lda = c.ld_dh; w.B = c.xb; w.ldb = c.ld_xb; w.rows = c.x->rows; w.n_cells = c.B; w.n_genes = c.G;
       w.C = c.dW; w.ldc = c.ldc; w.C2 = c.dW2; w.c_split_row = c.n_first; w.M = c.N1; w.N = c.G; w.K = c.B;
+      w.out_scale = c.scale_ws + 1;
     }
     // tile: the one that gets BOTH groups into the fewest rounds of 256 one-per-CU workgroups (64-gene tiles are the faster ones alone)
     const int n64 = (a.G + 63) / 64 + (b.G + 63) / 64, n96 = (a.G + 95) / 96 + (b.G + 95) / 96;
@@ -1170,9 +1252,9 @@ extern "C" int spv_enc_fc1_bwd_grouped(const spv_fc1_bwd_args* g, int32_t n_grou
   }
   for (; i < n_groups; ++i) {
     const spv_fc1_bwd_args& a = g[i];
-    int rc = spv_enc_fc1_bwd_prep(a.dh1, a.h1, a.B, a.N1, a.dh_hi, a.dh_lo, a.ld_dh, a.Bp, a.part, a.db, a.db2, a.n_first, stream);
+    int rc = spv_enc_fc1_bwd_prep(a.dh1, a.h1, a.B, a.N1, a.dh_hi, a.dh_lo, a.ld_dh, a.Bp, a.part, a.db, a.db2, a.n_first, a.scale_ws, stream);
     if (rc != SPV_OK) return rc;
-    rc = spv_enc_fc1_wgrad(a.x, a.B, a.G, a.dh_hi, a.dh_lo, a.ld_dh, a.N1, a.nsplit, a.dW, a.dW2, a.n_first, a.ldc, a.xb, a.ld_xb, stream);
+    rc = spv_enc_fc1_wgrad(a.x, a.B, a.G, a.dh_hi, a.dh_lo, a.ld_dh, a.N1, a.nsplit, a.dW, a.dW2, a.n_first, a.ldc, a.xb, a.ld_xb, a.scale_ws, stream);
     if (rc != SPV_OK) return rc;
   }
   return SPV_OK;
@@ -1232,7 +1314,7 @@ extern "C" int spv_plan_expert_bwd(const spv_plan_expert_args* a, void* stream) 
   return launch_status("spv_plan_expert_bwd");
 }
 
-// bf16(log1p(x)) of a whole resident count matrix and library = log(sum_g log1p(x)) per cell, once per data set:
+// f16(log1p(x)) of a whole resident count matrix and library = log(sum_g log1p(x)) per cell, once per data set:
 // one workgroup per cell, fixed-order block reduction.
 __global__ __launch_bounds__(256) void prepare_log1p_kernel(const void* X, long ldx, int col_off, int is_u16, int G, bf16_t* xb, long ld_xb,
                                                             float* library) {
@@ -1246,7 +1328,7 @@ __global__ __launch_bounds__(256) void prepare_log1p_kernel(const void* X, long 
                              : reinterpret_cast<const float*>(X)[cell * ldx + col_off + g];
       v = log1p_count(c);
     }
-    xb[cell * ld_xb + g] = f2bf(v);
+    xb[cell * ld_xb + g] = f2h(v);   // IEEE half: log1p(count) <= 11.1, 11 significant bits (spv_common.h)
     acc += v;
   }
   s_sum[threadIdx.x] = acc;

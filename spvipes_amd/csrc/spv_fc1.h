@@ -1,4 +1,7 @@
-// Encoder fc1 forward for the resident bf16 log1p image, N1 = 2H = 256 output columns (the reference's default H = 128):
+// Encoder fc1 forward for the resident 16-bit log1p image, N1 = 2H = 256 output columns (the reference's default H = 128).
+// Operand words are IEEE f16 (spv_common.h: 11 significant bits instead of bf16's 8 at the same MFMA rate; the weight image
+// carries W * SPV_FC1_W_SCALE, undone by the epilogue's acc_scale; the dh image of the weight gradient a per-step power of two,
+// undone through GemmParams::out_scale):
 //
 //   slab[split][cell][col] = sum_{k in split} log1p(X)[rows[cell]][k] * W[col][k]      (module/spVIPESmodule.py:428-435,
 //                                                                                       nn/networks.py:119, both encoders)
@@ -137,7 +140,7 @@ __device__ __forceinline__ void fc1_fwd_dma_body(const GemmParams& p, const int 
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32h(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
       if (more && ks < 3) issue2(t + 2, 2 * ks);
     }
     __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
@@ -164,7 +167,7 @@ __device__ __forceinline__ void fc1_fwd_dma_body(const GemmParams& p, const int 
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(a[i], b[j], acc[i][j]);
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma32h(a[i], b[j], acc[i][j]);
       if (F1_SPREAD) __builtin_amdgcn_sched_barrier(0);   // keep the DMA pieces where they are written, between the k-steps
     }
 #endif
@@ -202,10 +205,10 @@ __global__ __launch_bounds__(512) void fc1_fwd_dma_pair_kernel(GemmParams p0, Ge
 // h1[cell][col] = relu(bias[col] + sum_splits S[split][...]), library from the data set's table (spv_prepare_log1p).
 // One thread per (tile, qq, lane): 16 bytes of every split's slab in, four floats (rows jj + 8 qq + 4 h of the tile) out.
 struct Fc1EpiArgs { const float* slabs; int splits; long slab_elems; int M; int N1; const float* bias; const float* bias2; int n_first; float* h1; float* library;
-                    const float* library_all; const int* rows; };
+                    const float* library_all; const int* rows; float acc_scale; };
 __device__ __forceinline__ void fc1_epilogue_tiled_body(const float* slabs, int splits, long slab_elems, int M, const int N1, const float* bias,
                                                         const float* bias2, int n_first, float* h1, float* library,
-                                                        const float* library_all, const int* rows) {
+                                                        const float* library_all, const int* rows, const float acc_scale) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // float4 index inside one slab
   if (idx * 4 < slab_elems) {
     const long tile = idx >> 8;
@@ -222,18 +225,18 @@ __device__ __forceinline__ void fc1_epilogue_tiled_body(const float* slabs, int 
     const long row0 = tm * 32 + 8 * qq + 4 * h;
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj)
-      if (row0 + jj < M) h1[(row0 + jj) * N1 + col] = fmaxf(s[jj] + bv, 0.f);   // relu(fc1(x)), nn/networks.py:119
+      if (row0 + jj < M) h1[(row0 + jj) * N1 + col] = fmaxf(s[jj] * acc_scale + bv, 0.f);   // relu(fc1(x)), nn/networks.py:119
   }
   if (idx < M) library[idx] = library_all[rows ? rows[idx] : (int)idx];   // log(sum_g log1p(x)), module/spVIPESmodule.py:435
 }
 __global__ __launch_bounds__(256) void fc1_epilogue_tiled_kernel(const float* slabs, int splits, long slab_elems, int M, int N1, const float* bias,
                                                                  const float* bias2, int n_first, float* h1, float* library,
-                                                                 const float* library_all, const int* rows) {
-  fc1_epilogue_tiled_body(slabs, splits, slab_elems, M, N1, bias, bias2, n_first, h1, library, library_all, rows);
+                                                                 const float* library_all, const int* rows, float acc_scale) {
+  fc1_epilogue_tiled_body(slabs, splits, slab_elems, M, N1, bias, bias2, n_first, h1, library, library_all, rows, acc_scale);
 }
 __global__ __launch_bounds__(256) void fc1_epilogue_tiled_pair_kernel(Fc1EpiArgs a0, Fc1EpiArgs a1) {   // blockIdx.y = group
   const Fc1EpiArgs a = blockIdx.y ? a1 : a0;
-  fc1_epilogue_tiled_body(a.slabs, a.splits, a.slab_elems, a.M, a.N1, a.bias, a.bias2, a.n_first, a.h1, a.library, a.library_all, a.rows);
+  fc1_epilogue_tiled_body(a.slabs, a.splits, a.slab_elems, a.M, a.N1, a.bias, a.bias2, a.n_first, a.h1, a.library, a.library_all, a.rows, a.acc_scale);
 }
 
 // ---- fc1 weight gradient:  dW[n1][gene] = sum_cell dh[cell][n1] * log1p(X)[rows[cell]][gene]   (backward of nn/networks.py:119) -------
@@ -397,13 +400,14 @@ __device__ __forceinline__ void fc1_wgrad_dma_body(const GemmParams& p, const in
 #pragma unroll
       for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
-        for (int j = 0; j < Cfg::TN; ++j) acc[i][j] = mfma32(join8(ra[set][i][0], ra[set][i][1]), join8(rb[set][j][0], rb[set][j][1]), acc[i][j]);
+        for (int j = 0; j < Cfg::TN; ++j) acc[i][j] = mfma32h(join8(ra[set][i][0], ra[set][i][1]), join8(rb[set][j][0], rb[set][j][1]), acc[i][j]);
       if (more) issueA(t + 2, ks);   // A_PIECES == 4 == k-steps per tile
       __builtin_amdgcn_sched_barrier(0);
     }
   }
   // ---- dW rows 0 .. 127 -> p.C, rows 128 .. 255 -> p.C2 (the two encoders' weight gradients), fp32 [128][ldc] ----------------------
   const int r = lane & 31;
+  const float oscale = *(p.out_scale ? p.out_scale : &g_spv_one);   // 1 / (power-of-two scale of the f16 dh image)
 #pragma unroll
   for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
@@ -414,7 +418,7 @@ __device__ __forceinline__ void fc1_wgrad_dma_body(const GemmParams& p, const in
       for (int q = 0; q < 16; ++q) {
         const int row = mtile * FW_BM + wm * (FW_BM / Cfg::WAVES_M) + 32 * i + crow(q, h);
         float* dst = (row >= p.c_split_row) ? p.C2 + (long)(row - p.c_split_row) * p.ldc + col : p.C + (long)row * p.ldc + col;
-        *dst = acc[i][j][q];
+        *dst = acc[i][j][q] * oscale;
       }
     }
 }

@@ -43,6 +43,7 @@ struct GemmParams {
   float* rowsum;     // [splits][M] partial sums of log1p(x) (natural-A counts), nullable
   float* C; long ldc; long slab_stride;
   float* C2; int c_split_row;   // optional: rows >= c_split_row of an EPI_STORE output go to C2 (row - c_split_row), same ldc
+  const float* out_scale;       // optional (EPI_STORE): device scalar the accumulators are multiplied by on the way out (1 / scale of an f16 dh image)
   int M, N, K;
   int k_per_split;   // multiple of 32
   int epi;
@@ -63,8 +64,12 @@ __host__ __device__ constexpr int nat_pitch(int bk) { return bk + 8; }  // BK k 
 // PF_: operand tiles each thread keeps in flight in registers (HBM latency is ~10 MFMA phases of a tile: one tile
 // ahead leaves the kernel latency-bound at ~1 workgroup per CU).  With PF_ > 1 the LDS image is double buffered
 // when it fits, which also drops one of the two barriers per tile.
-template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ_, bool B_KMAJ_, int A_SRC_, int B_SRC_, typename CT_, int NSPLIT_, int BK_ = 32, int PF_ = 1, int OCC_ = 1>
+// HALF_: the 16-bit operand words are IEEE f16 instead of bf16 (the encoder's first layer in the NSPLIT == 1 mode, spv_common.h):
+// counts decode to f16(log1p), the MFMA is v_mfma_f32_32x32x16_f16.
+template <int BM_, int BN_, int WM_, int WN_, bool A_KMAJ_, bool B_KMAJ_, int A_SRC_, int B_SRC_, typename CT_, int NSPLIT_, int BK_ = 32, int PF_ = 1, int OCC_ = 1, bool HALF_ = false>
 struct GemmCfg {
+  static constexpr bool HALF = HALF_;
+  static_assert(!HALF_ || NSPLIT_ == 1, "f16 operands have no hi/lo split");
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BK = BK_, PF = PF_, OCC = OCC_;  // OCC: waves per SIMD to fit (register budget)
   static constexpr int NAT_PITCH = nat_pitch(BK_);
   static constexpr bool A_KMAJ = A_KMAJ_, B_KMAJ = B_KMAJ_;
@@ -218,6 +223,11 @@ struct Stager {
     for (int j = 0; j < 4; ++j) {
       const float x0 = log1p_count(v[2 * j]), x1 = log1p_count(v[2 * j + 1]);
       sum += x0 + x1;
+      if constexpr (Cfg::HALF) {
+        hw[j] = pack2h(x0, x1);
+        lw[j] = 0u;
+        continue;
+      }
       bf16_t h0, l0, h1, l1;
       split_bf16(x0, h0, l0);
       split_bf16(x1, h1, l1);
@@ -346,7 +356,10 @@ __global__ __launch_bounds__(256, Cfg::OCC) void gemm_kernel(GemmParams p) {
               if constexpr (Cfg::NSPLIT == 3) b_lo = frag_natural(b_lo_img, Cfg::B_PITCH, c0, ks, lane);
             }
 #pragma unroll
-            for (int i = 0; i < Cfg::TM; ++i) acc[i][j] = mfma32_split<Cfg::NSPLIT>(a_hi[i], a_lo[i], b_hi, b_lo, acc[i][j]);
+            for (int i = 0; i < Cfg::TM; ++i) {
+              if constexpr (Cfg::HALF) acc[i][j] = mfma32h(a_hi[i], b_hi, acc[i][j]);
+              else acc[i][j] = mfma32_split<Cfg::NSPLIT>(a_hi[i], a_lo[i], b_hi, b_lo, acc[i][j]);
+            }
           }
         }
         if constexpr (Cfg::NBUF == 2) buf ^= 1;
@@ -379,6 +392,7 @@ __global__ __launch_bounds__(256, Cfg::OCC) void gemm_kernel(GemmParams p) {
       }
     return;
   }
+  const float oscale = *(p.out_scale ? p.out_scale : &g_spv_one);
 #pragma unroll
   for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
@@ -389,8 +403,8 @@ __global__ __launch_bounds__(256, Cfg::OCC) void gemm_kernel(GemmParams p) {
         const int row = m0 + wm * (Cfg::BM / Cfg::WM) + 32 * i + crow(q, h);
         if (row < p.M && col < p.N) {
           float* dst = (p.C2 != nullptr && row >= p.c_split_row) ? p.C2 + (long)(row - p.c_split_row) * p.ldc + col : C + (long)row * p.ldc + col;
-          if (p.epi == EPI_ATOMIC) atomicAdd(dst, acc[i][j][q]);
-          else *dst = acc[i][j][q];
+          if (p.epi == EPI_ATOMIC) atomicAdd(dst, acc[i][j][q] * oscale);
+          else *dst = acc[i][j][q] * oscale;
         }
       }
     }

@@ -260,8 +260,8 @@ class spVIPESmodule(nn.Module):
     def enable_device_rng(self, device, key: int, counter0: int = 0) -> None:
         """Draw the step's standard-normal noise with ``spv_randn`` (counter-based, keyed by ``key`` and a device-resident step counter
         that the optimiser's Adam launch increments) instead of torch's generator; the dropout masks use the same counter as seed.
-        The noise is a function of (key, counter) alone: forward passes between two optimiser steps (validation batches) see the same
-        draws on different cells, and setting ``_rng_counter`` reproduces a step."""
+        The noise is a function of (key, counter) alone: setting ``_rng_counter`` reproduces a step.  Eval-mode forward passes
+        (validation, ``get_latent_representation``) advance the counter themselves, one tick per batch."""
         self._rng_counter = torch.full((), int(counter0), dtype=torch.int64, device=device)
         self._rng_key = int(key) & 0xFFFFFFFFFFFFFFFF
 
@@ -347,6 +347,11 @@ class spVIPESmodule(nn.Module):
             if ctr is not None and ctr.device == dev0:   # counter-based device generator (train.Trainer.DEVICE_RNG, spv_randn)
                 flat = torch.empty(total, dtype=torch.float32, device=dev0)
                 _abi.call("spv_randn", _abi.ptr(flat), total, _abi.ptr(ctr), self._rng_key, _abi.stream_ptr())
+                if not self.training:
+                    # eval-mode forward passes (get_latent_representation, validation) are followed by no optimiser step, which is what
+                    # advances the counter during training: advance it here, or every batch would be perturbed by the SAME noise matrix
+                    # (the reference draws fresh torch.randn noise per batch: model/spvipes.py:536-538, nn/networks.py:128-134)
+                    _abi.call("spv_counter_bump", _abi.ptr(ctr), _abi.stream_ptr())
             else:
                 flat = torch.randn(total, device=dev0)
             off = 0

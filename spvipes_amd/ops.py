@@ -51,7 +51,7 @@ class GroupCounts:
         return self.X.shape[0]
 
     def log1p_image(self):
-        """(bf16 log1p(x) of every cell [n_cells][ld >= round_up(G, 96), multiple of 128], library = log(sum_g log1p(x)) per cell), built on first use
+        """(f16 log1p(x) of every cell [n_cells][ld >= round_up(G, 96), multiple of 128], library = log(sum_g log1p(x)) per cell), built on first use
         by spv_prepare_log1p: the same arithmetic the reference does per minibatch (module/spVIPESmodule.py:428-435)."""
         if self._xb is None:
             ld = round_up(round_up(self.G, 96), 128)   # (96: the gene tile of the fc1 weight-gradient GEMM)
@@ -206,6 +206,25 @@ def _pack(src: torch.Tensor, dst_hi: torch.Tensor, dst_lo: Optional[torch.Tensor
                             (ptr(dst_lo) + off) if dst_lo is not None else None, ld_dst, dst_col_off, Rp, cs, stream_ptr())
 
 
+def fc1_w_scale() -> float:
+    """power of two the f16 fc1 weight image is multiplied by (csrc/spv_common.h: SPV_FC1_W_SCALE)"""
+    return float(_abi.load().spv_fc1_w_scale())
+
+
+def _pack_fc1_weights(w_priv, w_sh, W_hi, W_lo, H: int) -> None:
+    """[W_private; W_shared] -> the fc1 weight operand image: bf16 hi / lo in "fp32" mode (W_lo given), IEEE f16 words of
+    W * fc1_w_scale() in the one-MFMA mode (nn/networks.py:119's weight, both encoders stacked)"""
+    if W_lo is not None:
+        _pack(w_priv, W_hi, W_lo, dst_row_off=0, rows_cover=H)
+        _pack(w_sh, W_hi, W_lo, dst_row_off=H, rows_cover=W_hi.shape[0] - H)
+        return
+    ld = W_hi.shape[1]
+    for w, r0, cover in ((w_priv, 0, H), (w_sh, H, W_hi.shape[0] - H)):
+        if w.dtype != torch.float32 or w.dim() != 2 or w.stride(1) != 1:
+            raise _abi.SpvError("pack source must be fp32 [R][C] with unit column stride")
+        _abi.call("spv_pack_f16", ptr(w), w.stride(0), w.shape[0], w.shape[1], ptr(W_hi) + r0 * ld * 2, ld, cover, ld, fc1_w_scale(), stream_ptr())
+
+
 def _bf16_image(ws: Workspace, name: str, rows: int, cols: int, lo: bool):
     hi = ws.get(name + "_hi", (rows, cols), torch.int16)
     return hi, (ws.get(name + "_lo", (rows, cols), torch.int16) if lo else None)
@@ -234,8 +253,7 @@ class EncoderFC1(torch.autograd.Function):
         N1p, Gp = round_up(N1, bn), round_up(G, 64)
         W_hi, W_lo = _bf16_image(ws, "fc1_W", N1p, Gp, nsplit == 3)
         if W_lo is not None or ws.fresh.get("fc1_W") != image_token(w_priv, w_sh):   # (else: Adam has just rewritten the image)
-            _pack(w_priv, W_hi, W_lo, dst_row_off=0, rows_cover=H)
-            _pack(w_sh, W_hi, W_lo, dst_row_off=H, rows_cover=N1p - H)
+            _pack_fc1_weights(w_priv, w_sh, W_hi, W_lo, H)
         f32c = lambda t: t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
         b_priv, b_sh = f32c(b_priv), f32c(b_sh)
         h1 = torch.empty((B, N1), dtype=torch.float32, device=w_priv.device)
@@ -277,12 +295,13 @@ class EncoderFC1(torch.autograd.Function):
         dh1 = dh1 if (dh1.dtype == torch.float32 and dh1.is_contiguous()) else dh1.float().contiguous()
         dh_hi, dh_lo = _bf16_image(ws, "fc1_dh", Bp, N1p, nsplit == 3)
         part = ws.get("fc1_db_part", (Bp // 16, N1), torch.float32)
+        scale_ws = ws.get("fc1_dh_scale", (2 + Bp // 16,), torch.float32) if nsplit == 1 else None   # {scale, 1 / scale, block maxima} of the f16 dh image
         # (kernel target, autograd return): with the trainer's gradient sink the kernels write straight into .grad
         (dWp, rWp), (dbp, rbp), (dWs, rWs), (dbs, rbs) = grad_out(w_priv), grad_out(b_priv), grad_out(w_sh), grad_out(b_sh)
-        _abi.call("spv_enc_fc1_bwd_prep", ptr(dh1), ptr(h1), B, N1, ptr(dh_hi), ptr(dh_lo), N1p, Bp, ptr(part), ptr(dbp), ptr(dbs), H, stream_ptr())
+        _abi.call("spv_enc_fc1_bwd_prep", ptr(dh1), ptr(h1), B, N1, ptr(dh_hi), ptr(dh_lo), N1p, Bp, ptr(part), ptr(dbp), ptr(dbs), H, ptr(scale_ws), stream_ptr())
         cs = ctx.counts.c_struct(ctx.rows)
         _abi.call("spv_enc_fc1_wgrad", C.byref(cs), B, G, ptr(dh_hi), ptr(dh_lo), N1p, N1, nsplit, ptr(dWp), ptr(dWs), H, G,
-                  ptr(ctx.xb), ctx.ld_xb, stream_ptr())
+                  ptr(ctx.xb), ctx.ld_xb, ptr(scale_ws), stream_ptr())
         return None, None, None, rWp, rbp, rWs, rbs, None, None
 
 
@@ -310,8 +329,7 @@ class EncoderFC1Grouped(torch.autograd.Function):
             N1p, Gp = round_up(N1, bn), round_up(G, 64)
             W_hi, W_lo = _bf16_image(ws, "fc1_W", N1p, Gp, nsplit == 3)
             if W_lo is not None or ws.fresh.get("fc1_W") != image_token(w_priv, w_sh):   # (else: Adam has just rewritten the image)
-                _pack(w_priv, W_hi, W_lo, dst_row_off=0, rows_cover=H)
-                _pack(w_sh, W_hi, W_lo, dst_row_off=H, rows_cover=N1p - H)
+                _pack_fc1_weights(w_priv, w_sh, W_hi, W_lo, H)
             b_priv, b_sh = f32c(b_priv), f32c(b_sh)
             h1 = torch.empty((B, N1), dtype=torch.float32, device=w_priv.device)
             library = torch.empty((B,), dtype=torch.float32, device=w_priv.device)
@@ -367,6 +385,7 @@ class EncoderFC1Grouped(torch.autograd.Function):
                 dh1 = dh1 if (dh1.dtype == torch.float32 and dh1.is_contiguous()) else dh1.float().contiguous()
                 dh_hi, dh_lo = _bf16_image(ws, "fc1_dh", Bp, N1p, nsplit == 3)
                 part = ws.get("fc1_db_part", (Bp // 16, N1), torch.float32)
+                scale_ws = ws.get("fc1_dh_scale", (2 + Bp // 16,), torch.float32) if nsplit == 1 else None
                 (dWp, rWp), (dbp, rbp), (dWs, rWs), (dbs, rbs) = grad_out(w_priv), grad_out(b_priv), grad_out(w_sh), grad_out(b_sh)
                 cs = counts.c_struct(rows)
                 a = args[k]
@@ -374,8 +393,8 @@ class EncoderFC1Grouped(torch.autograd.Function):
                 a.B, a.G, a.N1, a.n_first, a.nsplit, a.Bp = B, G, N1, H, nsplit, Bp
                 a.dh_hi, a.dh_lo, a.ld_dh, a.part = ptr(dh_hi), ptr(dh_lo), N1p, ptr(part)
                 a.db, a.db2, a.dW, a.dW2, a.ldc = ptr(dbp), ptr(dbs), ptr(dWp), ptr(dWs), G
-                a.xb, a.ld_xb = ptr(xb), ld_xb
-                keep += [cs, dh1, dh_hi, dh_lo, part, dWp, dbp, dWs, dbs]
+                a.xb, a.ld_xb, a.scale_ws = ptr(xb), ld_xb, ptr(scale_ws)
+                keep += [cs, dh1, dh_hi, dh_lo, part, dWp, dbp, dWs, dbs, scale_ws]
                 rets[4 * g: 4 * g + 4] = [rWp, rbp, rWs, rbs]
             _abi.call("spv_enc_fc1_bwd_grouped", args, len(live), stream_ptr())
         return (None,) * 5 + tuple(rets)

@@ -170,7 +170,7 @@ class Trainer:
             N1 = 2 * H
             bn = 32 if N1 <= 32 else (128 if N1 <= 128 else 256)
             img = ops._bf16_image(ws, "fc1_W", ops.round_up(N1, bn), ops.round_up(G, 64), False)[0]
-            out.append((ws, "fc1_W", img, [(ep.fc1.weight, 0, 0), (es.fc1.weight, H, 0)], (ep.fc1.weight, es.fc1.weight)))
+            out.append((ws, "fc1_W", img, [(ep.fc1.weight, 0, 0), (es.fc1.weight, H, 0)], (ep.fc1.weight, es.fc1.weight)))   # (f16 words of W * ops.fc1_w_scale())
             dec = m.decoders[g]
             Wm, bm = dec.mixture.linear.weight, dec.mixture.linear.bias
             img = ops._bf16_image(ws, "dec_Wm", ops.round_up(G, 256), KMP, False)[0]
@@ -181,6 +181,7 @@ class Trainer:
         if not self.IMAGES_BY_ADAM or self.module.nsplit != 1:
             self._img_specs, self._img_plan = [], None
             return
+        from . import ops
         specs = self._image_specs()
         offs = {}
         for p_ in self.fp.params:
@@ -195,6 +196,7 @@ class Trainer:
                 d.begin, d.count = offs[id(par)], par.numel()
                 d.cols = par.shape[1] if par.dim() == 2 else 1
                 d.row_off, d.col_off, d.ld, d.dst = row_off, col_off, img.shape[1], _abi.ptr(img)
+                d.fmt, d.scale = (_abi.IMAGE_F16, ops.fc1_w_scale()) if key == "fc1_W" else (_abi.IMAGE_BF16, 1.0)
                 descs.append(d)
         if not descs or len(descs) > _abi.ADAM_MAX_IMAGES:
             self._img_specs, self._img_plan = [], None
@@ -229,8 +231,7 @@ class Trainer:
         for ws, key, img, parts, _tok in self._img_specs:
             if key == "fc1_W":
                 (wp, _, _), (wsh, H, _) = parts
-                ops._pack(wp, img, None, dst_row_off=0, rows_cover=H)
-                ops._pack(wsh, img, None, dst_row_off=H, rows_cover=img.shape[0] - H)
+                ops._pack_fc1_weights(wp, wsh, img, None, H)
             else:
                 (Wm, _, _), (bm, _, _) = parts
                 ops._pack(Wm, img, None, extra_col=bm)

@@ -1,6 +1,8 @@
 """Direct checks of the auxiliary C-ABI entry points against plain torch on the same inputs."""
 import ctypes as C
 
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -91,6 +93,7 @@ def test_loss_assemble_matches_torch(dev, B, nkl):
 
 @pytest.mark.parametrize("B,H", [(50, 8), (4096, 128)])
 def test_fc1_bwd_prep_matches_torch(dev, B, H):
+    """split mode ("fp32" precision): bf16 hi / lo images of dpre = dh1 * (h1 > 0) and the bias gradients"""
     from spvipes_amd import _abi
     from spvipes_amd._abi import ptr, round_up, stream_ptr
     g = torch.Generator(device=dev).manual_seed(H)
@@ -102,7 +105,7 @@ def test_fc1_bwd_prep_matches_torch(dev, B, H):
     lo = torch.full((Bp, ld), 77, dtype=torch.int16, device=dev)
     part = torch.empty(Bp // 16, N1, device=dev)
     db, db2 = torch.empty(H, device=dev), torch.empty(H, device=dev)
-    _abi.call("spv_enc_fc1_bwd_prep", ptr(dh1), ptr(h1), B, N1, ptr(hi), ptr(lo), ld, Bp, ptr(part), ptr(db), ptr(db2), H, stream_ptr())
+    _abi.call("spv_enc_fc1_bwd_prep", ptr(dh1), ptr(h1), B, N1, ptr(hi), ptr(lo), ld, Bp, ptr(part), ptr(db), ptr(db2), H, None, stream_ptr())
     dpre = dh1 * (h1 > 0)
     hi_f = (hi.to(torch.int32) << 16).view(torch.float32)
     lo_f = (lo.to(torch.int32) << 16).view(torch.float32)
@@ -111,6 +114,55 @@ def test_fc1_bwd_prep_matches_torch(dev, B, H):
     assert float(hi_f[B:].abs().max() if Bp > B else 0) == 0 and float(hi_f[:, N1:].abs().max() if ld > N1 else 0) == 0
     want = dpre.double().sum(0)
     torch.testing.assert_close(torch.cat([db, db2]).double(), want, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("magnitude", [1.0, 3e-7, 2e5, 0.0])
+@pytest.mark.parametrize("B,H", [(50, 8), (4096, 128), (1000, 256)])
+def test_fc1_bwd_prep_f16_image_and_its_scale(dev, B, H, magnitude):
+    """one-MFMA mode (img_lo == NULL): the dh image is f16(dpre * scale) with scale the power of two that brings max |dpre| into
+    [4096, 8192) -- whatever the magnitude of the gradient (loss-mean factors of 1e-7, exploding gradients, all zeros) -- and the
+    record {scale, 1 / scale} the weight-gradient kernel multiplies by; bias gradients as in split mode"""
+    import math
+    from spvipes_amd import _abi
+    from spvipes_amd._abi import ptr, round_up, stream_ptr
+    g = torch.Generator(device=dev).manual_seed(H)
+    N1 = 2 * H
+    dh1 = torch.randn(B, N1, generator=g, device=dev) * magnitude
+    h1 = torch.relu(torch.randn(B, N1, generator=g, device=dev))
+    Bp, ld = round_up(B, 64), round_up(N1, 128)
+    img = torch.full((Bp, ld), 77, dtype=torch.int16, device=dev)
+    part = torch.empty(Bp // 16, N1, device=dev)
+    scale_ws = torch.full((2 + Bp // 16,), float("nan"), device=dev)
+    db, db2 = torch.empty(H, device=dev), torch.empty(H, device=dev)
+    _abi.call("spv_enc_fc1_bwd_prep", ptr(dh1), ptr(h1), B, N1, ptr(img), None, ld, Bp, ptr(part), ptr(db), ptr(db2), H, ptr(scale_ws), stream_ptr())
+    dpre = dh1 * (h1 > 0)
+    amax = float(dpre.abs().max())
+    scale = 1.0 if amax == 0.0 else 2.0 ** (13 - math.frexp(amax)[1])
+    assert float(scale_ws[0]) == scale and float(scale_ws[1]) == 1.0 / scale
+    got = img.view(torch.float16).float()
+    assert torch.equal(got[:B, :N1], (dpre * scale).to(torch.float16).float())
+    if amax > 0:
+        assert 4096 <= float(got.abs().max()) < 8192 + 1
+    assert float(got[B:].abs().max() if Bp > B else 0) == 0 and float(got[:, N1:].abs().max() if ld > N1 else 0) == 0
+    torch.testing.assert_close(torch.cat([db, db2]).double(), dpre.double().sum(0), rtol=1e-5, atol=1e-4 * max(magnitude, 1e-30))
+
+
+def test_pack_f16_scales_saturates_and_pads(dev):
+    """spv_pack_f16: f16(W * scale), zero padding outside the source, saturation instead of infinities, NaN stays NaN"""
+    from spvipes_amd import _abi
+    from spvipes_amd._abi import ptr, stream_ptr
+    g = torch.Generator().manual_seed(3)
+    R, Cc, Rp, ld = 37, 70, 64, 128
+    W = (torch.randn(R, Cc, generator=g) * 0.01)
+    W[0, 0], W[0, 1], W[0, 2], W[1, 0] = 1e9, -1e9, float("nan"), 1e-9
+    Wd = W.to(dev)
+    img = torch.full((Rp, ld), 77, dtype=torch.int16, device=dev)
+    _abi.call("spv_pack_f16", ptr(Wd), Wd.stride(0), R, Cc, ptr(img), ld, Rp, ld, 256.0, stream_ptr())
+    got = img.view(torch.float16).float().cpu()
+    want = (W * 256.0).clamp(-65504, 65504).to(torch.float16).float()
+    assert torch.equal(got[:R, :Cc].nan_to_num(nan=-7.0), want.nan_to_num(nan=-7.0))
+    assert float(got[0, 0]) == 65504.0 and float(got[0, 1]) == -65504.0 and math.isnan(float(got[0, 2]))
+    assert float(got[R:].abs().max()) == 0 and float(got[:, Cc:].abs().max()) == 0
 
 
 def test_plan_experts_match_dense_autograd(dev):
@@ -185,8 +237,8 @@ def test_fused_latent_gradient_matches_gemm_path(dev):
 
 @pytest.mark.parametrize("B,G,H,gather", [(100, 333, 64, True), (256, 1000, 128, True), (64, 2001, 16, False)])
 def test_fc1_resident_log1p_image_matches_count_decoding(dev, B, G, H, gather):
-    """bf16 mode: the fc1 GEMMs fed from the resident bf16 log1p image (spv_prepare_log1p + gathered plain operand) against
-    the same GEMMs decoding the counts on the fly -- identical bf16 operands, so only the fp32 summation order differs."""
+    """bf16 mode: the fc1 GEMMs fed from the resident f16 log1p image (spv_prepare_log1p + gathered plain operand) against
+    the same GEMMs decoding the counts on the fly -- identical f16 operands, so only the fp32 summation order differs."""
     from spvipes_amd import ops
     rng = np.random.default_rng(B + G)
     n_cells = B + 37

@@ -1,5 +1,5 @@
 """GPU: ONE whole training step at the BASELINE.json shapes through the shipped path -- ``Trainer`` -> ``spVIPESmodule``
--> ``EncoderFC1`` (resident bf16 log1p image in bf16 mode) / ``EncoderTails`` / PoE / ``DecoderFused`` (two streams,
+-> ``EncoderFC1`` (resident f16 log1p image in bf16 mode) / ``EncoderTails`` / PoE / ``DecoderFused`` (two streams,
 fused-dz softmax backward, gradient sink into the flat buffer), resident uint16 counts, no graph -- against the CPU
 oracle on the same parameters, minibatch rows and noise (reference path: module/spVIPESmodule.py:425-899).
 
@@ -7,17 +7,19 @@ Shapes: C2 (B 4096, G 10 000, H 128, 25/10; bf16 and fp32), C3's per-GPU shard (
 (G 30 000, paired PoE on a sparse transport plan, fp32; B 1024).  C4 (3 groups) has no reference to compare with
 (data/prepare_adatas.py:94-95) and is covered by tests/test_gpu_three_groups.py as a consistency check only.
 
-Tolerances (bound  <-  worst value measured over the four cases on the MI355X, round 2):
-  ELBO at kl_weight = 1           fp32 mode <= 2e-4  <- 2.2e-7;    bf16 mode <= 1e-3  <- 1.4e-6      (north-star: 1e-3)
-  per-cell reconstruction terms   fp32 <= 2e-4  <- 1.4e-6;         bf16 <= 2e-3  <- 4.7e-4
-  per-cell KL terms               fp32 <= 1e-3  <- 3.0e-5;         bf16 <= 5e-2  <- 1.3e-2
-  private / PoE logtheta_loc      fp32 <= 1e-3 of the column scale  <- 1.2e-5;   bf16 <= 2e-2  <- 6.0e-3
-  gradients per parameter kind    relative L2:        fp32 <= 5e-3  <- 2.3e-3;   bf16 <= 8e-2  <- 4.3e-2
+Tolerances (bound  <-  worst value measured over the four cases on the MI355X, round 3: the encoder's first layer now runs on
+IEEE f16 operand images in bf16 mode -- csrc/spv_common.h -- which is what brought the latent means inside the north star's 1e-3;
+round 2's bf16 operands gave 6.0e-3 on the means and 1.3e-2 on the KL terms):
+  ELBO at kl_weight = 1           fp32 mode <= 2e-4  <- 2.2e-7;    bf16 mode <= 1e-3  <- 2.2e-7      (north-star: 1e-3)
+  per-cell reconstruction terms   fp32 <= 2e-4  <- 1.4e-6;         bf16 <= 5e-4  <- 9.6e-5
+  per-cell KL terms               fp32 <= 1e-3  <- 3.0e-5;         bf16 <= 2e-3  <- 1.4e-3
+  private / PoE logtheta_loc      fp32 <= 1e-3 of the column scale  <- 1.2e-5;   bf16 <= 1e-3  <- 6.5e-4   (north-star: 1e-3)
+  gradients per parameter kind    relative L2:        fp32 <= 5e-3  <- 2.3e-3;   bf16 <= 3e-2  <- 1.6e-2
                                   max error / max:    fp32 <= 3e-2  <- 1.6e-2 (fc2: a rectifier whose pre-activation sits within
                                   rounding of zero flips for one cell and moves that unit's whole gradient row; every kind
-                                  NOT behind a rectifier is below 3e-3);     bf16 <= 0.12  <- 6.6e-2
-  (bf16 mode rounds the GEMM operands AND stores the three [B, G] gradient arrays of the decoder as bf16: the gradient noise is
-  what that storage format gives, two orders of magnitude above the fp32 mode's.)
+                                  NOT behind a rectifier is below 3e-3);     bf16 <= 8e-2  <- 4.2e-2
+  (bf16 mode stores the three [B, G] gradient arrays of the decoder as bf16 and rounds the decoder GEMM operands to bf16: the
+  gradient noise is what that storage format gives.)
 """
 import os
 
@@ -27,7 +29,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-GRAD_MAX_BF16, GRAD_L2_BF16, GRAD_MAX_FP32, GRAD_L2_FP32 = 0.12, 8e-2, 3e-2, 5e-3   # see the module docstring
+GRAD_MAX_BF16, GRAD_L2_BF16, GRAD_MAX_FP32, GRAD_L2_FP32 = 8e-2, 3e-2, 3e-2, 5e-3   # see the module docstring
 
 
 @pytest.fixture(scope="module")
@@ -154,9 +156,9 @@ def check(got, want, precision, label):
     if os.environ.get("SPV_PARITY_REPORT_ONLY") == "1":
         return m
     assert m["elbo_rel"] <= (2e-4 if fp32 else 1e-3), m
-    assert m["rec_rel"] <= (2e-4 if fp32 else 2e-3), m
-    assert m["kl_rel"] <= (1e-3 if fp32 else 5e-2), m
-    assert m["private_loc"] <= (1e-3 if fp32 else 2e-2) and m["poe_loc"] <= (1e-3 if fp32 else 2e-2), m
+    assert m["rec_rel"] <= (2e-4 if fp32 else 5e-4), m
+    assert m["kl_rel"] <= (1e-3 if fp32 else 2e-3), m
+    assert m["private_loc"] <= 1e-3 and m["poe_loc"] <= 1e-3, m   # north star: latent means within 1e-3, BOTH precision modes
     bound_max, bound_l2 = (GRAD_MAX_FP32, GRAD_L2_FP32) if fp32 else (GRAD_MAX_BF16, GRAD_L2_BF16)
     bad = {k: (kinds[k], l2[k]) for k in kinds if kinds[k] > bound_max or l2[k] > bound_l2}
     assert not bad, (bad, bound_max, bound_l2)
