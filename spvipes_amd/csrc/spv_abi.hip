@@ -884,6 +884,9 @@ __global__ void fill_i32_kernel(int32_t* p, long n, int32_t v) {
 static int zero_fill(void* p, size_t bytes, hipStream_t s) {
   const long n = (long)(bytes / 4);
   if (n <= 0) return SPV_OK;
+  // DIAGNOSTIC switch (tools/graph_dump.py): the round-2 form, a memset NODE in a captured step, to dump that graph's edges
+  static const bool memset_nodes = getenv("SPV_MEMSET_NODES") && atoi(getenv("SPV_MEMSET_NODES")) == 1;
+  if (memset_nodes) return hipMemsetAsync(p, 0, bytes, s) == hipSuccess ? SPV_OK : SPV_ERR_LAUNCH;
   hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (float*)p, n);
   return hipGetLastError() == hipSuccess ? SPV_OK : SPV_ERR_LAUNCH;
 }

@@ -35,6 +35,14 @@ __device__ __forceinline__ float pn_sum32(float v) {
   return v;
 }
 
+// component code of a cell, or -1 when the stored value is not an integral code in [0, ncomp) (negative, too large, NaN): such a
+// cell has no component -- it contributes to no component mean and receives no expert (its posterior is fused with the prior
+// alone), exactly what the two-group cluster path does with a component that the other group lacks.  The host validates the
+// codes once per data set (train.Trainer); this keeps a raw module call with bad codes from indexing outside the tables.
+__device__ __forceinline__ int pn_code(float v, int ncomp) {
+  return (v >= 0.f && v < (float)ncomp) ? (int)v : -1;
+}
+
 // K1: per (segment, group) partial sums of (loc | logvar | 1) per component; thread d owns column d, cells in order
 __global__ __launch_bounds__(128) void pn_stats_kernel(PoeN a) {
   __shared__ float acc[PN_CMAX][2 * 32 + 1];
@@ -43,7 +51,8 @@ __global__ __launch_bounds__(128) void pn_stats_kernel(PoeN a) {
   for (int c = 0; c < a.ncomp; ++c) acc[c][d] = 0.f;
   const int per = (a.B[g] + PN_SEG - 1) / PN_SEG, lo = seg * per, hi = min(a.B[g], lo + per);
   for (int b = lo; b < hi; ++b) {
-    const int c = (int)a.comp[g][b];
+    const int c = pn_code(a.comp[g][b], a.ncomp);
+    if (c < 0) continue;
     acc[c][d] += (d < 2 * a.n) ? a.stats[g][(long)b * a.ld[g] + d] : 1.0f;
   }
   float* out = a.part + ((long)(g * PN_SEG + seg) * a.ncomp) * W;
@@ -73,12 +82,12 @@ __global__ __launch_bounds__(256) void pn_fuse_fwd_kernel(PoeN a) {
   float z = -INFINITY, klt = 0.f, jl = 0.f, jv = 0.f, sc = 0.f;
   const long i = (long)b * n + d;
   if (ok) {
-    const int c = (int)a.comp[g][b];
+    const int c = pn_code(a.comp[g][b], a.ncomp);
     const float* own = a.stats[g] + (long)b * a.ld[g];
     const float inv = expf(-own[n + d]);
     float prec = 1.0f + inv, num = own[d] * inv;
     for (int h = 0; h < a.ngroups; ++h) {
-      if (h == g) continue;
+      if (h == g || c < 0) continue;
       const float* m = a.mean + ((long)h * a.ncomp + c) * W;
       if (m[W - 1] > 0.f) {
         const float w = expf(-m[n + d]);
@@ -133,7 +142,8 @@ __global__ __launch_bounds__(64) void pn_comp_bwd_kernel(PoeN a) {
     if (g == h) continue;
     const int per = (a.B[g] + PN_SEG - 1) / PN_SEG, lo = seg * per, hi = min(a.B[g], lo + per);
     for (int b = lo; b < hi; ++b) {
-      const int c = (int)a.comp[g][b];
+      const int c = pn_code(a.comp[g][b], a.ncomp);
+      if (c < 0) continue;
       const float* m = a.mean + ((long)h * a.ncomp + c) * W;
       if (m[W - 1] <= 0.f) continue;
       const float w = expf(-m[n + d]);
@@ -151,7 +161,8 @@ __global__ __launch_bounds__(256) void pn_apply_bwd_kernel(PoeN a) {
   const int h = blockIdx.y, n = a.n, W = 2 * n + 1;
   const int b = blockIdx.x * 8 + (threadIdx.x >> 5), d = threadIdx.x & 31;
   if (b >= a.B[h] || d >= n) return;
-  const int c = (int)a.comp[h][b];
+  const int c = pn_code(a.comp[h][b], a.ncomp);
+  if (c < 0) return;
   const float cnt = a.mean[((long)h * a.ncomp + c) * W + W - 1];
   float sl = 0.f, sv = 0.f;
   for (int seg = 0; seg < PN_SEG; ++seg) {

@@ -275,7 +275,7 @@ class DecoderFused(torch.autograd.Function):
         red.nprob = 0
         if _ops.OVERLAP_SMALL:
             torch.cuda.current_stream(dev).wait_stream(side)
-        streams = group_streams(dev, NG)
+        streams = group_streams(dev, NG) if _ops.FWD_GROUP_STREAMS else [torch.cuda.current_stream(dev)] * NG
         fork(streams)
         for g in range(NG):
           with torch.cuda.stream(streams[g]):
@@ -376,9 +376,9 @@ class DecoderFused(torch.autograd.Function):
         # returning.  Same-box A/B: SPV_DEFER_BC 1.90 -> 1.82 ms.  (Measured and left out: running the softmax fix BESIDE
         # the d A_m GEMM + trunk backward instead of ahead of them, +0.01 ms.)
         cur = torch.cuda.current_stream(dev)
-        streams = group_streams(dev, NG)
+        streams = group_streams(dev, NG) if _ops.BWD_GROUP_STREAMS else [cur] * NG
         side = group_streams(dev, 3)[2] if _ops.DEFER_WM else cur
-        stages = [_DecoderBwd(g, ctx.P[g], ctx.saved_g[g], ctx.Wps[g], ws[g], B, Bp, Gs[g], Gps[g], nsplit, ctx.grads_f32, pair=(NG == 2)) for g in range(NG)]
+        stages = [_DecoderBwd(g, ctx.P[g], ctx.saved_g[g], ctx.Wps[g], ws[g], B, Bp, Gs[g], Gps[g], nsplit, ctx.grads_f32, pair=(NG == 2 and _ops.BWD_GROUP_STREAMS)) for g in range(NG)]
         d_slabs, bc_slabs, ef_slabs = [None] * NG, [None] * NG, [None] * NG
         # bf16 mode with the regressor GEMMs deferred to the side stream: the critical chain only needs the latent gradient, which
         # the READ-ONLY pass spv_dec_dz gives (168 MB read per group instead of 336 MB read + written); the in-place fix of

@@ -47,13 +47,6 @@ class LossOutput:
     reconstruction_loss_mean: Optional[torch.Tensor] = None  # 0-dim: batch mean of the summed reconstruction terms (this build's extra)
 
 
-def kl_normal_std(loc: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
-    """KL(N(loc, scale) || N(0, 1)) summed over the latent dimension (spVIPESmodule.py:841-868) for encoder outputs that did
-    not come out of the fused kernels (injected-mask / ragged inference batches)."""
-    var = scale * scale
-    return (0.5 * (var + loc * loc - 1.0 - torch.log(var))).sum(dim=1)
-
-
 # ---- parameter containers with the reference's state_dict layout ---------------------------------
 class _LazyMeans(dict):
     """extra_metrics of LossOutput (spVIPESmodule.py:884-897): batch means, evaluated when first read so that a
@@ -442,7 +435,8 @@ class spVIPESmodule(nn.Module):
         if pre_stream is not None and not (self.n_groups == 2 and self.use_labels and labels is not None):
             torch.cuda.current_stream(dev0).wait_stream(pre_stream)
             pre_stream = None
-        if self.n_groups > 2:
+        if self.n_groups > 2 or (isinstance(self.transport_plan, str) and self.transport_plan == "components"):
+            # (the N-expert component PoE; with exactly two groups it is reachable through transport_plan="components" only)
             poe_stats = self._components_poe_hip(shared_stats, processed_labels if processed_labels is not None else (list(labels.values()) if labels else None), noise)
         elif self.use_labels and labels is not None:
             # label-based PoE (priority as spVIPESmodule.py:492-493): pairing + fusion + draw + KL in HIP
@@ -596,9 +590,12 @@ class spVIPESmodule(nn.Module):
         else:
             klw = torch.full((), float(kl_weight), dtype=torch.float32, device=dev)
         px = {g: generative_outputs["private_poe"][str(g)]["px"] for g in gs}
-        pr, po = inference_outputs["private_stats"], inference_outputs["poe_stats"]
-        kl_p = {g: self._kl_private[g] if g in self._kl_private else kl_normal_std(pr[g]["logtheta_loc"], pr[g]["logtheta_scale"]) for g in gs}
-        kl_q = {g: self._kl_poe[g] if g in self._kl_poe else kl_normal_std(po[g]["logtheta_loc"], po[g]["logtheta_qz"].scale) for g in gs}
+        # the four KL terms (spVIPESmodule.py:841-868) come out of the kernels that sampled the latents (spv_enc_sample_fwd, spv_poe_fuse_fwd /
+        # spv_poe_comp_fwd) -- every batch shape, ragged and injected-mask inference batches included, goes through them
+        if any(g not in self._kl_private or g not in self._kl_poe for g in gs):
+            raise RuntimeError("loss() needs the outputs of this module's latest inference() call (the KL terms are produced there)")
+        kl_p = {g: self._kl_private[g] for g in gs}
+        kl_q = {g: self._kl_poe[g] for g in gs}
         lat = [t for g in gs for t in (px[g].private_log_z, px[g].poe_log_z)]
         kls = [t for g in gs for t in (kl_p[g], kl_q[g])]
         self._cut = None

@@ -153,6 +153,10 @@ DEFER_BC = os.environ.get("SPV_DEFER_BC", "1") != "0"  # regressor weight-gradie
 # Measured at C2, same box, alternating (round 2): OFF 1.690 / 1.690 ms per step, ON 1.745 / 1.737 ms -- the second pass over the two
 # gradient arrays (2 x 168 MB more HBM reads per step) costs more than the shorter critical chain gains.  Kept as a switch, off.
 DZ_ONLY = os.environ.get("SPV_DZ_ONLY", "0") != "0"
+# the two groups' decoder-forward chains (logits GEMM, softmax statistics, likelihood) / d A_m GEMMs on two streams (parallel graph
+# branches) or one after the other on the caller's stream (every fork / join of graph branches leaves the GPU idle for >= 10 us)
+FWD_GROUP_STREAMS = os.environ.get("SPV_FWD_GROUP_STREAMS", "1") != "0"
+BWD_GROUP_STREAMS = os.environ.get("SPV_BWD_GROUP_STREAMS", "1") != "0"
 _PENDING: list = []
 _PENDING_KEEP: list = []
 

@@ -51,6 +51,51 @@ def default_max_epochs(n_obs: int) -> int:
     return int(min(round((20000 / n_obs) * 400), 400))
 
 
+def sync_float_buffers(module: torch.nn.Module, world: int) -> None:
+    """Average every floating-point buffer of ``module`` (the BatchNorm running means / variances) over the ranks with ONE
+    all-reduce.  Parameters are identical on all ranks by construction (same reduced gradient, same Adam step); BatchNorm running
+    statistics are not -- every rank updates them from its own minibatches and they are in no gradient bucket -- so eval-mode
+    forward passes (validation, ``get_latent_representation``) would otherwise see a different model on every rank."""
+    if world <= 1:
+        return
+    bufs = [b for b in module.buffers() if b.is_floating_point() and b.numel()]
+    if not bufs:
+        return
+    flat = torch.cat([b.detach().reshape(-1).to(torch.float32) for b in bufs])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.div_(world)
+    off = 0
+    with torch.no_grad():
+        for b in bufs:
+            b.copy_(flat[off:off + b.numel()].view_as(b))
+            off += b.numel()
+
+
+class EarlyStopping:
+    """scvi-tools / Lightning ``EarlyStopping`` on a minimised metric (patience, min_delta) whose decision is COLLECTIVE: with more
+    than one rank the monitored value is averaged over the ranks before it is compared, so every rank sees the same number and
+    leaves the epoch loop in the same epoch (a rank that stopped alone would leave its peers blocked in the next all-reduce)."""
+
+    def __init__(self, patience: int, min_delta: float, world: int = 1, device=None):
+        self.patience, self.min_delta, self.world, self.device = int(patience), float(min_delta), int(world), device
+        self.best, self.bad_epochs = float("inf"), 0
+
+    def reduced(self, value: float) -> float:
+        if self.world <= 1:
+            return float(value)
+        t = torch.tensor([float(value)], dtype=torch.float64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t) / self.world
+
+    def should_stop(self, value: float) -> bool:
+        v = self.reduced(value)
+        if v < self.best - self.min_delta:
+            self.best, self.bad_epochs = v, 0
+            return False
+        self.bad_epochs += 1
+        return self.bad_epochs >= self.patience
+
+
 class FlatParams:
     """Re-homes every trainable parameter of a module into one contiguous fp32 buffer (and its
     gradient into a second one), so that the all-reduce and the optimiser each touch one array."""
@@ -123,6 +168,9 @@ class Trainer:
                 lf = l.flatten().to(torch.float32)
                 if lf.numel() and not bool(((lf >= 0) & (lf < _abi.POE_LMAX) & (lf == lf.floor())).all()):
                     raise ValueError(f"{what} of group {g} must be integral codes in [0, {_abi.POE_LMAX})")
+                n_comp = getattr(module, "n_components", None)
+                if what == "cluster components" and module.n_groups > 2 and n_comp is not None and lf.numel() and float(lf.max()) >= n_comp:
+                    raise ValueError(f"cluster components of group {g} must be codes in [0, n_components = {n_comp})")
         self.device = counts[0].X.device
         self.fp = FlatParams(module, late=lambda name: name.startswith("encoder_"))
         self.opt = HipAdam(self.fp, lr=lr, eps=eps, weight_decay=weight_decay)
@@ -278,7 +326,16 @@ class Trainer:
         nn_ops.GRAD_SINK = True  # small-layer gradients land directly in the flat buffer (see nn_ops.grad_out)
         ops.DEFER_JOIN = True    # side-stream gradient GEMMs are joined here, after the whole backward pass
         try:
-            lo.loss.backward()
+            cut = self.module._cut
+            if cut is not None:
+                # split backward pass: the gradients of the tensors that cross from the encoders into the decoder are TAKEN from the
+                # engine (autograd.grad), not accumulated into leaf .grad fields -- accumulation clones a gradient that reaches several
+                # leaves (the four KL vectors share one), and inside a captured step a clone is a memcpy NODE; like the memset nodes
+                # (profiles/r03_graph_edges_*.json) those are kept off the captured path.  Parameter gradients need no
+                # accumulation either: with the gradient sink every kernel writes its slice of the flat buffer itself.
+                self._cut_grads = torch.autograd.grad(lo.loss, list(cut[1]), allow_unused=True)
+            else:
+                lo.loss.backward()
         finally:
             nn_ops.GRAD_SINK = False
             ops.DEFER_JOIN = False
@@ -290,8 +347,8 @@ class Trainer:
         """second half of a split backward pass: PoE, encoder tails, fc1 (gradient bucket ``fp.grad[fp.split:]``)"""
         from . import nn_ops, ops
 
-        outs, cut = self.module._cut
-        pairs = [(o, c.grad) for o, c in zip(outs, cut) if c.grad is not None and o.requires_grad]
+        outs, _cut = self.module._cut
+        pairs = [(o, g) for o, g in zip(outs, self._cut_grads) if g is not None and o.requires_grad]
         nn_ops.GRAD_SINK = True
         ops.DEFER_JOIN = True
         try:
@@ -301,7 +358,7 @@ class Trainer:
             ops.DEFER_JOIN = False
             ops.join_pending()
             ops.join_all_side_streams(self.device)
-        self.module._cut = None
+        self.module._cut = self._cut_grads = None
 
     def capture(self, rows: Sequence[torch.Tensor], warmup: int = 3) -> None:
         """Capture forward + loss + backward of one step into a hipGraph (``torch.cuda.CUDAGraph``): the ~100
@@ -331,14 +388,21 @@ class Trainer:
         if self.world > 1:
             torch.cuda.synchronize(self.device)
             mode = {"capture_error_mode": "thread_local"}
-        g = torch.cuda.CUDAGraph()
+        # SPV_GRAPH_KEEP=1 (tools/graph_dump.py): keep the captured hipGraph_t alive beside its executable, so that its nodes and
+        # edges can be read back (CUDAGraph.raw_cuda_graph) -- what the replay honours is then on record, not inferred
+        keep = os.environ.get("SPV_GRAPH_KEEP") == "1"
+        g = torch.cuda.CUDAGraph(keep_graph=True) if keep else torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, **mode):
             self._static_lo = self._forward_backward(self._static_rows, self._klw)
+        if keep:
+            g.instantiate()
         self.graph = g
         if self.overlap:
-            g2 = torch.cuda.CUDAGraph()
+            g2 = torch.cuda.CUDAGraph(keep_graph=True) if keep else torch.cuda.CUDAGraph()
             with torch.cuda.graph(g2, pool=g.pool(), **mode):
                 self._backward_encoders()
+            if keep:
+                g2.instantiate()
             self.graph2 = g2
 
     def step(self, rows: Sequence[torch.Tensor], kl_weight: Optional[float] = None, noise=None, optimizer_step: bool = True):
@@ -407,7 +471,9 @@ class Trainer:
         """Mean loss / reconstruction / KL over the held-out validation cells (module in eval mode, kl_weight 1, full batches
         in the reference's loader order: the validation loader is built like the training one, drop_last=True,
         data/_multi_datasplitter.py:81-98).  None when a group has no full validation batch.  In a data-parallel job every
-        rank evaluates the same cells (validation rows are not sharded), so all ranks reach the same early-stopping decision."""
+        rank evaluates the same cells (validation rows are not sharded) on the same model (``fit`` averages the BatchNorm running
+        statistics over the ranks first); the draws still differ per rank (rank-offset counters), which is why ``fit`` takes the
+        early-stopping decision on the rank-averaged metric (``EarlyStopping``)."""
         B = sampler.batch_size
         nb = [len(v) // B for v in sampler.val_idx]
         if not nb or min(nb) == 0:
@@ -442,7 +508,7 @@ class Trainer:
             raise ValueError("early_stopping needs at least one full validation batch per group (train_size < 1 / validation_size > 0)")
         for k in ("elbo_validation", "reconstruction_loss_validation", "kl_local_validation", "validation_loss"):
             self.history.setdefault(k, [])
-        best, bad_epochs = float("inf"), 0
+        stopper = EarlyStopping(early_stopping_patience, early_stopping_min_delta, self.world, self.device) if early_stopping else None
         self.module.train()
         for ep in range(max_epochs):
             self.epoch = ep
@@ -468,17 +534,14 @@ class Trainer:
                 self.history["kl_local_train"].append(kl / n)
                 self.history["elbo_train"].append((rec + kl) / n)
             if check_val_every_n_epoch and (ep + 1) % check_val_every_n_epoch == 0:
+                sync_float_buffers(self.module, self.world)   # every rank validates the same model
                 vm = self.validation_metrics(sampler)
-                if vm is not None:
+                if vm is not None:   # (the same on every rank: it depends on the split sizes only)
                     for k, v in vm.items():
                         self.history[k].append(v)
-                    if early_stopping:
-                        if vm["elbo_validation"] < best - early_stopping_min_delta:
-                            best, bad_epochs = vm["elbo_validation"], 0
-                        else:
-                            bad_epochs += 1
-                            if bad_epochs >= early_stopping_patience:
-                                self.stopped_epoch = ep
-                                break
+                    if stopper is not None and stopper.should_stop(vm["elbo_validation"]):   # collective: all ranks leave together
+                        self.stopped_epoch = ep
+                        break
+        sync_float_buffers(self.module, self.world)   # ranks end with one model, BatchNorm running statistics included
         self.module.eval()  # scvi's TrainRunner leaves the module in eval mode
         return self.history

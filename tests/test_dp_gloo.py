@@ -88,3 +88,57 @@ def test_late_parameters_form_the_second_bucket():
     fp.zero_grad()
     ((net(x) - y) ** 2).mean().backward()
     assert float(fp.grad[:fp.split].abs().max()) > 0 and float(fp.grad[fp.split:].abs().max()) > 0
+
+
+# ---- collective early stopping + BatchNorm buffer sync (a rank that stops alone deadlocks its peers) ---------------------
+def _es_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from spvipes_amd.train import EarlyStopping, sync_float_buffers
+    # rank-local validation curves that would stop the ranks in DIFFERENT epochs if each decided alone
+    curves = {0: [10.0, 9.0, 9.5, 9.6, 9.7, 9.8, 9.9], 1: [10.0, 9.0, 8.0, 7.0, 7.5, 7.6, 7.7]}
+    es = EarlyStopping(patience=2, min_delta=0.0, world=world)
+    stopped, n_reduce = None, 0
+    for ep, v in enumerate(curves[rank]):
+        g = torch.ones(3) * (rank + 1)
+        dist.all_reduce(g)            # the step's gradient all-reduce: a rank that left the loop alone would hang its peer here
+        n_reduce += 1
+        if es.should_stop(v):
+            stopped = ep
+            break
+    bn = torch.nn.BatchNorm1d(4)
+    with torch.no_grad():
+        bn.running_mean.fill_(float(rank))          # ranks hold different running statistics
+        bn.running_var.fill_(1.0 + 2.0 * rank)
+    sync_float_buffers(bn, world)
+    q.put((rank, stopped, n_reduce, bn.running_mean.clone(), bn.running_var.clone(), int(bn.num_batches_tracked)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_early_stopping_decision_is_collective_and_bn_buffers_are_averaged():
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_es_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # alone, rank 0 would stop at epoch 3 (best 9.0 at epoch 1) and rank 1 at epoch 5 (best 7.0 at epoch 3); on the rank mean
+    # [10, 9, 8.75, 8.3, 8.6, 8.7, 8.8] both stop at epoch 5
+    assert got[0][1] == got[1][1] == 5 and got[0][2] == got[1][2] == 6
+    for r in range(world):
+        assert torch.equal(got[r][3], torch.full((4,), 0.5)) and torch.equal(got[r][4], torch.full((4,), 2.0)) and got[r][5] == 0
+
+
+def test_early_stopping_single_rank_matches_lightning_rule():
+    from spvipes_amd.train import EarlyStopping
+    es = EarlyStopping(patience=2, min_delta=0.5)
+    out = [es.should_stop(v) for v in (10.0, 9.8, 9.4, 9.3, 9.2)]   # 9.8 is no improvement by > 0.5; 9.4 is; then two bad epochs
+    assert out == [False, False, False, False, True]

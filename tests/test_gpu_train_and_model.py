@@ -366,33 +366,47 @@ def test_adam_written_weight_images_are_bit_identical_to_repacking(dev):
         assert torch.equal(x, img), key
 
 
-@pytest.mark.parametrize("mode,precision", [("label", "bf16"), ("label", "fp32"), ("cluster", "bf16"), ("paired", "fp32")])
-def test_every_gradient_element_is_overwritten_by_a_step(dev, mode, precision):
+@pytest.mark.parametrize("mode,precision,H,overlap,graph", [
+    ("label", "bf16", 128, False, False), ("label", "fp32", 128, False, False), ("cluster", "bf16", 128, False, False), ("paired", "fp32", 128, False, False),
+    ("label", "bf16", 256, False, False), ("label", "bf16", 128, True, True), ("label", "bf16", 256, True, True), ("paired", "fp32", 128, True, False),
+    ("three", "bf16", 256, False, False), ("three", "bf16", 256, True, True), ("three", "fp32", 128, False, True)])
+def test_every_gradient_element_is_overwritten_by_a_step(dev, mode, precision, H, overlap, graph):
     """train.Trainer does not zero the flat gradient buffer at the start of a step (ZERO_GRADS_EACH_STEP off): that is only right
-    while every gradient kernel overwrites.  Fill the buffer with NaN, run forward + backward, and no parameter may hold a NaN."""
+    while every gradient kernel overwrites.  Fill the buffer with NaN, run forward + backward, and no parameter may hold a NaN --
+    for every PoE mode, both precisions, n_hidden 128 / 256 (one / two 256-unit halves in the fc1 kernels), the three-group path
+    (PoEComponents, decoder chunks of <= 2 groups), the split backward pass of a data-parallel job (``overlap``) and its two
+    captured graphs (``graph``): an accumulate-or-skip kernel anywhere would feed stale gradients to Adam."""
     import scipy.sparse as sp
     from spvipes_amd.data import MinibatchSampler, make_synthetic_group
     from spvipes_amd.module import spVIPESmodule
     from spvipes_amd.train import Trainer
-    groups = [make_synthetic_group(g, 1024, 300, dev) for g in range(2)]
+    NG = 3 if mode == "three" else 2
+    Gs = (300, 260, 340)[:NG] if NG == 3 else (300, 300)
+    groups = [make_synthetic_group(g % 2, 1024, Gs[g], dev) for g in range(NG)]
     torch.manual_seed(0)
-    kw = dict(n_hidden=128, n_dimensions_shared=10, n_dimensions_private=5, precision=precision)
+    kw = dict(n_hidden=H, n_dimensions_shared=10, n_dimensions_private=5, precision=precision)
     if mode == "label":
         module = spVIPESmodule({0: 300, 1: 300}, use_labels=True, **kw).to(dev)
-        trainer = Trainer(module, [g.counts for g in groups], labels=[g.labels for g in groups])
+        trainer = Trainer(module, [g.counts for g in groups], labels=[g.labels for g in groups], overlap_allreduce=overlap)
+    elif mode == "three":
+        module = spVIPESmodule({g: Gs[g] for g in range(3)}, transport_plan="components", pair_data=False, allow_more_groups=True, n_components=10, **kw).to(dev)
+        trainer = Trainer(module, [g.counts for g in groups], components=[g.labels for g in groups], overlap_allreduce=overlap)
     else:
         rng = np.random.default_rng(0)
         n = 1024
         i, j, v = np.repeat(np.arange(n), 3), rng.integers(0, n, size=3 * n), rng.random(3 * n).astype(np.float32) + 0.1
         P = sp.coo_matrix((v, (i, j)), shape=(n, n)).tocsr()
         module = spVIPESmodule({0: 300, 1: 300}, use_labels=False, transport_plan=P, pair_data=(mode == "paired"), **kw).to(dev)
-        trainer = Trainer(module, [g.counts for g in groups], components=[g.labels for g in groups] if mode == "cluster" else None)
+        trainer = Trainer(module, [g.counts for g in groups], components=[g.labels for g in groups] if mode == "cluster" else None, overlap_allreduce=overlap)
     assert not trainer.ZERO_GRADS_EACH_STEP
-    sampler = MinibatchSampler([1024, 1024], 256, dev, seed=0)
+    sampler = MinibatchSampler([1024] * NG, 256, dev, seed=0)
     module.train()
     rows = next(iter(sampler.epoch()))
+    if graph:
+        trainer.capture(rows, warmup=1)
     trainer.step(rows, kl_weight=1.0)
     trainer.fp.grad.fill_(float("nan"))
     trainer.step(rows, kl_weight=1.0, optimizer_step=False)
+    torch.cuda.synchronize()
     bad = [(n_, int(torch.isnan(p.grad).sum())) for n_, p in module.named_parameters() if p.grad is not None and bool(torch.isnan(p.grad).any())]
     assert not bad, bad

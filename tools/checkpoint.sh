@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box): bash tools/ckpt_r02.sh <tag>   -- the round's evidence set: GPU tests, bench lines of every BASELINE config,
+# usage (GPU box): bash tools/checkpoint.sh <tag>   -- one evidence set (copy what is to be judged from gpurun_out/ into profiles/): GPU tests, bench lines of every BASELINE config,
 # rocprofv3 kernel statistics (default and single-stream), PMC passes for the likelihood kernel and the fc1 DMA GEMM, step timeline
 set -e -o pipefail
 export TMPDIR=/tmp

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box): bash tools/r02_probe8.sh  -- LDS-DMA 320-column decoder GEMMs alone (tools/probes/dec_gemm_bench.hip)
+# usage (GPU box): bash tools/probes/run_dec_gemm_bench.sh  -- LDS-DMA 320-column decoder GEMMs alone (tools/probes/dec_gemm_bench.hip)
 set -e -o pipefail
 cd $GRAFT_REPO_ROOT/tools/probes
 mkdir -p $GRAFT_REPO_ROOT/gpurun_out/r02_probe8

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box): bash tools/r02_probe9.sh -- PMC passes over the stand-alone decoder GEMM probe (LDS conflicts, MFMA busy, waits)
+# usage (GPU box): bash tools/probes/run_dec_gemm_pmc.sh -- PMC passes over the stand-alone decoder GEMM probe (LDS conflicts, MFMA busy, waits)
 set -e -o pipefail
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02_probe9; mkdir -p $O

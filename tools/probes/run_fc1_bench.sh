@@ -1,6 +1,6 @@
 #!/bin/bash
 set -e -o pipefail
-cd "$(dirname "$0")/probes"
+cd "$(dirname "$0")"
 O=../../gpurun_out/r02_probe5; mkdir -p $O
 for pp in 0 1; do
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -DF1_PIPE=$pp -o /tmp/fc1_bench_$pp fc1_bench.hip 2>/dev/null
