@@ -262,7 +262,12 @@ typedef struct spv_adam_image {
  * touched: the image must have been produced by spv_pack_bf16 once.  n_images may be 0. */
 int spv_adam_step_images(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                          float weight_decay, float bc1, float bc2, float grad_scale, const spv_adam_image* images, int32_t n_images,
-                         int64_t* step_counter, void* stream);   /* step_counter (nullable): device int64 incremented by one per call */
+                         int64_t* step_counter, const int64_t* t_dev, double beta1_d, double beta2_d, void* stream);
+/* step_counter (nullable): device int64 incremented by one per call (the counter spv_randn / the dropout masks are keyed by).
+ * t_dev (nullable): device int64 = optimiser steps ALREADY taken; when given, bc1 / bc2 are ignored and the bias corrections
+ * 1 - beta^(t_dev + 1) are formed on the device from beta1_d / beta2_d (double, as torch.optim.Adam forms them on the host): no
+ * argument of the launch changes from step to step, so it can be part of the step's captured graph.  The kernel does not write
+ * t_dev: advance it with spv_counter_bump after the launch. */
 
 /* Up to SPV_MAXP gathers / copies of 4-byte words in one launch: dst[i] = src[idx ? idx[i] : i], i < count (the minibatch's label
  * gathers, labels[rows] of every group -- the reference's loader does this on the host: data/_multi_datasplitter.py:65-98 -- and the

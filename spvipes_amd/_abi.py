@@ -233,7 +233,8 @@ _SIGNATURES = {
     "spv_loss_assemble": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "spv_adam_step_images": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
-                                       C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+                                       C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
+                                       C.c_void_p]),
     "spv_gather_u32": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "spv_randn": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_uint64, C.c_void_p]),
     "spv_counter_bump": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -641,8 +641,17 @@ struct AdamImages { int n; spv_adam_image img[SPV_ADAM_MAX_IMAGES]; };
 
 __global__ void adam_images_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                    long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2, float gscale, AdamImages im,
-                                   long long* step_counter) {
+                                   long long* step_counter, const long long* t_dev, double b1d, double b2d) {
   if (step_counter && blockIdx.x == 0 && threadIdx.x == 0) *step_counter += 1;   // (read by the NEXT step's spv_randn / dropout: stream order)
+  if (t_dev) {
+    // bias corrections 1 - beta^t from the DEVICE-resident count of completed steps (t = *t_dev + 1), in double like torch.optim.Adam's
+    // host arithmetic: the launch then carries no per-step host value and can sit inside the captured graph of the step.  Nobody
+    // writes *t_dev while this kernel runs (the caller advances it with spv_counter_bump afterwards).  beta^t by repeated squaring.
+    long long e = *t_dev + 1;
+    double r1 = 1.0, r2 = 1.0, x1 = b1d, x2 = b2d;
+    while (e > 0) { if (e & 1) { r1 *= x1; r2 *= x2; } x1 *= x1; x2 *= x2; e >>= 1; }
+    bc1 = (float)(1.0 - r1); bc2 = (float)(1.0 - r2);
+  }
   const long stride = (long)gridDim.x * blockDim.x * 4;
   const float step = lr / bc1, isq = rsqrtf(bc2);
   for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
@@ -696,7 +705,7 @@ __global__ void adam_images_kernel(float* __restrict__ p, const float* __restric
 
 extern "C" int spv_adam_step_images(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                                     float weight_decay, float bc1, float bc2, float grad_scale, const spv_adam_image* images, int32_t n_images,
-                                    int64_t* step_counter, void* stream) {
+                                    int64_t* step_counter, const int64_t* t_dev, double beta1_d, double beta2_d, void* stream) {
   if (!p || !g || !m || !v || n < 0 || n_images < 0 || n_images > SPV_ADAM_MAX_IMAGES || (n_images && !images)) return fail(SPV_ERR_ARG, "spv_adam_step_images: bad arguments%s");
   if (n == 0) return SPV_OK;
   if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15)
@@ -714,7 +723,7 @@ extern "C" int spv_adam_step_images(float* p, const float* g, float* m, float* v
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adam_images_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, lr, beta1, beta2, eps,
-                     weight_decay, bc1, bc2, grad_scale, im, (long long*)step_counter);
+                     weight_decay, bc1, bc2, grad_scale, im, (long long*)step_counter, (const long long*)t_dev, beta1_d, beta2_d);
   return launch_status("spv_adam_step_images");
 }
 
@@ -954,9 +963,11 @@ extern "C" int spv_zsplit_fwd(const spv_zsplit_args* a, void* stream) {
   if (!a || a->B <= 0 || a->n_p <= 0 || a->n_s <= 0 || a->ngroups <= 0 || a->ngroups > 2) return fail(SPV_ERR_ARG, "spv_zsplit_fwd: bad shape%s");
   for (int g = 0; g < a->ngroups; ++g) if (!a->priv[g] || !a->poe[g] || !a->zcat[g]) return fail(SPV_ERR_ARG, "spv_zsplit_fwd: null pointer%s");
   const long tot = (long)a->B * (a->n_p + a->n_s);
-  hipLaunchKernelGGL(zsplit_fwd_kernel, dim3((unsigned)((tot + 255) / 256), a->ngroups), dim3(256), 0, (hipStream_t)stream, *a);
-  bool pack = false;
-  for (int g = 0; g < a->ngroups; ++g) pack = pack || a->am_hi[g] || a->aps_hi[g];
+  bool pack = false, pack_all = true;
+  for (int g = 0; g < a->ngroups; ++g) { pack = pack || a->am_hi[g] || a->aps_hi[g]; pack_all = pack_all && a->am_hi[g] && a->aps_hi[g]; }
+  // with both operand images requested for every group ONE kernel writes zcat and the images (zsplit_pack_kernel computes the latents'
+  // positions itself); otherwise zcat first, then whatever images were asked for
+  if (!pack_all) hipLaunchKernelGGL(zsplit_fwd_kernel, dim3((unsigned)((tot + 255) / 256), a->ngroups), dim3(256), 0, (hipStream_t)stream, *a);
   if (pack) {
     if (a->Bp < a->B || a->n_p + 1 > SPV_DEC_KP || a->n_s + 1 > SPV_DEC_KS || a->am_cols < a->n_p + a->n_s + 1 || a->am_cols < 0 ||
         a->ld_am < a->am_col + a->am_cols)

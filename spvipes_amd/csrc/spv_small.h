@@ -838,7 +838,14 @@ __global__ __launch_bounds__(256) void zsplit_fwd_kernel(ZsplitArgs a) {
   const float v = (zc < a.n_p) ? a.priv[g][(long)b * a.n_p + zc] : a.poe[g][(long)b * a.n_s + zc - a.n_p];
   a.zcat[g][i] = v;
 }
-// the same latents as the decoder's packed bf16 operand images (see spv_zsplit_args): one thread per image element
+// column c of zcat = [z_private | z_shared] for cell b, straight from the two latents (the A6 quirk above)
+__device__ __forceinline__ float zcat_value(const ZsplitArgs& a, int g, int b, int c) {
+  const int zc = (c < a.n_p) ? a.n_s + c : c - a.n_p;   // column of Z = cat(private_log_z, poe_log_z)
+  const float pv = a.priv[g][(long)b * a.n_p + min(zc, a.n_p - 1)], qv = a.poe[g][(long)b * a.n_s + max(zc - a.n_p, 0)];   // (both loads unconditional)
+  return (zc < a.n_p) ? pv : qv;
+}
+// zcat AND the decoder's packed bf16 operand images of the same latents (see spv_zsplit_args) in one pass: one thread per image
+// element; the threads of the mixture-operand tail also store zcat (its columns are the first n_p + n_s of that tail)
 __global__ __launch_bounds__(256) void zsplit_pack_kernel(ZsplitArgs a) {
   const int g = blockIdx.y;
   const int nt = a.n_p + a.n_s;
@@ -846,18 +853,21 @@ __global__ __launch_bounds__(256) void zsplit_pack_kernel(ZsplitArgs a) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long)a.Bp * wcols) return;
   const int b = (int)(i / wcols), c = (int)(i % wcols);
-  const float* z = a.zcat[g] + (long)b * nt;              // [z_private | z_shared], written by zsplit_fwd_kernel
+  const int bb = min(b, a.B - 1);
   float v = 0.f;
   bf16_t* dh; bf16_t* dl; long o;
   if (c < DEC_PACK_KPS) {
-    if (b < a.B) {
-      if (c < DEC_PACK_KP) v = (c < a.n_p) ? z[c] : (c == a.n_p ? 1.f : 0.f);
-      else { const int cs = c - DEC_PACK_KP; v = (cs < a.n_s) ? z[a.n_p + cs] : (cs == a.n_s ? 1.f : 0.f); }
-    }
+    const int cs = (c < DEC_PACK_KP) ? c : c - DEC_PACK_KP, n = (c < DEC_PACK_KP) ? a.n_p : a.n_s, zoff = (c < DEC_PACK_KP) ? 0 : a.n_p;
+    const float z = zcat_value(a, g, bb, zoff + min(cs, n - 1));
+    if (b < a.B) v = (cs < n) ? z : (cs == n ? 1.f : 0.f);
     dh = a.aps_hi[g]; dl = a.aps_lo[g]; o = (long)b * DEC_PACK_KPS + c;
   } else {
     const int cm = c - DEC_PACK_KPS;
-    if (b < a.B) v = (cm < nt) ? z[cm] : (cm == nt ? 1.f : 0.f);
+    const float z = zcat_value(a, g, bb, min(cm, nt - 1));
+    if (b < a.B) {
+      v = (cm < nt) ? z : (cm == nt ? 1.f : 0.f);
+      if (cm < nt) a.zcat[g][(long)b * nt + cm] = z;
+    }
     dh = a.am_hi[g]; dl = a.am_lo[g]; o = (long)b * a.ld_am + a.am_col + cm;
   }
   if (dh == nullptr) return;

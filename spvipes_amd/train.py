@@ -129,28 +129,31 @@ class FlatParams:
 
 
 class HipAdam:
-    """torch.optim.Adam semantics on a FlatParams buffer, one kernel launch (spv_adam_step)."""
+    """torch.optim.Adam semantics on a FlatParams buffer, one kernel launch (spv_adam_step_images).  The number of steps taken
+    lives on the DEVICE (``t_dev``): the kernel forms the bias corrections 1 - beta^t itself, so no argument of the launch changes
+    from step to step and the launch can be captured into the step's hipGraph (``Trainer.capture``, single-rank jobs)."""
 
     def __init__(self, fp: FlatParams, lr=1e-3, betas=(0.9, 0.999), eps=0.01, weight_decay=1e-6):
         self.fp, self.lr, self.betas, self.eps, self.wd = fp, lr, betas, eps, weight_decay
         self.m = torch.zeros_like(fp.flat)
         self.v = torch.zeros_like(fp.flat)
-        self.t = 0
+        self.t = 0   # host copy of the step count (bookkeeping only: the kernel reads t_dev)
+        self.t_dev = torch.zeros((), dtype=torch.int64, device=fp.flat.device)
 
     def step(self, grad_scale: float = 1.0, images=None, counter=None):
-        """``images``: optional ctypes array of SpvAdamImage -- bf16 operand images the kernel rewrites from the updated values;
+        """``images``: optional ctypes array of SpvAdamImage -- 16-bit operand images the kernel rewrites from the updated values;
         ``counter``: optional 0-dim int64 device tensor the kernel increments (the step counter the module's noise is keyed by)"""
         self.t += 1
+        self.launch(grad_scale, images, counter)
+
+    def launch(self, grad_scale: float = 1.0, images=None, counter=None):
+        """the two launches of one step (Adam, then the device step count + 1); captured as they are by ``Trainer.capture``"""
         b1, b2 = self.betas
-        if (images is not None and len(images)) or counter is not None:
-            n_img = len(images) if images is not None else 0
-            _abi.call("spv_adam_step_images", _abi.ptr(self.fp.flat), _abi.ptr(self.fp.grad), _abi.ptr(self.m), _abi.ptr(self.v),
-                      self.fp.numel, self.lr, b1, b2, self.eps, self.wd, 1.0 - b1 ** self.t, 1.0 - b2 ** self.t,
-                      grad_scale, images if n_img else None, n_img, _abi.ptr(counter), _abi.stream_ptr())
-            return
-        _abi.call("spv_adam_step", _abi.ptr(self.fp.flat), _abi.ptr(self.fp.grad), _abi.ptr(self.m), _abi.ptr(self.v),
-                  self.fp.numel, self.lr, b1, b2, self.eps, self.wd, 1.0 - b1 ** self.t, 1.0 - b2 ** self.t,
-                  grad_scale, _abi.stream_ptr())
+        n_img = len(images) if images is not None else 0
+        _abi.call("spv_adam_step_images", _abi.ptr(self.fp.flat), _abi.ptr(self.fp.grad), _abi.ptr(self.m), _abi.ptr(self.v),
+                  self.fp.numel, self.lr, b1, b2, self.eps, self.wd, 1.0, 1.0,
+                  grad_scale, images if n_img else None, n_img, _abi.ptr(counter), _abi.ptr(self.t_dev), float(b1), float(b2), _abi.stream_ptr())
+        _abi.call("spv_counter_bump", _abi.ptr(self.t_dev), _abi.stream_ptr())
 
 
 class Trainer:
@@ -203,6 +206,7 @@ class Trainer:
     ZERO_GRADS_EACH_STEP = os.environ.get("SPV_ZERO_GRADS", "0") != "0"
     DEVICE_RNG = os.environ.get("SPV_DEVICE_RNG", "1") != "0"
     MULTI_GATHER = os.environ.get("SPV_MULTI_GATHER", "1") != "0"   # the groups' label gathers / row-index copies as one launch each (spv_gather_u32)
+    ADAM_IN_GRAPH = os.environ.get("SPV_ADAM_IN_GRAPH", "1") != "0"  # single rank: the Adam launch is the captured graph's last node
 
     def _image_specs(self):
         """[(workspace, key, image tensor, [(parameter, rows_off, col_off)], token parameters)] for every packed weight image"""
@@ -326,6 +330,9 @@ class Trainer:
         nn_ops.GRAD_SINK = True  # small-layer gradients land directly in the flat buffer (see nn_ops.grad_out)
         ops.DEFER_JOIN = True    # side-stream gradient GEMMs are joined here, after the whole backward pass
         try:
+            one = getattr(self, "_one", None)   # the backward seed d loss / d loss = 1, kept: autograd would otherwise launch a fill kernel per step
+            if one is None or one.device != lo.loss.device:
+                one = self._one = torch.ones((), dtype=torch.float32, device=lo.loss.device)
             cut = self.module._cut
             if cut is not None:
                 # split backward pass: the gradients of the tensors that cross from the encoders into the decoder are TAKEN from the
@@ -333,9 +340,9 @@ class Trainer:
                 # leaves (the four KL vectors share one), and inside a captured step a clone is a memcpy NODE; like the memset nodes
                 # (profiles/r03_graph_edges_*.json) those are kept off the captured path.  Parameter gradients need no
                 # accumulation either: with the gradient sink every kernel writes its slice of the flat buffer itself.
-                self._cut_grads = torch.autograd.grad(lo.loss, list(cut[1]), allow_unused=True)
+                self._cut_grads = torch.autograd.grad(lo.loss, list(cut[1]), grad_outputs=one, allow_unused=True)
             else:
-                lo.loss.backward()
+                lo.loss.backward(gradient=one)
         finally:
             nn_ops.GRAD_SINK = False
             ops.DEFER_JOIN = False
@@ -392,8 +399,15 @@ class Trainer:
         # edges can be read back (CUDAGraph.raw_cuda_graph) -- what the replay honours is then on record, not inferred
         keep = os.environ.get("SPV_GRAPH_KEEP") == "1"
         g = torch.cuda.CUDAGraph(keep_graph=True) if keep else torch.cuda.CUDAGraph()
+        # single-rank jobs: the optimiser launch is the LAST node of the graph (nothing has to happen between the backward pass and
+        # Adam; every per-step value it needs is device resident: HipAdam.t_dev, module._rng_counter) -- the replay then ends with the
+        # parameters updated instead of leaving a host launch (and its ~15-20 us of idle GPU) behind it.  Data-parallel jobs keep
+        # Adam outside: the all-reduce comes between.
+        self._adam_in_graph = bool(self.ADAM_IN_GRAPH and self.world == 1 and not self.overlap)
         with torch.cuda.graph(g, **mode):
             self._static_lo = self._forward_backward(self._static_rows, self._klw)
+            if self._adam_in_graph:
+                self.opt.launch(grad_scale=1.0, images=self._img_plan, counter=getattr(self.module, "_rng_counter", None))
         if keep:
             g.instantiate()
         self.graph = g
@@ -449,7 +463,12 @@ class Trainer:
             self._ev_ar[0].record()
             dist.all_reduce(self.fp.grad, op=dist.ReduceOp.SUM)  # ONE collective for the whole flat buffer (the north_star form)
             self._ev_ar[1].record()
-        if optimizer_step:
+        if self.graph is not None and getattr(self, "_adam_in_graph", False):
+            if not optimizer_step:
+                raise ValueError("this trainer's captured graph contains the optimiser step: use an eager step for optimizer_step=False")
+            self.opt.t += 1   # (the launch itself was part of the replay)
+            self.global_step += 1
+        elif optimizer_step:
             plan = getattr(self, "_img_plan", None)
             if plan is not None and not self._images_are_fresh():
                 plan = None   # (somebody wrote to a parameter since the images were made: plain Adam, and the images are rebuilt next step)

@@ -49,9 +49,9 @@ def test_flat_gradient_allreduce_equals_mean_of_rank_gradients():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    got = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=300)
         assert p.exitcode == 0
     # single-process reference: mean of the two ranks' gradients on the same two minibatches
     grads = []
@@ -126,9 +126,9 @@ def test_early_stopping_decision_is_collective_and_bn_buffers_are_averaged():
     procs = [ctx.Process(target=_es_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    got = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=300)
         assert p.exitcode == 0
     # alone, rank 0 would stop at epoch 3 (best 9.0 at epoch 1) and rank 1 at epoch 5 (best 7.0 at epoch 3); on the rank mean
     # [10, 9, 8.75, 8.3, 8.6, 8.7, 8.8] both stop at epoch 5

@@ -369,7 +369,7 @@ def test_adam_written_weight_images_are_bit_identical_to_repacking(dev):
 @pytest.mark.parametrize("mode,precision,H,overlap,graph", [
     ("label", "bf16", 128, False, False), ("label", "fp32", 128, False, False), ("cluster", "bf16", 128, False, False), ("paired", "fp32", 128, False, False),
     ("label", "bf16", 256, False, False), ("label", "bf16", 128, True, True), ("label", "bf16", 256, True, True), ("paired", "fp32", 128, True, False),
-    ("three", "bf16", 256, False, False), ("three", "bf16", 256, True, True), ("three", "fp32", 128, False, True)])
+    ("three", "bf16", 256, False, False), ("three", "bf16", 256, True, True), ("three", "fp32", 128, True, True)])
 def test_every_gradient_element_is_overwritten_by_a_step(dev, mode, precision, H, overlap, graph):
     """train.Trainer does not zero the flat gradient buffer at the start of a step (ZERO_GRADS_EACH_STEP off): that is only right
     while every gradient kernel overwrites.  Fill the buffer with NaN, run forward + backward, and no parameter may hold a NaN --
