@@ -241,6 +241,12 @@ int spv_dec_dz(const spv_dec_params* p, const float* Tp, const float* Ts, float*
  * through the two rate heads, columns 0..15 = sum_g tP[b][g] * W'_p[g][.], columns 16..47 = sum_g tS[b][g] * W'_s[g][.]
  * (sum the slabs with spv_reduce_slabs): replaces the two [B,G] x [G,K] GEMMs over tP and tS. */
 int spv_dec_softmax_bwd(const spv_dec_params* p, const float* Tp, const float* Ts, float* dz_part, void* stream);
+/* bf16 mode: ONE read-only pass over t_P / t_S for everything the backward pass needs from them (nn/networks.py:314-320 through
+ * autograd): the latent gradient of the two rate heads (dz_part, as above) and the two regressor weight gradients
+ * d [W'_p | c_p] = t'_P^T [z_p | 1], d [W'_s | c_s] = t'_S^T [z_s | 1] as one partial slab per 128-cell workgroup row:
+ * dwp_part [Bp / 128][G][16], dws_part [Bp / 128][G][32] (sum with spv_reduce_slabs).  t_P / t_S stay uncorrected -- nothing reads
+ * them afterwards: replaces spv_dec_softmax_bwd + spv_dec_heads_wgrad (336 MB less [B, G] traffic per group at B 4096 x G 10 000). */
+int spv_dec_heads_bwd(const spv_dec_params* p, const float* Tp, const float* Ts, float* dz_part, float* dwp_part, float* dws_part, void* stream);
 
 /* One 16-bit operand image kept in step with a parameter by spv_adam_step_images: the `count` fp32 values at flat offset `begin`
  * (a multiple of 4) are a row-major matrix with `cols` columns; element (r, c) is also written to
@@ -311,6 +317,9 @@ typedef struct spv_linear_prob {
   int32_t N, K;
   const float* keep;               /* forward, drop_p > 0 only: optional [B][N] keep-mask (1 = keep, row pitch N) used INSTEAD of the
                                       counter-based draw -- the dropout mask of nn/networks.py:121 injected by a caller (parity tests) */
+  const float* W2; int32_t n_w2;   /* dgrad only, optional: rows n >= n_w2 of the [N][K] weight are W2[n - n_w2] (two layers that read the
+                                      same input -- the mu / logvar heads, nn/networks.py:123-124 -- back-propagate into it in ONE launch:
+                                      dY = their gradients side by side [B][N], N = the two widths together); W2 == NULL: one matrix */
 } spv_linear_prob;
 typedef struct spv_linear_batch {
   spv_linear_prob p[SPV_MAXP];
@@ -364,6 +373,15 @@ typedef struct spv_sample_prob {
 typedef struct spv_sample_batch { spv_sample_prob p[SPV_MAXP]; int32_t nprob, B; } spv_sample_batch;
 int spv_enc_sample_fwd(const spv_sample_batch* a, void* stream);
 int spv_enc_sample_bwd(const spv_sample_batch* a, void* stream);
+/* The encoder heads' BatchNorm + sampling as ONE pair of launches per direction (nn/networks.py:123-129 and its autograd):
+ * bn->p[2e], bn->p[2e + 1] = the BatchNorm problems of encoder e's mu / logvar heads (N = n <= 32, their outputs Y the two halves of
+ * sb->p[e].post [B][2n], in the backward their dY the two halves of sb->p[e].d_post), sb->p[e] the sampling problem.
+ *   forward : bn_stats + one kernel that finalises the statistics, normalises, samples and forms the KL (same bits as
+ *             spv_bn_fwd + spv_enc_sample_fwd, two launches fewer)
+ *   backward: one kernel for d_post and the BatchNorm partial sums + one that finalises d gamma / d beta and applies
+ *             (training-mode statistics only; eval mode: spv_enc_sample_bwd + spv_bn_bwd) */
+int spv_enc_heads_fwd(const spv_bn_batch* bn, const spv_sample_batch* sb, void* stream);
+int spv_enc_heads_bwd(const spv_bn_batch* bn, const spv_sample_batch* sb, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Label-based Product of Experts on device (module/spVIPESmodule.py:583-718 + _poe2 :282-379).
@@ -379,6 +397,11 @@ int spv_poe_partner(const float* labels0, const float* labels1, int32_t B0, int3
                     int32_t* rank0, int32_t* rank1, int32_t* tables, int32_t* partner0, int32_t* mode0,
                     int32_t* partner1, int32_t* mode1, int32_t* err, void* stream);
 
+/* the ranking half of spv_poe_partner alone (one launch): rank of every cell within its label, the cells of each label in batch
+ * order, tables[2][2][SPV_POE_LMAX] = per group (count, start) per label */
+int spv_poe_rank(const float* labels0, const float* labels1, int32_t B0, int32_t B1, int32_t* order0, int32_t* order1,
+                 int32_t* rank0, int32_t* rank1, int32_t* tables, int32_t* err, void* stream);
+
 typedef struct spv_poe_args {
   const float* stats[2]; int64_t ld[2];   /* shared encoders' (loc | logvar) rows, [B][ld], logvar at column n */
   const int32_t* partner[2]; const int32_t* mode[2];
@@ -392,6 +415,10 @@ typedef struct spv_poe_args {
   const float* expert[2]; int64_t ld_expert[2];  /* cluster PoE: plan-weighted experts [B][ld] (loc | logvar) fused in
                                                     place of the encoder statistics; NULL = label / paired PoE      */
   float* d_expert[2];                      /* backward output for expert (zeroed by the call itself)                */
+  /* label PoE, forward only: when lab[0] != NULL spv_poe_fuse_fwd derives every cell's partner / mode itself from the ranking left
+   * by spv_poe_rank (labels, rank within label, cells of each label in batch order, per-label count / start tables) and STORES them
+   * through partner / mode (which are then outputs) for the backward pass -- the separate lookup launch of spv_poe_partner is gone */
+  const float* lab[2]; const int32_t* order[2]; const int32_t* rank[2]; const int32_t* tables;
 } spv_poe_args;
 int spv_poe_fuse_fwd(const spv_poe_args* a, void* stream);
 int spv_poe_fuse_bwd(const spv_poe_args* a, void* stream);
@@ -483,6 +510,11 @@ typedef struct spv_fold_prob {
   float* red_part;                                         /* [ceil(G/256) + 1][K + K*K]  */
   float* dz; int64_t lddz;                                 /* backward out (+=): [B][lddz] */
   int32_t G, Gp, K;
+  /* optional: the latent-slicing backward (spVIPESmodule.py:733-754, see spv_zsplit_args) done by the same kernel -- dz then is this
+   * problem's column block (first column zcol) of d zcat [B][n_p + n_s], which is only READ, and the finished column c of d zcat goes
+   * to d private_log_z / d poe_log_z (out_priv [B][n_p], out_poe [B][n_s]) instead of back into dz: no spv_zsplit_bwd launch.  The two
+   * problems of a group (private block, shared block) together cover every column exactly once. */
+  int32_t zcol; float* out_priv; float* out_poe; int32_t n_p, n_s;
 } spv_fold_prob;
 typedef struct spv_fold_batch { spv_fold_prob p[SPV_MAXP]; int32_t nprob, B, training; float eps, momentum; } spv_fold_batch;
 int spv_bn_fold_fwd(const spv_fold_batch* a, void* stream);

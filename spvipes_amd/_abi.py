@@ -60,7 +60,7 @@ BN_ROWS = 32  # rows per workgroup of the BatchNorm kernels (sizes their partial
 class SpvLinearProb(C.Structure):
     _fields_ = [("X", C.c_void_p), ("ldx", C.c_int64), ("W", C.c_void_p), ("bias", C.c_void_p), ("Y", C.c_void_p), ("ldy", C.c_int64),
                 ("dY", C.c_void_p), ("lddy", C.c_int64), ("dX", C.c_void_p), ("lddx", C.c_int64), ("dW", C.c_void_p), ("db", C.c_void_p),
-                ("N", C.c_int32), ("K", C.c_int32), ("keep", C.c_void_p)]
+                ("N", C.c_int32), ("K", C.c_int32), ("keep", C.c_void_p), ("W2", C.c_void_p), ("n_w2", C.c_int32)]
 
 
 class SpvLinearBatch(C.Structure):
@@ -96,7 +96,7 @@ class SpvPoeArgs(C.Structure):
                 ("kl", C.c_void_p * 2), ("g_loc", C.c_void_p * 2), ("g_logvar", C.c_void_p * 2), ("g_scale", C.c_void_p * 2),
                 ("g_logz", C.c_void_p * 2), ("g_kl", C.c_void_p * 2), ("d_stats", C.c_void_p * 2), ("B", C.c_int32 * 2), ("n", C.c_int32),
                 ("clamp_scale", C.c_int32), ("lone_passthrough", C.c_int32), ("expert", C.c_void_p * 2), ("ld_expert", C.c_int64 * 2),
-                ("d_expert", C.c_void_p * 2)]
+                ("d_expert", C.c_void_p * 2), ("lab", C.c_void_p * 2), ("order", C.c_void_p * 2), ("rank", C.c_void_p * 2), ("tables", C.c_void_p)]
 
 
 SPV_POE_MAXG, POE_COMP_SEG, POE_COMP_CMAX = 4, 16, 64
@@ -168,7 +168,8 @@ class SpvFoldProb(C.Structure):
                 ("zsum", C.c_void_p), ("zz", C.c_void_p), ("z", C.c_void_p), ("ldz", C.c_int64), ("stat", C.c_void_p),
                 ("img_hi", C.c_void_p), ("img_lo", C.c_void_p), ("ld_img", C.c_int64), ("col_off", C.c_int32), ("slot", C.c_int32),
                 ("dWeff", C.c_void_p), ("ld_dw", C.c_int64), ("dW", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
-                ("red_part", C.c_void_p), ("dz", C.c_void_p), ("lddz", C.c_int64), ("G", C.c_int32), ("Gp", C.c_int32), ("K", C.c_int32)]
+                ("red_part", C.c_void_p), ("dz", C.c_void_p), ("lddz", C.c_int64), ("G", C.c_int32), ("Gp", C.c_int32), ("K", C.c_int32),
+                ("zcol", C.c_int32), ("out_priv", C.c_void_p), ("out_poe", C.c_void_p), ("n_p", C.c_int32), ("n_s", C.c_int32)]
 
 
 class SpvFoldBatch(C.Structure):
@@ -207,6 +208,7 @@ _SIGNATURES = {
     "spv_dec_materialize": (C.c_int, [C.POINTER(SpvDecParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "spv_dec_dz": (C.c_int, [C.POINTER(SpvDecParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "spv_dec_softmax_bwd": (C.c_int, [C.POINTER(SpvDecParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "spv_dec_heads_bwd": (C.c_int, [C.POINTER(SpvDecParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "spv_linear_fwd": (C.c_int, [C.POINTER(SpvLinearBatch), C.c_void_p]),
     "spv_linear_dgrad": (C.c_int, [C.POINTER(SpvLinearBatch), C.c_void_p]),
     "spv_linear_wgrad": (C.c_int, [C.POINTER(SpvLinearBatch), C.c_void_p, C.c_int64, C.c_void_p]),
@@ -214,8 +216,11 @@ _SIGNATURES = {
     "spv_bn_bwd": (C.c_int, [C.POINTER(SpvBnBatch), C.c_void_p]),
     "spv_enc_sample_fwd": (C.c_int, [C.POINTER(SpvSampleBatch), C.c_void_p]),
     "spv_enc_sample_bwd": (C.c_int, [C.POINTER(SpvSampleBatch), C.c_void_p]),
+    "spv_enc_heads_fwd": (C.c_int, [C.POINTER(SpvBnBatch), C.POINTER(SpvSampleBatch), C.c_void_p]),
+    "spv_enc_heads_bwd": (C.c_int, [C.POINTER(SpvBnBatch), C.POINTER(SpvSampleBatch), C.c_void_p]),
     "spv_poe_partner": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "spv_poe_rank": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "spv_poe_fuse_fwd": (C.c_int, [C.POINTER(SpvPoeArgs), C.c_void_p]),
     "spv_poe_fuse_bwd": (C.c_int, [C.POINTER(SpvPoeArgs), C.c_void_p]),
     "spv_plan_invmap": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),

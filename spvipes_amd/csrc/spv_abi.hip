@@ -513,7 +513,7 @@ extern "C" int spv_dec_dz(const spv_dec_params* q, const float* Tp, const float*
   if (!Tp || !Ts || !p.tP || !p.tS || !p.lse_p || !p.lse_s || !dz_part) return fail(SPV_ERR_ARG, "spv_dec_dz: null pointer%s");
   if (p.n_gene_tiles != p.Gp / 32) return fail(SPV_ERR_ARG, "spv_dec_dz: n_gene_tiles must be Gp / 32%s");
   if (p.grads_f32) return fail(SPV_ERR_UNSUPPORTED, "spv_dec_dz: needs bf16 gradient arrays%s");
-  hipLaunchKernelGGL((dec_softmax_bwd_kernel<bf16_t, true, false>), dim3(p.Bp / DEC_CELLS_PER_WG, p.gene_splits), dim3(256), 0, (hipStream_t)stream, p, Tp, Ts, dz_part);
+  hipLaunchKernelGGL((dec_softmax_bwd_kernel<bf16_t, true, false>), dim3(p.Bp / DEC_CELLS_PER_WG, p.gene_splits), dim3(256), 0, (hipStream_t)stream, p, Tp, Ts, dz_part, (float*)nullptr, (float*)nullptr);
   return launch_status("spv_dec_dz");
 }
 
@@ -526,10 +526,28 @@ extern "C" int spv_dec_softmax_bwd(const spv_dec_params* q, const float* Tp, con
   if (dz_part && p.grads_f32) return fail(SPV_ERR_ARG, "spv_dec_softmax_bwd: the fused latent gradient needs bf16 gradient arrays%s");
   dim3 grid(p.Bp / DEC_CELLS_PER_WG, p.gene_splits);
   hipStream_t s = (hipStream_t)stream;
-  if (p.grads_f32) hipLaunchKernelGGL((dec_softmax_bwd_kernel<split_t, false>), grid, dim3(256), 0, s, p, Tp, Ts, (float*)nullptr);
-  else if (dz_part) hipLaunchKernelGGL((dec_softmax_bwd_kernel<bf16_t, true>), grid, dim3(256), 0, s, p, Tp, Ts, dz_part);
-  else hipLaunchKernelGGL((dec_softmax_bwd_kernel<bf16_t, false>), grid, dim3(256), 0, s, p, Tp, Ts, (float*)nullptr);
+  float* const none = nullptr;
+  if (p.grads_f32) hipLaunchKernelGGL((dec_softmax_bwd_kernel<split_t, false>), grid, dim3(256), 0, s, p, Tp, Ts, none, none, none);
+  else if (dz_part) hipLaunchKernelGGL((dec_softmax_bwd_kernel<bf16_t, true>), grid, dim3(256), 0, s, p, Tp, Ts, dz_part, none, none);
+  else hipLaunchKernelGGL((dec_softmax_bwd_kernel<bf16_t, false>), grid, dim3(256), 0, s, p, Tp, Ts, none, none, none);
   return launch_status("spv_dec_softmax_bwd");
+}
+
+// One read-only pass over t_P / t_S (bf16 gradient arrays) for everything the backward pass needs from them: the latent gradient of the
+// two rate heads (dz_part, as spv_dec_softmax_bwd) AND the two regressor weight gradients as per-workgroup-row partial slabs
+// dwp_part [Bp / 128][G][16], dws_part [Bp / 128][G][32] (sum with spv_reduce_slabs).  t_P / t_S are left uncorrected: nothing reads
+// them afterwards.  Replaces spv_dec_softmax_bwd + spv_dec_heads_wgrad in bf16 mode.
+extern "C" int spv_dec_heads_bwd(const spv_dec_params* q, const float* Tp, const float* Ts, float* dz_part, float* dwp_part, float* dws_part, void* stream) {
+  DecParams p;
+  int rc = to_dec(q, p);
+  if (rc != SPV_OK) return rc;
+  if (!Tp || !Ts || !p.tP || !p.tS || !p.lse_p || !p.lse_s || !dz_part || !dwp_part || !dws_part) return fail(SPV_ERR_ARG, "spv_dec_heads_bwd: null pointer%s");
+  if (p.n_gene_tiles != p.Gp / 32) return fail(SPV_ERR_ARG, "spv_dec_heads_bwd: n_gene_tiles must be Gp / 32%s");
+  if (p.grads_f32) return fail(SPV_ERR_UNSUPPORTED, "spv_dec_heads_bwd: bf16 gradient arrays only%s");
+  if (p.Bp % DEC_CELLS_PER_WG) return fail(SPV_ERR_ARG, "spv_dec_heads_bwd: Bp must be a multiple of 128%s");
+  dim3 grid(p.Bp / DEC_CELLS_PER_WG, p.gene_splits);
+  hipLaunchKernelGGL((dec_softmax_bwd_kernel<bf16_t, true, false, true>), grid, dim3(256), 0, (hipStream_t)stream, p, Tp, Ts, dz_part, dwp_part, dws_part);
+  return launch_status("spv_dec_heads_bwd");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -797,6 +815,10 @@ static int check_bn(const spv_bn_batch* a, const char* who) {
   }
   return SPV_OK;
 }
+static bool bn_all_narrow(const spv_bn_batch* a) {   // every problem N <= 64: the consumers finalise the statistics themselves
+  for (int i = 0; i < a->nprob; ++i) if (a->p[i].N > 64) return false;
+  return true;
+}
 extern "C" int spv_bn_fwd(const spv_bn_batch* a, void* stream) {
   int rc = check_bn(a, "spv_bn_fwd");
   if (rc) return rc;
@@ -806,10 +828,15 @@ extern "C" int spv_bn_fwd(const spv_bn_batch* a, void* stream) {
   int nmax = 0;
   for (int i = 0; i < a->nprob; ++i) nmax = a->p[i].N > nmax ? a->p[i].N : nmax;
   if (a->training) hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(256), 0, s, *a);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((nmax + 63) / 64, a->nprob), dim3(256), 0, s, *a);
   int rmax = a->B;
   for (int i = 0; i < a->nprob; ++i) if (a->p[i].img_hi && a->p[i].img_rows > rmax) rmax = a->p[i].img_rows;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3((rmax + BN_ROWS - 1) / BN_ROWS, a->nprob), dim3(256), 0, s, *a);
+  const dim3 agrid((rmax + BN_ROWS - 1) / BN_ROWS, a->nprob);
+  if (bn_all_narrow(a)) {   // two launches: every workgroup of the second re-derives its columns' statistics from the partials
+    hipLaunchKernelGGL(bn_apply_fin_kernel, agrid, dim3(256), 0, s, *a);
+  } else {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((nmax + 63) / 64, a->nprob), dim3(256), 0, s, *a);
+    hipLaunchKernelGGL(bn_apply_kernel, agrid, dim3(256), 0, s, *a);
+  }
   return launch_status("spv_bn_fwd");
 }
 extern "C" int spv_bn_bwd(const spv_bn_batch* a, void* stream) {
@@ -822,8 +849,12 @@ extern "C" int spv_bn_bwd(const spv_bn_batch* a, void* stream) {
   int nmax = 0;
   for (int i = 0; i < a->nprob; ++i) nmax = a->p[i].N > nmax ? a->p[i].N : nmax;
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, s, *a);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((nmax + 63) / 64, a->nprob), dim3(256), 0, s, *a);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, s, *a);
+  if (bn_all_narrow(a)) {
+    hipLaunchKernelGGL(bn_bwd_apply_fin_kernel, grid, dim3(256), 0, s, *a);
+  } else {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((nmax + 63) / 64, a->nprob), dim3(256), 0, s, *a);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, s, *a);
+  }
   return launch_status("spv_bn_bwd");
 }
 
@@ -833,6 +864,51 @@ static int check_sample(const spv_sample_batch* a, const char* who) {
     if (a->p[i].n <= 0 || a->p[i].n > 32 || !a->p[i].post || !a->p[i].eps || !a->p[i].scale) return fail(SPV_ERR_ARG, "%s: bad problem", who);
   return SPV_OK;
 }
+// encoder heads in two launches per direction (csrc/spv_small.h: enc_heads_*): bn->p[2e], bn->p[2e + 1] = the BatchNorm problems of
+// encoder e's mu / logvar heads, sb->p[e] its sampling problem
+static int check_heads(const spv_bn_batch* bn, const spv_sample_batch* sb, const char* who) {
+  int rc = check_bn(bn, who);
+  if (rc) return rc;
+  rc = check_sample(sb, who);
+  if (rc) return rc;
+  if (bn->nprob != 2 * sb->nprob || bn->B != sb->B || bn->relu) return fail(SPV_ERR_ARG, "%s: two BatchNorm problems per sampling problem, same batch, no relu", who);
+  for (int e = 0; e < sb->nprob; ++e) {
+    const spv_bn_prob &q0 = bn->p[2 * e], &q1 = bn->p[2 * e + 1];
+    const int n = sb->p[e].n;
+    if (q0.N != n || q1.N != n || q0.img_hi || q1.img_hi) return fail(SPV_ERR_ARG, "%s: head widths differ from the sampling problem's n", who);
+    if (q0.Y != sb->p[e].post || q1.Y != sb->p[e].post + n || q0.ldy != 2 * n || q1.ldy != 2 * n)
+      return fail(SPV_ERR_ARG, "%s: the BatchNorm outputs must be the two halves of the sampling problem's post [B][2n]", who);
+  }
+  return SPV_OK;
+}
+extern "C" int spv_enc_heads_fwd(const spv_bn_batch* bn, const spv_sample_batch* sb, void* stream) {
+  int rc = check_heads(bn, sb, "spv_enc_heads_fwd");
+  if (rc) return rc;
+  for (int i = 0; i < sb->nprob; ++i) if (!sb->p[i].logz || !sb->p[i].theta || !sb->p[i].kl) return fail(SPV_ERR_ARG, "spv_enc_heads_fwd: null output%s");
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned nb = (bn->B + BN_ROWS - 1) / BN_ROWS;
+  if (bn->training) hipLaunchKernelGGL(bn_stats_kernel, dim3(nb, bn->nprob), dim3(256), 0, s, *bn);
+  hipLaunchKernelGGL(enc_heads_bn_sample_fwd_kernel, dim3(nb, sb->nprob), dim3(256), 0, s, *bn, *sb);
+  return launch_status("spv_enc_heads_fwd");
+}
+extern "C" int spv_enc_heads_bwd(const spv_bn_batch* bn, const spv_sample_batch* sb, void* stream) {
+  int rc = check_heads(bn, sb, "spv_enc_heads_bwd");
+  if (rc) return rc;
+  for (int i = 0; i < sb->nprob; ++i) if (!sb->p[i].d_post) return fail(SPV_ERR_ARG, "spv_enc_heads_bwd: null output%s");
+  for (int i = 0; i < bn->nprob; ++i) {
+    const spv_bn_prob& q = bn->p[i];
+    if (!q.dX || !q.dgamma || !q.dbeta) return fail(SPV_ERR_ARG, "spv_enc_heads_bwd: null pointer%s");
+    const int e = i / 2, n = sb->p[e].n;
+    if (q.dY != sb->p[e].d_post + (i & 1) * n || q.lddy != 2 * n) return fail(SPV_ERR_ARG, "spv_enc_heads_bwd: dY must be the halves of d_post [B][2n]%s");
+  }
+  if (!bn->training) return fail(SPV_ERR_UNSUPPORTED, "spv_enc_heads_bwd: training-mode BatchNorm only (use spv_enc_sample_bwd + spv_bn_bwd)%s");
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned nb = (bn->B + BN_ROWS - 1) / BN_ROWS;
+  hipLaunchKernelGGL(enc_heads_bwd_reduce_kernel, dim3(nb, sb->nprob), dim3(256), 0, s, *bn, *sb);
+  hipLaunchKernelGGL(bn_bwd_apply_fin_kernel, dim3(nb, bn->nprob), dim3(256), 0, s, *bn);
+  return launch_status("spv_enc_heads_bwd");
+}
+
 extern "C" int spv_enc_sample_fwd(const spv_sample_batch* a, void* stream) {
   int rc = check_sample(a, "spv_enc_sample_fwd");
   if (rc) return rc;
@@ -863,6 +939,12 @@ extern "C" int spv_poe_partner(const float* labels0, const float* labels1, int32
                      tables, partner0, mode0, partner1, mode1);
   return launch_status("spv_poe_partner");
 }
+extern "C" int spv_poe_rank(const float* labels0, const float* labels1, int32_t B0, int32_t B1, int32_t* order0, int32_t* order1,
+                            int32_t* rank0, int32_t* rank1, int32_t* tables, int32_t* err, void* stream) {
+  if (!labels0 || !labels1 || !order0 || !order1 || !rank0 || !rank1 || !tables || !err || B0 <= 0 || B1 <= 0) return fail(SPV_ERR_ARG, "spv_poe_rank: bad arguments%s");
+  hipLaunchKernelGGL(poe_rank_kernel, dim3(2), dim3(512), 0, (hipStream_t)stream, labels0, labels1, B0, B1, order0, order1, rank0, rank1, tables, err);
+  return launch_status("spv_poe_rank");
+}
 static int check_poe(const spv_poe_args* a, const char* who) {
   if (!a || a->n <= 0 || a->n > 32 || a->B[0] <= 0 || a->B[1] <= 0) return fail(SPV_ERR_ARG, "%s: bad shape (latent dimension <= 32)", who);
   for (int g = 0; g < 2; ++g)
@@ -875,6 +957,10 @@ extern "C" int spv_poe_fuse_fwd(const spv_poe_args* a, void* stream) {
   int rc = check_poe(a, "spv_poe_fuse_fwd");
   if (rc) return rc;
   for (int g = 0; g < 2; ++g) if (!a->logvar[g] || !a->logz[g] || !a->theta[g] || !a->kl[g]) return fail(SPV_ERR_ARG, "spv_poe_fuse_fwd: null output%s");
+  if (a->lab[0] || a->lab[1]) {
+    if (!a->lab[0] || !a->lab[1] || !a->order[0] || !a->order[1] || !a->rank[0] || !a->rank[1] || !a->tables || a->expert[0] || a->expert[1])
+      return fail(SPV_ERR_ARG, "spv_poe_fuse_fwd: the label lookup needs lab, order, rank of both groups and tables (and no plan experts)%s");
+  }
   const int Bm = a->B[0] > a->B[1] ? a->B[0] : a->B[1];
   hipLaunchKernelGGL(poe_fuse_fwd_kernel, dim3((Bm + 7) / 8, 2), dim3(256), 0, (hipStream_t)stream, *a);
   return launch_status("spv_poe_fuse_fwd");
@@ -1021,8 +1107,12 @@ extern "C" int spv_bn_fold_bwd(const spv_fold_batch* a, void* stream) {
   }
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_fold_bwd_kernel, dim3((gmax + 255) / 256, a->nprob), dim3(FOLD_BWD_THREADS), 0, s, *a);
-  if (a->training) {
-    hipLaunchKernelGGL(fold_red_finalize_kernel, dim3((FOLD_KMAX + FOLD_KMAX * FOLD_KMAX + 63) / 64, a->nprob), dim3(256), 0, s, *a);
+  if (a->training) {   // (the sum over the gene blocks' partials happens inside zstats_bwd_kernel)
+    for (int i = 0; i < a->nprob; ++i) {
+      const spv_fold_prob& q = a->p[i];
+      if (q.out_priv && (!q.out_poe || q.n_p <= 0 || q.n_s <= 0 || q.zcol < 0 || q.zcol + q.K > q.n_p + q.n_s))
+        return fail(SPV_ERR_ARG, "spv_bn_fold_bwd: bad latent-slicing outputs%s");
+    }
     hipLaunchKernelGGL(zstats_bwd_kernel, dim3((a->B + 63) / 64, a->nprob), dim3(256), 0, s, *a);
   }
   return launch_status("spv_bn_fold_bwd");

@@ -724,18 +724,31 @@ __device__ __forceinline__ void decode4(const u4v& x, float (&v)[4]) {   // hi +
 // latents through the two rate heads,  dz_p[cell][k] = sum_gene t'_P[gene][cell] W'_p[gene][k]  (and dz_s), accumulated
 // over the split's genes and written as one partial slab per split -- the two [B,G] x [G,16|32] GEMMs of the backward
 // pass and their re-read of t'_P / t'_S disappear.
-constexpr int SMB_SUB = 320;            // genes of the transposed slice resident in LDS at a time
+constexpr int SMB_SUB = 160;            // genes of the transposed slice resident in LDS at a time (320 before the weight-gradient fusion took its share of LDS: 2 workgroups per CU must fit)
 constexpr int SMB_PITCH = SMB_SUB + 4;  // bf16 per row: 648 B = 162 dwords = 2 x 81: the 32 rows an 8-byte fragment read touches start on 32 distinct even banks
                                         // (the first choice, 656 B = 4 x 41 dwords, put rows r and r + 16 on the same banks: SQ_LDS_BANK_CONFLICT 3.7 M per launch)
 
 // WRITE = false: read-only variant (FUSE only): the latent gradient alone, t_P / t_S stay uncorrected.  The backward pass's
 // critical chain (latent gradient -> trunk / PoE / encoder backward) then waits for a pass that only READS the two gradient
 // arrays; the in-place correction the regressor weight-gradient GEMMs need runs beside that chain on the side stream.
-template <typename GT, bool FUSE, bool WRITE = true>
-__global__ __launch_bounds__(256) void dec_softmax_bwd_kernel(DecParams p, const float* Tp, const float* Ts, float* dz_part) {
+//
+// HEADS (FUSE, read-only): the same corrected tile also yields the two regressor weight gradients,
+//   d W'_p[gene][k] = sum_cell t'_P[gene][cell] z_p[cell][k]   (and d W'_s),   z = the latent operand image [cell][48] ( | 1 column = d c),
+// a contraction over CELLS: every wave parks its 32-cell x 32-gene tile (bf16, cells on rows) in LDS, one barrier, and two of the four
+// waves (alternating by tile parity) run the 128-cell contraction of one head each with transposed LDS reads, the latent image of the
+// workgroup's cells resident in registers as the B operand.  One partial [G][16] / [G][32] slab per 128-cell workgroup row, summed in
+// order by spv_reduce_slabs.  With it nothing re-reads t_P / t_S after this pass: no write-back (168 MB per group) and no
+// spv_dec_heads_wgrad pass (another 168 MB read) -- the [B, G] traffic of the decoder backward drops from 924 to ~600 MB per group.
+constexpr int SMB_ZPITCH = 96;   // bf16 per row of the latent image in LDS: 48 dwords, a k-major pitch whose transposed reads are conflict free (kmajor_pitch)
+constexpr int SMB_TILE_ELEMS = DEC_CELLS_PER_WG * 32;   // one head's parked tile: [128 cells][32 genes] bf16 (k-major for the transposed reads)
+template <typename GT, bool FUSE, bool WRITE = true, bool HEADS = false>
+__global__ __launch_bounds__(256, 2) void dec_softmax_bwd_kernel(DecParams p, const float* Tp, const float* Ts, float* dz_part, float* dwp_part, float* dws_part) {
   typedef typename Raw4<GT>::type raw_t;
+  static_assert(!HEADS || (FUSE && !WRITE), "the weight-gradient fusion rides on the read-only fused pass");
   const long plane = (long)p.Bp * p.Gp;
   __shared__ __attribute__((aligned(16))) bf16_t s_wT[FUSE ? DEC_KPS * SMB_PITCH : 8];
+  __shared__ __attribute__((aligned(16))) bf16_t s_tile[HEADS ? 2 * 2 * SMB_TILE_ELEMS : 8];   // [tile parity][head][cell][gene]
+  __shared__ __attribute__((aligned(16))) bf16_t s_z[HEADS ? DEC_CELLS_PER_WG * SMB_ZPITCH : 8];  // the workgroup's rows of the latent image [cell][48 | pad]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
   const int cell_tile = blockIdx.x * (DEC_CELLS_PER_WG / 32) + wave;
   const int cell0 = cell_tile * 32;
@@ -753,17 +766,34 @@ __global__ __launch_bounds__(256) void dec_softmax_bwd_kernel(DecParams p, const
   f16v accP, accS;
 #pragma unroll
   for (int q = 0; q < 16; ++q) { accP[q] = 0.f; accS[q] = 0.f; }
+  // HEADS: this wave's role in the weight-gradient contraction (waves 0 / 2: private head on even / odd tiles, waves 1 / 3: shared head); its
+  // B operand z[cell][column of the head] comes out of the LDS copy of the workgroup's 128 latent-image rows by transposed reads
+  const int head_role = wave & 1;
+  if constexpr (HEADS) {
+    const int cb0 = blockIdx.x * DEC_CELLS_PER_WG;
+    for (int i = threadIdx.x; i < DEC_CELLS_PER_WG * (DEC_KPS / 8); i += 256) {   // (Bp is a multiple of 128: in bounds; rows >= B hold zeros)
+      const int row = i / (DEC_KPS / 8), c8 = (i % (DEC_KPS / 8)) * 8;
+      *reinterpret_cast<u4v*>(s_z + row * SMB_ZPITCH + c8) = *reinterpret_cast<const u4v*>(p.Aps_hi + (long)(cb0 + row) * DEC_KPS + c8);
+    }
+    // (made visible by the first barrier of the tile loop, which every wave passes before the first contraction)
+  }
   if (ntile > 0) {   // (block-uniform)
     const long trow = (long)cell_tile * p.n_gene_tiles;
     PsW wA;
-    raw_t rpA[4], rsA[4];
+    // two register stages for the gradient words, used alternately (the loop below is unrolled by two, so the roles are static):
+    // read-modify-write variants request tile t + 1 at the top of tile t; the read-only HEADS variant has nothing to drain and keeps
+    // TWO tiles in flight -- tile t + 2 is requested into tile t's registers as soon as they have been decoded (with one barrier per
+    // tile the four waves cannot drift apart, and a single tile of prefetch left the pass latency bound at 2.1 TB/s)
+    raw_t rp0[4], rs0[4], rp1[4], rs1[4];
     load_ps_w(p, gbeg, lane, wA);
-    {
-      const long tb = (trow + (gbeg >> 5)) * 1024 + lane * 4;
+    auto request = [&](int t, raw_t (&rp)[4], raw_t (&rs)[4]) {
+      const long tb = (trow + ((gbeg + 32 * min(t, ntile - 1)) >> 5)) * 1024 + lane * 4;
 #pragma unroll
-      for (int qq = 0; qq < 4; ++qq) { rpA[qq] = load4_raw<GT>(p.tP, tb + 256 * qq, plane); rsA[qq] = load4_raw<GT>(p.tS, tb + 256 * qq, plane); }
-    }
-    for (int t = 0; t < ntile; ++t) {
+      for (int qq = 0; qq < 4; ++qq) { rp[qq] = load4_raw<GT>(p.tP, tb + 256 * qq, plane); rs[qq] = load4_raw<GT>(p.tS, tb + 256 * qq, plane); }
+    };
+    request(0, rp0, rs0);
+    if constexpr (HEADS) request(1, rp1, rs1);
+    auto tile = [&](const int t, raw_t (&rpA)[4], raw_t (&rsA)[4], raw_t (&rpB)[4], raw_t (&rsB)[4]) {
       const int g0 = gbeg + 32 * t, gn = gbeg + 32 * min(t + 1, ntile - 1);
       if constexpr (FUSE) {
         if (t % (SMB_SUB / 32) == 0) {  // (re)stage W'^T for the next SMB_SUB genes: s_wT[k][gene - g0]
@@ -785,12 +815,12 @@ __global__ __launch_bounds__(256) void dec_softmax_bwd_kernel(DecParams p, const
       ys = mfma32_split<3>(wA.hi[1], wA.lo[1], cf.hi[1], cf.lo[1], ys);
       ys = mfma32_split<3>(wA.hi[2], wA.lo[2], cf.hi[2], cf.lo[2], ys);
       PsW wB;
-      raw_t rpB[4], rsB[4];
       load_ps_w(p, gn, lane, wB);
-      const long tbase = (trow + (g0 >> 5)) * 1024 + lane * 4, tnext = (trow + (gn >> 5)) * 1024 + lane * 4;
-#pragma unroll
-      for (int qq = 0; qq < 4; ++qq) { rpB[qq] = load4_raw<GT>(p.tP, tnext + 256 * qq, plane); rsB[qq] = load4_raw<GT>(p.tS, tnext + 256 * qq, plane); }
-      float cp[16], cs[16];
+      const long tbase = (trow + (g0 >> 5)) * 1024 + lane * 4;
+      if constexpr (!HEADS) request(t + 1, rpB, rsB);
+      // corrected values as packed bf16 pairs straight away (register [qq] = genes 8 qq + 4 h + {0,1 | 2,3}): what the MFMA operands
+      // and the parked tiles hold, and half the registers of 2 x 16 floats
+      unsigned cpk[8], csk[8];
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
         const int g = g0 + 8 * qq + 4 * h;
@@ -803,21 +833,22 @@ __global__ __launch_bounds__(256) void dec_softmax_bwd_kernel(DecParams p, const
           const bool ok = (g + j < p.G) && (cell < p.B);
           vp[j] = ok ? vp[j] - fast_exp(yp[q] - lp) * tpb : 0.f;
           vs[j] = ok ? vs[j] - fast_exp(ys[q] - ls) * tsb : 0.f;
-          cp[q] = vp[j]; cs[q] = vs[j];
         }
+        cpk[2 * qq] = pack2bf(vp[0], vp[1]); cpk[2 * qq + 1] = pack2bf(vp[2], vp[3]);
+        csk[2 * qq] = pack2bf(vs[0], vs[1]); csk[2 * qq + 1] = pack2bf(vs[2], vs[3]);
         if constexpr (WRITE) {
           store4_grad<GT>(p.tP, tbase + 256 * qq, plane, vp);
           store4_grad<GT>(p.tS, tbase + 256 * qq, plane, vs);
         }
       }
+      if constexpr (HEADS) request(t + 2, rpA, rsA);   // this tile's registers are free again: the tile after next goes into them
       if constexpr (FUSE) {
         const int gl = (g0 - gbeg) % SMB_SUB;   // offset of this tile inside the staged slice
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
           // B operand: this lane's genes 16m + 4h + {0..3} and 16m + 8 + 4h + {0..3} (registers 8m .. 8m + 7), as stored (bf16)
-          s8v bP, bS;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) { bP[i] = (short)f2bf(cp[8 * m + i]); bS[i] = (short)f2bf(cs[8 * m + i]); }
+          const u4v bPw = u4v{cpk[4 * m], cpk[4 * m + 1], cpk[4 * m + 2], cpk[4 * m + 3]}, bSw = u4v{csk[4 * m], csk[4 * m + 1], csk[4 * m + 2], csk[4 * m + 3]};
+          const s8v bP = *reinterpret_cast<const s8v*>(&bPw), bS = *reinterpret_cast<const s8v*>(&bSw);
           // A operand: row k = lane & 31 of W'^T at the same genes
           const bf16_t* wr = s_wT + gl + 16 * m + 4 * h;
           const u2v p0 = *reinterpret_cast<const u2v*>(wr + (r & 15) * SMB_PITCH), p1 = *reinterpret_cast<const u2v*>(wr + (r & 15) * SMB_PITCH + 8);
@@ -827,11 +858,45 @@ __global__ __launch_bounds__(256) void dec_softmax_bwd_kernel(DecParams p, const
           const u4v as4 = u4v{s0[0], s0[1], s1[0], s1[1]};
           accP = mfma32(*reinterpret_cast<const s8v*>(&ap), bP, accP);
           accS = mfma32(*reinterpret_cast<const s8v*>(&as4), bS, accS);
+          if constexpr (HEADS) {   // park the tile: row = this wave's cell, the lane's two 4-gene chunks of this half
+            bf16_t* tp_ = s_tile + ((t & 1) * 2 + 0) * SMB_TILE_ELEMS + (wave * 32 + r) * 32 + 16 * m + 4 * h;
+            bf16_t* ts_ = tp_ + SMB_TILE_ELEMS;
+            *reinterpret_cast<u2v*>(tp_) = u2v{bPw[0], bPw[1]};
+            *reinterpret_cast<u2v*>(tp_ + 8) = u2v{bPw[2], bPw[3]};
+            *reinterpret_cast<u2v*>(ts_) = u2v{bSw[0], bSw[1]};
+            *reinterpret_cast<u2v*>(ts_ + 8) = u2v{bSw[2], bSw[3]};
+          }
+        }
+      }
+      if constexpr (HEADS) {
+        // all four waves' tiles of this gene tile are in LDS after the barrier; the buffer of parity t & 1 is next written two tiles
+        // later, behind the NEXT barrier, by which time its readers (before that barrier in program order) are done: one barrier per tile
+        __syncthreads();
+        if ((wave >> 1) == (t & 1)) {   // (wave-uniform) this tile's two working waves
+          const bf16_t* img = s_tile + ((t & 1) * 2 + head_role) * SMB_TILE_ELEMS;
+          f16v accW;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) accW[q] = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks)   // A[gene][cell] and B[cell][column], k = cells: both by transposed reads of k-major images
+            accW = mfma32(frag_kmajor(img, 32, 0, 16 * ks, lane), frag_kmajor(s_z, SMB_ZPITCH, head_role ? DEC_KP : 0, 16 * ks, lane), accW);
+          // accW[q]: row = gene g0 + crow(q, h), column = r of this head
+          const int nk = head_role ? DEC_KS : DEC_KP;
+          float* out = (head_role ? dws_part : dwp_part) + (long)blockIdx.x * p.G * nk;
+          if (r < nk) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+              const int g = g0 + crow(q, h);
+              if (g < p.G) out[(long)g * nk + r] = accW[q];
+            }
+          }
         }
       }
       wA = wB;
-#pragma unroll
-      for (int qq = 0; qq < 4; ++qq) { rpA[qq] = rpB[qq]; rsA[qq] = rsB[qq]; }
+    };
+    for (int t = 0; t < ntile; t += 2) {   // (block-uniform trip structure: the barriers inside `tile` are reached by every wave)
+      tile(t, rp0, rs0, rp1, rs1);
+      if (t + 1 < ntile) tile(t + 1, rp1, rs1, rp0, rs0);
     }
   }
   if constexpr (FUSE) {   // acc[q]: row = crow(q, h) = k, column = lane & 31 = cell; one slab per split, zeros for empty splits

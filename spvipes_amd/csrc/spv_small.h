@@ -138,6 +138,8 @@ __device__ __forceinline__ void linear_dgrad_body(const LinearBatch& a) {
   const float* gr = q.dY + (long)min(row, a.B - 1) * q.lddy;
   const float* yr = MASKED ? q.Y + (long)min(row, a.B - 1) * q.ldy : gr;
   const float* wc = q.W + min(col, q.K - 1);
+  const float* wc2 = (q.W2 ? q.W2 : q.W) + min(col, q.K - 1);   // rows >= nw2 of the weight come from a second matrix (spv_linear_prob.W2)
+  const int nw2 = q.W2 ? q.n_w2 : q.N;
   f16v acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -145,7 +147,13 @@ __device__ __forceinline__ void linear_dgrad_body(const LinearBatch& a) {
   auto fetch = [&](int n, float (&g)[8], float (&w)[8]) {
     load8<VEC>(gr + n, gr, q.N - n, g);
     if constexpr (MASKED) { float y[8]; load8<VEC>(yr + n, yr, q.N - n, y); apply_mask8(a, g, y); }
-    load8_strided(wc, q.K, n, q.N, w);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {   // (column walk over the weight rows n + j; unconditional loads from a selected address)
+      const int r = n + j;
+      const bool ok = r < q.N;
+      const float t = *((r < nw2) ? wc + (long)(ok ? r : 0) * q.K : wc2 + (long)(ok ? r - nw2 : 0) * q.K);
+      w[j] = ok ? t : 0.f;
+    }
   };
   fetch(8 * h, ga, wb);
   for (int n0 = 0; n0 < q.N; n0 += 16) {
@@ -338,14 +346,67 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(BnBatch a) {
   if (ok && ty == 0) { q.stats[2 * j] = mean; q.stats[2 * j + 1] = rsqrtf(var + a.eps); }
 }
 
-__global__ __launch_bounds__(256) void bn_apply_kernel(BnBatch a) {
+// (mean, 1 / sqrt(var + eps)) of column j of problem q from the per-block partials, by a whole workgroup: the threads with
+// `group` in 0..3 sum blocks group, group + 4, ... in order, the four sums are added in order -- the association of
+// bn_finalize_kernel, so a launch that folds the finalisation into its consumer (N <= 64: a problem's partials are a few KB) produces
+// the same bits.  EVERY thread of the workgroup calls it (three barriers); threads with group < 0 only read the result.  `col` < 64 is
+// the LDS column of (q, j) in this workgroup.  `writer`: this thread also updates the running statistics and stores q.stats (one
+// thread per column, in exactly one workgroup per problem).
+__device__ __forceinline__ void bn_block_stats(const BnBatch& a, const BnProb& q, int j, bool col_ok, int group, int col, bool writer,
+                                               float (*s_p)[64], float& mean, float& rstd) {
+  const int nblk = (a.B + BN_ROWS - 1) / BN_ROWS;
+  float m = 0.f, var = 1.f;
+  if (a.training) {   // (uniform)
+    float tot = 0.f;
+    if (col_ok && group >= 0)
+#pragma unroll 8
+      for (int k = group; k < nblk; k += 4) tot += q.part[((long)k * q.N + j) * 2] * (float)(min((k + 1) * BN_ROWS, a.B) - k * BN_ROWS);
+    if (group >= 0) s_p[group][col] = tot;
+    __syncthreads();
+    m = (((s_p[0][col] + s_p[1][col]) + s_p[2][col]) + s_p[3][col]) / (float)a.B;
+    __syncthreads();
+    float m2 = 0.f;
+    if (col_ok && group >= 0)
+#pragma unroll 8
+      for (int k = group; k < nblk; k += 4) {
+        const float cnt = (float)(min((k + 1) * BN_ROWS, a.B) - k * BN_ROWS), d = q.part[((long)k * q.N + j) * 2] - m;
+        m2 += q.part[((long)k * q.N + j) * 2 + 1] + cnt * d * d;
+      }
+    if (group >= 0) s_p[group][col] = m2;
+    __syncthreads();
+    var = (((s_p[0][col] + s_p[1][col]) + s_p[2][col]) + s_p[3][col]) / (float)a.B;
+    if (writer && col_ok) {
+      q.running_mean[j] = (1.f - a.momentum) * q.running_mean[j] + a.momentum * m;
+      q.running_var[j] = (1.f - a.momentum) * q.running_var[j] + a.momentum * var * ((float)a.B / fmaxf((float)a.B - 1.f, 1.f));
+    }
+  } else if (col_ok) {
+    m = q.running_mean[j];
+    var = q.running_var[j];
+  }
+  mean = m;
+  rstd = rsqrtf(var + a.eps);
+  if (writer && col_ok) { q.stats[2 * j] = mean; q.stats[2 * j + 1] = rstd; }
+}
+
+// FIN: the statistics are finalised here from the partials (all problems N <= 64; no bn_finalize_kernel launch before this one)
+template <bool FIN>
+__device__ __forceinline__ void bn_apply_body(const BnBatch& a, float (*s_p)[64]) {
   const BnProb& q = a.p[blockIdx.y];
   const int rows = (q.img_hi != nullptr && q.img_rows > a.B) ? q.img_rows : a.B;   // image rows beyond the batch are zero filled
   const int b0 = blockIdx.x * BN_ROWS, b1 = min(b0 + BN_ROWS, rows);
   const int NC = pow2_at_least(q.N), RS = 256 / NC;
   const int c = threadIdx.x % NC, slot = threadIdx.x / NC;
-  if (c >= q.N || b0 >= rows) return;
-  const float mean = q.stats[2 * c], sc = q.stats[2 * c + 1] * q.gamma[c], be = q.beta[c];
+  float mean, rstd;
+  if constexpr (FIN) {
+    if (b0 >= rows) return;   // (workgroup-uniform: nobody is left waiting at the barriers below)
+    // NC <= 64, so there are at least four row slots: slots 0..3 are the four partial groups, the others read the result
+    bn_block_stats(a, q, c, c < q.N, slot < 4 ? slot : -1, c, blockIdx.x == 0 && slot == 0, s_p, mean, rstd);
+    if (c >= q.N) return;
+  } else {
+    if (c >= q.N || b0 >= rows) return;
+    mean = q.stats[2 * c]; rstd = q.stats[2 * c + 1];
+  }
+  const float sc = rstd * q.gamma[c], be = q.beta[c];
 #pragma unroll 4
   for (int b = b0 + slot; b < b1; b += RS) {
     // (the load is unconditional -- rows of the image padding re-read the last batch row -- so that the unrolled iterations' loads
@@ -361,6 +422,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnBatch a) {
       if (q.img_lo != nullptr) q.img_lo[(long)b * q.ld_img + c] = lo;
     }
   }
+}
+__global__ __launch_bounds__(256) void bn_apply_kernel(BnBatch a) {
+  bn_apply_body<false>(a, nullptr);
+}
+__global__ __launch_bounds__(256) void bn_apply_fin_kernel(BnBatch a) {
+  __shared__ float s_p[4][64];
+  bn_apply_body<true>(a, s_p);
 }
 
 // (RELU / TRAINING are template parameters: a load in the arm of a run-time branch is waited for inside that arm, and the unrolled row
@@ -421,16 +489,36 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBatch a) {
   }
 }
 
-template <bool RELU, bool TRAINING>
-__device__ __forceinline__ void bn_bwd_apply_body(const BnBatch& a) {
+// FIN: d gamma / d beta are summed here from the per-block partials (all problems N <= 64; no bn_bwd_finalize_kernel launch before this
+// one): the first four row slots take blocks slot, slot + 4, ... in order, the four sums are added in order (bn_bwd_finalize_kernel's
+// association); workgroup 0 of a problem stores the two parameter gradients.
+template <bool RELU, bool TRAINING, bool FIN>
+__device__ __forceinline__ void bn_bwd_apply_body(const BnBatch& a, float (*s_g)[64], float (*s_gx)[64]) {
   const BnProb& q = a.p[blockIdx.y];
   const int b0 = blockIdx.x * BN_ROWS, b1 = min(b0 + BN_ROWS, a.B);
   const float invB = 1.0f / (float)a.B;
   const int NC = pow2_at_least(q.N), RS = 256 / NC;
   const int c = threadIdx.x % NC, slot = threadIdx.x / NC;
-  if (c >= q.N) return;
+  float db, dg;
+  if constexpr (FIN) {
+    if (b0 >= a.B) return;   // (workgroup-uniform)
+    const int nblk = (a.B + BN_ROWS - 1) / BN_ROWS;
+    float sg = 0.f, sgx = 0.f;
+    if (c < q.N && slot < 4)
+#pragma unroll 8
+      for (int k = slot; k < nblk; k += 4) { sg += q.part[((long)k * q.N + c) * 2]; sgx += q.part[((long)k * q.N + c) * 2 + 1]; }
+    if (slot < 4) { s_g[slot][c] = sg; s_gx[slot][c] = sgx; }
+    __syncthreads();
+    if (c >= q.N) return;
+    db = ((s_g[0][c] + s_g[1][c]) + s_g[2][c]) + s_g[3][c];
+    dg = ((s_gx[0][c] + s_gx[1][c]) + s_gx[2][c]) + s_gx[3][c];
+    if (blockIdx.x == 0 && slot == 0) { q.dbeta[c] = db; q.dgamma[c] = dg; }
+  } else {
+    if (c >= q.N) return;
+    db = q.dbeta[c]; dg = q.dgamma[c];  // written by bn_bwd_finalize_kernel
+  }
   const float mean = q.stats[2 * c], inv = q.stats[2 * c + 1], gi = q.gamma[c] * inv;
-  const float msg = q.dbeta[c] * invB, msgx = q.dgamma[c] * invB;  // written by bn_bwd_finalize_kernel
+  const float msg = db * invB, msgx = dg * invB;
 #pragma unroll 4
   for (int b = b0 + slot; b < b1; b += RS) {
     const float g = bn_masked_dy<RELU>(q, b, c);
@@ -445,8 +533,13 @@ __device__ __forceinline__ void bn_bwd_apply_body(const BnBatch& a) {
   }
 }
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBatch a) {
-  if (a.relu) { if (a.training) bn_bwd_apply_body<true, true>(a); else bn_bwd_apply_body<true, false>(a); }
-  else { if (a.training) bn_bwd_apply_body<false, true>(a); else bn_bwd_apply_body<false, false>(a); }
+  if (a.relu) { if (a.training) bn_bwd_apply_body<true, true, false>(a, nullptr, nullptr); else bn_bwd_apply_body<true, false, false>(a, nullptr, nullptr); }
+  else { if (a.training) bn_bwd_apply_body<false, true, false>(a, nullptr, nullptr); else bn_bwd_apply_body<false, false, false>(a, nullptr, nullptr); }
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply_fin_kernel(BnBatch a) {
+  __shared__ float s_g[4][64], s_gx[4][64];
+  if (a.relu) { if (a.training) bn_bwd_apply_body<true, true, true>(a, s_g, s_gx); else bn_bwd_apply_body<true, false, true>(a, s_g, s_gx); }
+  else { if (a.training) bn_bwd_apply_body<false, true, true>(a, s_g, s_gx); else bn_bwd_apply_body<false, false, true>(a, s_g, s_gx); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -505,6 +598,105 @@ __global__ __launch_bounds__(256) void enc_sample_bwd_kernel(SampleBatch a) {
   const float gv = ld_or_zero(q.g_logvar, ig) + 0.5f * sc * gs - 0.5f * gk;
   q.d_post[(long)b * 2 * n + d] = gl;
   q.d_post[(long)b * 2 * n + n + d] = gv;
+}
+
+// ---- encoder heads: BatchNorm (statistics finalised here) + sampling + KL in ONE launch ---------------------------------------------
+// bn.p[2e], bn.p[2e + 1] = the BatchNorm problems of encoder e's mu / logvar heads (N = n each), sb.p[e] its sampling problem whose
+// `post` is where the two BatchNorm outputs land side by side ([B][2n]).  Workgroup = 32 rows of one encoder; lane = column of
+// (loc | logvar), wave w = rows b0 + w, b0 + w + 4, ...  The three kernels this replaces (bn_finalize, bn_apply, enc_sample_fwd) evaluated
+// the same expressions in the same order: the outputs are bit-identical to theirs.
+__global__ __launch_bounds__(256) void enc_heads_bn_sample_fwd_kernel(BnBatch a, SampleBatch sbat) {
+  __shared__ float s_p[4][64];
+  const int e = blockIdx.y;
+  const SampleProb& sq = sbat.p[e];
+  const int n = sq.n;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool col_ok = lane < 2 * n;
+  const int half = (lane >= n && col_ok) ? 1 : 0, j = col_ok ? lane - half * n : 0;
+  const BnProb& q = a.p[2 * e + half];
+  const int b0 = blockIdx.x * BN_ROWS;
+  if (b0 >= a.B) return;   // (workgroup-uniform)
+  float mean, rstd;
+  bn_block_stats(a, q, j, col_ok, wave, lane, blockIdx.x == 0 && wave == 0, s_p, mean, rstd);
+  const float sc_bn = rstd * q.gamma[j], be = q.beta[j];
+  const float* X = q.X + j;
+  float* Y = q.Y + j;
+  constexpr int RPW = BN_ROWS / 4;   // rows per wave
+  float x[RPW], ep[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {   // all loads first (clamped rows: unconditional)
+    const int b = min(b0 + wave + 4 * r, a.B - 1);
+    x[r] = X[(long)b * q.ldx];
+    ep[r] = sq.eps[(long)b * n + min(lane, n - 1)];
+  }
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const int b = b0 + wave + 4 * r;
+    const bool row_ok = b < a.B;   // (wave-uniform)
+    const float y = (x[r] - mean) * sc_bn + be;       // bn_apply_kernel's expression
+    if (row_ok && col_ok) Y[(long)b * q.ldy] = y;
+    // sampling (enc_sample_fwd_kernel): lane d < n holds loc, lane n + d logvar
+    const float lv = __shfl(y, min(lane + n, 63), 64);
+    const bool ok = row_ok && lane < n;
+    float sc = 0.f, z = -INFINITY, klt = 0.f;
+    if (ok) {
+      sc = expf(0.5f * lv);
+      z = y + sc * ep[r];
+      klt = 0.5f * (sc * sc + y * y - 1.0f - lv);
+    }
+    const float mx = max32(z);
+    const float ex = ok ? expf(z - mx) : 0.f;
+    const float sum = sum32(ex), kl = sum32(klt);
+    if (ok) {
+      const long i = (long)b * n + lane;
+      sq.scale[i] = sc; sq.logz[i] = z; sq.theta[i] = ex / sum;
+    }
+    if (row_ok && lane == 0) sq.kl[b] = kl;
+  }
+}
+
+// backward, first launch: d_post from the upstream gradients (enc_sample_bwd_kernel's expressions) and, from the same registers, the
+// per-block partial sums of BatchNorm's backward (sum g, sum g xhat per column).  Same workgroup shape as the forward kernel; the
+// four waves' partials are added in wave order.
+__global__ __launch_bounds__(256) void enc_heads_bwd_reduce_kernel(BnBatch a, SampleBatch sbat) {
+  __shared__ float s_g[4][64], s_gx[4][64];
+  const int e = blockIdx.y;
+  const SampleProb& sq = sbat.p[e];
+  const int n = sq.n;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool col_ok = lane < 2 * n;
+  const int half = (lane >= n && col_ok) ? 1 : 0, j = col_ok ? lane - half * n : 0;
+  const BnProb& q = a.p[2 * e + half];
+  const int b0 = blockIdx.x * BN_ROWS;
+  if (b0 >= a.B) return;
+  const float mean = q.stats[2 * j], inv = q.stats[2 * j + 1];
+  constexpr int RPW = BN_ROWS / 4;
+  float sg = 0.f, sgx = 0.f;
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const int b = b0 + wave + 4 * r;
+    const bool row_ok = b < a.B;
+    const int bb = min(b, a.B - 1);
+    const long i = (long)bb * n + j;
+    const float gk = ld_or_zero(sq.g_kl, bb);
+    const float loc = sq.post[(long)bb * 2 * n + j], sc = sq.scale[i];
+    const float gz = ld_or_zero(sq.g_logz, i);
+    const long ig = sq.g_ld ? (long)bb * sq.g_ld + j : i;
+    const float gl = ld_or_zero(sq.g_loc, ig) + gz + gk * loc;
+    const float gs = ld_or_zero(sq.g_scale, i) + gz * sq.eps[i] + gk * sc;
+    const float gv = ld_or_zero(sq.g_logvar, ig) + 0.5f * sc * gs - 0.5f * gk;
+    const float g = (row_ok && col_ok) ? (half ? gv : gl) : 0.f;
+    const float xv = q.X[(long)bb * q.ldx + j];
+    if (row_ok && col_ok) sq.d_post[(long)b * 2 * n + lane] = g;
+    sg += g;
+    sgx += g * (xv - mean) * inv;
+  }
+  s_g[wave][lane] = sg; s_gx[wave][lane] = sgx;
+  __syncthreads();
+  if (wave == 0 && col_ok) {
+    q.part[((long)blockIdx.x * q.N + j) * 2] = ((s_g[0][lane] + s_g[1][lane]) + s_g[2][lane]) + s_g[3][lane];
+    q.part[((long)blockIdx.x * q.N + j) * 2 + 1] = ((s_gx[0][lane] + s_gx[1][lane]) + s_gx[2][lane]) + s_gx[3][lane];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -654,7 +846,16 @@ __global__ __launch_bounds__(256) void poe_fuse_fwd_kernel(PoeArgs a) {
   float z = -INFINITY, klt = 0.f, jl = 0.f, jv = 0.f, sc = 0.f;
   const long i = (long)b * n + d;
   if (ok) {
-    const int m = a.mode[g][b], pr = a.partner[g][b];
+    int m, pr;
+    if (a.lab[0] != nullptr) {   // (uniform) label PoE: partner / mode from the other group's tables, as poe_lookup_kernel derives them
+      const int L = min(max((int)a.lab[g][b], 0), POE_LMAX - 1), k = a.rank[g][b];
+      const int co = a.tables[(o * 2 + 0) * POE_LMAX + L], so = a.tables[(o * 2 + 1) * POE_LMAX + L];
+      m = (k < co) ? 0 : (co > 0 ? 1 : 2);
+      pr = (m == 0) ? a.order[o][so + k] : -1;
+      if (d == 0) { const_cast<int*>(a.mode[g])[b] = m; const_cast<int*>(a.partner[g])[b] = pr; }   // kept for the backward pass
+    } else {
+      m = a.mode[g][b]; pr = a.partner[g][b];
+    }
     const float* own = a.stats[g] + (long)b * a.ld[g];           // (loc | logvar) rows of the shared encoder
     const float* self = a.expert[g] ? a.expert[g] + (long)b * a.ld_expert[g] : own;
     const float* oth = a.expert[o] ? a.expert[o] + (long)(pr < 0 ? 0 : pr) * a.ld_expert[o] : a.stats[o] + (long)(pr < 0 ? 0 : pr) * a.ld[o];
@@ -1082,14 +1283,27 @@ __global__ __launch_bounds__(256) void fold_red_finalize_kernel(FoldBatch a) {
   if (ty == 0 && i < nred) q.red_part[(long)nblk * nred + i] = ((s_p[0][tx] + s_p[1][tx]) + s_p[2][tx]) + s_p[3][tx];
 }
 
-// d z[b][k] (+)= d zbar[k] / B + (1/B) sum_l (dC + dC^T)[k][l] (z[b][l] - zbar[l]);   red = row nblk of red_part
+// d z[b][k] (+)= d zbar[k] / B + (1/B) sum_l (dC + dC^T)[k][l] (z[b][l] - zbar[l]), with (d zbar | dC) = the sum over the gene blocks of
+// bn_fold_bwd_kernel's partials, taken HERE by every workgroup (block order within four interleaved groups, groups added in order:
+// fold_red_finalize_kernel's association -- that launch is no longer needed in front of this one; workgroup 0 still leaves the sum in
+// row nblk of red_part).  With q.out_priv set the finished d zcat columns of this problem go straight to d private_log_z / d poe_log_z
+// (the latent-slicing backward, zsplit_bwd_kernel) instead of back into q.dz.
 __global__ __launch_bounds__(256) void zstats_bwd_kernel(FoldBatch a) {
   const FoldProb& q = a.p[blockIdx.y];
   __shared__ float s_zbar[FOLD_KMAX], s_dz[FOLD_KMAX], s_S[FOLD_KMAX * FOLD_KMAX], s_red[FOLD_KMAX + FOLD_KMAX * FOLD_KMAX];
   const int K = q.K, nred = K + K * K;
   const int nblk = (q.G + 255) / 256;
   const float invB = 1.0f / (float)a.B;
-  for (int i = threadIdx.x; i < nred; i += 256) s_red[i] = q.red_part[(long)nblk * nred + i];
+  for (int i = threadIdx.x; i < nred; i += 256) {
+    float g4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < nblk; k0 += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const float v = q.red_part[(long)min(k0 + u, nblk - 1) * nred + i]; g4[u] += (k0 + u < nblk) ? v : 0.f; }
+    }
+    const float r = ((g4[0] + g4[1]) + g4[2]) + g4[3];
+    s_red[i] = r;
+    if (blockIdx.x == 0) q.red_part[(long)nblk * nred + i] = r;
+  }
   for (int i = threadIdx.x; i < K; i += 256) s_zbar[i] = q.zsum[i] * invB;
   __syncthreads();
   for (int i = threadIdx.x; i < K; i += 256) s_dz[i] = s_red[i] * invB;
@@ -1102,7 +1316,15 @@ __global__ __launch_bounds__(256) void zstats_bwd_kernel(FoldBatch a) {
   for (int k = part; k < K; k += 4) {
     float v = s_dz[k];
     for (int l = 0; l < K; ++l) v += s_S[k * K + l] * (zrow[l] - s_zbar[l]);
-    q.dz[(long)b * q.lddz + k] += v;
+    const float out = q.dz[(long)b * q.lddz + k] + v;
+    if (q.out_priv != nullptr) {
+      const int c = q.zcol + k;                                   // column of zcat = [z_private | z_shared]
+      const int zc = (c >= q.n_p) ? c - q.n_p : c + q.n_s;        // the column of Z = cat(private_log_z, poe_log_z) it came from
+      if (zc < q.n_p) q.out_priv[(long)b * q.n_p + zc] = out;
+      else q.out_poe[(long)b * q.n_s + zc - q.n_p] = out;
+    } else {
+      q.dz[(long)b * q.lddz + k] = out;
+    }
   }
 }
 

@@ -76,6 +76,13 @@ class _DecoderBwd:
         if self.heads_dma:
             mt, kt = -(-G // 128), Bp // 64   # 128-gene workgroup tiles, two workgroups per CU
             self.csp_n = max(1, min(512 // mt if mt <= 512 else 1, max(kt // 4, 1)))
+        # bf16 mode: the regressor weight gradients come out of the softmax-fix pass itself (spv_dec_heads_bwd), one partial slab per
+        # 128-cell workgroup row
+        self.fused_heads = bool(_ops.FUSED_HEADS and not _ops.DZ_ONLY and self.fused_dz and self.heads_dma and Bp % DEC_CELLS_PER_WG == 0)
+        if self.fused_heads:
+            self.csp_n = Bp // DEC_CELLS_PER_WG
+            self.dwp_part = wsg.get("dec_dWp", (self.csp_n, G, DEC_KP), torch.float32)
+            self.dws_part = wsg.get("dec_dWs", (self.csp_n, G, DEC_KS), torch.float32)
         # bf16 mode: the two 320-column GEMMs run the LDS-DMA 128 x 320 kernels, which want their own split counts
         # (d A_m of the two groups run side by side on the group streams; d W_m one after the other on the side stream)
         self.ksp_m = self._splits(False, B, G, self.ksp_m, 128 if (pair and _ops.DEC_PAIR_SPLITS) else 256)
@@ -89,6 +96,10 @@ class _DecoderBwd:
         return t[:self.Bp], t[self.Bp:]
 
     def softmax(self):
+        if self.fused_heads:
+            _abi.call("spv_dec_heads_bwd", C.byref(self.P), ptr(self.S["Tp"]), ptr(self.S["Ts"]), ptr(self.dz_part), ptr(self.dwp_part),
+                      ptr(self.dws_part), stream_ptr())
+            return
         _abi.call("spv_dec_softmax_bwd", C.byref(self.P), ptr(self.S["Tp"]), ptr(self.S["Ts"]), ptr(self.dz_part), stream_ptr())
 
     def dz_only(self):
@@ -125,6 +136,8 @@ class _DecoderBwd:
                            self.ksp_m, self.wsg, "dec_dAm", a_tiles=self.T)
 
     def gemm_bc(self):
+        if self.fused_heads:   # already produced by softmax() (spv_dec_heads_bwd): hand the partial slabs to the reduction
+            return self.dwp_part, self.dws_part
         (Aps_hi, Aps_lo), (tP_hi, tP_lo), (tS_hi, tS_lo) = self.S["Aps"], self._operand("tP"), self._operand("tS")
         if self.heads_dma:   # bf16 mode: both heads in one LDS-DMA streaming pass (csrc/spv_dec_gemm.h)
             b = self.wsg.get("dec_dWp", (self.csp_n, self.G, DEC_KP), torch.float32)
@@ -515,6 +528,7 @@ class DecoderFused(torch.autograd.Function):
         _abi.call("spv_linear_dgrad", C.byref(bd), stream_ptr())
         # ---- BatchNorm-fold backward (+ the z statistics it used) ------------------------------------
         fb = ctx.fb
+        d_priv, d_poe = [new(B, n_p) for _ in range(NG)], [new(B, n_s) for _ in range(NG)]
         dWraw = [[pg[g][0][0], pg[g][3][0]] for g in range(NG)]
         dgam = [[pg[g][1][0], pg[g][4][0]] for g in range(NG)]
         dbet = [[pg[g][2][0], pg[g][5][0]] for g in range(NG)]
@@ -525,6 +539,8 @@ class DecoderFused(torch.autograd.Function):
                 q.dWeff, q.ld_dw, q.dW, q.dgamma, q.dbeta = ptr(dweff), ld, ptr(dWraw[g][k]), ptr(dgam[g][k]), ptr(dbet[g][k])
                 q.red_part = ptr(ws[g].get(f"fold_red_{k}", (-(-Gs[g] // 256) + 1, n + n * n), torch.float32))
                 q.dz, q.lddz = _fptr(d_zcat[g], zoff), nt
+                if training:   # the latent-slicing backward rides in the same kernel (spv_fold_prob.out_priv)
+                    q.zcol, q.out_priv, q.out_poe, q.n_p, q.n_s = zoff, ptr(d_priv[g]), ptr(d_poe[g]), n_p, n_s
                 i += 1
         if da_first:   # the rate heads' latent gradient (softmax fix on the side stream) joins d_zcat here
             cur.wait_event(sm_done)
@@ -536,13 +552,13 @@ class DecoderFused(torch.autograd.Function):
             ev.record(cur)
             issue_wm(ev)
         _abi.call("spv_bn_fold_bwd", C.byref(fb), stream_ptr())
-        # ---- latent slicing backward ------------------------------------------------------------------
-        d_priv, d_poe = [new(B, n_p) for _ in range(NG)], [new(B, n_s) for _ in range(NG)]
-        za = SpvZsplitArgs()
-        za.B, za.n_p, za.n_s, za.ngroups = B, n_p, n_s, NG
-        for g in range(NG):
-            za.d_zcat[g], za.d_priv[g], za.d_poe[g] = ptr(d_zcat[g]), ptr(d_priv[g]), ptr(d_poe[g])
-        _abi.call("spv_zsplit_bwd", C.byref(za), stream_ptr())
+        # ---- latent slicing backward (training: already done by the z-statistics kernel of spv_bn_fold_bwd) ---------------------
+        if not training:
+            za = SpvZsplitArgs()
+            za.B, za.n_p, za.n_s, za.ngroups = B, n_p, n_s, NG
+            for g in range(NG):
+                za.d_zcat[g], za.d_priv[g], za.d_poe[g] = ptr(d_zcat[g]), ptr(d_priv[g]), ptr(d_poe[g])
+            _abi.call("spv_zsplit_bwd", C.byref(za), stream_ptr())
         grads = []
         for g in range(NG):
             grads += [d_priv[g], d_poe[g]]

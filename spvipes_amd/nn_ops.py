@@ -30,9 +30,9 @@ def _lin_batch(B: int, relu: bool = False, drop_p: float = 0.0, seed=0, accumula
 
 
 def _add_lin(b: SpvLinearBatch, *, N: int, K: int, W=None, X=None, ldx=0, bias=None, Y=None, ldy=0, dY=None, lddy=0, dX=None, lddx=0,
-             dW=None, db=None, keep=None) -> None:
+             dW=None, db=None, keep=None, W2=None, n_w2=0) -> None:
     q = b.p[b.nprob]
-    q.X, q.ldx, q.W, q.bias, q.Y, q.ldy, q.keep = X, ldx, W, bias, Y, ldy, keep
+    q.X, q.ldx, q.W, q.bias, q.Y, q.ldy, q.keep, q.W2, q.n_w2 = X, ldx, W, bias, Y, ldy, keep, W2, n_w2
     q.dY, q.lddy, q.dX, q.lddx, q.dW, q.db, q.N, q.K = dY, lddy, dX, lddx, dW, db, N, K
     b.nprob += 1
 
@@ -86,7 +86,8 @@ N_ENC_PARAMS = 10
 
 
 class EncoderTails(torch.autograd.Function):
-    """All encoders' tails in 4 forward / 7 backward launches.
+    """All encoders' tails in 4 forward / 8 backward launches (fc2, heads, BatchNorm statistics, [finalise + normalise + sample + KL];
+    backward: [sampling + BatchNorm partial sums], [finalise + apply], heads wgrad + reduce, 2 x heads dgrad, fc2 wgrad + reduce, fc2 dgrad).
 
     inputs : h1 per group ([B, 2H]: private | shared halves), then per encoder its 10 parameters
     outputs: per encoder (loc, logvar, scale, log_z, theta, kl)  -- theta is not differentiable here
@@ -142,8 +143,8 @@ class EncoderTails(torch.autograd.Function):
                 q.gamma, q.beta, q.running_mean, q.running_var = ptr(g), ptr(be), ptr(mod.running_mean), ptr(mod.running_var)
                 q.stats, q.part, q.N = ptr(st[half]), ptr(part), s.n
                 bn.nprob += 1
-        _abi.call("spv_bn_fwd", C.byref(bn), stream_ptr())
-        # 4. scale, reparameterised draw, softmax, KL
+        # 4. scale, reparameterised draw, softmax, KL -- in the same launch as the BatchNorm apply (spv_enc_heads_fwd: batch statistics,
+        #    then ONE kernel that finalises them, normalises, samples and forms the KL)
         scale = [new(B, s.n) for s in specs]
         logz = [new(B, s.n) for s in specs]
         theta = [new(B, s.n) for s in specs]
@@ -153,7 +154,7 @@ class EncoderTails(torch.autograd.Function):
         for i, s in enumerate(specs):
             q = sb.p[i]
             q.post, q.n, q.eps, q.scale, q.logz, q.theta, q.kl = ptr(post[i]), s.n, ptr(eps[i].contiguous()), ptr(scale[i]), ptr(logz[i]), ptr(theta[i]), ptr(kl[i])
-        _abi.call("spv_enc_sample_fwd", C.byref(sb), stream_ptr())
+        _abi.call("spv_enc_heads_fwd", C.byref(bn), C.byref(sb), stream_ptr())
         ctx.specs, ctx.training, ctx.dp, ctx.seed, ctx.ws, ctx.n_groups, ctx.B, ctx.H = specs, training, dp, seed, ws, n_groups, B, H
         ctx.eps = [e.contiguous() for e in eps]
         ctx.save_for_backward(*tensors, *h2, *pre, *post, *stats, *scale)
@@ -195,7 +196,9 @@ class EncoderTails(torch.autograd.Function):
             q = sb.p[i]
             q.post, q.n, q.eps, q.scale = ptr(post[i]), s.n, ptr(ctx.eps[i]), ptr(scale[i])
             q.g_loc, q.g_logvar, q.g_scale, q.g_logz, q.g_kl, q.d_post, q.g_ld = ptr(gl), ptr(gv), ptr(gs), ptr(gz), ptr(gk), ptr(d_post[i]), g_ld
-        _abi.call("spv_enc_sample_bwd", C.byref(sb), stream_ptr())
+        fused = bool(ctx.training)   # spv_enc_heads_bwd: sampling backward + BatchNorm partial sums in one kernel, finalise + apply in a second
+        if not fused:
+            _abi.call("spv_enc_sample_bwd", C.byref(sb), stream_ptr())
         # 2. BatchNorm backward -> d_pre, d gamma / beta
         d_pre = [new(B, 2 * s.n) for s in specs]
         # parameter gradients: (write target, autograd return value) per parameter of each encoder
@@ -215,7 +218,10 @@ class EncoderTails(torch.autograd.Function):
                 q.dgamma, q.dbeta = ptr(d_gb[i][2 * half]), ptr(d_gb[i][2 * half + 1])
                 bn.nprob += 1
                 k += 1
-        _abi.call("spv_bn_bwd", C.byref(bn), stream_ptr())
+        if fused:
+            _abi.call("spv_enc_heads_bwd", C.byref(bn), C.byref(sb), stream_ptr())
+        else:
+            _abi.call("spv_bn_bwd", C.byref(bn), stream_ptr())
         # 3. head weight gradients
         dWmu, dbmu, dWlv, dblv = ([pg[i][2][0] for i in range(E)], [pg[i][3][0] for i in range(E)], [pg[i][4][0] for i in range(E)], [pg[i][5][0] for i in range(E)])
         b = _lin_batch(B)
@@ -224,12 +230,12 @@ class EncoderTails(torch.autograd.Function):
             _add_lin(b, N=s.n, K=H, W=ptr(par[i][4]), X=ptr(h2[i]), ldx=H, dY=_fptr(d_pre[i], s.n), lddy=2 * s.n, dW=ptr(dWlv[i]), db=ptr(dblv[i]))
         _wgrad(b, ws if not isinstance(ws, (list, tuple)) else ws[0])
         # 4. d h2 = d_pre_mu Wmu + d_pre_lv Wlv
+        #    one launch: the contraction runs over the 2n columns of d_pre, rows 0..n-1 of the weight from Wmu, rows n.. from Wlv
         dh2 = [new(B, H) for _ in specs]
-        for half, acc in ((0, False), (1, True)):
-            b = _lin_batch(B, accumulate=acc)
-            for i, s in enumerate(specs):
-                _add_lin(b, N=s.n, K=H, W=ptr(par[i][2 + 2 * half]), dY=_fptr(d_pre[i], half * s.n), lddy=2 * s.n, dX=ptr(dh2[i]), lddx=H)
-            _abi.call("spv_linear_dgrad", C.byref(b), stream_ptr())
+        b = _lin_batch(B)
+        for i, s in enumerate(specs):
+            _add_lin(b, N=2 * s.n, K=H, W=ptr(par[i][2]), W2=ptr(par[i][4]), n_w2=s.n, dY=ptr(d_pre[i]), lddy=2 * s.n, dX=ptr(dh2[i]), lddx=H)
+        _abi.call("spv_linear_dgrad", C.byref(b), stream_ptr())
         # 5./6. fc2 backward (relu + dropout mask recovered from the saved h2 > 0)
         dW2, db2 = [pg[i][0][0] for i in range(E)], [pg[i][1][0] for i in range(E)]
         # every column block of h1 that an encoder reads gets written by the dgrad below; zero only what none covers
@@ -266,8 +272,9 @@ def _loc_logvar_block(loc: torch.Tensor, logvar: torch.Tensor):
 
 
 def label_partners(labels: Sequence[torch.Tensor], ws):
-    """(partner, mode) of every cell of both minibatches from the label codes alone (spv_poe_partner): no dependence on
-    the encoders, so ``module.inference`` launches it on a side stream while the fc1 GEMMs run."""
+    """Ranking of both minibatches' cells within their labels (spv_poe_rank: no dependence on the encoders, so ``module.inference``
+    may launch it beside the fc1 GEMMs) and the buffers the fusion kernel then fills / reads: returns
+    (partner, mode, lab, order, rank, tables); partner / mode are written by spv_poe_fuse_fwd, which does the per-cell lookup itself."""
     dev = labels[0].device
     lab = [l.flatten().contiguous().float() for l in labels]
     Bs = [lab[0].numel(), lab[1].numel()]
@@ -278,13 +285,13 @@ def label_partners(labels: Sequence[torch.Tensor], ws):
     mode = [torch.empty(Bs[g], dtype=torch.int32, device=dev) for g in range(2)]
     err = ws.get("poe_err", (1,), torch.int32, zero=True)
     tables = ws.get("poe_tables", (2, 2, 1024), torch.int32)
-    _abi.call("spv_poe_partner", ptr(lab[0]), ptr(lab[1]), Bs[0], Bs[1], ptr(order[0]), ptr(order[1]), ptr(rank[0]), ptr(rank[1]),
-              ptr(tables), ptr(partner[0]), ptr(mode[0]), ptr(partner[1]), ptr(mode[1]), ptr(err), stream_ptr())
-    return partner, mode, lab
+    _abi.call("spv_poe_rank", ptr(lab[0]), ptr(lab[1]), Bs[0], Bs[1], ptr(order[0]), ptr(order[1]), ptr(rank[0]), ptr(rank[1]),
+              ptr(tables), ptr(err), stream_ptr())
+    return partner, mode, lab, order, rank, tables
 
 
 class PoELabel(torch.autograd.Function):
-    """Both groups' label-based PoE in 2 forward launches (pairing + fusion/draw/KL) and 1 backward launch.
+    """Both groups' label-based PoE in 2 forward launches (ranking; lookup + fusion / draw / KL) and 2 backward launches (fill, scatter).
     inputs : loc0, logvar0, loc1, logvar1 (shared-encoder statistics); outputs per group
     (loc*, logvar*, scale*, log_z, theta, kl) -- theta not differentiable.  ``pre``: the result of ``label_partners`` when
     the caller has already launched the pairing."""
@@ -296,7 +303,7 @@ class PoELabel(torch.autograd.Function):
         dev = loc0.device
         n = loc0.shape[1]
         Bs = [loc0.shape[0], loc1.shape[0]]
-        partner, mode, _lab = pre if pre is not None else label_partners(labels, ws)
+        partner, mode, lab, order, rank, tables = pre if pre is not None else label_partners(labels, ws)
         blocks = [_loc_logvar_block(loc0, logvar0), _loc_logvar_block(loc1, logvar1)]
         new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         out = {k: [new(Bs[g], n) for g in range(2)] for k in ("loc", "logvar", "scale", "logz", "theta")}
@@ -308,6 +315,8 @@ class PoELabel(torch.autograd.Function):
             a.stats[g], a.ld[g], a.partner[g], a.mode[g], a.eps[g], a.B[g] = blocks[g][1], blocks[g][2], ptr(partner[g]), ptr(mode[g]), ptr(eps[g]), Bs[g]
             a.loc[g], a.logvar[g], a.scale[g], a.logz[g], a.theta[g] = (ptr(out[k][g]) for k in ("loc", "logvar", "scale", "logz", "theta"))
             a.kl[g] = ptr(kl[g])
+            a.lab[g], a.order[g], a.rank[g] = ptr(lab[g]), ptr(order[g]), ptr(rank[g])   # the fusion kernel looks the partners up itself
+        a.tables = ptr(tables)
         _abi.call("spv_poe_fuse_fwd", C.byref(a), stream_ptr())
         ctx.blocks, ctx.eps, ctx.partner, ctx.mode, ctx.n, ctx.Bs = blocks, eps, partner, mode, n, Bs
         ctx.save_for_backward(out["loc"][0], out["loc"][1], out["scale"][0], out["scale"][1])

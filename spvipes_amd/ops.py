@@ -141,6 +141,9 @@ LABEL_PRE = os.environ.get("SPV_LABEL_PRE", "0") != "0"  # label pairing on a si
 FC1_PAIR_SPLITS = os.environ.get("SPV_FC1_PAIR_SPLITS", "1") != "0"  # grouped fc1 forward: K splits sized for the pair's shared grid
 DEC_PAIR_SPLITS = os.environ.get("SPV_DEC_PAIR_SPLITS", "1") != "0"  # d A_m GEMMs of the two groups: K splits sized so that the pair shares one round
 HEADS_DMA = os.environ.get("SPV_HEADS_DMA", "1") != "0"  # both regressor weight gradients in one LDS-DMA pass (spv_dec_heads_wgrad)
+# bf16 mode: the softmax fix, the latent gradient AND the regressor weight gradients from ONE read-only pass over t_P / t_S
+# (spv_dec_heads_bwd): no write-back of the corrected arrays, no second pass over them
+FUSED_HEADS = os.environ.get("SPV_FUSED_HEADS", "1") != "0"
 # workgroups the softmax-statistics / softmax-fix kernels are split into (cell blocks x gene splits).  512 = ONE round of two workgroups per CU, and half the
 # per-split partials (statistics, latent gradient) to write and re-read.  Same-box A/B 1024 / 768 / 512 / 384 / 256 at C2: 1.440 / 1.438 / 1.412 / 1.417 / 1.426 ms;
 # C3 2.39 -> 2.36, C4 3.90 -> 3.88, C5 8.29 -> 8.18, C1 unchanged

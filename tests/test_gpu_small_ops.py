@@ -134,8 +134,28 @@ def test_label_pairing_matches_the_reference_rule(B0, B1, nlab):
     rng = np.random.default_rng(B0 + B1 + nlab)
     labs = [rng.integers(0, nlab, size=B0), rng.integers(0, nlab + 2, size=B1)]   # group 1 also has labels group 0 never sees
     t = [torch.tensor(l, dtype=torch.float32, device=dev).unsqueeze(1) for l in labs]
-    partner, mode, _ = label_partners(t, ops.Workspace(dev))
+    # (a) the stand-alone pairing entry point (rank + lookup kernels)
+    from spvipes_amd import _abi
+    from spvipes_amd._abi import ptr, stream_ptr
+    lab = [x.flatten().contiguous() for x in t]
+    i32 = lambda k: torch.empty(k, dtype=torch.int32, device=dev)
+    order, rank, partner_a, mode_a = [i32(B0), i32(B1)], [i32(B0), i32(B1)], [i32(B0), i32(B1)], [i32(B0), i32(B1)]
+    tables, err = torch.empty(2, 2, 1024, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+    _abi.call("spv_poe_partner", ptr(lab[0]), ptr(lab[1]), B0, B1, ptr(order[0]), ptr(order[1]), ptr(rank[0]), ptr(rank[1]), ptr(tables),
+              ptr(partner_a[0]), ptr(mode_a[0]), ptr(partner_a[1]), ptr(mode_a[1]), ptr(err), stream_ptr())
+    # (b) the shipped path: spv_poe_rank, then the lookup INSIDE the fusion kernel (PoELabel), which stores partner / mode for its backward
+    from spvipes_amd.nn_ops import PoELabel
+    n = 5
+    gen = torch.Generator(device=dev).manual_seed(1)
+    mk = lambda B: torch.randn(B, n, generator=gen, device=dev)
+    ws = ops.Workspace(dev)
+    pre = label_partners(t, ws)
+    PoELabel.apply([t[0], t[1]], [mk(B0), mk(B1)], ws, pre, mk(B0), mk(B0), mk(B1), mk(B1))
+    partner, mode = pre[0], pre[1]
     torch.cuda.synchronize()
+    assert int(err) == 0
+    for g in (0, 1):
+        assert torch.equal(partner[g], partner_a[g]) and torch.equal(mode[g], mode_a[g])
     for g in (0, 1):
         o = 1 - g
         where = {}
