@@ -157,6 +157,13 @@ __device__ __forceinline__ s8v frag_kmajor(const bf16_t* img, int pitch, int col
   return out;
 }
 
+// Workgroup barrier that orders LDS traffic only: wait for this wave's LDS operations, then s_barrier.  __syncthreads() is a workgroup
+// FENCE plus the barrier, and the fence also drains every global load / store the wave has in flight (s_waitcnt vmcnt(0)): a kernel
+// that keeps tiles of prefetch in flight across the barrier loses them at every barrier and runs at memory LATENCY.  Use this one where
+// the only data handed between the waves goes through LDS.  (The "memory" clobber keeps the compiler from moving memory operations
+// across it.)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---- cross-lane helpers ------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

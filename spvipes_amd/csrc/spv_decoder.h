@@ -786,10 +786,39 @@ __global__ __launch_bounds__(256, 2) void dec_softmax_bwd_kernel(DecParams p, co
     // tile the four waves cannot drift apart, and a single tile of prefetch left the pass latency bound at 2.1 TB/s)
     raw_t rp0[4], rs0[4], rp1[4], rs1[4];
     load_ps_w(p, gbeg, lane, wA);
+    // HEADS (bf16 words): 16-byte loads -- a lane pair (2i, 2i + 1) fetches the pair's 16 bytes of word group qq = 2 pr (even lane) and
+    // 2 pr + 1 (odd lane) and the halves are swapped between the two lanes when the tile is decoded (`unswap`): half the load
+    // instructions, each 1 KiB per wave instead of 512 B (8-byte accesses run at 0.54-0.70 of the 16-byte rate: MI355X_MICROARCH.md)
     auto request = [&](int t, raw_t (&rp)[4], raw_t (&rs)[4]) {
       const long tb = (trow + ((gbeg + 32 * min(t, ntile - 1)) >> 5)) * 1024 + lane * 4;
+      if constexpr (HEADS) {
+        const long tb2 = tb - (lane & 1) * 4 + (lane & 1) * 256;   // the pair's first word, in group 2 pr + (lane & 1)
 #pragma unroll
-      for (int qq = 0; qq < 4; ++qq) { rp[qq] = load4_raw<GT>(p.tP, tb + 256 * qq, plane); rs[qq] = load4_raw<GT>(p.tS, tb + 256 * qq, plane); }
+        for (int pr = 0; pr < 2; ++pr) {
+          const u4v a = *reinterpret_cast<const u4v*>(reinterpret_cast<const bf16_t*>(p.tP) + tb2 + 512 * pr);
+          const u4v b = *reinterpret_cast<const u4v*>(reinterpret_cast<const bf16_t*>(p.tS) + tb2 + 512 * pr);
+          rp[2 * pr] = u2v{a[0], a[1]}; rp[2 * pr + 1] = u2v{a[2], a[3]};   // (still swapped: see unswap)
+          rs[2 * pr] = u2v{b[0], b[1]}; rs[2 * pr + 1] = u2v{b[2], b[3]};
+        }
+      } else {
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) { rp[qq] = load4_raw<GT>(p.tP, tb + 256 * qq, plane); rs[qq] = load4_raw<GT>(p.tS, tb + 256 * qq, plane); }
+      }
+    };
+    // after a HEADS request: r[2 pr] = the pair's EVEN-lane words and r[2 pr + 1] its ODD-lane words, of group 2 pr on even lanes and of
+    // group 2 pr + 1 on odd lanes; each lane keeps its own words of its group and trades the other half with its neighbour
+    auto unswap = [&](raw_t (&r4)[4]) {
+      if constexpr (HEADS) {
+        const bool odd = lane & 1;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          const u2v lo = r4[2 * pr], hi = r4[2 * pr + 1];
+          const u2v send = odd ? lo : hi;   // the neighbour's words
+          const u2v recv = u2v{(unsigned)__shfl_xor((int)send[0], 1, 64), (unsigned)__shfl_xor((int)send[1], 1, 64)};
+          r4[2 * pr] = odd ? recv : lo;       // own words of group 2 pr
+          r4[2 * pr + 1] = odd ? hi : recv;   // own words of group 2 pr + 1
+        }
+      }
     };
     request(0, rp0, rs0);
     if constexpr (HEADS) request(1, rp1, rs1);
@@ -797,7 +826,7 @@ __global__ __launch_bounds__(256, 2) void dec_softmax_bwd_kernel(DecParams p, co
       const int g0 = gbeg + 32 * t, gn = gbeg + 32 * min(t + 1, ntile - 1);
       if constexpr (FUSE) {
         if (t % (SMB_SUB / 32) == 0) {  // (re)stage W'^T for the next SMB_SUB genes: s_wT[k][gene - g0]
-          __syncthreads();
+          lds_barrier();
           const int ng = min(SMB_SUB, gend - g0);
           for (int i = threadIdx.x; i < ng * (DEC_KPS / 8); i += 256) {
             const int gl = i / (DEC_KPS / 8), c8 = (i % (DEC_KPS / 8)) * 8;
@@ -805,7 +834,7 @@ __global__ __launch_bounds__(256, 2) void dec_softmax_bwd_kernel(DecParams p, co
 #pragma unroll
             for (int j = 0; j < 8; ++j) s_wT[(c8 + j) * SMB_PITCH + gl] = (bf16_t)w[j];
           }
-          __syncthreads();
+          lds_barrier();
         }
       }
       f16v yp, ys;
@@ -821,6 +850,8 @@ __global__ __launch_bounds__(256, 2) void dec_softmax_bwd_kernel(DecParams p, co
       // corrected values as packed bf16 pairs straight away (register [qq] = genes 8 qq + 4 h + {0,1 | 2,3}): what the MFMA operands
       // and the parked tiles hold, and half the registers of 2 x 16 floats
       unsigned cpk[8], csk[8];
+      unswap(rpA);
+      unswap(rsA);
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
         const int g = g0 + 8 * qq + 4 * h;
@@ -871,7 +902,7 @@ __global__ __launch_bounds__(256, 2) void dec_softmax_bwd_kernel(DecParams p, co
       if constexpr (HEADS) {
         // all four waves' tiles of this gene tile are in LDS after the barrier; the buffer of parity t & 1 is next written two tiles
         // later, behind the NEXT barrier, by which time its readers (before that barrier in program order) are done: one barrier per tile
-        __syncthreads();
+        lds_barrier();
         if ((wave >> 1) == (t & 1)) {   // (wave-uniform) this tile's two working waves
           const bf16_t* img = s_tile + ((t & 1) * 2 + head_role) * SMB_TILE_ELEMS;
           f16v accW;
