@@ -174,6 +174,44 @@ def _pmc_fields(args):
     return traffic, "profiles/" + os.path.basename(files[-1]) + " (raw FETCH_SIZE + WRITE_SIZE, KiB -> bytes)", busy
 
 
+def _pmc_decoder_chain(args):
+    """[B, G] traffic of the whole decoder + likelihood chain of ONE group-step (likelihood, one-pass decoder backward, d A_m and d W_m GEMMs,
+    logits GEMM, softmax statistics) from the newest committed --pmc passes, against SURVEY 8d's algorithmic bytes for that chain:
+    2 B G s_x (x read by the likelihood forward and backward) + 40 bytes per decoder parameter.  FETCH_SIZE is doubled for the kernels
+    whose reads are 16 B / lane (LDS-DMA GEMMs, the one-pass backward): MI355X_MICROARCH.md, HBM section; the likelihood kernel's
+    8 B / lane reads are outside the calibrated widths and stay raw.  None unless the passes were taken on this run's workload."""
+    import re
+    latest = os.path.join(ROOT, "profiles", "LATEST")
+    if not os.path.exists(latest):
+        return None
+    tag = open(latest).read().strip()
+    mine = f"{args.config} {args.precision} {args.count_dtype} B{args.batch_size} G{args.genes}"
+    kernels = [("dec_nb_kernel", 1, 1.0), ("dec_softmax_bwd_kernel", 1, 2.0), ("dec_gemm320_dma4_kernel", 2, 2.0), ("dec_logits_dma_kernel", 1, 2.0),
+               ("dec_lse_kernel", 1, 1.0)]   # (name, launches per group-step, FETCH_SIZE factor)
+    per, total = {}, 0.0
+    for name, n, ff in kernels:
+        f = os.path.join(ROOT, "profiles", f"{tag}_pmc_{name}.txt")
+        if not os.path.exists(f):
+            return None
+        txt = open(f).read()
+        m = re.search(r"^# workload: (.*)$", txt, re.M)
+        if not m or m.group(1).strip() != mine:
+            return None
+        fe = re.search(r"FETCH_SIZE\s+n=\s*\d+\s+avg=\s*([0-9.]+)", txt)
+        wr = re.search(r"WRITE_SIZE\s+n=\s*\d+\s+avg=\s*([0-9.]+)", txt)
+        if not (fe and wr):
+            return None
+        b = (float(fe.group(1)) * ff + float(wr.group(1))) * 1024.0 * n
+        per[name] = b
+        total += b
+    B, G, n_s, n_p = args.batch_size, args.genes, args.n_shared, args.n_private
+    sx = 2 if args.count_dtype == "u16" else 4
+    p_dec = G * (n_p + 2) + G * (n_s + 2) + ((n_s + n_p) * 256 + 3 * 256) + G * (256 + n_s + n_p + 1) + G
+    alg = 2.0 * B * G * sx + 40.0 * p_dec
+    return {"traffic_bytes_per_group_step": total, "algorithmic_bytes_per_group_step": alg, "ratio": total / alg, "per_kernel_bytes": per,
+            "source": f"profiles/{tag}_pmc_<kernel>.txt (FETCH_SIZE x2 where reads are 16 B / lane, + WRITE_SIZE)"}
+
+
 def synthetic_plan(n0, n1, k=8, seed=2000):
     """the transport plan of the OT configs, defined implicitly as a permutation + k random neighbours per
     row (CSR, never densified)."""
@@ -317,7 +355,7 @@ def main(argv=None):
                 yield rows
 
     it = batches()
-    prof_names = ["spv_dec_nb_fwd", "spv_dec_logits", "spv_enc_fc1_fwd", "spv_enc_fc1_wgrad", "spv_dec_lse", "spv_dec_softmax_bwd",
+    prof_names = ["spv_dec_nb_fwd", "spv_dec_logits", "spv_enc_fc1_fwd", "spv_enc_fc1_wgrad", "spv_dec_lse", "spv_dec_softmax_bwd", "spv_dec_heads_bwd",
                   "spv_gemm_bf16", "spv_dec_heads_wgrad", "spv_adam_step", "spv_adam_step_images", "spv_enc_fc1_fwd_grouped", "spv_enc_fc1_bwd_grouped"]
     use_graph = not args.no_graph
     delta = delta_state = None
@@ -439,6 +477,7 @@ def main(argv=None):
                 "avg_launch_ms": nb_avg, "algorithmic_bytes_per_launch": nb_bytes,
                 "mfma_view": {"achieved_TFLOPs": nb_flops / (nb_avg * 1e-3) / 1e12, "peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS,
                               "frac": nb_flops / (nb_avg * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS},
+                "decoder_chain": _pmc_decoder_chain(args),
                 "per_entry_point": per_kernel}
         fc1_ms = prof.get("spv_enc_fc1_fwd", [])
         if not fc1_ms and prof.get("spv_enc_fc1_fwd_grouped"):   # one launch per kernel for all groups: per-group share of the entry point
@@ -454,7 +493,7 @@ def main(argv=None):
             "value": value, "unit": "cells/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_median": median_ms,
             "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32(split-bf16)", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32(split-bf16)",   # (bf16 mode: bf16 decoder operands, f16 encoder fc1 operands, fp32 accumulation) "data": "synthetic",
             "config": {"workload": f"{NG} groups x {args.cells} cells x {G} genes per GPU, {poe_txt}, n_shared={n_s} n_private={n_p} "
                                    f"n_hidden={H}, batch {B} cells/group/step/GPU, counts resident as {args.count_dtype} ({CONFIGS[args.config]['what']})",
                        "preset": args.config,

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; T=$1
 mkdir -p $O
 cd $R
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/${T}_gpu_tests.txt 2>&1 || { tail -30 $O/${T}_gpu_tests.txt; exit 1; }
+timeout -k 10 900 python -m pytest tests -m gpu -x -q --ignore=_prev > $O/${T}_gpu_tests.txt 2>&1 || { tail -30 $O/${T}_gpu_tests.txt; exit 1; }
 tail -2 $O/${T}_gpu_tests.txt
 timeout -k 10 600 python bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err
 cat $O/${T}_bench.json | cut -c1-400
@@ -26,7 +26,7 @@ cd $R
 { echo "# workload: c2 bf16 u16 B4096 G10000"; for d in fetch write valu wave mfma; do f=$(find $O/${T}_pmc_$d -name "*counter_collection.csv" | head -1); echo "== --pmc pass: $d"; [ -n "$f" ] && python tools/pmc_summary.py $f dec_nb_kernel; done; } > $O/${T}_pmc_dec_nb_kernel.txt
 { echo "# workload: c2 bf16 u16 B4096 G10000"; for d in fetch write valu wave mfma; do f=$(find $O/${T}_pmc_$d -name "*counter_collection.csv" | head -1); echo "== --pmc pass: $d"; [ -n "$f" ] && python tools/pmc_summary.py $f fc1_fwd_dma_pair_kernel; done; } > $O/${T}_pmc_fc1_fwd_dma_pair_kernel.txt
 { echo "# workload: c2 bf16 u16 B4096 G10000"; for d in fetch write valu wave mfma; do f=$(find $O/${T}_pmc_$d -name "*counter_collection.csv" | head -1); echo "== --pmc pass: $d"; [ -n "$f" ] && python tools/pmc_summary.py $f fc1_wgrad_dma_pair_kernel; done; } > $O/${T}_pmc_fc1_wgrad_dma_pair_kernel.txt
-for k in dec_gemm320_dma4_kernel dec_heads_wgrad_dma_kernel dec_logits_dma_kernel dec_softmax_bwd_kernel; do
+for k in dec_gemm320_dma4_kernel dec_logits_dma_kernel dec_softmax_bwd_kernel dec_lse_kernel reduce_slabs_kernel adam_images_kernel; do
   { echo "# workload: c2 bf16 u16 B4096 G10000"; for d in fetch write valu wave mfma; do f=$(find $O/${T}_pmc_$d -name "*counter_collection.csv" | head -1); echo "== --pmc pass: $d"; [ -n "$f" ] && python tools/pmc_summary.py $f $k; done; } > $O/${T}_pmc_$k.txt
 done
 cat $O/${T}_pmc_fc1_fwd_dma_pair_kernel.txt
@@ -34,3 +34,5 @@ f=$(find $O/${T}_prof_serial -name "*kernel_stats.csv" | head -1); cp $f $O/${T}
 f=$(find $O/${T}_prof -name "*kernel_stats.csv" | head -1); cp $f $O/${T}_rocprofv3_kernel_stats.csv; python tools/prof_summary.py $f 38 40 > $O/${T}_rocprofv3_kernel_stats_summary.txt
 bash tools/timeline.sh $T > /dev/null 2>&1 || true
 cp $O/${T}_timeline.txt $O/${T}_step_timeline.txt 2>/dev/null || true
+SPV_PARITY_REPORT_ONLY=1 timeout -k 10 600 python -m pytest tests/test_gpu_fullsize_parity.py -x -q -s 2>&1 | grep -E "fullsize parity|grad |passed|failed" > $O/${T}_fullsize_parity_report.txt || true
+mkdir -p $O/${T}_graph_edges && timeout -k 10 300 python tools/graph_dump.py $O/${T}_graph_edges/shipped_single --config single > $O/${T}_graph_edges/dump.log 2>&1 || true
