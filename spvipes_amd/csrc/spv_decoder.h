@@ -890,12 +890,17 @@ __global__ __launch_bounds__(256, 2) void dec_softmax_bwd_kernel(DecParams p, co
           accP = mfma32(*reinterpret_cast<const s8v*>(&ap), bP, accP);
           accS = mfma32(*reinterpret_cast<const s8v*>(&as4), bS, accS);
           if constexpr (HEADS) {   // park the tile: row = this wave's cell, the lane's two 4-gene chunks of this half
-            bf16_t* tp_ = s_tile + ((t & 1) * 2 + 0) * SMB_TILE_ELEMS + (wave * 32 + r) * 32 + 16 * m + 4 * h;
+            // 64-byte rows: a row's eight 8-byte chunks are stored XOR-swizzled with (row >> 1) & 7, so that the 16 lanes of a store
+            // (16 consecutive rows, one chunk each) and the 4 rows x 4 chunks of a transposed read both land on distinct banks
+            // (unswizzled: SQ_LDS_BANK_CONFLICT 10.0 M cycles per launch, 4-way on every store)
+            const int row = wave * 32 + r, sw = (row >> 1) & 7;
+            bf16_t* tp_ = s_tile + ((t & 1) * 2 + 0) * SMB_TILE_ELEMS + row * 32;
             bf16_t* ts_ = tp_ + SMB_TILE_ELEMS;
-            *reinterpret_cast<u2v*>(tp_) = u2v{bPw[0], bPw[1]};
-            *reinterpret_cast<u2v*>(tp_ + 8) = u2v{bPw[2], bPw[3]};
-            *reinterpret_cast<u2v*>(ts_) = u2v{bSw[0], bSw[1]};
-            *reinterpret_cast<u2v*>(ts_ + 8) = u2v{bSw[2], bSw[3]};
+            const int ca = 4 * (((4 * m + h)) ^ sw), cb = 4 * (((4 * m + 2 + h)) ^ sw);
+            *reinterpret_cast<u2v*>(tp_ + ca) = u2v{bPw[0], bPw[1]};
+            *reinterpret_cast<u2v*>(tp_ + cb) = u2v{bPw[2], bPw[3]};
+            *reinterpret_cast<u2v*>(ts_ + ca) = u2v{bSw[0], bSw[1]};
+            *reinterpret_cast<u2v*>(ts_ + cb) = u2v{bSw[2], bSw[3]};
           }
         }
       }
@@ -909,8 +914,15 @@ __global__ __launch_bounds__(256, 2) void dec_softmax_bwd_kernel(DecParams p, co
 #pragma unroll
           for (int q = 0; q < 16; ++q) accW[q] = 0.f;
 #pragma unroll
-          for (int ks = 0; ks < 8; ++ks)   // A[gene][cell] and B[cell][column], k = cells: both by transposed reads of k-major images
-            accW = mfma32(frag_kmajor(img, 32, 0, 16 * ks, lane), frag_kmajor(s_z, SMB_ZPITCH, head_role ? DEC_KP : 0, 16 * ks, lane), accW);
+          for (int ks = 0; ks < 8; ++ks) {  // A[gene][cell] and B[cell][column], k = cells: both by transposed reads of k-major images
+            // A: the parked tile, chunk-swizzled as stored (frag_kmajor's addressing with the XOR applied per row)
+            const int gi = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+            const int row0 = 16 * ks + 8 * h + q4, row1 = row0 + 4, chunk = 4 * (gi & 1) + p4;
+            const s4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(img + row0 * 32 + 4 * (chunk ^ ((row0 >> 1) & 7))));
+            const s4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(img + row1 * 32 + 4 * (chunk ^ ((row1 >> 1) & 7))));
+            const s8v af = s8v{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            accW = mfma32(af, frag_kmajor(s_z, SMB_ZPITCH, head_role ? DEC_KP : 0, 16 * ks, lane), accW);
+          }
           // accW[q]: row = gene g0 + crow(q, h), column = r of this head
           const int nk = head_role ? DEC_KS : DEC_KP;
           float* out = (head_role ? dws_part : dwp_part) + (long)blockIdx.x * p.G * nk;
