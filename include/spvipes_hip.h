@@ -244,7 +244,8 @@ int spv_dec_softmax_bwd(const spv_dec_params* p, const float* Tp, const float* T
 /* bf16 mode: ONE read-only pass over t_P / t_S for everything the backward pass needs from them (nn/networks.py:314-320 through
  * autograd): the latent gradient of the two rate heads (dz_part, as above) and the two regressor weight gradients
  * d [W'_p | c_p] = t'_P^T [z_p | 1], d [W'_s | c_s] = t'_S^T [z_s | 1] as one partial slab per 128-cell workgroup row:
- * dwp_part [Bp / 128][G][16], dws_part [Bp / 128][G][32] (sum with spv_reduce_slabs).  t_P / t_S stay uncorrected -- nothing reads
+ * dwp_part, dws_part [Bp / 128][Gp][32] each (row pitch 32 for both heads; the private head's columns >= 16 are zeros; sum the first
+ * G rows x 16 / 32 columns with spv_reduce_slabs).  t_P / t_S stay uncorrected -- nothing reads
  * them afterwards: replaces spv_dec_softmax_bwd + spv_dec_heads_wgrad (336 MB less [B, G] traffic per group at B 4096 x G 10 000). */
 int spv_dec_heads_bwd(const spv_dec_params* p, const float* Tp, const float* Ts, float* dz_part, float* dwp_part, float* dws_part, void* stream);
 

@@ -953,4 +953,199 @@ __global__ __launch_bounds__(256, 2) void dec_softmax_bwd_kernel(DecParams p, co
   }
 }
 
+// ---- one-pass decoder backward, second form (round 3): the same arithmetic as dec_softmax_bwd_kernel<bf16_t, true, false, true> with an
+// instruction stream that is IDENTICAL for every wave and every tile, so that hipcc's s_waitcnt counts are exact.
+//
+// What was wrong with the first form (found in its disassembly): the weight-gradient contraction ran on two of the four waves per tile
+// (wave-uniform branch), and those waves stored their [32 genes x 16 | 32] block with 16 global stores inside that branch.  vmcnt retires
+// in order and counts stores; at a control-flow join the compiler has to assume the path WITHOUT the stores, so the wait for the next
+// tile's weight fragments became vmcnt(4) -- which, on a wave that had just stored, also waits for its two tiles of prefetched gradient
+// words and for 12 of the 16 stores.  Every tile started with a full HBM round trip (2.3 TB/s).  The periodic re-staging of W'^T had a
+// vmcnt(0) of its own every five tiles.
+//
+// Here: (1) every wave takes part in every tile's contraction -- wave w owns head w & 1 and gene half w >> 1 and computes its
+// [16 genes x 32 columns] block with v_mfma_f32_16x16x32_bf16 over the workgroup's 128 cells (4 k-steps x 2 column blocks; the private
+// head's second block multiplies the zero padding of its 32-column latent image, so both heads run the same 8 MFMAs and 8 stores);
+// (2) the partial slabs are [Bp / 128][Gp][32] for both heads, stored unconditionally (padding genes are zero rows, padding columns zero);
+// (3) W'^T is staged one 32-gene tile at a time, double buffered, its 16-byte global loads issued at the top of the previous tile by
+// 192 threads: one load per tile, no drain.  Per tile and wave the vector-memory stream is: 6 fragment loads, 1 staging load, 4 tile
+// loads (two tiles ahead), 8 stores -- in that order, always.
+constexpr int HB_WT_PITCH = 36;   // bf16 per row of a staged W'^T tile [48][32 | 4 pad]: 18 dwords, 32 rows on 32 distinct even banks
+__global__ __launch_bounds__(256, 2) void dec_heads_bwd_kernel(DecParams p, const float* Tp, const float* Ts, float* dz_part, float* dwp_part, float* dws_part) {
+  __shared__ __attribute__((aligned(16))) bf16_t s_wT[2 * DEC_KPS * HB_WT_PITCH];                 // [tile parity][k][gene of the tile]
+  __shared__ __attribute__((aligned(16))) bf16_t s_tile[2 * 2 * SMB_TILE_ELEMS];                  // [tile parity][head][cell][gene], chunk-swizzled
+  __shared__ __attribute__((aligned(16))) bf16_t s_zh[2 * DEC_CELLS_PER_WG * 32];                 // [head][cell][32 columns] of the latent image (private: 16 + zeros)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
+  const int cell_tile = blockIdx.x * (DEC_CELLS_PER_WG / 32) + wave;
+  const int cell0 = cell_tile * 32;
+  const int cell = cell0 + r;
+  const int split = blockIdx.y;
+  PsFrags cf;
+  load_ps_cell_frags(p, cell0, lane, cf);
+  const float lp = p.lse_p[cell], ls = p.lse_s[cell];
+  const float tpb = Tp[cell], tsb = Ts[cell];
+  const int gbeg = split * p.genes_per_split;
+  int gend = gbeg + p.genes_per_split;
+  if (gend > p.Gp) gend = p.Gp;
+  if (gend > ((p.G + 31) & ~31)) gend = (p.G + 31) & ~31;
+  const int ntile = (gend - gbeg) >> 5;
+  f16v accP, accS;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { accP[q] = 0.f; accS[q] = 0.f; }
+  if (ntile > 0) {   // (block-uniform)
+    // ---- the workgroup's 128 rows of the latent image, one 32-column image per head ----------------------------------------------
+    {
+      const int cb0 = blockIdx.x * DEC_CELLS_PER_WG;
+      for (int i = threadIdx.x; i < 2 * DEC_CELLS_PER_WG * 4; i += 256) {   // 8-element chunks: 4 per row and head
+        const int hd = i / (DEC_CELLS_PER_WG * 4), row = (i / 4) % DEC_CELLS_PER_WG, c8 = (i % 4) * 8;
+        u4v v = u4v{0u, 0u, 0u, 0u};
+        if (hd == 1 || c8 < DEC_KP) v = *reinterpret_cast<const u4v*>(p.Aps_hi + (long)(cb0 + row) * DEC_KPS + (hd ? DEC_KP : 0) + c8);
+        *reinterpret_cast<u4v*>(s_zh + (hd * DEC_CELLS_PER_WG + row) * 32 + c8) = v;
+      }
+    }
+    // ---- W'^T staging: thread i < 192 owns gene i / 6 of a tile and the 8 columns 8 (i % 6) .. ------------------------------------
+    // 192 pieces (32 genes x 6 chunks of 8 columns) for 256 threads: threads 192.. repeat the pieces 0..63 (same value to the same LDS
+    // word: harmless).  NO branch around either half: behind an `if (thread < 192)` hipcc sinks the load into the branch, next to the
+    // LDS stores, and drains the whole queue for it (s_waitcnt vmcnt(0)) once per tile
+    const int st_i = (threadIdx.x < 192) ? (int)threadIdx.x : (int)threadIdx.x - 192;
+    const int st_g = st_i / (DEC_KPS / 8), st_c = (st_i % (DEC_KPS / 8)) * 8;
+    auto wt_load = [&](int t) -> u4v {
+      const int g0 = gbeg + 32 * min(t, ntile - 1);
+      return *reinterpret_cast<const u4v*>(p.Wps_hi + (long)(g0 + st_g) * DEC_KPS + st_c);
+    };
+    auto wt_store = [&](int t, const u4v& w) {
+      bf16_t* dst = s_wT + (t & 1) * DEC_KPS * HB_WT_PITCH + st_c * HB_WT_PITCH + st_g;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { dst[(2 * j) * HB_WT_PITCH] = (bf16_t)(w[j] & 0xFFFFu); dst[(2 * j + 1) * HB_WT_PITCH] = (bf16_t)(w[j] >> 16); }
+    };
+    const long trow = (long)cell_tile * p.n_gene_tiles;
+    PsW wA;
+    u2v rp0[4], rs0[4], rp1[4], rs1[4];
+    load_ps_w(p, gbeg, lane, wA);
+    auto request = [&](int t, u2v (&rp)[4], u2v (&rs)[4]) {   // 16-byte loads of the lane pair's words, unswapped at decode (see the first form)
+      const long tb = (trow + ((gbeg + 32 * min(t, ntile - 1)) >> 5)) * 1024 + lane * 4;
+      const long tb2 = tb - (lane & 1) * 4 + (lane & 1) * 256;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const u4v a = *reinterpret_cast<const u4v*>(reinterpret_cast<const bf16_t*>(p.tP) + tb2 + 512 * pr);
+        const u4v b = *reinterpret_cast<const u4v*>(reinterpret_cast<const bf16_t*>(p.tS) + tb2 + 512 * pr);
+        rp[2 * pr] = u2v{a[0], a[1]}; rp[2 * pr + 1] = u2v{a[2], a[3]};
+        rs[2 * pr] = u2v{b[0], b[1]}; rs[2 * pr + 1] = u2v{b[2], b[3]};
+      }
+    };
+    auto unswap = [&](u2v (&r4)[4]) {
+      const bool odd = lane & 1;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const u2v lo = r4[2 * pr], hi = r4[2 * pr + 1];
+        const u2v send = odd ? lo : hi;
+        const u2v recv = u2v{(unsigned)__shfl_xor((int)send[0], 1, 64), (unsigned)__shfl_xor((int)send[1], 1, 64)};
+        r4[2 * pr] = odd ? recv : lo;
+        r4[2 * pr + 1] = odd ? hi : recv;
+      }
+    };
+    wt_store(0, wt_load(0));
+    request(0, rp0, rs0);
+    request(1, rp1, rs1);
+    lds_barrier();   // latent images and the first W'^T tile are in LDS
+    const int head = wave & 1, gh = wave >> 1;   // this wave's share of every tile's weight-gradient contraction
+    float* const wout = (head ? dws_part : dwp_part) + (long)blockIdx.x * p.Gp * 32;
+    // No validity masks on the elements: cells beyond the batch hold t = 0 and T = 0 (the likelihood pass writes them with weight 0), so
+    // their corrected values are exact zeros; padding genes (>= G) get t' = -softmax * T != 0, but they meet W' rows that are zero in
+    // the packed image (nothing reaches the latent gradient) and their weight-gradient rows are never read by the reduction.
+    auto tile = [&](const int t, u2v (&rpA)[4], u2v (&rsA)[4]) {
+      const int g0 = gbeg + 32 * t, gn = gbeg + 32 * min(t + 1, ntile - 1);
+      f16v yp, ys;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { yp[q] = 0.f; ys[q] = 0.f; }
+      yp = mfma32_split<3>(wA.hi[0], wA.lo[0], cf.hi[0], cf.lo[0], yp);
+      ys = mfma32_split<3>(wA.hi[1], wA.lo[1], cf.hi[1], cf.lo[1], ys);
+      ys = mfma32_split<3>(wA.hi[2], wA.lo[2], cf.hi[2], cf.lo[2], ys);
+      PsW wB;
+      load_ps_w(p, gn, lane, wB);                 // 6 loads: next tile's W' fragments
+      const u4v wst = wt_load(t + 1);             // 1 load : next tile's W'^T piece
+      unsigned cpk[8], csk[8];
+      unswap(rpA);
+      unswap(rsA);
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        float vp[4], vs[4];
+        decode4(rpA[qq], vp);
+        decode4(rsA[qq], vs);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int q = 4 * qq + j;
+          vp[j] = vp[j] - fast_exp(yp[q] - lp) * tpb;
+          vs[j] = vs[j] - fast_exp(ys[q] - ls) * tsb;
+        }
+        cpk[2 * qq] = pack2bf(vp[0], vp[1]); cpk[2 * qq + 1] = pack2bf(vp[2], vp[3]);
+        csk[2 * qq] = pack2bf(vs[0], vs[1]); csk[2 * qq + 1] = pack2bf(vs[2], vs[3]);
+      }
+      request(t + 2, rpA, rsA);                   // 4 loads: the tile after next, into the registers just decoded
+      const bf16_t* wT = s_wT + (t & 1) * DEC_KPS * HB_WT_PITCH;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const u4v bPw = u4v{cpk[4 * m], cpk[4 * m + 1], cpk[4 * m + 2], cpk[4 * m + 3]}, bSw = u4v{csk[4 * m], csk[4 * m + 1], csk[4 * m + 2], csk[4 * m + 3]};
+        const s8v bP = *reinterpret_cast<const s8v*>(&bPw), bS = *reinterpret_cast<const s8v*>(&bSw);
+        const bf16_t* wr = wT + 16 * m + 4 * h;
+        const u2v p0 = *reinterpret_cast<const u2v*>(wr + (r & 15) * HB_WT_PITCH), p1 = *reinterpret_cast<const u2v*>(wr + (r & 15) * HB_WT_PITCH + 8);
+        const u2v s0 = *reinterpret_cast<const u2v*>(wr + (DEC_KP + r) * HB_WT_PITCH), s1 = *reinterpret_cast<const u2v*>(wr + (DEC_KP + r) * HB_WT_PITCH + 8);
+        u4v ap = u4v{p0[0], p0[1], p1[0], p1[1]};
+        if (r >= DEC_KP) ap = u4v{0u, 0u, 0u, 0u};   // the private head has 16 rows
+        const u4v as4 = u4v{s0[0], s0[1], s1[0], s1[1]};
+        accP = mfma32(*reinterpret_cast<const s8v*>(&ap), bP, accP);
+        accS = mfma32(*reinterpret_cast<const s8v*>(&as4), bS, accS);
+        // park the tile (64-byte rows, chunks XOR-swizzled with (row >> 1) & 7: conflict-free stores and transposed reads)
+        const int row = wave * 32 + r, sw = (row >> 1) & 7;
+        bf16_t* tp_ = s_tile + ((t & 1) * 2 + 0) * SMB_TILE_ELEMS + row * 32;
+        bf16_t* ts_ = tp_ + SMB_TILE_ELEMS;
+        const int ca = 4 * ((4 * m + h) ^ sw), cb = 4 * ((4 * m + 2 + h) ^ sw);
+        *reinterpret_cast<u2v*>(tp_ + ca) = u2v{bPw[0], bPw[1]};
+        *reinterpret_cast<u2v*>(tp_ + cb) = u2v{bPw[2], bPw[3]};
+        *reinterpret_cast<u2v*>(ts_ + ca) = u2v{bSw[0], bSw[1]};
+        *reinterpret_cast<u2v*>(ts_ + cb) = u2v{bSw[2], bSw[3]};
+      }
+      wt_store(t + 1, wst);   // buffer (t + 1) & 1 was last read during tile t - 1, i.e. before the previous barrier
+      lds_barrier();          // the four parked tiles of gene tile t and the next W'^T tile are visible
+      // ---- weight-gradient block of this wave: D[16 genes][32 columns] = sum over 128 cells, v_mfma_f32_16x16x32_bf16 ----------------
+      {
+        const bf16_t* img = s_tile + ((t & 1) * 2 + head) * SMB_TILE_ELEMS;
+        const bf16_t* zi = s_zh + head * DEC_CELLS_PER_WG * 32;
+        const int kq = 8 * (lane >> 4) + ((lane & 15) >> 2), p4 = lane & 3;   // row inside a 32-cell k-step this lane addresses; its 4-column group
+        f4acc d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int row0 = 32 * ks + kq, row1 = row0 + 4, chunk = 4 * gh + p4;
+          const s4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(img + row0 * 32 + 4 * (chunk ^ ((row0 >> 1) & 7))));
+          const s4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(img + row1 * 32 + 4 * (chunk ^ ((row1 >> 1) & 7))));
+          const s4v b00 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(zi + row0 * 32 + 4 * p4));
+          const s4v b01 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(zi + row1 * 32 + 4 * p4));
+          const s4v b10 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(zi + row0 * 32 + 16 + 4 * p4));
+          const s4v b11 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(zi + row1 * 32 + 16 + 4 * p4));
+          const s8v af = s8v{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+          d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, s8v{b00[0], b00[1], b00[2], b00[3], b01[0], b01[1], b01[2], b01[3]}, d0, 0, 0, 0);
+          d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, s8v{b10[0], b10[1], b10[2], b10[3], b11[0], b11[1], b11[2], b11[3]}, d1, 0, 0, 0);
+        }
+        // d[j]: gene g0 + 16 gh + 4 (lane >> 4) + j, column (lane & 15) (+ 16 for d1); rows < Gp always (gend <= Gp): 8 unconditional stores
+        float* o = wout + (long)(g0 + 16 * gh + 4 * (lane >> 4)) * 32 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o[j * 32] = d0[j]; o[j * 32 + 16] = d1[j]; }
+      }
+      wA = wB;
+    };
+    for (int t = 0; t < ntile; t += 2) {   // (block-uniform trip structure: every wave reaches every barrier)
+      tile(t, rp0, rs0);
+      if (t + 1 < ntile) tile(t + 1, rp1, rs1);
+    }
+  }
+  // acc[q]: row = crow(q, h) = k, column = lane & 31 = cell; one slab per split, zeros for empty splits
+  float* out = dz_part + ((long)split * p.Bp + cell) * DEC_KPS;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int k = crow(q, h);
+    if (k < DEC_KP) out[k] = accP[q];
+    out[DEC_KP + k] = accS[q];
+  }
+}
+
 }  // namespace spv
