@@ -244,10 +244,10 @@ int spv_dec_softmax_bwd(const spv_dec_params* p, const float* Tp, const float* T
 /* bf16 mode: ONE read-only pass over t_P / t_S for everything the backward pass needs from them (nn/networks.py:314-320 through
  * autograd): the latent gradient of the two rate heads (dz_part, as above) and the two regressor weight gradients
  * d [W'_p | c_p] = t'_P^T [z_p | 1], d [W'_s | c_s] = t'_S^T [z_s | 1] as one partial slab per 128-cell workgroup row:
- * dwp_part, dws_part [Bp / 128][Gp][32] each (row pitch 32 for both heads; the private head's columns >= 16 are zeros; sum the first
- * G rows x 16 / 32 columns with spv_reduce_slabs).  t_P / t_S stay uncorrected -- nothing reads
+ * dw_part [Bp / 128][Gp][48], a row = [d W'_p | d c_p | 0.. (16 columns) | d W'_s | d c_s | 0.. (32 columns)] like the regressor operand
+ * image (sum the first G rows with spv_reduce_slabs, columns 0..15 and 16..47).  t_P / t_S stay uncorrected -- nothing reads
  * them afterwards: replaces spv_dec_softmax_bwd + spv_dec_heads_wgrad (336 MB less [B, G] traffic per group at B 4096 x G 10 000). */
-int spv_dec_heads_bwd(const spv_dec_params* p, const float* Tp, const float* Ts, float* dz_part, float* dwp_part, float* dws_part, void* stream);
+int spv_dec_heads_bwd(const spv_dec_params* p, const float* Tp, const float* Ts, float* dz_part, float* dw_part, void* stream);
 
 /* One 16-bit operand image kept in step with a parameter by spv_adam_step_images: the `count` fp32 values at flat offset `begin`
  * (a multiple of 4) are a row-major matrix with `cols` columns; element (r, c) is also written to

@@ -535,21 +535,20 @@ extern "C" int spv_dec_softmax_bwd(const spv_dec_params* q, const float* Tp, con
 
 // One read-only pass over t_P / t_S (bf16 gradient arrays) for everything the backward pass needs from them: the latent gradient of the
 // two rate heads (dz_part, as spv_dec_softmax_bwd) AND the two regressor weight gradients as per-workgroup-row partial slabs
-// dwp_part, dws_part [Bp / 128][Gp][32] each (private head: columns >= 16 are zero; sum the first 16 / 32 columns of the first G rows
-// with spv_reduce_slabs).  t_P / t_S are left uncorrected: nothing reads
+// dw_part [Bp / 128][Gp][48] = [d W'_p (16 columns) | d W'_s (32 columns)] (sum the first G rows with spv_reduce_slabs).  t_P / t_S are left uncorrected: nothing reads
 // them afterwards.  Replaces spv_dec_softmax_bwd + spv_dec_heads_wgrad in bf16 mode.
-extern "C" int spv_dec_heads_bwd(const spv_dec_params* q, const float* Tp, const float* Ts, float* dz_part, float* dwp_part, float* dws_part, void* stream) {
+extern "C" int spv_dec_heads_bwd(const spv_dec_params* q, const float* Tp, const float* Ts, float* dz_part, float* dw_part, void* stream) {
   DecParams p;
   int rc = to_dec(q, p);
   if (rc != SPV_OK) return rc;
-  if (!Tp || !Ts || !p.tP || !p.tS || !p.lse_p || !p.lse_s || !dz_part || !dwp_part || !dws_part) return fail(SPV_ERR_ARG, "spv_dec_heads_bwd: null pointer%s");
+  if (!Tp || !Ts || !p.tP || !p.tS || !p.lse_p || !p.lse_s || !dz_part || !dw_part) return fail(SPV_ERR_ARG, "spv_dec_heads_bwd: null pointer%s");
   if (p.n_gene_tiles != p.Gp / 32) return fail(SPV_ERR_ARG, "spv_dec_heads_bwd: n_gene_tiles must be Gp / 32%s");
   if (p.grads_f32) return fail(SPV_ERR_UNSUPPORTED, "spv_dec_heads_bwd: bf16 gradient arrays only%s");
   if (p.Bp % DEC_CELLS_PER_WG) return fail(SPV_ERR_ARG, "spv_dec_heads_bwd: Bp must be a multiple of 128%s");
   dim3 grid(p.Bp / DEC_CELLS_PER_WG, p.gene_splits);
   // (the partial slabs cover gene rows the splits do not reach only when genes_per_split * gene_splits < round_up(G, 32): the host sizes
   // the splits to cover; rows in [round_up(G, 32), Gp) are never written and never read)
-  hipLaunchKernelGGL(dec_heads_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, p, Tp, Ts, dz_part, dwp_part, dws_part);
+  hipLaunchKernelGGL(dec_heads_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, p, Tp, Ts, dz_part, dw_part);
   return launch_status("spv_dec_heads_bwd");
 }
 

@@ -964,14 +964,14 @@ __global__ __launch_bounds__(256, 2) void dec_softmax_bwd_kernel(DecParams p, co
 // vmcnt(0) of its own every five tiles.
 //
 // Here: (1) every wave takes part in every tile's contraction -- wave w owns head w & 1 and gene half w >> 1 and computes its
-// [16 genes x 32 columns] block with v_mfma_f32_16x16x32_bf16 over the workgroup's 128 cells (4 k-steps x 2 column blocks; the private
-// head's second block multiplies the zero padding of its 32-column latent image, so both heads run the same 8 MFMAs and 8 stores);
-// (2) the partial slabs are [Bp / 128][Gp][32] for both heads, stored unconditionally (padding genes are zero rows, padding columns zero);
+// workgroup's 128 cells with v_mfma_f32_16x16x32_bf16: the tile's six [16 genes x 16 columns] blocks (private | shared low | shared high
+// columns, two gene halves) are dealt two per wave (8 MFMAs and 8 stores each; two waves repeat a block, bit for bit, so that nobody's
+// stream differs); (2) ONE partial slab [Bp / 128][Gp][48] = [d W'_p | d W'_s], stored unconditionally (padding gene rows exist);
 // (3) W'^T is staged one 32-gene tile at a time, double buffered, its 16-byte global loads issued at the top of the previous tile by
 // 192 threads: one load per tile, no drain.  Per tile and wave the vector-memory stream is: 6 fragment loads, 1 staging load, 4 tile
 // loads (two tiles ahead), 8 stores -- in that order, always.
 constexpr int HB_WT_PITCH = 36;   // bf16 per row of a staged W'^T tile [48][32 | 4 pad]: 18 dwords, 32 rows on 32 distinct even banks
-__global__ __launch_bounds__(256, 2) void dec_heads_bwd_kernel(DecParams p, const float* Tp, const float* Ts, float* dz_part, float* dwp_part, float* dws_part) {
+__global__ __launch_bounds__(256, 2) void dec_heads_bwd_kernel(DecParams p, const float* Tp, const float* Ts, float* dz_part, float* dw_part) {
   __shared__ __attribute__((aligned(16))) bf16_t s_wT[2 * DEC_KPS * HB_WT_PITCH];                 // [tile parity][k][gene of the tile]
   __shared__ __attribute__((aligned(16))) bf16_t s_tile[2 * 2 * SMB_TILE_ELEMS];                  // [tile parity][head][cell][gene], chunk-swizzled
   __shared__ __attribute__((aligned(16))) bf16_t s_zh[2 * DEC_CELLS_PER_WG * 32];                 // [head][cell][32 columns] of the latent image (private: 16 + zeros)
@@ -1048,8 +1048,12 @@ __global__ __launch_bounds__(256, 2) void dec_heads_bwd_kernel(DecParams p, cons
     request(0, rp0, rs0);
     request(1, rp1, rs1);
     lds_barrier();   // latent images and the first W'^T tile are in LDS
-    const int head = wave & 1, gh = wave >> 1;   // this wave's share of every tile's weight-gradient contraction
-    float* const wout = (head ? dws_part : dwp_part) + (long)blockIdx.x * p.Gp * 32;
+    // this wave's share of every tile's weight-gradient contraction: two of the six [16 genes x 16 columns] blocks
+    // (block b = private | shared columns 0..15 | shared columns 16..31, gene half gh; role = 3 gh + b): wave w takes roles w and
+    // (w + 4) % 6 -- waves 2 and 3 repeat roles 0 and 1 as their second one (same operands, same bits, same address: a harmless duplicate
+    // that keeps the instruction stream of the four waves identical)
+    const int role0 = wave, role1 = (wave + 4) % 6;
+    float* const wslab = dw_part + (long)blockIdx.x * p.Gp * DEC_KPS;
     // No validity masks on the elements: cells beyond the batch hold t = 0 and T = 0 (the likelihood pass writes them with weight 0), so
     // their corrected values are exact zeros; padding genes (>= G) get t' = -softmax * T != 0, but they meet W' rows that are zero in
     // the packed image (nothing reaches the latent gradient) and their weight-gradient rows are never read by the reduction.
@@ -1107,29 +1111,36 @@ __global__ __launch_bounds__(256, 2) void dec_heads_bwd_kernel(DecParams p, cons
       }
       wt_store(t + 1, wst);   // buffer (t + 1) & 1 was last read during tile t - 1, i.e. before the previous barrier
       lds_barrier();          // the four parked tiles of gene tile t and the next W'^T tile are visible
-      // ---- weight-gradient block of this wave: D[16 genes][32 columns] = sum over 128 cells, v_mfma_f32_16x16x32_bf16 ----------------
+      // ---- this wave's two weight-gradient blocks: D[16 genes][16 columns] = sum over 128 cells, v_mfma_f32_16x16x32_bf16 ---------------
       {
-        const bf16_t* img = s_tile + ((t & 1) * 2 + head) * SMB_TILE_ELEMS;
-        const bf16_t* zi = s_zh + head * DEC_CELLS_PER_WG * 32;
         const int kq = 8 * (lane >> 4) + ((lane & 15) >> 2), p4 = lane & 3;   // row inside a 32-cell k-step this lane addresses; its 4-column group
+        const int b0 = role0 % 3, g0h = role0 / 3, b1 = role1 % 3, g1h = role1 / 3;
+        const bf16_t* img0 = s_tile + ((t & 1) * 2 + (b0 ? 1 : 0)) * SMB_TILE_ELEMS;
+        const bf16_t* img1 = s_tile + ((t & 1) * 2 + (b1 ? 1 : 0)) * SMB_TILE_ELEMS;
+        const bf16_t* z0 = s_zh + (b0 ? DEC_CELLS_PER_WG * 32 + 16 * (b0 - 1) : 0) + 4 * p4;   // latent image of the block's head, its 16 columns
+        const bf16_t* z1 = s_zh + (b1 ? DEC_CELLS_PER_WG * 32 + 16 * (b1 - 1) : 0) + 4 * p4;
         f4acc d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          const int row0 = 32 * ks + kq, row1 = row0 + 4, chunk = 4 * gh + p4;
-          const s4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(img + row0 * 32 + 4 * (chunk ^ ((row0 >> 1) & 7))));
-          const s4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(img + row1 * 32 + 4 * (chunk ^ ((row1 >> 1) & 7))));
-          const s4v b00 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(zi + row0 * 32 + 4 * p4));
-          const s4v b01 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(zi + row1 * 32 + 4 * p4));
-          const s4v b10 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(zi + row0 * 32 + 16 + 4 * p4));
-          const s4v b11 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(zi + row1 * 32 + 16 + 4 * p4));
-          const s8v af = s8v{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-          d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, s8v{b00[0], b00[1], b00[2], b00[3], b01[0], b01[1], b01[2], b01[3]}, d0, 0, 0, 0);
-          d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, s8v{b10[0], b10[1], b10[2], b10[3], b11[0], b11[1], b11[2], b11[3]}, d1, 0, 0, 0);
+          const int row0 = 32 * ks + kq, row1 = row0 + 4, s0 = (row0 >> 1) & 7, s1 = (row1 >> 1) & 7;
+          const s4v a00 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(img0 + row0 * 32 + 4 * ((4 * g0h + p4) ^ s0)));
+          const s4v a01 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(img0 + row1 * 32 + 4 * ((4 * g0h + p4) ^ s1)));
+          const s4v a10 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(img1 + row0 * 32 + 4 * ((4 * g1h + p4) ^ s0)));
+          const s4v a11 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(img1 + row1 * 32 + 4 * ((4 * g1h + p4) ^ s1)));
+          const s4v b00 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(z0 + row0 * 32));
+          const s4v b01 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(z0 + row1 * 32));
+          const s4v b10 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(z1 + row0 * 32));
+          const s4v b11 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)(z1 + row1 * 32));
+          d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(s8v{a00[0], a00[1], a00[2], a00[3], a01[0], a01[1], a01[2], a01[3]},
+                                                       s8v{b00[0], b00[1], b00[2], b00[3], b01[0], b01[1], b01[2], b01[3]}, d0, 0, 0, 0);
+          d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(s8v{a10[0], a10[1], a10[2], a10[3], a11[0], a11[1], a11[2], a11[3]},
+                                                       s8v{b10[0], b10[1], b10[2], b10[3], b11[0], b11[1], b11[2], b11[3]}, d1, 0, 0, 0);
         }
-        // d[j]: gene g0 + 16 gh + 4 (lane >> 4) + j, column (lane & 15) (+ 16 for d1); rows < Gp always (gend <= Gp): 8 unconditional stores
-        float* o = wout + (long)(g0 + 16 * gh + 4 * (lane >> 4)) * 32 + (lane & 15);
+        // d[j]: gene g0 + 16 gh + 4 (lane >> 4) + j, column 16 b + (lane & 15) of the 48-column slab; rows < Gp always: 8 unconditional stores
+        float* o0 = wslab + (long)(g0 + 16 * g0h + 4 * (lane >> 4)) * DEC_KPS + 16 * b0 + (lane & 15);
+        float* o1 = wslab + (long)(g0 + 16 * g1h + 4 * (lane >> 4)) * DEC_KPS + 16 * b1 + (lane & 15);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { o[j * 32] = d0[j]; o[j * 32 + 16] = d1[j]; }
+        for (int j = 0; j < 4; ++j) { o0[j * DEC_KPS] = d0[j]; o1[j * DEC_KPS] = d1[j]; }
       }
       wA = wB;
     };

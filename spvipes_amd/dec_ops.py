@@ -81,8 +81,7 @@ class _DecoderBwd:
         self.fused_heads = bool(_ops.FUSED_HEADS and not _ops.DZ_ONLY and self.fused_dz and self.heads_dma and Bp % DEC_CELLS_PER_WG == 0)
         if self.fused_heads:
             self.csp_n = Bp // DEC_CELLS_PER_WG
-            self.dwp_part = wsg.get("dec_dWp32", (self.csp_n, Gp, 32), torch.float32)   # both heads: 32-column slabs over the padded genes
-            self.dws_part = wsg.get("dec_dWs32", (self.csp_n, Gp, 32), torch.float32)
+            self.dw_part = wsg.get("dec_dW48", (self.csp_n, Gp, DEC_KPS), torch.float32)   # [d W'_p | d W'_s] rows over the padded genes
         # bf16 mode: the two 320-column GEMMs run the LDS-DMA 128 x 320 kernels, which want their own split counts
         # (d A_m of the two groups run side by side on the group streams; d W_m one after the other on the side stream)
         self.ksp_m = self._splits(False, B, G, self.ksp_m, 128 if (pair and _ops.DEC_PAIR_SPLITS) else 256)
@@ -97,8 +96,7 @@ class _DecoderBwd:
 
     def softmax(self):
         if self.fused_heads:
-            _abi.call("spv_dec_heads_bwd", C.byref(self.P), ptr(self.S["Tp"]), ptr(self.S["Ts"]), ptr(self.dz_part), ptr(self.dwp_part),
-                      ptr(self.dws_part), stream_ptr())
+            _abi.call("spv_dec_heads_bwd", C.byref(self.P), ptr(self.S["Tp"]), ptr(self.S["Ts"]), ptr(self.dz_part), ptr(self.dw_part), stream_ptr())
             return
         _abi.call("spv_dec_softmax_bwd", C.byref(self.P), ptr(self.S["Tp"]), ptr(self.S["Ts"]), ptr(self.dz_part), stream_ptr())
 
@@ -137,7 +135,7 @@ class _DecoderBwd:
 
     def gemm_bc(self):
         if self.fused_heads:   # already produced by softmax() (spv_dec_heads_bwd): hand the partial slabs to the reduction
-            return self.dwp_part, self.dws_part
+            return self.dw_part, self.dw_part   # (one 48-column slab: the reductions below pick their columns)
         (Aps_hi, Aps_lo), (tP_hi, tP_lo), (tS_hi, tS_lo) = self.S["Aps"], self._operand("tP"), self._operand("tS")
         if self.heads_dma:   # bf16 mode: both heads in one LDS-DMA streaming pass (csrc/spv_dec_gemm.h)
             b = self.wsg.get("dec_dWp", (self.csp_n, self.G, DEC_KP), torch.float32)
@@ -440,9 +438,12 @@ class DecoderFused(torch.autograd.Function):
         for g in range(NG):
             st, G, Gp = stages[g], Gs[g], Gps[g]
             if bc_slabs[g] is not None:
-                ssp, ldp, sss, lds_ = (st.Gp * 32, 32, st.Gp * 32, 32) if st.fused_heads else (G * DEC_KP, DEC_KP, G * DEC_KS, DEC_KS)
-                _add_red(red, bc_slabs[g][0], st.csp_n, ssp, ldp, G, DEC_KP, dWp[g], DEC_KP, alpha=al)      # d [W'_p | c_p]
-                _add_red(red, bc_slabs[g][1], st.csp_n, sss, lds_, G, DEC_KS, dWs[g], DEC_KS, alpha=al)      # d [W'_s | c_s]
+                if st.fused_heads:
+                    _add_red(red, bc_slabs[g][0], st.csp_n, st.Gp * DEC_KPS, DEC_KPS, G, DEC_KP, dWp[g], DEC_KP, alpha=al)                  # d [W'_p | c_p]
+                    _add_red(red, bc_slabs[g][1], st.csp_n, st.Gp * DEC_KPS, DEC_KPS, G, DEC_KS, dWs[g], DEC_KS, col_off=DEC_KP, alpha=al)  # d [W'_s | c_s]
+                else:
+                    _add_red(red, bc_slabs[g][0], st.csp_n, G * DEC_KP, DEC_KP, G, DEC_KP, dWp[g], DEC_KP, alpha=al)      # d [W'_p | c_p]
+                    _add_red(red, bc_slabs[g][1], st.csp_n, G * DEC_KS, DEC_KS, G, DEC_KS, dWs[g], DEC_KS, alpha=al)      # d [W'_s | c_s]
             _add_red(red, d_slabs[g], st.ksp_m, B * KMP, KMP, B, n_m, dAm[g], n_m, alpha=al)                          # d m (trunk output)
             # gradient reaching zcat directly: through the logits GEMM (columns n_m..) and the two regressors
             _add_red(red, d_slabs[g], st.ksp_m, B * KMP, KMP, B, nt, d_zcat[g], nt, col_off=n_m, alpha=al)
@@ -475,9 +476,12 @@ class DecoderFused(torch.autograd.Function):
                         st.softmax_fix()
                     b_, c = st.gemm_bc()
                     # (spv_dec_heads_bwd's slabs are [Gp][32] for both heads; the GEMM slabs [G][16] / [G][32])
-                    ssp, ldp, sss, lds_ = (st.Gp * 32, 32, st.Gp * 32, 32) if st.fused_heads else (G * DEC_KP, DEC_KP, G * DEC_KS, DEC_KS)
-                    _add_red(red_bc, b_, st.csp_n, ssp, ldp, G, DEC_KP, dWp[g], DEC_KP, alpha=g_loss)
-                    _add_red(red_bc, c, st.csp_n, sss, lds_, G, DEC_KS, dWs[g], DEC_KS, alpha=g_loss)
+                    if st.fused_heads:   # spv_dec_heads_bwd's slabs: [Gp][48], private columns first
+                        _add_red(red_bc, b_, st.csp_n, st.Gp * DEC_KPS, DEC_KPS, G, DEC_KP, dWp[g], DEC_KP, alpha=g_loss)
+                        _add_red(red_bc, c, st.csp_n, st.Gp * DEC_KPS, DEC_KPS, G, DEC_KS, dWs[g], DEC_KS, col_off=DEC_KP, alpha=g_loss)
+                    else:
+                        _add_red(red_bc, b_, st.csp_n, G * DEC_KP, DEC_KP, G, DEC_KP, dWp[g], DEC_KP, alpha=g_loss)
+                        _add_red(red_bc, c, st.csp_n, G * DEC_KS, DEC_KS, G, DEC_KS, dWs[g], DEC_KS, alpha=g_loss)
                 _run_red(red_bc)
                 if side is not cur:
                     bc_done = torch.cuda.Event()
