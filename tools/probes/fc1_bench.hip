@@ -12,7 +12,7 @@
 using namespace spv;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
-static unsigned short f2bf_host(float f) { unsigned u; std::memcpy(&u, &f, 4); u += 0x7FFF + ((u >> 16) & 1); return (unsigned short)(u >> 16); }
+static unsigned short f2bf_host(float f) { _Float16 hv = (_Float16)f; unsigned short u; std::memcpy(&u, &hv, 2); return u; }   // (f16 words: the kernels multiply with the f16 MFMA)
 template <typename T> static T* dalloc(size_t n) { T* p; CK(hipMalloc(&p, n * sizeof(T))); CK(hipMemset(p, 0, n * sizeof(T))); return p; }
 template <typename T> static T* upload(const std::vector<T>& v) { T* p = dalloc<T>(v.size()); CK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice)); return p; }
 
@@ -22,7 +22,7 @@ __global__ void naive_kernel(const unsigned short* A, long lda, const int* rows,
   const unsigned short* a = A + (long)rows[m] * lda;
   const unsigned short* w = W + (long)n * ldw;
   float s = 0.f;
-  for (int k = 0; k < K; ++k) s += bf2f(a[k]) * bf2f(w[k]);
+  for (int k = 0; k < K; ++k) s += h2f(a[k]) * h2f(w[k]);
   out[(long)m * N + n] = fmaxf(s, 0.f);
 }
 
@@ -45,18 +45,33 @@ int main(int argc, char** argv) {
   std::vector<float> bias(N1, 0.f), lib_all(NCELLS, 1.f);
   unsigned short* dA = upload(A); unsigned short* dW = upload(W); int* drows = upload(rows);
   float* dbias = upload(bias); float* dlib = upload(lib_all);
-  const int mtiles = (B + F1_BM - 1) / F1_BM;
+  const int use256 = 0;   // (a 256-cell-tile variant was measured in round 3 and dropped: docs/lab_notes.md D)
+  const int pair = getenv("F1_PAIR") ? atoi(getenv("F1_PAIR")) : 0;   // two groups' worth of workgroups in one grid (the second group = the same operands)
+  const int BMv = F1_BM;
+  const int mtiles = (B + BMv - 1) / BMv;
   const int ktiles = (G + F1_BK - 1) / F1_BK;
   if (splits <= 0) splits = std::max(1, std::min(16, std::min(256 / mtiles, ktiles / 4)));
-  const long slab_elems = (long)mtiles * F1_BM * F1_BN;
+  const long slab_elems = (long)mtiles * BMv * F1_BN;
   float* slabs = dalloc<float>((size_t)splits * slab_elems);
   float* h1 = dalloc<float>((size_t)B * N1); float* lib = dalloc<float>(B); float* ref = dalloc<float>((size_t)B * N1);
   GemmParams p{};
   p.A = dA; p.lda = lda; p.rows = drows; p.B = dW; p.ldb = ldw; p.C = slabs; p.M = B; p.N = N1; p.K = G;
   p.k_per_split = ((ktiles + splits - 1) / splits) * F1_BK; p.c_split_row = splits;
+  GemmParams p2 = p;   // the pair's second group: its own count image, rows, weights and slabs (same values, different memory)
+  if (pair) {
+    unsigned short* dA2 = dalloc<unsigned short>(A.size()); CK(hipMemcpy(dA2, dA, A.size() * 2, hipMemcpyDeviceToDevice));
+    unsigned short* dW2 = dalloc<unsigned short>(W.size()); CK(hipMemcpy(dW2, dW, W.size() * 2, hipMemcpyDeviceToDevice));
+    std::vector<int> rows2(B);
+    for (auto& r : rows2) r = (int)(uni(rng) * (distinct - 1));
+    p2.A = dA2; p2.B = dW2; p2.rows = upload(rows2); p2.C = dalloc<float>((size_t)splits * slab_elems);
+  }
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(fc1_fwd_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F1_LDS_BYTES));
-  auto gemm = [&]() { hipLaunchKernelGGL(fc1_fwd_dma_kernel, dim3(mtiles * splits), dim3(512), F1_LDS_BYTES, 0, p); };
-  auto epi = [&]() { hipLaunchKernelGGL(fc1_epilogue_tiled_kernel, dim3((unsigned)((slab_elems / 4 + 255) / 256)), dim3(256), 0, 0, slabs, splits, slab_elems, B, 256, dbias, (const float*)nullptr, 0, h1, lib, dlib, drows); };
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(fc1_fwd_dma_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F1_LDS_BYTES));
+  auto gemm = [&]() {
+    const int n = mtiles * splits;
+    { if (pair) hipLaunchKernelGGL(fc1_fwd_dma_pair_kernel, dim3(2 * n), dim3(512), F1_LDS_BYTES, 0, p, p2, n); else hipLaunchKernelGGL(fc1_fwd_dma_kernel, dim3(n), dim3(512), F1_LDS_BYTES, 0, p); }
+  };
+  auto epi = [&]() { hipLaunchKernelGGL(fc1_epilogue_tiled_kernel, dim3((unsigned)((slab_elems / 4 + 255) / 256)), dim3(256), 0, 0, slabs, splits, slab_elems, B, 256, dbias, (const float*)nullptr, 0, h1, lib, dlib, drows, 1.0f); };
   gemm(); epi();
   CK(hipDeviceSynchronize());
   hipLaunchKernelGGL(naive_kernel, dim3((N1 + 255) / 256, B), dim3(256), 0, 0, dA, lda, drows, dW, ldw, B, N1, G, ref);
@@ -66,7 +81,7 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(hr.data(), ref, hr.size() * 4, hipMemcpyDeviceToHost));
   double maxerr = 0, maxref = 0; size_t bad = 0;
   for (size_t i = 0; i < hh.size(); ++i) { const double e = fabs((double)hh[i] - hr[i]); maxerr = std::max(maxerr, e); maxref = std::max(maxref, (double)fabs(hr[i])); if (e > 1e-3 + 1e-3 * fabs(hr[i])) ++bad; }
-  printf("fc1_fwd_dma B=%d G=%d splits=%d grid=%dx%d: max |err| %.3e (max |ref| %.3e), %zu of %zu outside tolerance\n", B, G, splits, mtiles, splits, maxerr, maxref, bad, hh.size());
+  printf("fc1_fwd_dma%s%s B=%d G=%d splits=%d grid=%dx%d: max |err| %.3e (max |ref| %.3e), %zu of %zu outside tolerance\n", use256 ? "256" : "128", pair ? " pair" : "", B, G, splits, mtiles, splits, maxerr, maxref, bad, hh.size());
   hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
   const int reps = 50;
   for (int i = 0; i < 5; ++i) { gemm(); epi(); }
@@ -76,8 +91,8 @@ int main(int argc, char** argv) {
   for (int i = 0; i < reps; ++i) epi();
   CK(hipEventRecord(e2)); CK(hipEventSynchronize(e2));
   float ms1, ms2; CK(hipEventElapsedTime(&ms1, e0, e1)); CK(hipEventElapsedTime(&ms2, e1, e2));
-  const double us1 = ms1 * 1e3 / reps, us2 = ms2 * 1e3 / reps, fl = 2.0 * B * (double)G * N1;
-  printf("  gemm %.1f us (%.0f TFLOP/s = %.1f %% of 2500; A stream %.2f TB/s)   epilogue %.1f us   total %.1f us\n", us1, fl / us1 / 1e6, fl / us1 / 1e6 / 25.0,
-         (double)B * G * 2 / us1 / 1e6, us2, us1 + us2);
+  const double us1 = ms1 * 1e3 / reps, us2 = ms2 * 1e3 / reps, fl = 2.0 * B * (double)G * N1 * (pair ? 2 : 1);
+  printf("  gemm %.1f us (%.0f TFLOP/s = %.1f %% of 2500; A stream %.2f TB/s)   epilogue %.1f us\n", us1, fl / us1 / 1e6, fl / us1 / 1e6 / 25.0,
+         (double)B * G * 2 * (pair ? 2 : 1) / us1 / 1e6, us2);
   return bad ? 1 : 0;
 }
