@@ -93,12 +93,17 @@ int spv_enc_fc1_fwd_uses_dma(int32_t B, int32_t G, int32_t N1, int32_t nsplit, i
  *   h1       : fp32 [B][N1];  library: fp32 [B]
  *   xb_all, library_all : optional (nsplit 1 only): f16(log1p(x)) of the WHOLE resident count matrix [n_cells][ld_xb] (zero
  *              padded to ld_xb >= round_up(G, 128)) and log(sum_g log1p(x)) per cell, both from spv_prepare_log1p; the GEMM
- *              then gathers plain bf16 rows through x->rows instead of decoding counts, and library is a table lookup */
+ *              then gathers plain bf16 rows through x->rows instead of decoding counts, and library is a table lookup
+ *   cov, cov_idx : optional (both or neither): one-hot batch covariates appended to the layer's input (nn/networks.py:105-119,
+ *              module/spVIPESmodule.py:133,440-445) as what they amount to: cov fp32 [n_batch][N1] = the weight columns of the
+ *              covariates, transposed, both encoders side by side; cov_idx int32 [B] = the batch code of every minibatch cell;
+ *              cov[cov_idx[b]][:] is added before the ReLU */
 int spv_enc_fc1_fwd(const spv_counts* x, int32_t B, int32_t G,
                     const uint16_t* W1_hi, const uint16_t* W1_lo, int64_t ldw, int32_t N1,
                     const float* bias, const float* bias2, int32_t n_first, int32_t nsplit, int32_t splits,
                     float* slabs, float* rowsum_ws, float* h1, float* library,
-                    const uint16_t* xb_all, int64_t ld_xb, const float* library_all, void* stream);
+                    const uint16_t* xb_all, int64_t ld_xb, const float* library_all,
+                    const float* cov, const int32_t* cov_idx, void* stream);
 
 /* Once per resident count matrix: xb[c][g] = f16(log1p(X[c][g])) (zero for g >= G, row pitch ld_xb) and
  * library[c] = log(sum_g log1p(X[c][g])) (module/spVIPESmodule.py:428-435 evaluated for every cell of the data set).
@@ -137,6 +142,7 @@ typedef struct spv_fc1_fwd_args {
   const float* bias; const float* bias2; int32_t n_first, nsplit, splits;
   float* slabs; float* rowsum_ws; float* h1; float* library;
   const uint16_t* xb_all; int64_t ld_xb; const float* library_all;
+  const float* cov; const int32_t* cov_idx;   /* optional batch covariates (see spv_enc_fc1_fwd) */
 } spv_fc1_fwd_args;
 int spv_enc_fc1_fwd_grouped(const spv_fc1_fwd_args* groups, int32_t n_groups, void* stream);
 

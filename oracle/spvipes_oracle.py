@@ -81,35 +81,39 @@ def init_state_dict(
     n_dimensions_private: int = 10,
     n_hidden_mix: int = 256,
     seed: int = 0,
+    n_batch: int = 0,
 ) -> SD:
     """A state_dict with the reference's key names and init distributions
     (spVIPESmodule.py:118-175; nn/networks.py:66-83,200-262).  The random stream
-    differs from the reference's; parity tests always load explicit weights."""
+    differs from the reference's; parity tests always load explicit weights.
+    ``n_batch`` > 1 widens every layer that takes covariates by n_batch input
+    columns (spVIPESmodule.py:132-133; nn/networks.py:60-68; scvi FCLayers)."""
     gen = torch.Generator().manual_seed(seed)
     sd: SD = {}
     n_s, n_p = n_dimensions_shared, n_dimensions_private
+    nc = n_batch if n_batch > 1 else 0
     for g, G in enumerate(groups_lengths):
         sd[f"px_r.{g}"] = torch.randn(G, generator=gen)
     for g, G in enumerate(groups_lengths):
         for kind, n_out in (("shared", n_s), ("private", n_p)):
             p = f"encoder_{g}_{kind}"
-            sd[p + ".fc1.weight"], sd[p + ".fc1.bias"] = _linear_init(n_hidden, G, True, gen)
+            sd[p + ".fc1.weight"], sd[p + ".fc1.bias"] = _linear_init(n_hidden, G + nc, True, gen)
             sd[p + ".fc2.weight"], sd[p + ".fc2.bias"] = _linear_init(n_hidden, n_hidden, True, gen)
             for head in ("mu_encoder", "lvar_encoder"):
                 sd[f"{p}.{head}.0.weight"], sd[f"{p}.{head}.0.bias"] = _linear_init(n_out, n_hidden, True, gen)
                 _bn_init(sd, f"{p}.{head}.1", n_out)
         d = f"decoder_{g}"
         L = "fc_layers.Layer 0"
-        sd[f"{d}.factor_regressor_private.{L}.0.weight"], _ = _linear_init(G, n_p, False, gen)
+        sd[f"{d}.factor_regressor_private.{L}.0.weight"], _ = _linear_init(G, n_p + nc, False, gen)
         _bn_init(sd, f"{d}.factor_regressor_private.{L}.1", G)
-        sd[f"{d}.factor_regressor_shared.{L}.0.weight"], _ = _linear_init(G, n_s, False, gen)
+        sd[f"{d}.factor_regressor_shared.{L}.0.weight"], _ = _linear_init(G, n_s + nc, False, gen)
         _bn_init(sd, f"{d}.factor_regressor_shared.{L}.1", G)
         sd[f"{d}.sigmoid_decoder.{L}.0.weight"], sd[f"{d}.sigmoid_decoder.{L}.0.bias"] = _linear_init(
-            n_hidden_mix, n_s + n_p, True, gen
+            n_hidden_mix, n_s + n_p + nc, True, gen
         )
         _bn_init(sd, f"{d}.sigmoid_decoder.{L}.1", n_hidden_mix)
         sd[f"{d}.mixture.{L}.0.weight"], sd[f"{d}.mixture.{L}.0.bias"] = _linear_init(
-            G, n_hidden_mix + n_s + n_p, True, gen
+            G, n_hidden_mix + n_s + n_p + nc, True, gen
         )
     return sd
 
@@ -146,10 +150,14 @@ def encoder_forward(
     dropout_rate: float = 0.0,
     dropout_mask: Optional[Tensor] = None,
     new_stats: Optional[dict] = None,
+    one_hot: Optional[Tensor] = None,
 ) -> Dict[str, Tensor]:
-    """nn/networks.py:85-140 without covariates (n_batch<=1 collapses cat_list, :62).
+    """nn/networks.py:85-140 (n_batch<=1 collapses cat_list, :62; else ``one_hot`` [B, n_batch]
+    is appended to the input of fc1, :105-119).
     ``eps`` is the standard-normal draw consumed by ``qz.rsample()`` (:128).
     ``dropout_mask`` is the keep-mask (1=keep) of ``self.drop`` (:121) in training."""
+    if one_hot is not None:
+        x = torch.cat((x, one_hot), dim=-1)  # :118
     h = F.relu(F.linear(x, sd[prefix + ".fc1.weight"], sd[prefix + ".fc1.bias"]))
     h = F.relu(F.linear(h, sd[prefix + ".fc2.weight"], sd[prefix + ".fc2.bias"]))
     if training and dropout_rate > 0:
@@ -339,30 +347,33 @@ def kl_normal_std(loc: Tensor, scale: Tensor) -> Tensor:
 
 def decoder_forward(
     sd: SD, prefix: str, z_private: Tensor, z_shared: Tensor, library: Tensor, training: bool,
-    new_stats: Optional[dict] = None,
+    new_stats: Optional[dict] = None, one_hot: Optional[Tensor] = None,
 ) -> Tuple[Tensor, Tensor, Tensor]:
     """nn/networks.py:314-325 (the dead px_scale/mixing lines :327-328 are skipped).
-    Returns (px_rate_private, px_rate_shared, px_mixing logits)."""
+    Returns (px_rate_private, px_rate_shared, px_mixing logits).
+    ``one_hot`` [B, n_batch]: every one of the four FCLayers sees cat(input, one_hot)
+    (scvi FCLayers.forward with n_cat_list=[n_batch], inject into the single layer)."""
     L = "fc_layers.Layer 0"
+    cov = (lambda t: t) if one_hot is None else (lambda t: torch.cat((t, one_hot), dim=-1))
     raw_p = batch_norm(
-        F.linear(z_private, sd[f"{prefix}.factor_regressor_private.{L}.0.weight"]),
+        F.linear(cov(z_private), sd[f"{prefix}.factor_regressor_private.{L}.0.weight"]),
         sd, f"{prefix}.factor_regressor_private.{L}.1", training, new_stats=new_stats, **BN_DEC,
     )
     rate_p = torch.exp(library) * torch.softmax(raw_p, dim=-1)
     raw_s = batch_norm(
-        F.linear(z_shared, sd[f"{prefix}.factor_regressor_shared.{L}.0.weight"]),
+        F.linear(cov(z_shared), sd[f"{prefix}.factor_regressor_shared.{L}.0.weight"]),
         sd, f"{prefix}.factor_regressor_shared.{L}.1", training, new_stats=new_stats, **BN_DEC,
     )
     rate_s = torch.exp(library) * torch.softmax(raw_s, dim=-1)
     zcat = torch.cat([z_private, z_shared], dim=1)
     m = F.relu(
         batch_norm(
-            F.linear(zcat, sd[f"{prefix}.sigmoid_decoder.{L}.0.weight"], sd[f"{prefix}.sigmoid_decoder.{L}.0.bias"]),
+            F.linear(cov(zcat), sd[f"{prefix}.sigmoid_decoder.{L}.0.weight"], sd[f"{prefix}.sigmoid_decoder.{L}.0.bias"]),
             sd, f"{prefix}.sigmoid_decoder.{L}.1", training, new_stats=new_stats, **BN_DEC,
         )
     )
     logits = F.linear(
-        torch.cat([m, zcat], dim=-1), sd[f"{prefix}.mixture.{L}.0.weight"], sd[f"{prefix}.mixture.{L}.0.bias"]
+        cov(torch.cat([m, zcat], dim=-1)), sd[f"{prefix}.mixture.{L}.0.weight"], sd[f"{prefix}.mixture.{L}.0.bias"]
     )
     return rate_p, rate_s, logits
 
@@ -407,6 +418,8 @@ def forward_loss(
     dropout_rate: float = 0.0,
     dropout_masks: Optional[Dict[str, Tensor]] = None,
     update_running_stats: bool = False,
+    batch_index: Optional[Sequence[Tensor]] = None,
+    n_batch: int = 0,
 ) -> Dict[str, object]:
     """One pass of inference -> generative -> loss for two groups.
 
@@ -415,8 +428,13 @@ def forward_loss(
     noise      : standard-normal draws: "enc_{g}_private", "enc_{g}_shared" [B_g, n],
                  "poe_{g}" [B_g, n_s].
     mode       : "label" (A4a) | "paired" (A4b) | "cluster" (A4c).
+    batch_index: with n_batch > 1, the integer batch code of every cell of every group
+                 (one-hot encoded and appended to the covariate-taking layers' inputs).
     """
     n_s, n_p = n_dimensions_shared, n_dimensions_private
+    one_hot = [None, None]
+    if n_batch > 1:
+        one_hot = [F.one_hot(b.flatten().long(), n_batch).to(torch.float32) for b in batch_index]
     new_stats: Optional[dict] = {} if (training and update_running_stats) else None
     x = [torch.log(1 + c) for c in counts]  # :432-433
     library = [torch.log(xs.sum(1)).unsqueeze(1) for xs in x]  # :435 (of the log1p'd values)
@@ -427,7 +445,7 @@ def forward_loss(
             store.append(
                 encoder_forward(
                     sd, f"encoder_{g}_{kind}", x[g], noise[f"enc_{g}_{kind}"], training,
-                    dropout_rate=dropout_rate, dropout_mask=dm, new_stats=new_stats,
+                    dropout_rate=dropout_rate, dropout_mask=dm, new_stats=new_stats, one_hot=one_hot[g],
                 )
             )
     if mode == "label":
@@ -447,7 +465,7 @@ def forward_loss(
     for g in range(2):
         z_private, z_shared = split_latents(private[g]["log_z"], poe[g]["logtheta_log_z"], n_s, n_p)
         rate_p, rate_s, logits = decoder_forward(
-            sd, f"decoder_{g}", z_private, z_shared, library[g], training, new_stats=new_stats
+            sd, f"decoder_{g}", z_private, z_shared, library[g], training, new_stats=new_stats, one_hot=one_hot[g]
         )
         px_r = torch.exp(sd[f"px_r.{g}"])  # :758
         logp = log_mixture_nb(x[g], rate_p, rate_s, px_r, logits)  # evaluated at x = log1p(count), :818-824
@@ -478,7 +496,7 @@ def param_names(sd: SD) -> List[str]:
     return [k for k in sd if not (k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked"))]
 
 
-def get_loadings(sd: SD, dataset: int, type_latent: str, eps: float = 1e-3) -> Tensor:
+def get_loadings(sd: SD, dataset: int, type_latent: str, eps: float = 1e-3, n_batch: int = 0) -> Tensor:
     """spVIPESmodule.get_loadings (spVIPESmodule.py:773-807): diag(gamma / sqrt(running_var + eps)) @ W of one factor
     regressor ([genes, latent dims]); the BatchNorm eps is the scvi FCLayers value 1e-3."""
     if type_latent not in ["shared", "private"]:
@@ -486,4 +504,5 @@ def get_loadings(sd: SD, dataset: int, type_latent: str, eps: float = 1e-3) -> T
     L = "fc_layers.Layer 0"
     pre = f"decoder_{dataset}.factor_regressor_{type_latent}.{L}"
     b = sd[pre + ".1.weight"] / torch.sqrt(sd[pre + ".1.running_var"] + eps)
-    return torch.matmul(torch.diag(b), sd[pre + ".0.weight"]).detach()
+    loadings = torch.matmul(torch.diag(b), sd[pre + ".0.weight"]).detach()
+    return loadings[:, :-n_batch] if n_batch > 1 else loadings  # :804-805 (the covariate columns)

@@ -106,7 +106,7 @@ class SpvFc1FwdArgs(C.Structure):
     _fields_ = [("x", C.POINTER(SpvCounts)), ("B", C.c_int32), ("G", C.c_int32), ("W1_hi", C.c_void_p), ("W1_lo", C.c_void_p), ("ldw", C.c_int64),
                 ("N1", C.c_int32), ("bias", C.c_void_p), ("bias2", C.c_void_p), ("n_first", C.c_int32), ("nsplit", C.c_int32), ("splits", C.c_int32),
                 ("slabs", C.c_void_p), ("rowsum_ws", C.c_void_p), ("h1", C.c_void_p), ("library", C.c_void_p), ("xb_all", C.c_void_p),
-                ("ld_xb", C.c_int64), ("library_all", C.c_void_p)]
+                ("ld_xb", C.c_int64), ("library_all", C.c_void_p), ("cov", C.c_void_p), ("cov_idx", C.c_void_p)]
 
 
 class SpvFc1BwdArgs(C.Structure):
@@ -188,7 +188,7 @@ _SIGNATURES = {
     "spv_enc_fc1_fwd_uses_dma": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64]),
     "spv_enc_fc1_fwd": (C.c_int, [C.POINTER(SpvCounts), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                   C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                  C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+                                  C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "spv_enc_fc1_fwd_grouped": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "spv_enc_fc1_bwd_grouped": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "spv_prepare_log1p": (C.c_int, [C.POINTER(SpvCounts), C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -137,15 +137,16 @@ extern "C" int spv_pack_f16(const float* src, int64_t ld_src, int32_t R, int32_t
 // ---------------------------------------------------------------------------------------------
 __global__ void fc1_epilogue_kernel(const float* slabs, const float* rowsum_ws, int splits, int B, int N1, const float* bias,
                                     const float* bias2, int n_first, float* h1, float* library, const float* library_all,
-                                    const int* rows, float acc_scale) {
+                                    const int* rows, float acc_scale, const float* cov, const int* cov_idx) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)B * N1;
   if (idx < total) {
     const int col = (int)(idx % N1);
     const float bv = (bias2 != nullptr && col >= n_first) ? bias2[col - n_first] : bias[col];
+    const float cv = cov ? cov[(long)cov_idx[idx / N1] * N1 + col] : 0.f;   // one-hot batch covariates (nn/networks.py:105-119): a per-cell bias row
     float v = 0.f;
     for (int s = 0; s < splits; ++s) v += slabs[(long)s * total + idx];
-    h1[idx] = fmaxf(v * acc_scale + bv, 0.f);  // relu(fc1(x)), nn/networks.py:119
+    h1[idx] = fmaxf(v * acc_scale + bv + cv, 0.f);  // relu(fc1(x)), nn/networks.py:119
   }
   if (idx < B) {
     if (library_all != nullptr) {  // precomputed per cell of the data set (spv_prepare_log1p)
@@ -188,8 +189,9 @@ static int fc1_bn(int N1) { return N1 <= 32 ? 32 : (N1 <= 128 ? 128 : 256); }
 extern "C" int spv_enc_fc1_fwd(const spv_counts* x, int32_t B, int32_t G, const uint16_t* W1_hi, const uint16_t* W1_lo,
                                int64_t ldw, int32_t N1, const float* bias, const float* bias2, int32_t n_first, int32_t nsplit,
                                int32_t splits, float* slabs, float* rowsum_ws, float* h1, float* library, const uint16_t* xb_all,
-                               int64_t ld_xb, const float* library_all, void* stream) {
+                               int64_t ld_xb, const float* library_all, const float* cov, const int32_t* cov_idx, void* stream) {
   if (!x || !x->X || !W1_hi || !bias || !slabs || !rowsum_ws || !h1 || !library) return fail(SPV_ERR_ARG, "spv_enc_fc1_fwd: null pointer%s");
+  if ((cov == nullptr) != (cov_idx == nullptr)) return fail(SPV_ERR_ARG, "spv_enc_fc1_fwd: cov and cov_idx go together%s");
   if (B <= 0 || G <= 0 || N1 <= 0 || splits <= 0 || (ldw % 32) != 0 || ldw < ((G + 31) & ~31)) return fail(SPV_ERR_ARG, "spv_enc_fc1_fwd: bad shape%s");
   if (nsplit != 1 && nsplit != 3) return fail(SPV_ERR_ARG, "spv_enc_fc1_fwd: nsplit must be 1 or 3%s");
   if (nsplit == 3 && !W1_lo) return fail(SPV_ERR_ARG, "spv_enc_fc1_fwd: nsplit=3 needs W1_lo%s");
@@ -227,7 +229,7 @@ extern "C" int spv_enc_fc1_fwd(const spv_counts* x, int32_t B, int32_t G, const 
     if (hipGetLastError() != hipSuccess) return launch_status("spv_enc_fc1_fwd dma gemm");
     const long slab_elems = (long)mtiles * F1_BM * N1;
     hipLaunchKernelGGL(fc1_epilogue_tiled_kernel, dim3((unsigned)((slab_elems / 4 + 255) / 256)), dim3(256), 0, s, slabs, splits, slab_elems, B, N1, bias, bias2, n_first, h1, library,
-                       library_all, x->rows, acc_scale);
+                       library_all, x->rows, acc_scale, cov, cov_idx);
     return launch_status("spv_enc_fc1_fwd dma epilogue");
   }
   if (xb_all != nullptr) {
@@ -239,7 +241,7 @@ extern "C" int spv_enc_fc1_fwd(const spv_counts* x, int32_t B, int32_t G, const 
   else return fail(SPV_ERR_ARG, "spv_enc_fc1_fwd: unknown count dtype%s");
   if (rc != SPV_OK) return launch_status("spv_enc_fc1_fwd gemm");
   const long total = (long)B * N1;
-  hipLaunchKernelGGL(fc1_epilogue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, slabs, rowsum_ws, splits, B, N1, bias, bias2, n_first, h1, library, xb_all ? library_all : nullptr, x->rows, acc_scale);
+  hipLaunchKernelGGL(fc1_epilogue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, slabs, rowsum_ws, splits, B, N1, bias, bias2, n_first, h1, library, xb_all ? library_all : nullptr, x->rows, acc_scale, cov, cov_idx);
   return launch_status("spv_enc_fc1_fwd epilogue");
 }
 
@@ -1298,8 +1300,8 @@ extern "C" int spv_enc_fc1_fwd_grouped(const spv_fc1_fwd_args* g, int32_t n_grou
     hipLaunchKernelGGL(fc1_fwd_dma_pair_kernel, dim3(mt0 * a.splits + mt1 * b.splits, a.N1 / F1_BN), dim3(512), F1_LDS_BYTES, s, p0, p1, mt0 * a.splits);
     if (hipGetLastError() != hipSuccess) return launch_status("spv_enc_fc1_fwd_grouped gemm");
     const long se0 = (long)mt0 * F1_BM * a.N1, se1 = (long)mt1 * F1_BM * b.N1;
-    const Fc1EpiArgs e0{a.slabs, a.splits, se0, a.B, a.N1, a.bias, a.bias2, a.n_first, a.h1, a.library, a.library_all, a.x->rows, 1.0f / SPV_FC1_W_SCALE};
-    const Fc1EpiArgs e1{b.slabs, b.splits, se1, b.B, b.N1, b.bias, b.bias2, b.n_first, b.h1, b.library, b.library_all, b.x->rows, 1.0f / SPV_FC1_W_SCALE};
+    const Fc1EpiArgs e0{a.slabs, a.splits, se0, a.B, a.N1, a.bias, a.bias2, a.n_first, a.h1, a.library, a.library_all, a.x->rows, 1.0f / SPV_FC1_W_SCALE, a.cov, a.cov_idx};
+    const Fc1EpiArgs e1{b.slabs, b.splits, se1, b.B, b.N1, b.bias, b.bias2, b.n_first, b.h1, b.library, b.library_all, b.x->rows, 1.0f / SPV_FC1_W_SCALE, b.cov, b.cov_idx};
     const long sem = se0 > se1 ? se0 : se1;
     hipLaunchKernelGGL(fc1_epilogue_tiled_pair_kernel, dim3((unsigned)((sem / 4 + 255) / 256), 2), dim3(256), 0, s, e0, e1);
     if (hipGetLastError() != hipSuccess) return launch_status("spv_enc_fc1_fwd_grouped epilogue");
@@ -1307,7 +1309,7 @@ extern "C" int spv_enc_fc1_fwd_grouped(const spv_fc1_fwd_args* g, int32_t n_grou
   for (; i < n_groups; ++i) {   // a leftover group, or shapes the LDS-DMA kernel does not take: the per-group entry point
     const spv_fc1_fwd_args& a = g[i];
     const int rc = spv_enc_fc1_fwd(a.x, a.B, a.G, a.W1_hi, a.W1_lo, a.ldw, a.N1, a.bias, a.bias2, a.n_first, a.nsplit, a.splits, a.slabs, a.rowsum_ws, a.h1,
-                                   a.library, a.xb_all, a.ld_xb, a.library_all, stream);
+                                   a.library, a.xb_all, a.ld_xb, a.library_all, a.cov, a.cov_idx, stream);
     if (rc != SPV_OK) return rc;
   }
   return SPV_OK;

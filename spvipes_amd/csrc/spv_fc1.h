@@ -205,10 +205,11 @@ __global__ __launch_bounds__(512) void fc1_fwd_dma_pair_kernel(GemmParams p0, Ge
 // h1[cell][col] = relu(bias[col] + sum_splits S[split][...]), library from the data set's table (spv_prepare_log1p).
 // One thread per (tile, qq, lane): 16 bytes of every split's slab in, four floats (rows jj + 8 qq + 4 h of the tile) out.
 struct Fc1EpiArgs { const float* slabs; int splits; long slab_elems; int M; int N1; const float* bias; const float* bias2; int n_first; float* h1; float* library;
-                    const float* library_all; const int* rows; float acc_scale; };
+                    const float* library_all; const int* rows; float acc_scale; const float* cov; const int* cov_idx; };
 __device__ __forceinline__ void fc1_epilogue_tiled_body(const float* slabs, int splits, long slab_elems, int M, const int N1, const float* bias,
                                                         const float* bias2, int n_first, float* h1, float* library,
-                                                        const float* library_all, const int* rows, const float acc_scale) {
+                                                        const float* library_all, const int* rows, const float acc_scale,
+                                                        const float* cov, const int* cov_idx) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // float4 index inside one slab
   if (idx * 4 < slab_elems) {
     const long tile = idx >> 8;
@@ -225,18 +226,23 @@ __device__ __forceinline__ void fc1_epilogue_tiled_body(const float* slabs, int 
     const long row0 = tm * 32 + 8 * qq + 4 * h;
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj)
-      if (row0 + jj < M) h1[(row0 + jj) * N1 + col] = fmaxf(s[jj] * acc_scale + bv, 0.f);   // relu(fc1(x)), nn/networks.py:119
+      if (row0 + jj < M) {
+        // one-hot batch covariates appended to the layer's input (nn/networks.py:105-119) = one more per-cell bias row: cov[batch][col]
+        const float cv = cov ? cov[(long)cov_idx[row0 + jj] * N1 + col] : 0.f;
+        h1[(row0 + jj) * N1 + col] = fmaxf(s[jj] * acc_scale + bv + cv, 0.f);   // relu(fc1(x)), nn/networks.py:119
+      }
   }
   if (idx < M) library[idx] = library_all[rows ? rows[idx] : (int)idx];   // log(sum_g log1p(x)), module/spVIPESmodule.py:435
 }
 __global__ __launch_bounds__(256) void fc1_epilogue_tiled_kernel(const float* slabs, int splits, long slab_elems, int M, int N1, const float* bias,
                                                                  const float* bias2, int n_first, float* h1, float* library,
-                                                                 const float* library_all, const int* rows, float acc_scale) {
-  fc1_epilogue_tiled_body(slabs, splits, slab_elems, M, N1, bias, bias2, n_first, h1, library, library_all, rows, acc_scale);
+                                                                 const float* library_all, const int* rows, float acc_scale,
+                                                                 const float* cov, const int* cov_idx) {
+  fc1_epilogue_tiled_body(slabs, splits, slab_elems, M, N1, bias, bias2, n_first, h1, library, library_all, rows, acc_scale, cov, cov_idx);
 }
 __global__ __launch_bounds__(256) void fc1_epilogue_tiled_pair_kernel(Fc1EpiArgs a0, Fc1EpiArgs a1) {   // blockIdx.y = group
   const Fc1EpiArgs a = blockIdx.y ? a1 : a0;
-  fc1_epilogue_tiled_body(a.slabs, a.splits, a.slab_elems, a.M, a.N1, a.bias, a.bias2, a.n_first, a.h1, a.library, a.library_all, a.rows, a.acc_scale);
+  fc1_epilogue_tiled_body(a.slabs, a.splits, a.slab_elems, a.M, a.N1, a.bias, a.bias2, a.n_first, a.h1, a.library, a.library_all, a.rows, a.acc_scale, a.cov, a.cov_idx);
 }
 
 // ---- fc1 weight gradient:  dW[n1][gene] = sum_cell dh[cell][n1] * log1p(X)[rows[cell]][gene]   (backward of nn/networks.py:119) -------

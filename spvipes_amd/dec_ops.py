@@ -578,7 +578,7 @@ class DecoderFused(torch.autograd.Function):
 
 @torch.no_grad()
 def materialize_decoder(decoder, px_r: torch.Tensor, private_log_z: torch.Tensor, poe_log_z: torch.Tensor, library: torch.Tensor,
-                        training: bool, nsplit: int, ws: Workspace) -> dict:
+                        training: bool, nsplit: int, ws: Workspace, par=None) -> dict:
     """The decoder outputs the reference's ``generative`` returns for ONE group (module/spVIPESmodule.py:751-768,
     nn/networks.py:314-325): {"px_scale_private", "px_scale_shared", "px_rate_private", "px_rate_shared", "px_mixing"}
     as fp32 [B, G] tensors + "px_r" = exp(px_r).  The training step never needs them (the fused likelihood kernel consumes
@@ -587,7 +587,7 @@ def materialize_decoder(decoder, px_r: torch.Tensor, private_log_z: torch.Tensor
     momentum 0), mixing trunk, logits GEMM, softmax statistics -- and then ``spv_dec_materialize``."""
     dev = private_log_z.device
     cont = lambda t: t if (t.is_contiguous() and t.dtype == torch.float32) else t.contiguous().float()
-    par = decoder_params(decoder, px_r)
+    par = list(par) if par is not None else decoder_params(decoder, px_r)   # (``par``: spVIPESmodule._decoder_operands' covariate-extended set)
     pz, qz = cont(private_log_z), cont(poe_log_z)
     B, n_p, n_s = pz.shape[0], pz.shape[1], qz.shape[1]
     nt = n_p + n_s

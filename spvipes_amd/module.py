@@ -107,14 +107,42 @@ class _FC1(nn.Module):
 
 
 class LinearDecoderSPVIPE(nn.Module):
-    """Parameters of nn/networks.py:185-262."""
+    """Parameters of nn/networks.py:185-262.  ``n_cov``: one-hot batch covariate columns every layer's input is extended by
+    (scvi FCLayers with n_cat_list=[n_batch], inject_covariates: the layer sees cat(x, one_hot(batch)))."""
 
-    def __init__(self, n_input_private: int, n_input_shared: int, n_output: int, n_hidden: int = N_HIDDEN_MIX):
+    def __init__(self, n_input_private: int, n_input_shared: int, n_output: int, n_hidden: int = N_HIDDEN_MIX, n_cov: int = 0):
         super().__init__()
-        self.factor_regressor_private = _FC1(n_input_private, n_output, bias=False, batch_norm=True)
-        self.factor_regressor_shared = _FC1(n_input_shared, n_output, bias=False, batch_norm=True)
-        self.sigmoid_decoder = _FC1(n_input_shared + n_input_private, n_hidden, bias=True, batch_norm=True)
-        self.mixture = _FC1(n_hidden + n_input_shared + n_input_private, n_output, bias=True, batch_norm=False)
+        self.factor_regressor_private = _FC1(n_input_private + n_cov, n_output, bias=False, batch_norm=True)
+        self.factor_regressor_shared = _FC1(n_input_shared + n_cov, n_output, bias=False, batch_norm=True)
+        self.sigmoid_decoder = _FC1(n_input_shared + n_input_private + n_cov, n_hidden, bias=True, batch_norm=True)
+        self.mixture = _FC1(n_hidden + n_input_shared + n_input_private + n_cov, n_output, bias=True, batch_norm=False)
+
+
+class CovariateColumns(torch.autograd.Function):
+    """W [R][b + n_cov] (reference column order: ..., columns a..b-1, then the n_cov covariate columns) -> the column order the
+    fused decoder contracts against, [W[:, :a] | covariates | W[:, a:b] | n_cov zero columns]: the decoder op sees the covariates
+    as n_cov extra latent dimensions behind z_private AND behind z_shared (spVIPESmodule.loss), a layer that reads both gets the
+    second copy with zero weights.  The backward pass writes the parameter's gradient buffer itself when the trainer's gradient
+    sink is on (nn_ops.grad_out), like every other parameter-gradient kernel of the step."""
+
+    @staticmethod
+    def forward(ctx, W, a: int, b: int):
+        n_cov = W.shape[1] - b
+        ctx.dims = (a, b, n_cov)
+        ctx.save_for_backward(W)
+        return torch.cat([W[:, :a], W[:, b:], W[:, a:b], W.new_zeros(W.shape[0], n_cov)], 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        from .nn_ops import grad_out
+
+        (W,) = ctx.saved_tensors
+        a, b, n_cov = ctx.dims
+        dst, ret = grad_out(W)
+        dst[:, :a].copy_(g[:, :a])
+        dst[:, a:b].copy_(g[:, a + n_cov: b + n_cov])
+        dst[:, b:].copy_(g[:, a: a + n_cov])
+        return ret, None, None
 
 
 class LazyNBMixture:
@@ -134,8 +162,10 @@ class LazyNBMixture:
             m = self._module
             if m is None:
                 raise _abi.SpvError("this LazyNBMixture was built without its module and cannot materialise the decoder outputs")
-            self._cache = materialize_decoder(m.decoders[self.group], m.px_r[self.group], self.private_log_z.detach(), self.poe_log_z.detach(),
-                                              self.library.detach(), m.training, m.nsplit, m._workspace(self.group, self.library.device))
+            with torch.no_grad():
+                first, second, par = m._decoder_operands(self.group, self.private_log_z.detach(), self.poe_log_z.detach())
+            self._cache = materialize_decoder(m.decoders[self.group], m.px_r[self.group], first, second,
+                                              self.library.detach(), m.training, m.nsplit, m._workspace(self.group, self.library.device), par=par)
         return self._cache
 
     mu1 = property(lambda self: self.materialize()["px_rate_private"])
@@ -205,8 +235,6 @@ class spVIPESmodule(nn.Module):
         n_components: Optional[int] = None,
     ):
         super().__init__()
-        if n_batch > 1:
-            raise NotImplementedError("batch covariates (n_batch > 1) are outside the accelerated path")
         if not (log_variational_inference and log_variational_generative):
             raise NotImplementedError("the fused kernels implement the reference defaults log_variational_*=True")
         if precision not in ("bf16", "fp32"):
@@ -219,6 +247,16 @@ class spVIPESmodule(nn.Module):
         self.n_groups, self.n_components = len(lengths), n_components
         self.n_dimensions_shared, self.n_dimensions_private = n_dimensions_shared, n_dimensions_private
         self.n_batch, self.n_hidden, self.dropout_rate = n_batch, n_hidden, dropout_rate
+        # batch covariates (spVIPESmodule.py:132-133, nn/networks.py:60-68): n_batch <= 1 collapses to no covariate column at all
+        self.n_cov = n_cov = n_batch if n_batch > 1 else 0
+        if n_cov:
+            from .dec_ops import DEC_KP, DEC_KS, KMP
+            if len(lengths) != 2:
+                raise NotImplementedError("batch covariates are implemented for two groups")
+            if n_dimensions_private + n_cov + 1 > DEC_KP or n_dimensions_shared + n_cov + 1 > DEC_KS or \
+                    N_HIDDEN_MIX + n_dimensions_private + n_dimensions_shared + 2 * n_cov + 1 > KMP:
+                raise NotImplementedError(f"n_batch = {n_batch} does not fit the decoder kernels' operand slots: n_private + n_batch <= {DEC_KP - 1}, "
+                                          f"n_shared + n_batch <= {DEC_KS - 1}")
         self.input_dims = {i: g for i, g in enumerate(lengths)}
         self.groups_barcodes, self.groups_genes = groups_obs_names, groups_var_names
         self.groups_obs_indices = groups_obs_indices
@@ -232,10 +270,10 @@ class spVIPESmodule(nn.Module):
         self.encoders, self.decoders = {}, {}
         for g, G in self.input_dims.items():
             enc = {
-                "shared": Encoder(G, n_dimensions_shared, n_hidden, dropout_rate),
-                "private": Encoder(G, n_dimensions_private, n_hidden, dropout_rate),
+                "shared": Encoder(G + n_cov, n_dimensions_shared, n_hidden, dropout_rate),
+                "private": Encoder(G + n_cov, n_dimensions_private, n_hidden, dropout_rate),
             }
-            dec = LinearDecoderSPVIPE(n_dimensions_private, n_dimensions_shared, G)
+            dec = LinearDecoderSPVIPE(n_dimensions_private, n_dimensions_shared, G, n_cov=n_cov)
             self.encoders[g], self.decoders[g] = enc, dec
             self.add_module(f"encoder_{g}_shared", enc["shared"])
             self.add_module(f"encoder_{g}_private", enc["private"])
@@ -281,6 +319,50 @@ class spVIPESmodule(nn.Module):
         sel = X.index_select(1, torch.as_tensor(idx, device=X.device)).contiguous()
         return GroupCounts(sel, len(idx), 0), None, X.shape[0]
 
+    def _covariates(self, batch_index, x, dev):
+        """Per group (batch codes int32 [B], one_hot(batch) fp32 [B][n_batch]) for a module built with n_batch > 1 (the reference
+        appends the one-hot rows to the input of fc1 and of every decoder layer: nn/networks.py:105-119, 314-325), else None.
+        Codes of a raw ("X") minibatch are range-checked here (torch's one_hot raises in the reference); a resident data set's are
+        checked once by train.Trainer."""
+        if not self.n_cov:
+            return None
+        out = {}
+        for g in sorted(x.keys()):
+            b = batch_index[g] if batch_index is not None else None
+            if b is None:
+                raise ValueError(f"n_batch = {self.n_batch}: the minibatch of group {g} carries no '{BATCH_KEY}' codes")
+            idx = b.flatten().to(device=dev, dtype=torch.int32).contiguous()
+            if idx.numel() != self._step_inputs[g][2]:
+                raise ValueError("batch codes do not match the minibatch size")
+            if X_KEY in x[g] and idx.numel() and not bool(((idx >= 0) & (idx < self.n_cov)).all()):
+                raise ValueError(f"batch codes must lie in [0, n_batch = {self.n_batch})")
+            oh = torch.zeros((idx.numel(), self.n_cov), dtype=torch.float32, device=dev)
+            oh.scatter_(1, idx.long().unsqueeze(1), 1.0)
+            out[g] = (idx, oh)
+        return out
+
+    def _decoder_operands(self, g: int, private_log_z, poe_log_z):
+        """(first latent, second latent, the decoder's 13 parameters) as DecoderFused / materialize_decoder take them.  Without
+        covariates: the two latents and the parameters themselves.  With n_batch > 1 the decoder's four layers see
+        cat(input, one_hot(batch)) (nn/networks.py:314-325): the one-hot rows become n_batch extra latent dimensions behind the
+        decoder's z_private and behind its z_shared -- Z' = [z_shared | one_hot | z_private | one_hot] is cut by the op's own slicing
+        (spVIPESmodule.py:753-754) into exactly those two inputs -- and the two layers that read both (mixing trunk, mixture) get
+        their weight columns in that order with zeros for the second copy (CovariateColumns)."""
+        from .dec_ops import decoder_params
+
+        par = decoder_params(self.decoders[g], self.px_r[g])
+        if not self.n_cov:
+            return private_log_z, poe_log_z, par
+        n_p, n_s, nb = self.n_dimensions_private, self.n_dimensions_shared, self.n_cov
+        oh = self._cov[g][1]
+        Z = torch.cat([private_log_z, poe_log_z], 1)
+        Zx = torch.cat([Z[:, :n_s], oh, Z[:, n_s:], oh], 1)   # [decoder z_shared | one_hot | decoder z_private | one_hot]
+        n_m = par[6].shape[0]
+        par = list(par)
+        par[6] = CovariateColumns.apply(par[6], n_p, n_p + n_s)
+        par[10] = CovariateColumns.apply(par[10], n_m + n_p, n_m + n_p + n_s)
+        return Zx[:, :n_p + nb].contiguous(), Zx[:, n_p + nb:].contiguous(), par
+
     # ---- protocol ----------------------------------------------------------------------------
     def _get_inference_input(self, tensors_by_group):
         x = {i: group for i, group in enumerate(tensors_by_group)}
@@ -324,6 +406,7 @@ class spVIPESmodule(nn.Module):
         for g, group in x.items():
             self._step_inputs[g] = self._counts_of(g, group)
         dev0 = self._step_inputs[groups_[0]][0].X.device
+        self._cov = self._covariates(batch_index, x, dev0)   # None, or per group (batch codes int32 [B], one_hot fp32 [B][n_batch])
         # Everything that does not depend on the encoders is issued BEFORE the fc1 GEMMs, so that it runs in the shadow of the
         # step's first launches instead of on the critical chain between fc1 and the encoder tails:
         # (1) every standard-normal draw of the step (encoder heads + PoE) out of ONE generator launch,
@@ -383,7 +466,7 @@ class spVIPESmodule(nn.Module):
                 ep, es = self.encoders[g]["private"], self.encoders[g]["shared"]
                 cl.append(counts); rl.append(rows); bl.append(B); wl.append(self._workspace(g, counts.X.device))
                 pl += [ep.fc1.weight, ep.fc1.bias, es.fc1.weight, es.fc1.bias]
-            outs_fc1 = _ops_mod.EncoderFC1Grouped.apply(cl, rl, bl, self.nsplit, wl, *pl)
+            outs_fc1 = _ops_mod.EncoderFC1Grouped.apply(cl, rl, bl, self.nsplit, wl, ([self._cov[g] for g in groups_] if self._cov else None), *pl)
             for i, g in enumerate(groups_):
                 h1s[g] = outs_fc1[2 * i]
                 library[g] = outs_fc1[2 * i + 1].unsqueeze(1)
@@ -395,7 +478,8 @@ class spVIPESmodule(nn.Module):
                 streams = group_streams(counts.X.device, len(x))  # each node's backward on its forward stream as well)
                 fork(streams)
             with torch.cuda.stream(streams[g % len(streams)]):
-                h1, lib = EncoderFC1.apply(counts, rows, B, ep.fc1.weight, ep.fc1.bias, es.fc1.weight, es.fc1.bias, self.nsplit, ws)
+                h1, lib = EncoderFC1.apply(counts, rows, B, ep.fc1.weight, ep.fc1.bias, es.fc1.weight, es.fc1.bias, self.nsplit, ws,
+                                           self._cov[g] if self._cov else None)
             h1s[g] = h1
             library[g] = lib.unsqueeze(1)
         if streams is not None:
@@ -613,10 +697,11 @@ class spVIPESmodule(nn.Module):
         rec = {}
         for c0 in range(0, len(gs), 2):
             ch = gs[c0:c0 + 2]
-            params = [t for g in ch for t in decoder_params(self.decoders[g], self.px_r[g])]
+            ops_ = [self._decoder_operands(g, lat[2 * (c0 + i)], lat[2 * (c0 + i) + 1]) for i, g in enumerate(ch)]
+            params = [t for o in ops_ for t in o[2]]
             res = DecoderFused.apply([self._step_inputs[g][0] for g in ch], [self._step_inputs[g][1] for g in ch], B0,
                                      [self.decoders[g] for g in ch], [px[g].library for g in ch], w_pad, self.training, self.nsplit,
-                                     [self._workspace(g, dev) for g in ch], klw, 2 * len(ch), *lat[2 * c0: 2 * c0 + 2 * len(ch)], *params,
+                                     [self._workspace(g, dev) for g in ch], klw, 2 * len(ch), *[t for o in ops_ for t in o[:2]], *params,
                                      *kls[2 * c0: 2 * c0 + 2 * len(ch)])
             loss = res[0] if loss is None else loss + res[0]
             rec_mean = res[1] if rec_mean is None else rec_mean + res[1]
@@ -647,4 +732,7 @@ class spVIPESmodule(nn.Module):
             raise ValueError(f"Invalid value for type_latent: {type_latent}. It can only be 'shared' or 'private'")
         reg = getattr(self.decoders[dataset], f"factor_regressor_{type_latent}")
         b = reg.bn.weight / torch.sqrt(reg.bn.running_var + reg.bn.eps)
-        return (b[:, None] * reg.linear.weight).detach().cpu().numpy()
+        loadings = (b[:, None] * reg.linear.weight).detach().cpu().numpy()
+        if self.n_batch > 1:
+            loadings = loadings[:, : -self.n_batch]   # (the covariate columns: spVIPESmodule.py:804-805)
+        return loadings

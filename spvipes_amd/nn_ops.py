@@ -46,7 +46,7 @@ GRAD_SINK = False
 
 def grad_out(param: torch.Tensor):
     """(tensor the kernel writes, value the autograd node returns) for one parameter's gradient."""
-    g = param.grad
+    g = param.grad if param.is_leaf else None   # (a derived tensor -- e.g. module.CovariateColumns' output -- has no gradient buffer of its own)
     if GRAD_SINK and g is not None and g.is_contiguous() and g.dtype == torch.float32:
         return g, None
     t = torch.empty_like(param, dtype=torch.float32)

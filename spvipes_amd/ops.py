@@ -248,21 +248,49 @@ def _fc1_splits(B: int, G: int, N1: int) -> int:
     return max(1, min(want, ktiles // 8 if ktiles >= 8 else 1, 16))
 
 
+
+def _fc1_cov_table(w_priv, w_sh, G: int):
+    """The weight columns of the one-hot batch covariates that follow the G gene columns of both encoders' fc1 (nn/networks.py:68,
+    105-119), as the table spv_enc_fc1_fwd adds before the ReLU: fp32 [n_batch][2H] (rows = batch codes).  None without covariates."""
+    if w_priv.shape[1] == G:
+        return None
+    return torch.cat([w_priv[:, G:], w_sh[:, G:]], 0).t().contiguous().float()
+
+
+def _fc1_cov_wgrad(dh1, h1, onehot, dWp, dWs, G: int, H: int, ws: "Workspace") -> None:
+    """d W[:, G:] of both encoders' fc1 = (relu'(h1) * dh1)^T one_hot(batch): the small-layer weight-gradient kernel with the one-hot
+    matrix as its input operand (spv_linear_wgrad masks dY by Y > 0 itself), copied into the covariate columns of the two gradients."""
+    from .nn_ops import _add_lin, _lin_batch, _wgrad
+
+    B, N1 = h1.shape
+    nb = onehot.shape[1]
+    dcov = torch.empty((N1, nb), dtype=torch.float32, device=h1.device)
+    b = _lin_batch(B, relu=True)
+    _add_lin(b, N=N1, K=nb, W=ptr(dcov), X=ptr(onehot), ldx=nb, Y=ptr(h1), ldy=N1, dY=ptr(dh1), lddy=N1, dW=ptr(dcov), db=None)
+    _wgrad(b, ws)
+    dWp[:, G:].copy_(dcov[:H])
+    dWs[:, G:].copy_(dcov[H:])
+
+
 class EncoderFC1(torch.autograd.Function):
-    """h1 = relu(log1p(X[rows, genes]) @ [W_private; W_shared]^T + b), library = log(sum log1p(x))."""
+    """h1 = relu(log1p(X[rows, genes]) @ [W_private; W_shared]^T + b), library = log(sum log1p(x)).
+    ``cov``: None, or (batch codes int32 [B], one_hot fp32 [B][n_batch]) when the fc1 weights carry n_batch covariate columns."""
 
     @staticmethod
-    def forward(ctx, counts: GroupCounts, rows, B: int, w_priv, b_priv, w_sh, b_sh, nsplit: int, ws: Workspace):
+    def forward(ctx, counts: GroupCounts, rows, B: int, w_priv, b_priv, w_sh, b_sh, nsplit: int, ws: Workspace, cov=None):
         ctx.set_materialize_grads(False)
-        H, G = w_priv.shape
+        H, G = w_priv.shape[0], counts.G
+        if (w_priv.shape[1] != G) != (cov is not None):
+            raise _abi.SpvError("fc1 weights with covariate columns need the minibatch's batch codes (and only they do)")
         N1 = 2 * H
         bn = 32 if N1 <= 32 else (128 if N1 <= 128 else 256)
         N1p, Gp = round_up(N1, bn), round_up(G, 64)
         W_hi, W_lo = _bf16_image(ws, "fc1_W", N1p, Gp, nsplit == 3)
         if W_lo is not None or ws.fresh.get("fc1_W") != image_token(w_priv, w_sh):   # (else: Adam has just rewritten the image)
-            _pack_fc1_weights(w_priv, w_sh, W_hi, W_lo, H)
+            _pack_fc1_weights(w_priv[:, :G], w_sh[:, :G], W_hi, W_lo, H)
         f32c = lambda t: t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
         b_priv, b_sh = f32c(b_priv), f32c(b_sh)
+        cov_tab = _fc1_cov_table(w_priv, w_sh, G)
         h1 = torch.empty((B, N1), dtype=torch.float32, device=w_priv.device)
         library = torch.empty((B,), dtype=torch.float32, device=w_priv.device)
         cs = counts.c_struct(rows)
@@ -282,9 +310,9 @@ class EncoderFC1(torch.autograd.Function):
             slabs = ws.get("fc1_slabs", (splits, B, N1), torch.float32)
         rowsum = ws.get("fc1_rowsum", (splits, B), torch.float32)
         _abi.call("spv_enc_fc1_fwd", C.byref(cs), B, G, ptr(W_hi), ptr(W_lo), Gp, N1, ptr(b_priv), ptr(b_sh), H, nsplit, splits, ptr(slabs),
-                                  ptr(rowsum), ptr(h1), ptr(library), ptr(xb), ld_xb, ptr(lib_all), stream_ptr())
+                                  ptr(rowsum), ptr(h1), ptr(library), ptr(xb), ld_xb, ptr(lib_all), ptr(cov_tab), ptr(cov[0]) if cov else None, stream_ptr())
         ctx.counts, ctx.rows, ctx.B, ctx.nsplit, ctx.ws, ctx.H, ctx.G = counts, rows, B, nsplit, ws, H, G
-        ctx.xb, ctx.ld_xb = xb, ld_xb
+        ctx.xb, ctx.ld_xb, ctx.cov = xb, ld_xb, cov
         ctx.save_for_backward(h1, w_priv, b_priv, w_sh, b_sh)
         ctx.mark_non_differentiable(library)
         return h1, library
@@ -294,7 +322,7 @@ class EncoderFC1(torch.autograd.Function):
         from .nn_ops import grad_out
 
         if dh1 is None:
-            return (None,) * 9
+            return (None,) * 10
         h1, w_priv, b_priv, w_sh, b_sh = ctx.saved_tensors
         B, H, G, ws, nsplit = ctx.B, ctx.H, ctx.G, ctx.ws, ctx.nsplit
         N1 = 2 * H
@@ -307,20 +335,23 @@ class EncoderFC1(torch.autograd.Function):
         (dWp, rWp), (dbp, rbp), (dWs, rWs), (dbs, rbs) = grad_out(w_priv), grad_out(b_priv), grad_out(w_sh), grad_out(b_sh)
         _abi.call("spv_enc_fc1_bwd_prep", ptr(dh1), ptr(h1), B, N1, ptr(dh_hi), ptr(dh_lo), N1p, Bp, ptr(part), ptr(dbp), ptr(dbs), H, ptr(scale_ws), stream_ptr())
         cs = ctx.counts.c_struct(ctx.rows)
-        _abi.call("spv_enc_fc1_wgrad", C.byref(cs), B, G, ptr(dh_hi), ptr(dh_lo), N1p, N1, nsplit, ptr(dWp), ptr(dWs), H, G,
+        _abi.call("spv_enc_fc1_wgrad", C.byref(cs), B, G, ptr(dh_hi), ptr(dh_lo), N1p, N1, nsplit, ptr(dWp), ptr(dWs), H, w_priv.shape[1],
                   ptr(ctx.xb), ctx.ld_xb, ptr(scale_ws), stream_ptr())
-        return None, None, None, rWp, rbp, rWs, rbs, None, None
+        if ctx.cov is not None:
+            _fc1_cov_wgrad(dh1, h1, ctx.cov[1], dWp, dWs, G, H, ws)
+        return None, None, None, rWp, rbp, rWs, rbs, None, None, None
 
 
 class EncoderFC1Grouped(torch.autograd.Function):
     """``EncoderFC1`` for several groups in one autograd node and -- for pairs of groups whose shapes take the LDS-DMA kernels -- ONE
     launch per kernel (spv_enc_fc1_fwd_grouped / spv_enc_fc1_bwd_grouped: both groups' tiles in one grid).  Two separate launches
     on two streams cannot overlap (each fills the chip with one-per-CU workgroups) and pay the fork / join of the graph branches.
-    inputs : per-group lists counts, rows, B, workspaces; then 4 parameters per group (w_priv, b_priv, w_sh, b_sh)
+    inputs : per-group lists counts, rows, B, workspaces, covariates (None, or per group (batch codes, one_hot): see EncoderFC1);
+             then 4 parameters per group (w_priv, b_priv, w_sh, b_sh)
     outputs: (h1_0, library_0, h1_1, library_1, ...)"""
 
     @staticmethod
-    def forward(ctx, counts, rows, Bs, nsplit: int, wss, *params):
+    def forward(ctx, counts, rows, Bs, nsplit: int, wss, covs, *params):
         ctx.set_materialize_grads(False)
         NG = len(counts)
         args = (_abi.SpvFc1FwdArgs * NG)()
@@ -330,14 +361,18 @@ class EncoderFC1Grouped(torch.autograd.Function):
         for g in range(NG):
             w_priv, b_priv, w_sh, b_sh = params[4 * g: 4 * g + 4]
             ws, B = wss[g], Bs[g]
-            H, G = w_priv.shape
+            H, G = w_priv.shape[0], counts[g].G
+            cov = covs[g] if covs is not None else None
+            if (w_priv.shape[1] != G) != (cov is not None):
+                raise _abi.SpvError("fc1 weights with covariate columns need the minibatch's batch codes (and only they do)")
             N1 = 2 * H
             bn = 32 if N1 <= 32 else (128 if N1 <= 128 else 256)
             N1p, Gp = round_up(N1, bn), round_up(G, 64)
             W_hi, W_lo = _bf16_image(ws, "fc1_W", N1p, Gp, nsplit == 3)
             if W_lo is not None or ws.fresh.get("fc1_W") != image_token(w_priv, w_sh):   # (else: Adam has just rewritten the image)
-                _pack_fc1_weights(w_priv, w_sh, W_hi, W_lo, H)
+                _pack_fc1_weights(w_priv[:, :G], w_sh[:, :G], W_hi, W_lo, H)
             b_priv, b_sh = f32c(b_priv), f32c(b_sh)
+            cov_tab = _fc1_cov_table(w_priv, w_sh, G)
             h1 = torch.empty((B, N1), dtype=torch.float32, device=w_priv.device)
             library = torch.empty((B,), dtype=torch.float32, device=w_priv.device)
             cs = counts[g].c_struct(rows[g])
@@ -362,10 +397,11 @@ class EncoderFC1Grouped(torch.autograd.Function):
             a.bias, a.bias2, a.n_first, a.nsplit, a.splits = ptr(b_priv), ptr(b_sh), H, nsplit, splits
             a.slabs, a.rowsum_ws, a.h1, a.library = ptr(slabs), ptr(rowsum), ptr(h1), ptr(library)
             a.xb_all, a.ld_xb, a.library_all = ptr(xb), ld_xb, ptr(lib_all)
-            keep += [cs, b_priv, b_sh, W_hi, W_lo, slabs, rowsum, xb, lib_all]
+            a.cov, a.cov_idx = ptr(cov_tab), (ptr(cov[0]) if cov else None)
+            keep += [cs, b_priv, b_sh, W_hi, W_lo, slabs, rowsum, xb, lib_all, cov_tab]
             outs += [h1, library]
             saved += [h1, w_priv, b_priv, w_sh, b_sh]
-            meta.append((counts[g], rows[g], B, H, G, ws, xb, ld_xb))
+            meta.append((counts[g], rows[g], B, H, G, ws, xb, ld_xb, cov))
         _abi.call("spv_enc_fc1_fwd_grouped", args, NG, stream_ptr())
         ctx.meta, ctx.nsplit, ctx.NG = meta, nsplit, NG
         ctx.save_for_backward(*saved)
@@ -382,10 +418,10 @@ class EncoderFC1Grouped(torch.autograd.Function):
         rets = [None] * (4 * NG)
         if live:
             args = (_abi.SpvFc1BwdArgs * len(live))()
-            keep = []
+            keep, covg = [], []
             for k, g in enumerate(live):
                 h1, w_priv, b_priv, w_sh, b_sh = saved[5 * g: 5 * g + 5]
-                counts, rows, B, H, G, ws, xb, ld_xb = ctx.meta[g]
+                counts, rows, B, H, G, ws, xb, ld_xb, cov = ctx.meta[g]
                 N1 = 2 * H
                 Bp, N1p = round_up(B, 64), round_up(N1, 128)
                 dh1 = grads[2 * g]
@@ -399,12 +435,16 @@ class EncoderFC1Grouped(torch.autograd.Function):
                 a.dh1, a.h1, a.x = ptr(dh1), ptr(h1), C.pointer(cs)
                 a.B, a.G, a.N1, a.n_first, a.nsplit, a.Bp = B, G, N1, H, nsplit, Bp
                 a.dh_hi, a.dh_lo, a.ld_dh, a.part = ptr(dh_hi), ptr(dh_lo), N1p, ptr(part)
-                a.db, a.db2, a.dW, a.dW2, a.ldc = ptr(dbp), ptr(dbs), ptr(dWp), ptr(dWs), G
+                a.db, a.db2, a.dW, a.dW2, a.ldc = ptr(dbp), ptr(dbs), ptr(dWp), ptr(dWs), w_priv.shape[1]
                 a.xb, a.ld_xb, a.scale_ws = ptr(xb), ld_xb, ptr(scale_ws)
                 keep += [cs, dh1, dh_hi, dh_lo, part, dWp, dbp, dWs, dbs, scale_ws]
                 rets[4 * g: 4 * g + 4] = [rWp, rbp, rWs, rbs]
+                if cov is not None:
+                    covg.append((dh1, h1, cov[1], dWp, dWs, G, H, ws))
             _abi.call("spv_enc_fc1_bwd_grouped", args, len(live), stream_ptr())
-        return (None,) * 5 + tuple(rets)
+            for c in covg:
+                _fc1_cov_wgrad(*c)
+        return (None,) * 6 + tuple(rets)
 
 
 # ------------------------------------------------------------------------------------------------

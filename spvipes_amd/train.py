@@ -162,8 +162,17 @@ class Trainer:
     def __init__(self, module: spVIPESmodule, counts: Sequence[GroupCounts], labels: Optional[Sequence[torch.Tensor]] = None,
                  components: Optional[Sequence[torch.Tensor]] = None, lr: float = 1e-3, eps: float = 0.01,
                  weight_decay: float = 1e-6, n_epochs_kl_warmup: Optional[int] = 400, n_steps_kl_warmup: Optional[int] = None,
-                 overlap_allreduce: Optional[bool] = None):
+                 overlap_allreduce: Optional[bool] = None, batch_codes: Optional[Sequence[torch.Tensor]] = None):
         self.module, self.counts, self.labels, self.components = module, list(counts), labels, components
+        # batch covariates (module built with n_batch > 1): one integer code per cell of every group, gathered per minibatch
+        self.batch_codes = None
+        if getattr(module, "n_cov", 0):
+            if batch_codes is None or len(batch_codes) != len(self.counts):
+                raise ValueError(f"the module was built with n_batch = {module.n_batch}: pass batch_codes (one code per cell and group)")
+            self.batch_codes = [b.flatten().to(device=counts[0].X.device, dtype=torch.int32).contiguous() for b in batch_codes]
+            for g, b in enumerate(self.batch_codes):   # (the fc1 epilogue indexes its covariate table with them: validated once, here)
+                if b.numel() and not bool(((b >= 0) & (b < module.n_cov)).all()):
+                    raise ValueError(f"batch codes of group {g} must lie in [0, n_batch = {module.n_batch})")
         for what, codes in (("labels", labels), ("cluster components", components)):
             if codes is None:   # (the pairing kernels index per-code tables: validated once, here, not per step)
                 continue
@@ -230,7 +239,8 @@ class Trainer:
         return out
 
     def _build_image_plan(self):
-        if not self.IMAGES_BY_ADAM or self.module.nsplit != 1:
+        if not self.IMAGES_BY_ADAM or self.module.nsplit != 1 or getattr(self.module, "n_cov", 0):
+            # (covariate columns: the images are not the parameters' own column layout -- the forward pass packs them every step)
             self._img_specs, self._img_plan = [], None
             return
         from . import ops
@@ -304,6 +314,8 @@ class Trainer:
                 lab = [self._labels_f32[g].index_select(0, r) for g, r in enumerate(rows)]
         for g, r in enumerate(rows):
             d = {"counts": self.counts[g], "rows": r, "groups": None, "batch": None}
+            if self.batch_codes is not None:
+                d["batch"] = self.batch_codes[g].index_select(0, r)
             d["indices"] = r.to(torch.float32).unsqueeze(1) if need_idx else None
             if lab is not None:
                 d["labels"] = lab[g].unsqueeze(1)

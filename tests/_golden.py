@@ -23,6 +23,18 @@ class Golden:
         self.kl_weight = float(self.raw["in/kl_weight"])
         self.H, self.n_s, self.n_p = (int(v) for v in self.raw["in/dims"])
         self.has_loss = "out/loss" in self.raw
+        self.n_batch = int(self.raw["in/n_batch"]) if "in/n_batch" in self.raw else 0   # batch covariates (n_batch > 1 cases)
+
+    def batch_kwargs(self):
+        """forward_loss keyword arguments of the covariate cases"""
+        if self.n_batch <= 1:
+            return {}
+        return {"n_batch": self.n_batch, "batch_index": [self.t("in/batch0", torch.int64), self.t("in/batch1", torch.int64)]}
+
+    def one_hot(self, grp, dtype=torch.float32):
+        if self.n_batch <= 1:
+            return None
+        return torch.nn.functional.one_hot(self.t(f"in/batch{grp}", torch.int64), self.n_batch).to(dtype)
 
     def t(self, key, dtype=torch.float32):
         return torch.tensor(self.raw[key]).to(dtype)

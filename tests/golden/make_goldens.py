@@ -101,7 +101,7 @@ def synth_counts(rng, B, G, p_nonzero=0.35, mean=3.0):
 
 
 def run_case(ref, name, *, B, G, H, n_s, n_p, mode, training=True, dropout=0.0, seed=0, kl_weight=1.0,
-             labels=None, n_cells=None, inference_only=False):
+             labels=None, n_cells=None, inference_only=False, n_batch=1):
     torch.manual_seed(seed)
     rng = np.random.default_rng(seed)
     G0, G1 = G
@@ -124,7 +124,7 @@ def run_case(ref, name, *, B, G, H, n_s, n_p, mode, training=True, dropout=0.0, 
         pair_data=(mode == "paired"),
         use_labels=(mode == "label"),
         n_labels=None,
-        n_batch=1,
+        n_batch=n_batch,
         n_hidden=H,
         n_dimensions_shared=n_s,
         n_dimensions_private=n_p,
@@ -152,6 +152,12 @@ def run_case(ref, name, *, B, G, H, n_s, n_p, mode, training=True, dropout=0.0, 
             "indices": torch.tensor(idx[g], dtype=torch.float32).unsqueeze(1),
         }
         tensors.append(d)
+    batch_codes = None
+    if n_batch > 1:   # batch covariates (spVIPESmodule.py:132-133): codes drawn AFTER everything the n_batch = 1 cases draw
+        batch_codes = [rng.integers(0, n_batch, size=Bg).astype(np.float32) for Bg in (B0, B1)]
+        batch_codes[0][0], batch_codes[1][-1] = 0.0, float(n_batch - 1)
+        for g in range(2):
+            tensors[g]["batch"] = torch.tensor(batch_codes[g]).unsqueeze(1)
     comps = None
     if mode == "label":
         if labels is None:
@@ -214,6 +220,9 @@ def run_case(ref, name, *, B, G, H, n_s, n_p, mode, training=True, dropout=0.0, 
         out["in/plan"] = plan
     if comps is not None:
         out["in/comp0"], out["in/comp1"] = comps
+    if batch_codes is not None:
+        out["in/n_batch"] = np.int32(n_batch)
+        out["in/batch0"], out["in/batch1"] = batch_codes
     for k, v in sd_before.items():
         out["sd/" + k] = v.numpy()
 
@@ -296,6 +305,10 @@ def main():
     run_case(ref, "paired_eval", B=(8, 8), mode="paired", training=False, seed=10, **base)
     run_case(ref, "cluster_train", B=(16, 16), mode="cluster", seed=11, **base)
     run_case(ref, "cluster_eval", B=(16, 16), mode="cluster", training=False, seed=12, **base)
+    # batch covariates (batch_key given: n_batch > 1, one-hot columns into fc1 and every decoder layer)
+    run_case(ref, "label_train_batch3", B=(16, 16), mode="label", seed=15, n_batch=3, **base)
+    run_case(ref, "label_eval_batch2", B=(16, 16), mode="label", training=False, seed=16, n_batch=2, **base)
+    run_case(ref, "paired_train_batch2", B=(16, 16), mode="paired", seed=17, n_batch=2, **base)
 
 
 if __name__ == "__main__":

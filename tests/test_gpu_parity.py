@@ -159,7 +159,7 @@ def test_encoder_fc1_resident_image_dma_path(dev, B, G, gather, H, grouped):
         counts2 = ops.GroupCounts(torch.tensor(X2.astype(np.uint16).view(np.int16)).to(dev), G2, 0, resident=True)
         rows2 = torch.tensor(rng.permutation(B2 + 5)[:B2], dtype=torch.int32, device=dev)
         params2 = [t.clone().to(dev).requires_grad_(True) for t in (mk(H, G2), mk(H), mk(H, G2), mk(H))]
-        outs = ops.EncoderFC1Grouped.apply([counts, counts2], [rows, rows2], [B, B2], 1, [ws, ops.Workspace(dev)], *params, *params2)
+        outs = ops.EncoderFC1Grouped.apply([counts, counts2], [rows, rows2], [B, B2], 1, [ws, ops.Workspace(dev)], None, *params, *params2)
         h1, lib, h1b = outs[0], outs[1], outs[2]
         ((h1 * dh.to(dev)).sum() + h1b.sum()).backward()
         single = ops.EncoderFC1.apply(counts2, rows2, B2, *[p_.detach().clone().requires_grad_(True) for p_ in params2], 1, ops.Workspace(dev))[0]
@@ -250,7 +250,7 @@ def _build(g: Golden, dev, precision):
     G0, G1 = g.raw["in/counts0"].shape[1], g.raw["in/counts1"].shape[1]
     plan = torch.tensor(g.raw["in/plan"]).to(dev) if "in/plan" in g.raw else None
     m = spVIPESmodule({0: G0, 1: G1}, transport_plan=plan, pair_data=(g.mode == "paired"), use_labels=(g.mode == "label"),
-                      n_batch=1, n_hidden=g.H, n_dimensions_shared=g.n_s, n_dimensions_private=g.n_p,
+                      n_batch=max(g.n_batch, 1), n_hidden=g.H, n_dimensions_shared=g.n_s, n_dimensions_private=g.n_p,
                       dropout_rate=g.dropout, precision=precision).to(dev)
     m.load_state_dict(g.state_dict())
     m.train(g.training)
@@ -262,6 +262,8 @@ def _build(g: Golden, dev, precision):
         d = {"X": torch.tensor(X).to(dev), "batch": torch.zeros(c.shape[0], 1, device=dev),
              "groups": torch.full((c.shape[0], 1), float(grp), device=dev),
              "indices": torch.tensor(g.raw[f"in/idx{grp}"], dtype=torch.float32, device=dev).unsqueeze(1)}
+        if g.n_batch > 1:   # batch covariates: the codes the reference one-hot encodes (nn/networks.py:105-119)
+            d["batch"] = torch.tensor(g.raw[f"in/batch{grp}"], device=dev).unsqueeze(1)
         if g.mode == "label":
             d["labels"] = torch.tensor(g.raw[f"in/labels{grp}"], device=dev).unsqueeze(1)
         if g.mode == "cluster":

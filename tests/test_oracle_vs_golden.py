@@ -18,7 +18,7 @@ def _run(g: Golden, dtype=torch.float32, requires_grad=False):
     out = O.forward_loss(
         sd, g.counts(dtype), n_dimensions_shared=g.n_s, n_dimensions_private=g.n_p, noise=g.noise(dtype),
         mode=g.mode, kl_weight=g.kl_weight, training=g.training, dropout_rate=g.dropout,
-        dropout_masks=g.dropout_masks(dtype), update_running_stats=True, **g.poe_inputs(dtype),
+        dropout_masks=g.dropout_masks(dtype), update_running_stats=True, **g.poe_inputs(dtype), **g.batch_kwargs(),
     ) if g.has_loss else None
     return sd, out
 
@@ -36,7 +36,7 @@ def test_inference_stats_match_reference(case):
         for kind, store in (("private", private), ("shared", shared)):
             dm = (g.dropout_masks() or {}).get(f"enc_{grp}_{kind}")
             st = O.encoder_forward(sd, f"encoder_{grp}_{kind}", x[grp], noise[f"enc_{grp}_{kind}"], g.training,
-                                   dropout_rate=g.dropout, dropout_mask=dm)
+                                   dropout_rate=g.dropout, dropout_mask=dm, one_hot=g.one_hot(grp))
             store.append(st)
             for k in ("logtheta_loc", "logtheta_logvar", "logtheta_scale", "log_z", "theta"):
                 torch.testing.assert_close(st[k], g.t(f"out/{kind}_{grp}/{k}"), rtol=2e-4, atol=2e-5, msg=lambda m: f"{kind}_{grp}/{k}: {m}")
@@ -117,6 +117,6 @@ def test_loadings_match_reference(case):
         sd.update(out["new_running_stats"])
     for grp in range(2):
         for t in ("private", "shared"):
-            torch.testing.assert_close(O.get_loadings(sd, grp, t), g.t(f"out/loadings_{grp}_{t}"), rtol=1e-5, atol=1e-7)
+            torch.testing.assert_close(O.get_loadings(sd, grp, t, n_batch=g.n_batch), g.t(f"out/loadings_{grp}_{t}"), rtol=1e-5, atol=1e-7)
     with pytest.raises(ValueError):
         O.get_loadings(sd, 0, "both")
