@@ -61,11 +61,15 @@ class spVIPES:
             transport_plan = torch.tensor(np.asarray(adata.uns[plan_key]), dtype=torch.float32, device=self.device)
         pair_data = "processed_transport_labels" not in adata.obs  # :249
         use_labels = setup.get("label_key") is not None  # :251
+        # batch covariates (setup_anndata(batch_key=...): CategoricalObsField(BATCH_KEY), :358; n_batch = its number of categories, :230):
+        # integer codes over the WHOLE AnnData; without a batch_key scvi registers one dummy category, i.e. no covariate column
+        batch_codes = _codes(adata.obs[setup["batch_key"]]) if setup.get("batch_key") else None
+        n_batch = int(batch_codes.max()) + 1 if batch_codes is not None and len(batch_codes) else 1
         self.module = spVIPESmodule(
             groups_lengths=groups_lengths, groups_obs_names=adata.uns.get("groups_obs_names"),
             groups_var_names=adata.uns.get("groups_var_names"), groups_var_indices=var_idx, groups_obs_indices=self.obs_idx,
             transport_plan=transport_plan, pair_data=pair_data, use_labels=use_labels,
-            n_labels=(len(np.unique(np.asarray(adata.obs[setup["label_key"]]))) if use_labels else None), n_batch=1,
+            n_labels=(len(np.unique(np.asarray(adata.obs[setup["label_key"]]))) if use_labels else None), n_batch=n_batch,
             n_hidden=n_hidden, n_dimensions_shared=n_dimensions_shared, n_dimensions_private=n_dimensions_private,
             dropout_rate=dropout_rate, precision=precision, **model_kwargs,
         ).to(self.device)
@@ -77,6 +81,8 @@ class spVIPES:
         self._components = ([torch.tensor(_codes(obs["processed_transport_labels"])[self.obs_idx[g]], device=self.device) for g in range(2)]
                             if (transport_plan is not None and not pair_data) else None)
         self._plan_indices = [torch.tensor(np.asarray(obs["indices"])[self.obs_idx[g]].astype(np.float32), device=self.device) for g in range(2)]
+        self._batch = ([torch.tensor(np.asarray(batch_codes)[self.obs_idx[g]].astype(np.int32), device=self.device) for g in range(2)]
+                       if n_batch > 1 else None)
         self.is_trained_ = False
         self.history: Dict[str, List[float]] = {}
 
@@ -85,8 +91,8 @@ class spVIPES:
     def setup_anndata(cls, adata, groups_key: str, match_clusters: bool = False, transport_plan_key: Optional[str] = None,
                       label_key: Optional[str] = None, batch_key: Optional[str] = None, layer: Optional[str] = None, **kwargs) -> None:
         """Registers the fields the model reads (:355-422).  Same arguments, priorities and errors."""
-        if batch_key is not None:
-            raise NotImplementedError("batch covariates are outside the accelerated path")
+        if batch_key is not None and batch_key not in adata.obs:
+            raise KeyError(f"batch_key '{batch_key}' not found in adata.obs")
         if groups_key not in adata.obs:
             raise KeyError(f"groups_key '{groups_key}' not found in adata.obs")
         if transport_plan_key is not None:
@@ -105,7 +111,7 @@ class spVIPES:
             if k not in adata.uns:
                 raise ValueError(f"adata.uns['{k}'] missing: build the AnnData with prepare_adatas (or the same schema)")
         adata.uns[_SETUP_KEY] = {"groups_key": groups_key, "match_clusters": match_clusters, "transport_plan_key": transport_plan_key,
-                                 "label_key": label_key, "layer": layer}
+                                 "label_key": label_key, "batch_key": batch_key, "layer": layer}
 
     # ------------------------------------------------------------------------------------------
     def _local_rows(self, g: int, indices: Sequence[int]) -> np.ndarray:
@@ -122,6 +128,8 @@ class spVIPES:
         for g, r in enumerate(rows):
             rl = r.long()
             d = {"counts": self.counts[g], "rows": r, "indices": self._plan_indices[g][rl].unsqueeze(1), "groups": None, "batch": None}
+            if self._batch is not None:
+                d["batch"] = self._batch[g][rl].unsqueeze(1)
             if self._labels is not None:
                 d["labels"] = self._labels[g][rl].unsqueeze(1)
             if self._components is not None:
@@ -151,7 +159,7 @@ class spVIPES:
                                    validation_size=validation_size, group_indices_list=local, rank=rank, world=world)
         trainer = Trainer(self.module, self.counts, lr=plan_kwargs.get("lr", 1e-3), eps=plan_kwargs.get("eps", 0.01),
                           weight_decay=plan_kwargs.get("weight_decay", 1e-6), n_epochs_kl_warmup=n_epochs_kl_warmup,
-                          n_steps_kl_warmup=n_steps_kl_warmup)
+                          n_steps_kl_warmup=n_steps_kl_warmup, batch_codes=self._batch)
         if world > 1:
             dist.broadcast(trainer.fp.flat, src=0)
             trainer.parameters_changed()

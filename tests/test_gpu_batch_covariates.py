@@ -61,10 +61,10 @@ def test_training_step_with_batch_covariates_matches_the_oracle(dev, precision, 
     inf, _gen = trainer.last_outputs
     torch.cuda.synchronize()
     sd, want = _oracle(module, groups, codes, rows, noise, n_s, n_p, nb, 0.7)
-    flat = trainer.fp.grad
-    assert bool(torch.isfinite(flat).all()), "a gradient element was not written"
+    for k, p in module.named_parameters():   # (the flat buffer's alignment padding between parameters is nobody's to write)
+        assert bool(torch.isfinite(p.grad).all()), f"gradient of {k} was not (fully) written"
     ltol, lat_tol, gtol = (2e-5, 2e-4, 5e-3) if precision == "fp32" else (1e-3, 5e-3, 6e-2)
-    assert abs(float(lo.loss.detach()) - float(want["loss"])) / abs(float(want["loss"])) < ltol
+    assert abs(float(lo.loss.detach()) - float(want["loss"].detach())) / abs(float(want["loss"].detach())) < ltol
     for g in range(2):
         for kind, key in (("private", "private_stats"), ("shared", "shared_stats")):
             a, b = inf[key][g]["logtheta_loc"].detach().cpu().double(), want[key][g]["logtheta_loc"].detach()
@@ -72,8 +72,14 @@ def test_training_step_with_batch_covariates_matches_the_oracle(dev, precision, 
     gmax = max(float(sd[k].grad.abs().max()) for k, _ in module.named_parameters() if sd[k].grad is not None)
     for k, p in module.named_parameters():
         ref = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
-        err = float((p.grad.detach().cpu().double() - ref).abs().max())
-        assert err < gtol * float(ref.abs().max()) + gtol * 2e-2 * gmax, f"{precision} grad {k}: {err:.3e} (max {float(ref.abs().max()):.3e})"
+        mine = p.grad.detach().cpu().double()
+        if precision == "fp32":
+            err = float((mine - ref).abs().max())
+            assert err < gtol * float(ref.abs().max()) + gtol * 2e-2 * gmax, f"{precision} grad {k}: {err:.3e} (max {float(ref.abs().max()):.3e})"
+        else:   # 16-bit operand mode: relative L2 per parameter, the measure and the bound of test_gpu_fullsize_parity.py (biases of a
+            #      layer in front of a train-mode BatchNorm have an analytically zero gradient: absolute floor)
+            err, nrm = float((mine - ref).norm()), float(ref.norm())
+            assert err < 8e-2 * nrm + 1e-3 * gmax, f"{precision} grad {k}: L2 err {err:.3e} of {nrm:.3e}"
     # the covariate columns themselves carry signal
     for g in range(2):
         w = module.encoders[g]["shared"].fc1.weight
@@ -135,3 +141,49 @@ def test_covariate_errors(dev):
     assert m1.encoders[0]["shared"].fc1.weight.shape == (16, 60) and m1.decoders[0].mixture.linear.weight.shape[1] == 256 + 35
     assert module.encoders[0]["shared"].fc1.weight.shape == (16, 62) and module.decoders[0].mixture.linear.weight.shape[1] == 256 + 35 + 2
     assert module.get_loadings(0, "shared").shape == (60, 25)
+
+
+def test_user_api_with_batch_key(dev):
+    """setup_anndata(batch_key=...) (model/spvipes.py:294,358): categorical codes over the whole AnnData, n_batch = their count; the
+    covariates reach training, validation-free latents and the loadings (whose covariate columns the reference drops, :804-805)."""
+    from spvipes_amd.model import spVIPES
+    from tests._duck import make_duck
+    ad = make_duck()
+    rng = np.random.default_rng(4)
+    ad.obs["donor"] = rng.choice(np.array(["d1", "d2", "d3"]), size=ad.n_obs)
+    with pytest.raises(KeyError):
+        spVIPES.setup_anndata(ad, groups_key="groups", label_key="cell_type", batch_key="nope")
+    spVIPES.setup_anndata(ad, groups_key="groups", label_key="cell_type", batch_key="donor")
+    torch.manual_seed(0)
+    model = spVIPES(ad, n_hidden=32, n_dimensions_shared=10, n_dimensions_private=5, precision="fp32")
+    assert model.module.n_batch == 3 and model.module.encoders[0]["shared"].fc1.weight.shape == (32, 96 + 3)
+    gi = [list(ad.uns["groups_obs_indices"][0]), list(ad.uns["groups_obs_indices"][1])]
+    model.train(gi, batch_size=64, max_epochs=6, train_size=1.0, n_epochs_kl_warmup=None, plan_kwargs={"lr": 5e-3})
+    h = model.history["train_loss"]
+    assert len(h) == 6 and all(np.isfinite(h)) and h[-1] < h[0], h
+    w0 = model.module.encoders[1]["private"].fc1.weight[:, 80:].detach().clone()
+    assert float(w0.abs().max()) > 0 and bool(torch.isfinite(w0).all())
+
+    def latents():
+        noise = lambda step, b0, b1: {**{f"enc_{g}_{k}": torch.randn(b, n, generator=torch.Generator().manual_seed(7 * step + g)).to(dev)
+                                         for g, b in ((0, b0), (1, b1)) for k, n in (("private", 5), ("shared", 10))},
+                                      **{f"poe_{g}": torch.randn(b, 10, generator=torch.Generator().manual_seed(99 + step + g)).to(dev) for g, b in ((0, b0), (1, b1))}}
+        return model.get_latent_representation(gi, batch_size=64, _noise=noise)
+
+    a = latents()
+    assert a["shared"][0].shape == (300, 10) and a["private"][1].shape == (260, 5)
+    assert all(np.isfinite(v).all() for d in a.values() for v in d.values())
+    b = latents()
+    np.testing.assert_array_equal(a["private"][0], b["private"][0])   # same noise, same codes: same latents
+    for t in model._batch:   # ... and other codes: other latents (the encoders read the covariates)
+        t.copy_((t + 1) % 3)
+    c = latents()
+    assert np.abs(c["private"][0] - a["private"][0]).max() > 1e-4
+    load = model.get_loadings()
+    assert load[(0, "shared")].shape == (96, 10) and load[(1, "private")].shape == (80, 5)
+    # a single category is "no covariates" (scvi registers one dummy batch without a batch_key)
+    ad1 = make_duck()
+    ad1.obs["donor"] = np.array(["only"] * ad1.n_obs)
+    spVIPES.setup_anndata(ad1, groups_key="groups", label_key="cell_type", batch_key="donor")
+    m1 = spVIPES(ad1, n_hidden=16, n_dimensions_shared=6, n_dimensions_private=3, precision="fp32")
+    assert m1.module.n_batch == 1 and m1._batch is None and m1.module.encoders[0]["shared"].fc1.weight.shape == (16, 96)
