@@ -312,8 +312,11 @@ static int gemm_dispatch(const GemmParams& p, int splits, hipStream_t s) {
 // Shapes the LDS-DMA 320-column kernels (spv_dec_gemm.h) take: bf16 mode, a tile-ordered [cells][genes] A operand, a 320-wide
 // k-major B image.  The tiled array must cover round_up(M, 128) x round_up(K, 64) (cells x genes, a_kmajor 0) or
 // round_up(K, 64) x round_up(M, 128) (a_kmajor 1): the decoder's Bp / Gp paddings (multiples of 128 / 256) do.
+// SPV_GEMM_DMA_SPLIT=0: "fp32" mode keeps the register-staged 64 x 320 kernel for the two 320-column GEMMs (A/B switch)
+static const bool g_dma_split = []() { const char* e = getenv("SPV_GEMM_DMA_SPLIT"); return !(e && e[0] == '0'); }();
 extern "C" int spv_gemm_bf16_uses_dma(int32_t a_kmajor, int32_t M, int32_t N, int32_t K, int32_t nsplit, int32_t a_tiles, int64_t ldb) {
-  if (nsplit != 1 || a_tiles <= 0 || N <= 32 || N > DG_BN || ldb != DG_BN || M <= 0 || K <= 0) return 0;
+  if ((nsplit != 1 && nsplit != 3) || a_tiles <= 0 || N <= 32 || N > DG_BN || ldb != DG_BN || M <= 0 || K <= 0) return 0;
+  if (nsplit == 3 && !g_dma_split) return 0;
   const long genes_needed = a_kmajor ? ((long)M + DG_BM - 1) / DG_BM * DG_BM : ((long)K + DG_BK - 1) / DG_BK * DG_BK;
   if ((long)a_tiles * 32 < genes_needed) return 0;
   return 1;
@@ -338,7 +341,22 @@ extern "C" int spv_gemm_bf16(int32_t a_kmajor, const uint16_t* A_hi, const uint1
   p.epi = EPI_STORE;
   p.tiles_inner = a_tiles;
   hipStream_t s = (hipStream_t)stream;
-  if (spv_gemm_bf16_uses_dma(a_kmajor, M, N, K, nsplit, a_tiles, ldb) && ((reinterpret_cast<uintptr_t>(A_hi) | reinterpret_cast<uintptr_t>(B_hi)) & 15) == 0) {
+  if (nsplit == 3 && spv_gemm_bf16_uses_dma(a_kmajor, M, N, K, nsplit, a_tiles, ldb) &&
+      ((reinterpret_cast<uintptr_t>(A_hi) | reinterpret_cast<uintptr_t>(B_hi) | reinterpret_cast<uintptr_t>(A_lo) | reinterpret_cast<uintptr_t>(B_lo)) & 15) == 0) {
+    // split-bf16 operands ("fp32" mode): the same tiles from hi and lo planes, 16-deep stages, three MFMAs per fragment pair
+    const int mtiles = (M + DG_BM - 1) / DG_BM;
+    p.c_split_row = splits;
+    static bool raised = false;
+    if (!raised) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm320_dma4s_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, D4S_LDS_BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm320_dma4s_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, D4S_LDS_BYTES);
+      raised = true;
+    }
+    if (a_kmajor) hipLaunchKernelGGL(dec_gemm320_dma4s_kernel<true>, dim3(mtiles * splits), dim3(512), D4S_LDS_BYTES, s, p);
+    else hipLaunchKernelGGL(dec_gemm320_dma4s_kernel<false>, dim3(mtiles * splits), dim3(512), D4S_LDS_BYTES, s, p);
+    return launch_status("spv_gemm_bf16 dma split");
+  }
+  if (nsplit == 1 && spv_gemm_bf16_uses_dma(a_kmajor, M, N, K, nsplit, a_tiles, ldb) && ((reinterpret_cast<uintptr_t>(A_hi) | reinterpret_cast<uintptr_t>(B_hi)) & 15) == 0) {
     // LDS-DMA kernels (spv_dec_gemm.h): 128 x 320 workgroup tiles, `splits` K ranges, four 28 KiB stages (measured at C2,
     // tools/probes/dec_gemm_bench.hip: d A_m 37.5 us, d W_m 38.9 us against 76.5 / 84.8 us for the register-staged 64 x 320 kernel below;
     // the two-stage x 64-deep version of the same kernel: 38.2 / 41.5 us)

@@ -290,6 +290,146 @@ __global__ __launch_bounds__(512) void dec_gemm320_dma4_kernel(GemmParams p) {
   }
 }
 
+// ---- the same two GEMMs on split-bf16 operands ("fp32" mode: x = hi + lo, x*y ~ hi*hi + hi*lo + lo*hi, three MFMAs) -----------------------
+// Both operands come as a hi and a lo plane (dL: two tile-ordered arrays; the k-major image: two [K][320] arrays).  A stage is 16 deep:
+// 4 KiB of dL per plane (the K half of four 32 x 32 tiles) + 10 KiB of the k-major operand per plane = 28 KiB, FOUR stages as in the
+// bf16 kernel above -- the same 8 + 20 DMA pieces per stage (wave w: one dL piece, plane w & 1; the k-major pieces: hi plane 0..9,
+// lo plane 10..19), the same counted waits -- and one k-step of 3 x 5 MFMAs per wave and stage.  The register-staged 64 x 320 kernel of
+// spv_gemm.h that served this mode before spends 717 / 638 us per group at C5's shard shape; see DESIGN.md section 4 for this one.
+constexpr int D4S_BK = 16;
+constexpr int D4S_A_BYTES = DG_BM * D4S_BK * 2, D4S_B_BYTES = D4S_BK * DG_B_ROW, D4S_STAGE = 2 * D4S_A_BYTES + 2 * D4S_B_BYTES;   // 2 x 4 K + 2 x 10 K
+constexpr int D4S_LDS_BYTES = D4_NBUF * D4S_STAGE;   // 114 688 B
+
+template <bool A_CELLS_ON_K>
+__global__ __launch_bounds__(512) void dec_gemm320_dma4s_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char d4s_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uniform_wave_id();
+  const int wm = wave >> 1, wn = wave & 1;
+  const int split = blockIdx.x % p.c_split_row, mtile = blockIdx.x / p.c_split_row;
+  const int m0 = mtile * DG_BM;
+  const int kbeg = split * p.k_per_split;
+  const int Kpad = (p.K + DG_BK - 1) / DG_BK * DG_BK;   // (the operands are padded to multiples of 64 along K)
+  int kend = kbeg + p.k_per_split;
+  if (kend > Kpad) kend = Kpad;
+  const int ntiles = (kend - kbeg) / D4S_BK;
+
+  lds_byte* const lds = (lds_byte*)(d4s_smem);
+  // A: per plane four half tiles of 1 KiB (stage tile i = the i-th 32-row block of the workgroup's M range; the K half alternates with
+  // the stage index).  Wave w copies half tile w >> 1 of plane w & 1.
+  //    d A_m: stage tile = cell tile, its K half = genes 16 (t & 1) .. + 15 = the first / second KiB of the tile;
+  //    d W_m: stage tile = gene tile, its K half = cells 16 (t & 1) .. + 15 = the first / second KiB of the RE-ORDERED tile image
+  //           [cell / 4][gene / 4][cell % 4][4 genes] (see dec_gemm320_dma_kernel), gathered 16 bytes at a time
+  const glb_byte* srcA;
+  long a_pair_step;   // byte advance of the A source per PAIR of stages (one 32-deep tile)
+  {
+    const long T = p.tiles_inner;
+    long tile0;
+    if constexpr (!A_CELLS_ON_K) { tile0 = ((long)(m0 / 32) + (wave >> 1)) * T + (kbeg / 32); a_pair_step = 2048; }
+    else { tile0 = (long)(kbeg / 32) * T + (m0 / 32) + (wave >> 1); a_pair_step = T * 2048; }
+    srcA = (glb_byte*)((wave & 1) ? p.A_lo : p.A) + tile0 * 2048;
+  }
+  // this lane's 16 bytes of the first / second K half of a tile
+  int a_half_off[2];
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+    int chunk = hf * 64 + lane;   // 16-byte chunk of the (LDS-order) tile image
+    if constexpr (A_CELLS_ON_K) {
+      const int cq = chunk >> 4, gp = (chunk >> 1) & 7, cpair = chunk & 1;
+      chunk = (gp >> 1) * 32 + (gp & 1) * 16 + 2 * cq + cpair;
+    }
+    a_half_off[hf] = chunk * 16;
+  }
+  // B: per plane 16 rows x 640 B = 10 pieces; piece q = wave + 8 i (i = 0..2, the third only for waves 0..3): plane q / 10, piece q % 10
+  const glb_byte* srcB[3];
+  int dstB[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int q = (wave + 8 * i) % 20;   // (% only tames the non-existent third piece of waves 4..7)
+    const int plane = q / 10, o = (q % 10) * 1024 + lane * 16;
+    const int row = o / DG_B_ROW, w = o % DG_B_ROW;
+    const int gran = (w >> 6) ^ ((row >> 1) & 1);
+    srcB[i] = (glb_byte*)(plane ? p.B_lo : p.B) + ((long)(kbeg + row) * DG_B_ROW) + gran * 64 + (w & 63);
+    dstB[i] = 2 * D4S_A_BYTES + plane * D4S_B_BYTES + (q % 10) * 1024;
+  }
+  auto issue = [&](int t) {
+    const int stage = (t % D4_NBUF) * D4S_STAGE;
+    dma16(srcA + (long)(t >> 1) * a_pair_step + a_half_off[t & 1], lds + stage + (wave & 1) * D4S_A_BYTES + (wave >> 1) * 1024);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (i == 2 && wave >= 4) break;   // (wave-uniform)
+      dma16(srcB[i] + (long)t * D4S_B_BYTES, lds + stage + dstB[i]);
+    }
+  };
+
+  f16v acc[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+
+  for (int t = 0; t < D4_NBUF - 1 && t < ntiles; ++t) issue(t);
+  const int gi = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3, h = lane >> 5, r = lane & 31;
+  const int in_gran = 32 * (gi & 1) + 8 * p4;
+  const int fB = (q4 >> 1) & 1;
+  const unsigned lds0 = lds_addr_of(d4s_smem);
+  for (int t = 0; t < ntiles; ++t) {
+    const int younger = min(ntiles - 1 - t, D4_NBUF - 2);
+    if (younger == 2) { if (wave < 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+    else if (younger == 1) { if (wave < 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    raw_barrier();
+    if (t + D4_NBUF - 1 < ntiles) issue(t + D4_NBUF - 1);
+    const unsigned st = lds0 + (t % D4_NBUF) * D4S_STAGE;
+    s4v ra[2][2], rb[2][5][2];   // [plane][..]
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      const unsigned stA = st + pl * D4S_A_BYTES, stB = st + 2 * D4S_A_BYTES + pl * D4S_B_BYTES;
+      if constexpr (!A_CELLS_ON_K) {   // half tile wm: genes 8 h .. + 7 of cell r = two 8-byte pieces
+        const unsigned ad = stA + wm * 1024 + h * 512 + r * 8;
+        lds_read8(ra[pl][0], ad);
+        lds_read8(ra[pl][1], ad + 256);
+      } else {                         // half tile wm: cells 8 h + q4 (+ 4), gene piece 4 (gi & 1) + p4
+        const unsigned ad = stA + wm * 1024 + (2 * h) * 256 + (4 * (gi & 1) + p4) * 32 + q4 * 8;
+        tr_issue(ra[pl][0], ad);
+        tr_issue(ra[pl][1], ad + 256);
+      }
+      const unsigned rowB = stB + (8 * h + q4) * DG_B_ROW + in_gran;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const unsigned ad = rowB + (((wn * 5 + j) ^ fB) * 64);
+        tr_issue(rb[pl][j][0], ad);
+        tr_issue(rb[pl][j][1], ad + 4 * DG_B_ROW);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[1][0]), "+v"(ra[1][1]),
+                 "+v"(rb[0][0][0]), "+v"(rb[0][0][1]), "+v"(rb[0][1][0]), "+v"(rb[0][1][1]), "+v"(rb[0][2][0]), "+v"(rb[0][2][1]), "+v"(rb[0][3][0]), "+v"(rb[0][3][1]),
+                 "+v"(rb[0][4][0]), "+v"(rb[0][4][1]), "+v"(rb[1][0][0]), "+v"(rb[1][0][1]), "+v"(rb[1][1][0]), "+v"(rb[1][1][1]), "+v"(rb[1][2][0]), "+v"(rb[1][2][1]),
+                 "+v"(rb[1][3][0]), "+v"(rb[1][3][1]), "+v"(rb[1][4][0]), "+v"(rb[1][4][1]));
+    const s8v a_hi = join8(ra[0][0], ra[0][1]), a_lo = join8(ra[1][0], ra[1][1]);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const s8v b_hi = join8(rb[0][j][0], rb[0][j][1]), b_lo = join8(rb[1][j][0], rb[1][j][1]);
+      acc[j] = mfma32(a_hi, b_lo, acc[j]);   // small terms first, as the register-staged kernel orders them (spv_gemm.h)
+      acc[j] = mfma32(a_lo, b_hi, acc[j]);
+      acc[j] = mfma32(a_hi, b_hi, acc[j]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  float* slab = p.C + (long)split * p.slab_stride;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int col = wn * 160 + 32 * j + r;
+    if (col >= p.N) continue;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = m0 + wm * 32 + crow(q, h);
+      if (row < p.M) slab[(long)row * p.ldc + col] = acc[j][q];
+    }
+  }
+}
+
 // ---- regressor weight gradients of both rate heads in one pass --------------------------------------------------------------------
 //   d [W'_p | c_p][gene][0..15] = sum_cell tP[cell][gene] * Aps[cell][0..15]
 //   d [W'_s | c_s][gene][0..31] = sum_cell tS[cell][gene] * Aps[cell][16..47]        (backward of the two factor regressors,
