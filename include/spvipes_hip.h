@@ -109,6 +109,11 @@ int spv_enc_fc1_fwd(const spv_counts* x, int32_t B, int32_t G,
  * library[c] = log(sum_g log1p(X[c][g])) (module/spVIPESmodule.py:428-435 evaluated for every cell of the data set).
  * x->rows is ignored.                                                                                               */
 int spv_prepare_log1p(const spv_counts* x, int32_t n_cells, int32_t G, uint16_t* xb, int64_t ld_xb, float* library, void* stream);
+/* The same for the "fp32" (nsplit 3) mode: bf16 hi words of log1p(x) and lo words (bf16(x - hi)), interleaved in blocks of 32 genes --
+ * words [64 b, 64 b + 32) of a row are the hi words of genes 32 b .. 32 b + 31, words [64 b + 32, 64 b + 64) their lo words (one
+ * 128-byte line = what one K tile of the LDS-DMA fc1 kernel takes from a row); ld_xb (words per row) a multiple of 128,
+ * >= 2 round_up(G, 64) for that kernel, zero padded.  spv_enc_fc1_fwd takes it as xb_all with nsplit 3 and that ld_xb. */
+int spv_prepare_log1p_split(const spv_counts* x, int32_t n_cells, int32_t G, uint16_t* xb, int64_t ld_xb, float* library, void* stream);
 
 /* fc1 weight gradient (autograd of nn/networks.py:119):  dW1[N1][G] = dh^T @ log1p(X[rows]).
  *   dh_hi/lo : [round_up(B,64)][ld_dh] (ld_dh >= round_up(N1,128), zero padded) from spv_enc_fc1_bwd_prep: nsplit 3 bf16 hi / lo,

@@ -179,8 +179,12 @@ static int fc1_fwd_dispatch(const GemmParams& p, int N1, int splits, hipStream_t
 // Shapes the LDS-DMA fc1 forward kernel (spv_fc1.h) takes: the resident bf16 log1p image, both encoders' 2H = 256 output columns,
 // operand images zero padded to multiples of 64 genes with 16-byte aligned rows.  The host asks through this entry point
 // because the path fixes the slab workspace: [splits][round_up(B, 128)][256] fp32 in accumulator-tile order.
+// SPV_FC1_DMA_SPLIT=0: "fp32" mode keeps the count-decoding register-staged fc1 kernels (A/B switch)
+static const bool g_fc1_dma_split = []() { const char* e = getenv("SPV_FC1_DMA_SPLIT"); return !(e && e[0] == '0'); }();
 extern "C" int spv_enc_fc1_fwd_uses_dma(int32_t B, int32_t G, int32_t N1, int32_t nsplit, int32_t have_xb, int64_t ldw, int64_t ld_xb) {
   const long G64 = (G + 63) & ~63L;
+  if (nsplit == 3)   // "fp32" mode: the resident image holds [hi | lo] halves per row (spv_prepare_log1p_split): ld_xb is the pitch of both
+    return g_fc1_dma_split && have_xb && (N1 == F1_BN || N1 == 2 * F1_BN) && B > 0 && G > 0 && ldw >= G64 && ld_xb >= 2 * G64 && (ldw % 8) == 0 && (ld_xb % 16) == 0;
   return have_xb && nsplit == 1 && (N1 == F1_BN || N1 == 2 * F1_BN) && B > 0 && G > 0 && ldw >= G64 && ld_xb >= G64 && (ldw % 8) == 0 && (ld_xb % 8) == 0;
 }
 
@@ -201,8 +205,10 @@ extern "C" int spv_enc_fc1_fwd(const spv_counts* x, int32_t B, int32_t G, const 
   p.rows = x->rows; p.counts_aligned = counts_aligned(x); p.col_off = x->col_off; p.n_cells = B; p.n_genes = G;
   p.rowsum = rowsum_ws;
   if (xb_all != nullptr) {  // log1p(x) of the whole data set is resident as bf16 (spv_prepare_log1p): plain gathered operand, no decode
-    if (nsplit != 1 || !library_all || ld_xb < ((G + 31) & ~31) || (ld_xb % 8)) return fail(SPV_ERR_ARG, "spv_enc_fc1_fwd: xb_all needs nsplit 1, library_all and ld_xb >= round_up(G, 32)%s");
+    if (!library_all || ld_xb < ((G + 31) & ~31) || (ld_xb % 8)) return fail(SPV_ERR_ARG, "spv_enc_fc1_fwd: xb_all needs library_all and ld_xb >= round_up(G, 32)%s");
+    if (nsplit == 3 && !spv_enc_fc1_fwd_uses_dma(B, G, N1, nsplit, 1, ldw, ld_xb)) return fail(SPV_ERR_ARG, "spv_enc_fc1_fwd: a split (nsplit 3) resident image is only taken by the LDS-DMA kernel (ask spv_enc_fc1_fwd_uses_dma)%s");
     p.A = xb_all; p.lda = ld_xb; p.rowsum = nullptr;
+    // (nsplit 3: hi / lo planes interleaved inside the rows, spv_prepare_log1p_split)
   }
   p.C = slabs; p.ldc = N1; p.slab_stride = (long)B * N1;
   p.M = B; p.N = N1; p.K = G;
@@ -218,6 +224,21 @@ extern "C" int spv_enc_fc1_fwd(const spv_counts* x, int32_t B, int32_t G, const 
   hipStream_t s = (hipStream_t)stream;
   int rc;
   const float acc_scale = (nsplit == 1) ? 1.0f / SPV_FC1_W_SCALE : 1.0f;   // the f16 weight image holds W * SPV_FC1_W_SCALE (spv_pack_f16)
+  if (nsplit == 3 && xb_all != nullptr) {
+    // "fp32" mode on a resident split image: the LDS-DMA kernel on hi / lo planes (spv_fc1.h: fc1_fwd_dma_body<true>)
+    if (((reinterpret_cast<uintptr_t>(xb_all) | reinterpret_cast<uintptr_t>(W1_hi) | reinterpret_cast<uintptr_t>(W1_lo)) & 15) != 0) return fail(SPV_ERR_ARG, "spv_enc_fc1_fwd: images must be 16-byte aligned%s");
+    const int mtiles = (B + F1_BM - 1) / F1_BM, kt = (G + F1_BK - 1) / F1_BK;
+    p.k_per_split = ((kt + splits - 1) / splits) * F1_BK;
+    p.c_split_row = splits;
+    static bool raised = false;
+    if (!raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fc1_fwd_dma_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F1_LDS_BYTES); raised = true; }
+    hipLaunchKernelGGL(fc1_fwd_dma_split_kernel, dim3(mtiles * splits, N1 / F1_BN), dim3(512), F1_LDS_BYTES, s, p);
+    if (hipGetLastError() != hipSuccess) return launch_status("spv_enc_fc1_fwd dma split gemm");
+    const long slab_elems = (long)mtiles * F1_BM * N1;
+    hipLaunchKernelGGL(fc1_epilogue_tiled_kernel, dim3((unsigned)((slab_elems / 4 + 255) / 256)), dim3(256), 0, s, slabs, splits, slab_elems, B, N1, bias, bias2, n_first, h1, library,
+                       library_all, x->rows, 1.0f, cov, cov_idx);
+    return launch_status("spv_enc_fc1_fwd dma split epilogue");
+  }
   if (spv_enc_fc1_fwd_uses_dma(B, G, N1, nsplit, xb_all != nullptr, ldw, ld_xb) && ((reinterpret_cast<uintptr_t>(xb_all) | reinterpret_cast<uintptr_t>(W1_hi)) & 15) == 0) {
     // LDS-DMA kernel (spv_fc1.h): 128-cell tiles, K split `splits` ways, slabs in accumulator-tile order [splits][Mp128][256]
     const int mtiles = (B + F1_BM - 1) / F1_BM, kt = (G + F1_BK - 1) / F1_BK;
@@ -1292,11 +1313,13 @@ extern "C" int spv_enc_fc1_bwd_prep(const float* dh1, const float* h1, int32_t B
 static bool fc1_fwd_dma_ok(const spv_fc1_fwd_args& a) {
   return a.x && a.x->X && a.W1_hi && a.bias && a.slabs && a.h1 && a.library && a.xb_all && a.library_all && a.B > 0 && a.G > 0 && a.splits > 0 &&
          spv_enc_fc1_fwd_uses_dma(a.B, a.G, a.N1, a.nsplit, 1, a.ldw, a.ld_xb) &&
-         ((reinterpret_cast<uintptr_t>(a.xb_all) | reinterpret_cast<uintptr_t>(a.W1_hi)) & 15) == 0;
+         ((reinterpret_cast<uintptr_t>(a.xb_all) | reinterpret_cast<uintptr_t>(a.W1_hi)) & 15) == 0 &&
+         (a.nsplit == 1 || (a.W1_lo && (reinterpret_cast<uintptr_t>(a.W1_lo) & 15) == 0));
 }
 static GemmParams fc1_fwd_dma_params(const spv_fc1_fwd_args& a) {
   GemmParams p{};
   p.A = a.xb_all; p.lda = a.ld_xb; p.B = a.W1_hi; p.ldb = a.ldw; p.rows = a.x->rows;
+  if (a.nsplit == 3) p.B_lo = a.W1_lo;   // "fp32" mode: hi / lo planes interleaved inside the image rows, hi / lo weight images
   p.n_cells = a.B; p.n_genes = a.G; p.C = a.slabs; p.ldc = a.N1; p.M = a.B; p.N = a.N1; p.K = a.G;
   const int kt = (a.G + F1_BK - 1) / F1_BK;
   p.k_per_split = ((kt + a.splits - 1) / a.splits) * F1_BK;
@@ -1310,16 +1333,22 @@ extern "C" int spv_enc_fc1_fwd_grouped(const spv_fc1_fwd_args* g, int32_t n_grou
   int i = 0;
   for (; i + 1 < n_groups; i += 2) {
     const spv_fc1_fwd_args &a = g[i], &b = g[i + 1];
-    if (!(fc1_fwd_dma_ok(a) && fc1_fwd_dma_ok(b) && a.N1 == b.N1)) break;
+    if (!(fc1_fwd_dma_ok(a) && fc1_fwd_dma_ok(b) && a.N1 == b.N1 && a.nsplit == b.nsplit)) break;
     const GemmParams p0 = fc1_fwd_dma_params(a), p1 = fc1_fwd_dma_params(b);
     const int mt0 = (a.B + F1_BM - 1) / F1_BM, mt1 = (b.B + F1_BM - 1) / F1_BM;
     static bool raised = false;
-    if (!raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fc1_fwd_dma_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F1_LDS_BYTES); raised = true; }
-    hipLaunchKernelGGL(fc1_fwd_dma_pair_kernel, dim3(mt0 * a.splits + mt1 * b.splits, a.N1 / F1_BN), dim3(512), F1_LDS_BYTES, s, p0, p1, mt0 * a.splits);
+    if (!raised) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fc1_fwd_dma_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F1_LDS_BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fc1_fwd_dma_split_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F1_LDS_BYTES);
+      raised = true;
+    }
+    const float acc_scale = (a.nsplit == 1) ? 1.0f / SPV_FC1_W_SCALE : 1.0f;
+    if (a.nsplit == 3) hipLaunchKernelGGL(fc1_fwd_dma_split_pair_kernel, dim3(mt0 * a.splits + mt1 * b.splits, a.N1 / F1_BN), dim3(512), F1_LDS_BYTES, s, p0, p1, mt0 * a.splits);
+    else hipLaunchKernelGGL(fc1_fwd_dma_pair_kernel, dim3(mt0 * a.splits + mt1 * b.splits, a.N1 / F1_BN), dim3(512), F1_LDS_BYTES, s, p0, p1, mt0 * a.splits);
     if (hipGetLastError() != hipSuccess) return launch_status("spv_enc_fc1_fwd_grouped gemm");
     const long se0 = (long)mt0 * F1_BM * a.N1, se1 = (long)mt1 * F1_BM * b.N1;
-    const Fc1EpiArgs e0{a.slabs, a.splits, se0, a.B, a.N1, a.bias, a.bias2, a.n_first, a.h1, a.library, a.library_all, a.x->rows, 1.0f / SPV_FC1_W_SCALE, a.cov, a.cov_idx};
-    const Fc1EpiArgs e1{b.slabs, b.splits, se1, b.B, b.N1, b.bias, b.bias2, b.n_first, b.h1, b.library, b.library_all, b.x->rows, 1.0f / SPV_FC1_W_SCALE, b.cov, b.cov_idx};
+    const Fc1EpiArgs e0{a.slabs, a.splits, se0, a.B, a.N1, a.bias, a.bias2, a.n_first, a.h1, a.library, a.library_all, a.x->rows, acc_scale, a.cov, a.cov_idx};
+    const Fc1EpiArgs e1{b.slabs, b.splits, se1, b.B, b.N1, b.bias, b.bias2, b.n_first, b.h1, b.library, b.library_all, b.x->rows, acc_scale, b.cov, b.cov_idx};
     const long sem = se0 > se1 ? se0 : se1;
     hipLaunchKernelGGL(fc1_epilogue_tiled_pair_kernel, dim3((unsigned)((sem / 4 + 255) / 256), 2), dim3(256), 0, s, e0, e1);
     if (hipGetLastError() != hipSuccess) return launch_status("spv_enc_fc1_fwd_grouped epilogue");
@@ -1464,6 +1493,43 @@ __global__ __launch_bounds__(256) void prepare_log1p_kernel(const void* X, long 
     __syncthreads();
   }
   if (threadIdx.x == 0) library[cell] = __logf(s_sum[0]);
+}
+
+// "fp32" mode: bf16 hi / lo planes of log1p(x) interleaved in blocks of 32 genes ([32 hi words | 32 lo words] = 128 bytes per block:
+// what one K tile of the LDS-DMA fc1 kernels takes from a row), ld_xb = 2 ldh words per row, + the library
+__global__ __launch_bounds__(256) void prepare_log1p_split_kernel(const void* X, long ldx, int col_off, int is_u16, int G, bf16_t* xb, long ld_xb,
+                                                                  float* library) {
+  __shared__ float s_sum[256];
+  const long cell = blockIdx.x;
+  const long ldh = ld_xb / 2;
+  float acc = 0.f;
+  for (int g = threadIdx.x; g < (int)ldh; g += 256) {
+    float v = 0.f;
+    if (g < G) {
+      const float c = is_u16 ? (float)reinterpret_cast<const unsigned short*>(X)[cell * ldx + col_off + g]
+                             : reinterpret_cast<const float*>(X)[cell * ldx + col_off + g];
+      v = log1p_count(c);
+    }
+    const bf16_t hi = f2bf(v);
+    const long o = cell * ld_xb + (long)(g >> 5) * 64 + (g & 31);
+    xb[o] = hi;
+    xb[o + 32] = f2bf(v - bf2f(hi));
+    acc += v;
+  }
+  s_sum[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) s_sum[threadIdx.x] += s_sum[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) library[cell] = __logf(s_sum[0]);
+}
+extern "C" int spv_prepare_log1p_split(const spv_counts* x, int32_t n_cells, int32_t G, uint16_t* xb, int64_t ld_xb, float* library, void* stream) {
+  if (!x || !x->X || !xb || !library || n_cells <= 0 || G <= 0 || ld_xb < 2 * (((long)G + 31) & ~31L) || (ld_xb % 128)) return fail(SPV_ERR_ARG, "spv_prepare_log1p_split: bad arguments (ld_xb a multiple of 128 words, >= 2 round_up(G, 32))%s");
+  if (x->dtype != SPV_COUNT_U16 && x->dtype != SPV_COUNT_F32) return fail(SPV_ERR_ARG, "spv_prepare_log1p_split: unknown count dtype%s");
+  hipLaunchKernelGGL(prepare_log1p_split_kernel, dim3((unsigned)n_cells), dim3(256), 0, (hipStream_t)stream, x->X, (long)x->ld, x->col_off,
+                     (int)(x->dtype == SPV_COUNT_U16), G, (bf16_t*)xb, (long)ld_xb, library);
+  return launch_status("spv_prepare_log1p_split");
 }
 
 extern "C" int spv_prepare_log1p(const spv_counts* x, int32_t n_cells, int32_t G, uint16_t* xb, int64_t ld_xb, float* library, void* stream) {

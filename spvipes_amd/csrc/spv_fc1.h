@@ -56,7 +56,14 @@ __device__ __forceinline__ s8v join8(const s4v& v0, const s4v& v1) { return s8v{
 // p.A = bf16 image [n_cells_total][lda] (zero padded to a multiple of 64 genes), p.rows = minibatch row index (nullable),
 // p.B = W bf16 [256][ldb] (zero padded likewise), p.C = slabs in tile order, p.M = cells in the minibatch, p.K = genes,
 // p.k_per_split multiple of 64, p.c_split_row = number of K splits.  grid = ceil(M / 128) * splits (1-D), 512 threads.
+// SPLIT ("fp32" mode): both operands come as bf16 hi / lo planes (p.A: the resident image of spv_prepare_log1p_split, planes interleaved
+// in blocks of 32 k values; p.B / p.B_lo: the two weight images).  A K tile is then 32 deep and an LDS row holds [32 hi words | 32 lo words] of its 32 k values -- the
+// DMA lanes of the upper four 16-byte chunks simply fetch from the lo plane -- so the stage image, the piece count, the swizzle and
+// the counted waits are those of the one-plane kernel; each of the two k-steps of a tile reads hi and lo fragments (chunks 2 ks + h
+// and 4 + 2 ks + h) and issues three bf16 MFMAs per fragment pair (hi*lo, lo*hi, hi*hi).
+template <bool SPLIT>
 __device__ __forceinline__ void fc1_fwd_dma_body(const GemmParams& p, const int blk, const int ntile, unsigned char* f1_smem) {
+  constexpr int TK = SPLIT ? F1_BK / 2 : F1_BK;   // k values per tile
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: the LDS-DMA destination must be
   const int wm = wave >> 2, wn = wave & 3;
@@ -68,7 +75,7 @@ __device__ __forceinline__ void fc1_fwd_dma_body(const GemmParams& p, const int 
   const int Kpad = (p.K + F1_BK - 1) / F1_BK * F1_BK;
   int kend = kbeg + p.k_per_split;
   if (kend > Kpad) kend = Kpad;
-  const int ntiles = (kend - kbeg) / F1_BK;   // may be <= 0 for a trailing split: its slab is zeros
+  const int ntiles = (kend - kbeg) / TK;   // may be <= 0 for a trailing split: its slab is zeros
 
   // ---- this lane's six DMA source rows (fixed over the K loop) ----------------------------------------------------------
   const int lr = lane >> 3, pos = lane & 7;
@@ -81,14 +88,17 @@ __device__ __forceinline__ void fc1_fwd_dma_body(const GemmParams& p, const int 
     if (cell > p.M - 1) cell = p.M - 1;   // rows beyond the minibatch re-read its last row; their outputs are never used
     const long ridx = p.rows ? (long)p.rows[cell] : (long)cell;
     const int c = pos ^ ((row >> 1) & 7);
-    src[i] = (glb_byte*)(p.A) + (ridx * p.lda + kbeg + 8 * c) * 2;
+    // (SPLIT: the image interleaves the planes in blocks of 32 k values, [32 hi words | 32 lo words]: a tile's row is ONE 128-byte line
+    //  here too -- with the planes in separate halves of the row the same kernel ran at 0.58 instead of 0.4x ms at C5: 64-byte requests)
+    src[i] = (glb_byte*)(p.A) + (ridx * p.lda + (SPLIT ? 2 : 1) * kbeg + 8 * c) * 2;
     dst_off[i] = piece * 1024;
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {   // B pieces 4 wave + i: rows (output columns) 8 (4 wave + i) + lr of W
     const int piece = 4 * wave + i, n = 8 * piece + lr + ntile * F1_BN;   // (ntile: which 256 of the N1 = 256 or 512 output columns)
     const int c = pos ^ ((n >> 1) & 7);
-    src[2 + i] = (glb_byte*)(p.B) + ((long)n * p.ldb + kbeg + 8 * c) * 2;
+    if constexpr (SPLIT) src[2 + i] = (glb_byte*)((c >> 2) ? p.B_lo : p.B) + ((long)n * p.ldb + kbeg + 8 * (c & 3)) * 2;
+    else src[2 + i] = (glb_byte*)(p.B) + ((long)n * p.ldb + kbeg + 8 * c) * 2;
     dst_off[2 + i] = F1_A_BYTES + piece * 1024;
   }
   lds_byte* const lds = (lds_byte*)(f1_smem);
@@ -96,7 +106,7 @@ __device__ __forceinline__ void fc1_fwd_dma_body(const GemmParams& p, const int 
     const int stage = (t % F1_NBUF) * F1_STAGE;
 #pragma unroll
     for (int i = i0; i < i0 + 2; ++i)
-      __builtin_amdgcn_global_load_lds(src[i] + (long)t * (F1_BK * 2), lds + stage + dst_off[i], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(src[i] + (long)t * ((SPLIT && i < 2) ? F1_BK * 2 : TK * 2), lds + stage + dst_off[i], 16, 0, 0);
   };
   auto issue = [&](int t) { issue2(t, 0); issue2(t, 2); issue2(t, 4); };
 
@@ -120,6 +130,36 @@ __device__ __forceinline__ void fc1_fwd_dma_body(const GemmParams& p, const int 
     __builtin_amdgcn_s_barrier();
     const bool more = t + 2 < ntiles;
     const unsigned char* st = f1_smem + (t % F1_NBUF) * F1_STAGE;
+    if constexpr (SPLIT) {
+      // every fragment of the tile is requested BEFORE tile t + 2's DMA goes out: hipcc treats an LDS read behind an LDS-DMA of the same
+      // block as a possible alias and drains the DMA queue in front of it (s_waitcnt vmcnt(0): no prefetch left at all -- first version)
+      s8v a_hi[2][2], a_lo[2][2], b_hi[2][2], b_lo[2][2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int chi = ((2 * ks + h) ^ sw) * 16, clo = ((4 + 2 * ks + h) ^ sw) * 16;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          a_hi[ks][i] = *reinterpret_cast<const s8v*>(st + a_row_off + i * 32 * 128 + chi);
+          a_lo[ks][i] = *reinterpret_cast<const s8v*>(st + a_row_off + i * 32 * 128 + clo);
+          b_hi[ks][i] = *reinterpret_cast<const s8v*>(st + b_row_off + i * 32 * 128 + chi);
+          b_lo[ks][i] = *reinterpret_cast<const s8v*>(st + b_row_off + i * 32 * 128 + clo);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) issue(t + 2);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc[i][j] = mfma32(a_hi[ks][i], b_lo[ks][j], acc[i][j]);
+            acc[i][j] = mfma32(a_lo[ks][i], b_hi[ks][j], acc[i][j]);
+            acc[i][j] = mfma32(a_hi[ks][i], b_hi[ks][j], acc[i][j]);
+          }
+      continue;
+    }
 #if F1_PIPE
     // fragments of k-step ks + 1 are requested before the MFMAs of k-step ks; tile t + 2's six DMA pieces go out two at a
     // time behind the MFMAs of the first three k-steps.  Order pinned with sched_group_barrier (DS read 0x100, MFMA 0x8,
@@ -191,7 +231,17 @@ __device__ __forceinline__ void fc1_fwd_dma_body(const GemmParams& p, const int 
 
 __global__ __launch_bounds__(512) void fc1_fwd_dma_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char f1_smem_[];
-  fc1_fwd_dma_body(p, blockIdx.x, blockIdx.y, f1_smem_);
+  fc1_fwd_dma_body<false>(p, blockIdx.x, blockIdx.y, f1_smem_);
+}
+__global__ __launch_bounds__(512) void fc1_fwd_dma_split_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char f1_smem_[];
+  fc1_fwd_dma_body<true>(p, blockIdx.x, blockIdx.y, f1_smem_);
+}
+__global__ __launch_bounds__(512) void fc1_fwd_dma_split_pair_kernel(GemmParams p0, GemmParams p1, int n0) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char f1_smem_[];
+  const bool first = (int)blockIdx.x < n0;
+  const GemmParams p = first ? p0 : p1;
+  fc1_fwd_dma_body<true>(p, first ? (int)blockIdx.x : (int)blockIdx.x - n0, blockIdx.y, f1_smem_);
 }
 // both groups of a step in ONE grid (workgroups 0 .. n0 - 1: the first group's): one launch instead of two launches on two streams
 // whose 2 x 256 one-per-CU workgroups can only run one after the other anyway -- without the fork / join of the graph branches
@@ -199,7 +249,7 @@ __global__ __launch_bounds__(512) void fc1_fwd_dma_pair_kernel(GemmParams p0, Ge
   extern __shared__ __attribute__((aligned(16))) unsigned char f1_smem_[];
   const bool first = (int)blockIdx.x < n0;   // (workgroup-uniform)
   const GemmParams p = first ? p0 : p1;
-  fc1_fwd_dma_body(p, first ? (int)blockIdx.x : (int)blockIdx.x - n0, blockIdx.y, f1_smem_);
+  fc1_fwd_dma_body<false>(p, first ? (int)blockIdx.x : (int)blockIdx.x - n0, blockIdx.y, f1_smem_);
 }
 
 // h1[cell][col] = relu(bias[col] + sum_splits S[split][...]), library from the data set's table (spv_prepare_log1p).

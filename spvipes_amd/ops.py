@@ -62,6 +62,31 @@ class GroupCounts:
             self._xb = (xb, lib)
         return self._xb
 
+    def log1p_image_split(self):
+        """"fp32" mode: (bf16 [hi | lo] halves of log1p(x) per row [n_cells][2 ldh], library), built on first use by spv_prepare_log1p_split"""
+        if getattr(self, "_xb_split", None) is None:
+            ldh = round_up(round_up(self.G, 96), 128)
+            xb = torch.empty((self.n_cells, 2 * ldh), dtype=torch.int16, device=self.X.device)
+            lib = torch.empty((self.n_cells,), dtype=torch.float32, device=self.X.device)
+            cs = self.c_struct(None)
+            _abi.call("spv_prepare_log1p_split", C.byref(cs), self.n_cells, self.G, ptr(xb), 2 * ldh, ptr(lib), stream_ptr())
+            self._xb_split = (xb, lib)
+        return self._xb_split
+
+    def fc1_image(self, nsplit: int, B: int, N1: int, Gp: int):
+        """(image, row pitch, library table) of the resident log1p image the fc1 kernels gather from, or (None, 0, None): the f16 image in
+        the one-MFMA mode; in "fp32" mode the [hi | lo] image when the LDS-DMA kernel takes the shape (it is the only consumer)."""
+        if not self.resident:
+            return None, 0, None
+        if nsplit == 1:
+            xb, lib = self.log1p_image()
+            return xb, xb.shape[1], lib
+        ld = 2 * round_up(round_up(self.G, 96), 128)
+        if not _abi.load().spv_enc_fc1_fwd_uses_dma(B, self.G, N1, nsplit, 1, Gp, ld):
+            return None, 0, None
+        xb, lib = self.log1p_image_split()
+        return xb, ld, lib
+
     def c_struct(self, rows: Optional[torch.Tensor]) -> SpvCounts:
         if rows is not None and (rows.dtype != torch.int32 or not rows.is_cuda or not rows.is_contiguous()):
             raise _abi.SpvError("row index must be a contiguous int32 tensor in HBM")
@@ -296,10 +321,7 @@ class EncoderFC1(torch.autograd.Function):
         cs = counts.c_struct(rows)
         # bf16 mode on a resident count matrix: log1p(x) of the whole data set sits in HBM as bf16 (built once, see
         # GroupCounts.log1p_image) and both fc1 GEMMs gather plain rows from it instead of decoding counts every step
-        xb, ld_xb, lib_all = None, 0, None
-        if nsplit == 1 and counts.resident:
-            xb, lib_all = counts.log1p_image()
-            ld_xb = xb.shape[1]
+        xb, ld_xb, lib_all = counts.fc1_image(nsplit, B, N1, Gp)
         if _abi.load().spv_enc_fc1_fwd_uses_dma(B, G, N1, nsplit, int(xb is not None), Gp, ld_xb):
             # LDS-DMA kernel (csrc/spv_fc1.h): 128-cell tiles x all 256 columns, K split so that ~one workgroup lands on every CU
             mt = -(-B // 128)
@@ -312,7 +334,7 @@ class EncoderFC1(torch.autograd.Function):
         _abi.call("spv_enc_fc1_fwd", C.byref(cs), B, G, ptr(W_hi), ptr(W_lo), Gp, N1, ptr(b_priv), ptr(b_sh), H, nsplit, splits, ptr(slabs),
                                   ptr(rowsum), ptr(h1), ptr(library), ptr(xb), ld_xb, ptr(lib_all), ptr(cov_tab), ptr(cov[0]) if cov else None, stream_ptr())
         ctx.counts, ctx.rows, ctx.B, ctx.nsplit, ctx.ws, ctx.H, ctx.G = counts, rows, B, nsplit, ws, H, G
-        ctx.xb, ctx.ld_xb, ctx.cov = xb, ld_xb, cov
+        ctx.xb, ctx.ld_xb, ctx.cov = (xb, ld_xb, cov) if nsplit == 1 else (None, 0, cov)   # (the weight gradient reads the f16 image only)
         ctx.save_for_backward(h1, w_priv, b_priv, w_sh, b_sh)
         ctx.mark_non_differentiable(library)
         return h1, library
@@ -376,10 +398,7 @@ class EncoderFC1Grouped(torch.autograd.Function):
             h1 = torch.empty((B, N1), dtype=torch.float32, device=w_priv.device)
             library = torch.empty((B,), dtype=torch.float32, device=w_priv.device)
             cs = counts[g].c_struct(rows[g])
-            xb, ld_xb, lib_all = None, 0, None
-            if nsplit == 1 and counts[g].resident:
-                xb, lib_all = counts[g].log1p_image()
-                ld_xb = xb.shape[1]
+            xb, ld_xb, lib_all = counts[g].fc1_image(nsplit, B, N1, Gp)
             if lib.spv_enc_fc1_fwd_uses_dma(B, G, N1, nsplit, int(xb is not None), Gp, ld_xb):
                 mt = -(-B // 128)
                 # K splits: the groups of a pair share one grid, so the 256 CUs are divided by the PAIR's workgroup count (FC1_PAIR_SPLITS:
@@ -401,7 +420,7 @@ class EncoderFC1Grouped(torch.autograd.Function):
             keep += [cs, b_priv, b_sh, W_hi, W_lo, slabs, rowsum, xb, lib_all, cov_tab]
             outs += [h1, library]
             saved += [h1, w_priv, b_priv, w_sh, b_sh]
-            meta.append((counts[g], rows[g], B, H, G, ws, xb, ld_xb, cov))
+            meta.append((counts[g], rows[g], B, H, G, ws) + ((xb, ld_xb) if nsplit == 1 else (None, 0)) + (cov,))   # (the weight gradient reads the f16 image only)
         _abi.call("spv_enc_fc1_fwd_grouped", args, NG, stream_ptr())
         ctx.meta, ctx.nsplit, ctx.NG = meta, nsplit, NG
         ctx.save_for_backward(*saved)
