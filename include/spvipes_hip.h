@@ -118,10 +118,12 @@ int spv_prepare_log1p_split(const spv_counts* x, int32_t n_cells, int32_t G, uin
 /* fc1 weight gradient (autograd of nn/networks.py:119):  dW1[N1][G] = dh^T @ log1p(X[rows]).
  *   dh_hi/lo : [round_up(B,64)][ld_dh] (ld_dh >= round_up(N1,128), zero padded) from spv_enc_fc1_bwd_prep: nsplit 3 bf16 hi / lo,
  *              nsplit 1 f16(dpre * scale) with dh_scale = that call's scale_ws ({scale, 1 / scale}: the result is multiplied by [1])
- *   xb       : optional (nsplit 1): the resident f16 log1p image of spv_prepare_log1p ([n_cells][ld_xb], gathered through
- *              x->rows); NULL = decode the counts here
+ *   xb       : optional: nsplit 1: the resident f16 log1p image of spv_prepare_log1p ([n_cells][ld_xb], gathered through x->rows);
+ *              nsplit 3: the resident split image of spv_prepare_log1p_split, where spv_enc_fc1_wgrad_split_uses_dma says so
+ *              (B <= 4096-ish: the row-index table of the minibatch sits in LDS); NULL = decode the counts here
  *   dW2      : optional second destination: rows >= rows_first go to dW2[row - rows_first] (the shared
  *              encoder's weight gradient, stored apart from the private encoder's)  */
+int spv_enc_fc1_wgrad_split_uses_dma(int32_t B, int32_t G, int32_t N1, int64_t ld_dh, int64_t ld_xb);   /* nsplit 3: may xb be passed? */
 int spv_enc_fc1_wgrad(const spv_counts* x, int32_t B, int32_t G,
                       const uint16_t* dh_hi, const uint16_t* dh_lo, int64_t ld_dh, int32_t N1,
                       int32_t nsplit, float* dW, float* dW2, int32_t rows_first, int64_t ldc,

@@ -189,6 +189,7 @@ _SIGNATURES = {
     "spv_enc_fc1_fwd": (C.c_int, [C.POINTER(SpvCounts), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                   C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "spv_enc_fc1_wgrad_split_uses_dma": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64]),
     "spv_enc_fc1_fwd_grouped": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "spv_enc_fc1_bwd_grouped": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "spv_prepare_log1p": (C.c_int, [C.POINTER(SpvCounts), C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

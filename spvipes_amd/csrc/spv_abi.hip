@@ -266,6 +266,12 @@ extern "C" int spv_enc_fc1_fwd(const spv_counts* x, int32_t B, int32_t G, const 
   return launch_status("spv_enc_fc1_fwd epilogue");
 }
 
+// 1 when spv_enc_fc1_wgrad takes a split (nsplit 3) resident image for these shapes (the LDS-DMA kernel is its only consumer)
+extern "C" int spv_enc_fc1_wgrad_split_uses_dma(int32_t B, int32_t G, int32_t N1, int64_t ld_dh, int64_t ld_xb) {
+  if (!g_fc1_dma_split || B <= 0 || G <= 0) return 0;
+  const int Kpad = (B + FW_BK - 1) / FW_BK * FW_BK;
+  return (N1 == FW_BM || N1 == 2 * FW_BM) && ld_dh == N1 && ld_xb >= 2 * (((long)G + 95) / 96 * 96) && (ld_xb % 128) == 0 && fw_lds_bytes(96, Kpad) <= 160 * 1024;
+}
 extern "C" int spv_enc_fc1_wgrad(const spv_counts* x, int32_t B, int32_t G, const uint16_t* dh_hi, const uint16_t* dh_lo,
                                  int64_t ld_dh, int32_t N1, int32_t nsplit, float* dW, float* dW2, int32_t rows_first, int64_t ldc,
                                  const uint16_t* xb, int64_t ld_xb, const float* dh_scale, void* stream) {
@@ -287,6 +293,23 @@ extern "C" int spv_enc_fc1_wgrad(const spv_counts* x, int32_t B, int32_t G, cons
   p.epi = EPI_STORE;
   hipStream_t s = (hipStream_t)stream;
   int rc;
+  if (xb != nullptr && nsplit == 3) {
+    // "fp32" mode on the resident split image (spv_prepare_log1p_split): the LDS-DMA kernel on hi / lo planes, 96-gene tiles
+    const int Kpad = (B + FW_BK - 1) / FW_BK * FW_BK;
+    if (!spv_enc_fc1_wgrad_split_uses_dma(B, G, N1, ld_dh, ld_xb) || rows_first != N1 / 2 || dW2 == nullptr ||
+        ((reinterpret_cast<uintptr_t>(xb) | reinterpret_cast<uintptr_t>(dh_hi) | reinterpret_cast<uintptr_t>(dh_lo)) & 15) != 0)
+      return fail(SPV_ERR_ARG, "spv_enc_fc1_wgrad: a split (nsplit 3) resident image is only taken by the LDS-DMA kernel (ask spv_enc_fc1_wgrad_split_uses_dma)%s");
+    p.B = xb; p.ldb = ld_xb;
+    // gene tile: 128 where that saves a round of one-per-CU workgroups over 96 (and its LDS need -- 144 KiB of stages + the row table -- fits)
+    const int mth = N1 / FW_BM, nb96 = (G + 95) / 96, nb128 = (G + 127) / 128;
+    static const int force_bn = getenv("SPV_FC1W_SPLIT_BN") ? atoi(getenv("SPV_FC1W_SPLIT_BN")) : 0;   // (A/B switch)
+    const bool fits128 = fw_lds_bytes(128, Kpad) <= 160 * 1024 && ld_xb >= 2 * (long)nb128 * 128;
+    const bool use128 = fits128 && (force_bn ? force_bn == 128 : (nb128 * mth + 255) / 256 < (nb96 * mth + 255) / 256);
+    void (*kfn)(GemmParams) = use128 ? fc1_wgrad_dma_split_kernel<128> : fc1_wgrad_dma_split_kernel<96>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(kfn, dim3(use128 ? nb128 : nb96, mth), dim3(512), fw_lds_bytes(use128 ? 128 : 96, Kpad), s, p);
+    return launch_status("spv_enc_fc1_wgrad dma split");
+  }
   if (xb != nullptr) {  // resident bf16 log1p(x) of the data set (spv_prepare_log1p): gathered plain k-major operand, no decode
     if (nsplit != 1 || ld_xb < ((G + 63) & ~63) || (ld_xb % 8)) return fail(SPV_ERR_ARG, "spv_enc_fc1_wgrad: xb needs nsplit 1 and ld_xb >= round_up(G, 64)%s");
     p.B = xb; p.ldb = ld_xb;

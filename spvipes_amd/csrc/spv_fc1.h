@@ -479,6 +479,174 @@ __device__ __forceinline__ void fc1_wgrad_dma_body(const GemmParams& p, const in
     }
 }
 
+// ---- the weight gradient on split-bf16 operands ("fp32" mode), 96- or 128-gene tiles -----------------------------------------------
+// p.A / p.A_lo = the hi / lo dh images [Kpad][lda], p.B = the resident image of spv_prepare_log1p_split (hi / lo interleaved per 32-gene
+// block).  A stage is 32 cells deep: LDS rows 0..31 hold the hi rows of its cells, rows 32..63 the lo rows, for both operands -- the
+// stage image, the piece counts and the counted waits are those of fc1_wgrad_dma_body<WG_BN>; each of the two k-steps reads hi and lo
+// fragments (rows r and r + 32) and issues three MFMAs per fragment pair.  Results straight into dW / dW2.  (128-gene tiles exist for
+// the round structure: at G = 30 000 they make 235 workgroups = ONE round of the 256 CUs per group where 96-gene tiles make 313 = two,
+// the second a quarter full: 373 -> 2xx us per group.)
+template <int WG_BN>
+__device__ __forceinline__ void fc1_wgrad_dma_split_body(const GemmParams& p, const int blk, const int mtile, unsigned char* fw_smem) {
+  typedef FwCfg<WG_BN> Cfg;
+  static_assert(WG_BN == 96 || WG_BN == 128, "gene tile");
+  constexpr int SK = FW_BK / 2;   // cells per stage
+  constexpr int TM = Cfg::TM, TN = Cfg::TN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uniform_wave_id();
+  const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
+  const int n0 = blk * WG_BN;
+  const int Kpad = (p.n_cells + FW_BK - 1) / FW_BK * FW_BK, ntiles = Kpad / SK;
+  int* rowtab = reinterpret_cast<int*>(fw_smem + Cfg::STAGE * FW_NBUF);
+  for (int k = tid; k < Kpad; k += 512) {
+    const int c = k < p.n_cells ? k : p.n_cells - 1;   // padding cells re-read the last row: their dh rows are zero
+    rowtab[k] = p.rows ? p.rows[c] : c;
+  }
+  __syncthreads();
+
+  lds_byte* const lds = (lds_byte*)(fw_smem);
+  // A pieces: LDS rows 2 piece + (lane >> 5), piece = 4 wave + i: plane = row >> 5, cell of the stage = row & 31
+  const glb_byte* srcA[Cfg::A_PIECES];
+#pragma unroll
+  for (int i = 0; i < Cfg::A_PIECES; ++i) {
+    const int piece = Cfg::A_PIECES * wave + i, row = 2 * piece + (lane >> 5), ch = lane & 31;
+    const int chs = (((ch >> 2) ^ (row & 3)) << 2) | (ch & 3);
+    srcA[i] = (glb_byte*)((row >> 5) ? p.A_lo : p.A) + ((long)(row & 31) * p.lda + mtile * FW_BM) * 2 + chs * 16;
+  }
+  // B pieces.  96 genes: piece = wave + 8 i (the second only for waves 0..3), pieces cross the 192-byte LDS rows, no swizzle;
+  // 128 genes: piece = 2 wave + i = LDS rows 4 piece + (lane >> 4), 64-byte granules XOR-ed with row & 3 (fc1_wgrad_dma_body)
+  int bcell[Cfg::B_PIECES], boff[Cfg::B_PIECES], bdst[Cfg::B_PIECES];
+#pragma unroll
+  for (int i = 0; i < Cfg::B_PIECES; ++i) {
+    int row, gl;   // LDS row, first of the chunk's 8 genes inside the tile
+    if constexpr (WG_BN == 96) {
+      const int o = (wave + 8 * i) * 1024 + lane * 16;
+      row = (o / Cfg::B_ROW) & (FW_BK - 1); gl = (o % Cfg::B_ROW) / 2;
+      bdst[i] = (wave + 8 * i) * 1024;
+    } else {
+      const int piece = Cfg::B_PIECES * wave + i, ch = lane & 15;
+      row = 4 * piece + (lane >> 4);
+      gl = ((((ch >> 2) ^ (row & 3)) << 2) | (ch & 3)) * 8;
+      bdst[i] = piece * 1024;
+    }
+    bcell[i] = row & 31;
+    int e = ((n0 + gl) >> 5) * 64 + (gl & 31) + 32 * (row >> 5);   // word offset inside the interleaved image row (n0 is a multiple of 32)
+    if ((long)e + 8 > p.ldb) e = 0;   // the last workgroup's columns beyond the image row: any in-bounds bytes do (never stored)
+    boff[i] = e * 2;
+  }
+  const glb_byte* const Bbase = (glb_byte*)(p.B);
+  auto issueA = [&](int t, int i) {
+    dma16(srcA[i] + (long)t * (SK * p.lda * 2), lds + (t % FW_NBUF) * Cfg::STAGE + (Cfg::A_PIECES * wave + i) * 1024);
+  };
+  auto issueB = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < Cfg::B_PIECES; ++i) {
+      if (WG_BN == 96 && i == 1 && wave >= 4) break;   // (wave-uniform)
+      const long ridx = rowtab[t * SK + bcell[i]];
+      dma16(Bbase + ridx * p.ldb * 2 + boff[i], lds + (t % FW_NBUF) * Cfg::STAGE + Cfg::A_BYTES + bdst[i]);
+    }
+  };
+  auto issue = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < Cfg::A_PIECES; ++i) issueA(t, i);
+    issueB(t);
+  };
+
+  f16v acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  if (ntiles > 0) issue(0);
+  if (ntiles > 1) issue(1);
+  const int gi = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3, h = lane >> 5;
+  const int in_gran = 32 * (gi & 1) + 8 * p4;
+  const unsigned lds0 = lds_addr_of(fw_smem);
+  for (int t = 0; t < ntiles; ++t) {
+    if (t + 1 < ntiles) {
+      if constexpr (WG_BN == 96) {
+        if (wave < 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      } else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    raw_barrier();
+    const bool more = t + 2 < ntiles;
+    if (more) issueB(t + 2);   // (first: its LDS-table reads are compiler-visible and must not sit between the asm reads below and their waits)
+    const unsigned stA = lds0 + (t % FW_NBUF) * Cfg::STAGE, stB = stA + Cfg::A_BYTES;
+    // 16 transposed reads per k-step and set: TM = 1, TN = 3 (96 genes) or TM = TN = 2 (128), hi and lo, two halves each
+    s4v rr[2][16];
+    auto reads = [&](int ks, int set) {
+      int n = 0;
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        const int row = 32 * pl + 16 * ks + 8 * h + q4;   // (row & 3) == q4
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const unsigned ad = stA + row * 512 + (((wm * TM + i) ^ q4) * 64) + in_gran;
+          tr_issue(rr[set][n++], ad);
+          tr_issue(rr[set][n++], ad + 4 * 512);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int f = (WG_BN == 128) ? q4 : 0;
+          const unsigned bd = stB + row * Cfg::B_ROW + (((wn * TN + j) ^ f) * 64) + in_gran;
+          tr_issue(rr[set][n++], bd);
+          tr_issue(rr[set][n++], bd + 4 * Cfg::B_ROW);
+        }
+      }
+    };
+    reads(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int set = ks;
+      if (ks == 0) {
+        reads(1, 1);   // (16 more reads; the counter saturates at 15: "all but the newest 15" covers the first k-step's 16)
+        asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(rr[0][0]), "+v"(rr[0][1]), "+v"(rr[0][2]), "+v"(rr[0][3]), "+v"(rr[0][4]), "+v"(rr[0][5]), "+v"(rr[0][6]), "+v"(rr[0][7]),
+                     "+v"(rr[0][8]), "+v"(rr[0][9]), "+v"(rr[0][10]), "+v"(rr[0][11]), "+v"(rr[0][12]), "+v"(rr[0][13]), "+v"(rr[0][14]), "+v"(rr[0][15]));
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rr[1][0]), "+v"(rr[1][1]), "+v"(rr[1][2]), "+v"(rr[1][3]), "+v"(rr[1][4]), "+v"(rr[1][5]), "+v"(rr[1][6]), "+v"(rr[1][7]),
+                     "+v"(rr[1][8]), "+v"(rr[1][9]), "+v"(rr[1][10]), "+v"(rr[1][11]), "+v"(rr[1][12]), "+v"(rr[1][13]), "+v"(rr[1][14]), "+v"(rr[1][15]));
+      }
+      // plane pl's reads sit at rr[set][8 pl ..]: first the TM A fragments (two halves each), then the TN B fragments
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const s8v a_hi = join8(rr[set][2 * i], rr[set][2 * i + 1]), a_lo = join8(rr[set][8 + 2 * i], rr[set][8 + 2 * i + 1]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const s8v b_hi = join8(rr[set][2 * TM + 2 * j], rr[set][2 * TM + 2 * j + 1]), b_lo = join8(rr[set][8 + 2 * TM + 2 * j], rr[set][8 + 2 * TM + 2 * j + 1]);
+          acc[i][j] = mfma32(a_hi, b_lo, acc[i][j]);
+          acc[i][j] = mfma32(a_lo, b_hi, acc[i][j]);
+          acc[i][j] = mfma32(a_hi, b_hi, acc[i][j]);
+        }
+      }
+      if (more) { issueA(t + 2, 2 * ks); issueA(t + 2, 2 * ks + 1); }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const int r = lane & 31;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * (WG_BN / Cfg::WAVES_N) + 32 * j + r;
+      if (col >= p.N) continue;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = mtile * FW_BM + wm * (FW_BM / Cfg::WAVES_M) + 32 * i + crow(q, h);
+        float* dst = (row >= p.c_split_row) ? p.C2 + (long)(row - p.c_split_row) * p.ldc + col : p.C + (long)row * p.ldc + col;
+        *dst = acc[i][j][q];
+      }
+    }
+}
+template <int WG_BN>
+__global__ __launch_bounds__(512) void fc1_wgrad_dma_split_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fw_smem_[];
+  fc1_wgrad_dma_split_body<WG_BN>(p, blockIdx.x, blockIdx.y, fw_smem_);
+}
+
 template <int WG_BN>
 __global__ __launch_bounds__(512) void fc1_wgrad_dma_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fw_smem_[];

@@ -274,6 +274,14 @@ def _fc1_splits(B: int, G: int, N1: int) -> int:
 
 
 
+def _wgrad_takes_image(nsplit: int, xb, ld_xb: int, B: int, G: int, N1: int) -> bool:
+    """may the fc1 weight gradient gather from the resident image the forward pass used? (the f16 image: always; the "fp32" mode's split
+    image: where its one consumer, the LDS-DMA kernel, takes the shape)"""
+    if xb is None:
+        return False
+    return nsplit == 1 or bool(_abi.load().spv_enc_fc1_wgrad_split_uses_dma(B, G, N1, round_up(N1, 128), ld_xb))
+
+
 def _fc1_cov_table(w_priv, w_sh, G: int):
     """The weight columns of the one-hot batch covariates that follow the G gene columns of both encoders' fc1 (nn/networks.py:68,
     105-119), as the table spv_enc_fc1_fwd adds before the ReLU: fp32 [n_batch][2H] (rows = batch codes).  None without covariates."""
@@ -334,7 +342,7 @@ class EncoderFC1(torch.autograd.Function):
         _abi.call("spv_enc_fc1_fwd", C.byref(cs), B, G, ptr(W_hi), ptr(W_lo), Gp, N1, ptr(b_priv), ptr(b_sh), H, nsplit, splits, ptr(slabs),
                                   ptr(rowsum), ptr(h1), ptr(library), ptr(xb), ld_xb, ptr(lib_all), ptr(cov_tab), ptr(cov[0]) if cov else None, stream_ptr())
         ctx.counts, ctx.rows, ctx.B, ctx.nsplit, ctx.ws, ctx.H, ctx.G = counts, rows, B, nsplit, ws, H, G
-        ctx.xb, ctx.ld_xb, ctx.cov = (xb, ld_xb, cov) if nsplit == 1 else (None, 0, cov)   # (the weight gradient reads the f16 image only)
+        ctx.xb, ctx.ld_xb, ctx.cov = (xb, ld_xb, cov) if _wgrad_takes_image(nsplit, xb, ld_xb, B, G, N1) else (None, 0, cov)
         ctx.save_for_backward(h1, w_priv, b_priv, w_sh, b_sh)
         ctx.mark_non_differentiable(library)
         return h1, library
@@ -420,7 +428,7 @@ class EncoderFC1Grouped(torch.autograd.Function):
             keep += [cs, b_priv, b_sh, W_hi, W_lo, slabs, rowsum, xb, lib_all, cov_tab]
             outs += [h1, library]
             saved += [h1, w_priv, b_priv, w_sh, b_sh]
-            meta.append((counts[g], rows[g], B, H, G, ws) + ((xb, ld_xb) if nsplit == 1 else (None, 0)) + (cov,))   # (the weight gradient reads the f16 image only)
+            meta.append((counts[g], rows[g], B, H, G, ws) + ((xb, ld_xb) if _wgrad_takes_image(nsplit, xb, ld_xb, B, G, N1) else (None, 0)) + (cov,))
         _abi.call("spv_enc_fc1_fwd_grouped", args, NG, stream_ptr())
         ctx.meta, ctx.nsplit, ctx.NG = meta, nsplit, NG
         ctx.save_for_backward(*saved)
