@@ -587,11 +587,11 @@ extern "C" int spv_dec_softmax_bwd(const spv_dec_params* q, const float* Tp, con
   if (rc != SPV_OK) return rc;
   if (!Tp || !Ts || !p.tP || !p.tS || !p.lse_p || !p.lse_s) return fail(SPV_ERR_ARG, "spv_dec_softmax_bwd: null pointer%s");
   if (p.n_gene_tiles != p.Gp / 32) return fail(SPV_ERR_ARG, "spv_dec_softmax_bwd: n_gene_tiles must be Gp / 32%s");
-  if (dz_part && p.grads_f32) return fail(SPV_ERR_ARG, "spv_dec_softmax_bwd: the fused latent gradient needs bf16 gradient arrays%s");
   dim3 grid(p.Bp / DEC_CELLS_PER_WG, p.gene_splits);
   hipStream_t s = (hipStream_t)stream;
   float* const none = nullptr;
-  if (p.grads_f32) hipLaunchKernelGGL((dec_softmax_bwd_kernel<split_t, false>), grid, dim3(256), 0, s, p, Tp, Ts, none, none, none);
+  if (p.grads_f32 && dz_part) hipLaunchKernelGGL((dec_softmax_bwd_kernel<split_t, true>), grid, dim3(256), 0, s, p, Tp, Ts, dz_part, none, none);
+  else if (p.grads_f32) hipLaunchKernelGGL((dec_softmax_bwd_kernel<split_t, false>), grid, dim3(256), 0, s, p, Tp, Ts, none, none, none);
   else if (dz_part) hipLaunchKernelGGL((dec_softmax_bwd_kernel<bf16_t, true>), grid, dim3(256), 0, s, p, Tp, Ts, dz_part, none, none);
   else hipLaunchKernelGGL((dec_softmax_bwd_kernel<bf16_t, false>), grid, dim3(256), 0, s, p, Tp, Ts, none, none, none);
   return launch_status("spv_dec_softmax_bwd");

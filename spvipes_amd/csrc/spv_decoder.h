@@ -718,7 +718,7 @@ __device__ __forceinline__ void decode4(const u4v& x, float (&v)[4]) {   // hi +
 // Software pipelined over 32-gene tiles: the next tile's fragments and gradient words are requested before the
 // current tile's stores are issued, so waiting for them never has to drain those stores (vmcnt is in order).
 //
-// FUSE (bf16 gradients only): the corrected tile sits in registers in MFMA accumulator layout [gene][cell]; read as the
+// FUSE (bf16 gradients; split-bf16 "fp32" gradient words: the same contraction on hi / lo pairs, three MFMAs): the corrected tile sits in registers in MFMA accumulator layout [gene][cell]; read as the
 // B operand of two more 32x32x16 MFMAs per head (k-slots = the lane's 2 x 4 consecutive genes, the A operand = the
 // transposed regressor slice W'^T[k][gene] staged in LDS with the same slot order) it yields the gradient reaching the
 // latents through the two rate heads,  dz_p[cell][k] = sum_gene t'_P[gene][cell] W'_p[gene][k]  (and dz_s), accumulated
@@ -746,7 +746,9 @@ __global__ __launch_bounds__(256, 2) void dec_softmax_bwd_kernel(DecParams p, co
   typedef typename Raw4<GT>::type raw_t;
   static_assert(!HEADS || (FUSE && !WRITE), "the weight-gradient fusion rides on the read-only fused pass");
   const long plane = (long)p.Bp * p.Gp;
+  constexpr bool SPLITG = FUSE && sizeof(raw_t) == sizeof(u4v);   // split-bf16 gradient words ("fp32" mode): the fused contraction runs on hi / lo pairs
   __shared__ __attribute__((aligned(16))) bf16_t s_wT[FUSE ? DEC_KPS * SMB_PITCH : 8];
+  __shared__ __attribute__((aligned(16))) bf16_t s_wT_lo[SPLITG ? DEC_KPS * SMB_PITCH : 8];
   __shared__ __attribute__((aligned(16))) bf16_t s_tile[HEADS ? 2 * 2 * SMB_TILE_ELEMS : 8];   // [tile parity][head][cell][gene]
   __shared__ __attribute__((aligned(16))) bf16_t s_z[HEADS ? DEC_CELLS_PER_WG * SMB_ZPITCH : 8];  // the workgroup's rows of the latent image [cell][48 | pad]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
@@ -833,6 +835,11 @@ __global__ __launch_bounds__(256, 2) void dec_softmax_bwd_kernel(DecParams p, co
             const s8v w = *reinterpret_cast<const s8v*>(p.Wps_hi + (long)(g0 + gl) * DEC_KPS + c8);
 #pragma unroll
             for (int j = 0; j < 8; ++j) s_wT[(c8 + j) * SMB_PITCH + gl] = (bf16_t)w[j];
+            if constexpr (SPLITG) {
+              const s8v wl = *reinterpret_cast<const s8v*>(p.Wps_lo + (long)(g0 + gl) * DEC_KPS + c8);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) s_wT_lo[(c8 + j) * SMB_PITCH + gl] = (bf16_t)wl[j];
+            }
           }
           lds_barrier();
         }
@@ -850,6 +857,7 @@ __global__ __launch_bounds__(256, 2) void dec_softmax_bwd_kernel(DecParams p, co
       // corrected values as packed bf16 pairs straight away (register [qq] = genes 8 qq + 4 h + {0,1 | 2,3}): what the MFMA operands
       // and the parked tiles hold, and half the registers of 2 x 16 floats
       unsigned cpk[8], csk[8];
+      unsigned cpl[SPLITG ? 8 : 1], csl[SPLITG ? 8 : 1];   // ... and, for split words, the bf16 of what the first rounding left
       unswap(rpA);
       unswap(rsA);
 #pragma unroll
@@ -867,6 +875,11 @@ __global__ __launch_bounds__(256, 2) void dec_softmax_bwd_kernel(DecParams p, co
         }
         cpk[2 * qq] = pack2bf(vp[0], vp[1]); cpk[2 * qq + 1] = pack2bf(vp[2], vp[3]);
         csk[2 * qq] = pack2bf(vs[0], vs[1]); csk[2 * qq + 1] = pack2bf(vs[2], vs[3]);
+        if constexpr (SPLITG) {
+          auto lo2 = [](unsigned hi2, float a, float b) { return pack2bf(a - __uint_as_float(hi2 << 16), b - __uint_as_float(hi2 & 0xffff0000u)); };
+          cpl[2 * qq] = lo2(cpk[2 * qq], vp[0], vp[1]); cpl[2 * qq + 1] = lo2(cpk[2 * qq + 1], vp[2], vp[3]);
+          csl[2 * qq] = lo2(csk[2 * qq], vs[0], vs[1]); csl[2 * qq + 1] = lo2(csk[2 * qq + 1], vs[2], vs[3]);
+        }
         if constexpr (WRITE) {
           store4_grad<GT>(p.tP, tbase + 256 * qq, plane, vp);
           store4_grad<GT>(p.tS, tbase + 256 * qq, plane, vs);
@@ -887,6 +900,19 @@ __global__ __launch_bounds__(256, 2) void dec_softmax_bwd_kernel(DecParams p, co
           u4v ap = u4v{p0[0], p0[1], p1[0], p1[1]};
           if (r >= DEC_KP) ap = u4v{0u, 0u, 0u, 0u};   // the private head has 16 rows
           const u4v as4 = u4v{s0[0], s0[1], s1[0], s1[1]};
+          if constexpr (SPLITG) {   // hi * lo, lo * hi, hi * hi (small terms first, as spv_gemm.h's mfma32_split)
+            const u4v bPl = u4v{cpl[4 * m], cpl[4 * m + 1], cpl[4 * m + 2], cpl[4 * m + 3]}, bSl = u4v{csl[4 * m], csl[4 * m + 1], csl[4 * m + 2], csl[4 * m + 3]};
+            const bf16_t* wl = s_wT_lo + gl + 16 * m + 4 * h;
+            const u2v lp0 = *reinterpret_cast<const u2v*>(wl + (r & 15) * SMB_PITCH), lp1 = *reinterpret_cast<const u2v*>(wl + (r & 15) * SMB_PITCH + 8);
+            const u2v ls0 = *reinterpret_cast<const u2v*>(wl + (DEC_KP + r) * SMB_PITCH), ls1 = *reinterpret_cast<const u2v*>(wl + (DEC_KP + r) * SMB_PITCH + 8);
+            u4v apl = u4v{lp0[0], lp0[1], lp1[0], lp1[1]};
+            if (r >= DEC_KP) apl = u4v{0u, 0u, 0u, 0u};
+            const u4v asl = u4v{ls0[0], ls0[1], ls1[0], ls1[1]};
+            accP = mfma32(*reinterpret_cast<const s8v*>(&ap), *reinterpret_cast<const s8v*>(&bPl), accP);
+            accP = mfma32(*reinterpret_cast<const s8v*>(&apl), bP, accP);
+            accS = mfma32(*reinterpret_cast<const s8v*>(&as4), *reinterpret_cast<const s8v*>(&bSl), accS);
+            accS = mfma32(*reinterpret_cast<const s8v*>(&asl), bS, accS);
+          }
           accP = mfma32(*reinterpret_cast<const s8v*>(&ap), bP, accP);
           accS = mfma32(*reinterpret_cast<const s8v*>(&as4), bS, accS);
           if constexpr (HEADS) {   // park the tile: row = this wave's cell, the lane's two 4-gene chunks of this half

@@ -62,7 +62,7 @@ class _DecoderBwd:
     def __init__(self, g: int, P, S, Wps_g, wsg, B: int, Bp: int, G: int, Gp: int, nsplit: int, grads_f32: bool, pair: bool = False):
         self.g, self.P, self.S, self.Wps_g, self.wsg = g, P, S, Wps_g, wsg
         self.B, self.Bp, self.G, self.Gp, self.nsplit, self.grads_f32 = B, Bp, G, Gp, nsplit, grads_f32
-        self.fused_dz = bool(_ops.FUSED_DZ and not grads_f32)
+        self.fused_dz = bool(_ops.FUSED_DZ and (not grads_f32 or _ops.FUSED_DZ_F32))
         self.dz_part = wsg.get("dec_dz_part", (P.gene_splits, Bp, DEC_KPS), torch.float32) if self.fused_dz else None
         self.T = T = Gp // 32
         bt = Bp // 32

@@ -174,6 +174,7 @@ FUSED_HEADS = os.environ.get("SPV_FUSED_HEADS", "1") != "0"
 # C3 2.39 -> 2.36, C4 3.90 -> 3.88, C5 8.29 -> 8.18, C1 unchanged
 GSPLIT_WANT = int(os.environ.get("SPV_GSPLIT_WANT", "512"))
 FUSED_DZ = os.environ.get("SPV_FUSED_DZ", "1") != "0"  # softmax fix also produces the latent gradient of the rate heads
+FUSED_DZ_F32 = os.environ.get("SPV_FUSED_DZ_F32", "1") != "0"   # "fp32" mode: the latent gradient of the rate heads comes out of the softmax-fix pass too (split-bf16 contraction)
 FUSED_PACK = os.environ.get("SPV_FUSED_PACK", "1") != "0"  # latent / trunk kernels also write the decoder's bf16 operand images
 DEFER_WM = os.environ.get("SPV_DEFER_WM", "1") != "0"  # mixture-weight gradient GEMMs on the late side stream
 DEFER_BC = os.environ.get("SPV_DEFER_BC", "1") != "0"  # regressor weight-gradient GEMMs beside the trunk backward (side stream)
