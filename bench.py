@@ -186,7 +186,7 @@ def _pmc_decoder_chain(args):
         return None
     tag = open(latest).read().strip()
     mine = f"{args.config} {args.precision} {args.count_dtype} B{args.batch_size} G{args.genes}"
-    kernels = [("dec_nb_kernel", 1, 1.0), ("dec_softmax_bwd_kernel", 1, 2.0), ("dec_gemm320_dma4_kernel", 2, 2.0), ("dec_logits_dma_kernel", 1, 2.0),
+    kernels = [("dec_nb_kernel", 1, 1.0), ("dec_heads_bwd_kernel", 1, 2.0), ("dec_gemm320_dma4_kernel", 2, 2.0), ("dec_logits_dma_kernel", 1, 2.0),
                ("dec_lse_kernel", 1, 1.0)]   # (name, launches per group-step, FETCH_SIZE factor)
     per, total = {}, 0.0
     for name, n, ff in kernels:
