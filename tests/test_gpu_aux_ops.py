@@ -263,3 +263,50 @@ def test_fc1_resident_log1p_image_matches_count_decoding(dev, B, G, H, gather):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))
     ref = torch.log(torch.log1p(torch.tensor(Xh[rows.cpu().numpy() if gather else np.arange(B)].astype(np.float64))).sum(1))
     torch.testing.assert_close(out[0][1].double().cpu(), ref, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,G,H,gather", [(100, 333, 128, True), (256, 1000, 128, True), (640, 2001, 128, False), (1000, 700, 256, True), (192, 26000, 128, True)])
+def test_fc1_split_resident_image_matches_count_decoding_fp32_mode(dev, B, G, H, gather):
+    """"fp32" mode: the fc1 GEMMs fed from the resident split-bf16 image (spv_prepare_log1p_split: hi / lo interleaved per 32-gene
+    block) through the LDS-DMA kernels -- forward, and the weight gradient with 96- or 128-gene tiles by round count (G 26 000: 128) --
+    against the count-decoding register-staged kernels on the same operands, and against an fp64 product: ragged cell counts (B not a
+    multiple of 128 / 64), gene counts that are no multiple of 32 / 96 / 128, both encoder widths."""
+    from spvipes_amd import _abi, ops
+    rng = np.random.default_rng(B + G)
+    n_cells = B + 37
+    Xh = (rng.poisson(2.0, size=(n_cells, G)) * (rng.random((n_cells, G)) < 0.3)).astype(np.uint16)
+    Xh[:, 0] += 1
+    X = torch.tensor(Xh.view(np.int16)).to(dev)
+    rows = torch.tensor(rng.permutation(n_cells)[:B].astype(np.int32), device=dev) if gather else None
+    g = torch.Generator().manual_seed(0)
+    base = [(torch.randn(*s, generator=g) * 0.1) for s in ((H, G), (H,), (H, G), (H,))]
+    dh = torch.randn(B, 2 * H, generator=g).to(dev)
+    out = []
+    for resident in (True, False):
+        counts = ops.GroupCounts(X, G, 0, resident=resident)
+        params = [t.clone().to(dev).requires_grad_(True) for t in base]
+        h1, lib = ops.EncoderFC1.apply(counts, rows, B, *params, 3, ops.Workspace(dev))
+        (h1 * dh).sum().backward()
+        torch.cuda.synchronize()
+        out.append((h1.detach(), lib.detach(), [p.grad.clone() for p in params]))
+        if resident:   # the path under test was really taken
+            ld = 2 * ops.round_up(ops.round_up(G, 96), 128)
+            assert _abi.load().spv_enc_fc1_fwd_uses_dma(B, G, 2 * H, 3, 1, ops.round_up(G, 64), ld) == 1
+            assert _abi.load().spv_enc_fc1_wgrad_split_uses_dma(B, G, 2 * H, 2 * H, ld) == 1
+            assert counts._xb_split is not None
+    torch.testing.assert_close(out[0][0], out[1][0], rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(out[0][1], out[1][1], rtol=1e-6, atol=1e-6)
+    for a, b in zip(out[0][2], out[1][2]):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=2e-5 * float(b.abs().max()))
+    # fp64 reference of the forward value and of the two weight gradients
+    idx = rows.cpu().numpy() if gather else np.arange(B)
+    x = torch.log1p(torch.tensor(Xh[idx].astype(np.float64)))
+    W = torch.cat([base[0], base[2]], 0).double()
+    bias = torch.cat([base[1], base[3]], 0).double()
+    pre = x @ W.t() + bias
+    # (split-bf16 products carry ~2^-17 relative error per term: three of the four hi / lo cross terms are kept)
+    tol = 1e-4 * max(1.0, (G / 1000.0) ** 0.5)   # (a random walk over G rounded terms)
+    torch.testing.assert_close(out[0][0].double().cpu(), torch.relu(pre), rtol=tol, atol=tol)
+    dW = ((dh.double().cpu() * (out[0][0].cpu() > 0)).t() @ x)   # (the ReLU mask of the run itself: a pre-activation within rounding of 0 may fall either way)
+    got = torch.cat([out[0][2][0], out[0][2][2]], 0).double().cpu()
+    assert float((got - dW).abs().max()) < 1e-4 * float(dW.abs().max()) + 1e-6
