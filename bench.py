@@ -506,6 +506,12 @@ def main(argv=None):
             "elbo_delta": delta,
             "roofline": roof,
         }
+        if world > 1:
+            # N > 1 lines default to preset c3 (the shape BASELINE quotes the scaling target on) while the N = 1 line of the same script is
+            # preset c2: a ratio of the two `value`s mixes workloads.  The one-GPU number of THIS line's per-GPU workload, measured in this
+            # job (rank 0 alone, collectives off), is repeated here at top level so that it cannot be missed.
+            out["n1_same_workload"] = {"value": n1_ref, "unit": "cells/s", "preset": args.config,
+                                       "what": "rank 0 alone on the same per-GPU workload and step form, collectives off, measured in this job after the timed region"}
         if world == 1 and not args.no_cpu_baseline and NG == 2:
             try:
                 out["cpu_baseline"] = cpu_baseline(groups, args, min(os.cpu_count() or 1, 16), plan)
