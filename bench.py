@@ -86,8 +86,8 @@ def parse(argv=None):
     ap.add_argument("--allreduce", default="auto", choices=["auto", "single", "overlap"],
                     help="gradient all-reduce of a data-parallel job: one collective after the backward pass, or two buckets with the "
                          "decoder bucket overlapped with the encoder half of the backward pass (auto: overlap when WORLD_SIZE > 1)")
-    ap.add_argument("--cpu-batch", type=int, default=1024, help="cells per group of the CPU baseline sample (about 10 s of CPU work at C2)")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-batch", type=int, default=None, help="cells per group of the CPU baseline sample (default: the timed batch size)")
+    ap.add_argument("--cpu-steps", type=int, default=1, help="timed CPU steps after one untimed one (one step of 2 x 4096 x 10 000 is ~5-10 s of host time)")
     args = ap.parse_args(argv)
     if args.config is None:
         args.config = "c2" if args.gpus <= 1 else "c3"
@@ -98,13 +98,46 @@ def parse(argv=None):
     return args
 
 
-def cpu_baseline(groups, args, n_threads, plan=None):
+def host_cpus():
+    """(threads this process may really use, logical CPUs of the host, CPU model string).  The first is what the baseline runs on and
+    reports as ``cores``: the scheduler affinity mask cut down by the cgroup CPU quota (a GPU box hands a 1-GPU job a share of a
+    large host: os.cpu_count() threads on a 16-CPU quota would time the oversubscription, not the cores)."""
+    logical = os.cpu_count() or 1
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else logical
+    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(f).read().split()
+            if f.endswith("cpu.max"):
+                if txt[0] != "max":
+                    usable = min(usable, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    usable = min(usable, max(1, int(q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()) + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return usable, logical, model
+
+
+def cpu_baseline(groups, args, plan=None):
     """The CPU oracle (oracle/spvipes_oracle.py, a port of the reference path pinned by goldens
-    generated from the reference) timed on this box's host cores: forward + loss + backward + Adam
-    on a bounded sample of the same workload."""
+    generated from the reference) timed on this box's host cores -- every core this process may use --
+    forward + loss + backward + Adam on a bounded sample of the same workload: ``--cpu-steps`` steps at the TIMED batch size."""
     from oracle import spvipes_oracle as O
 
+    n_threads, logical, cpu_model = host_cpus()
     torch.set_num_threads(n_threads)
+    if args.cpu_batch is None:
+        args.cpu_batch = args.batch_size
     Gs = [g.counts.G for g in groups]
     sd = O.init_state_dict(Gs, n_hidden=args.n_hidden, n_dimensions_shared=args.n_shared, n_dimensions_private=args.n_private, seed=0)
     names = O.param_names(sd)
@@ -137,8 +170,10 @@ def cpu_baseline(groups, args, n_threads, plan=None):
         if step > 0:  # first step pays allocator warm-up
             times.append(time.perf_counter() - t0)
     sec = float(np.mean(times))
-    return {"value": 2 * B / sec, "unit": "cells/s", "cores": n_threads, "kind": "port",
-            "sample": f"{args.cpu_steps} steps of 2 x {B} cells x {Gs[0]} genes (same synthetic data, fwd+loss+bwd+Adam), {sec:.2f} s/step"}
+    return {"value": 2 * B / sec, "unit": "cells/s", "cores": n_threads, "kind": "port", "cpu_model": cpu_model, "host_logical_cpus": logical,
+            "torch_threads": torch.get_num_threads(),
+            "sample": f"{args.cpu_steps} step(s) after one untimed step, 2 x {B} cells x {Gs[0]} genes = the timed minibatch shape "
+                      f"(same synthetic data, {args.poe} PoE, fwd+loss+bwd+Adam), {sec:.2f} s/step"}
 
 
 
@@ -280,17 +315,40 @@ def launcher_command(n: int, argv) -> list:
             "--master-port", str(port), os.path.abspath(__file__), *argv]
 
 
+def visible_gpu_count():
+    """GPUs this process would see, counted WITHOUT loading the HIP / HSA runtime (torch.cuda.device_count() may fall through to
+    hipGetDeviceCount, which initialises it in the launcher parent): KFD topology nodes with SIMDs, cut down by
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES.  None when sysfs says nothing (the ranks then fail loudly
+    themselves and the launcher forwards their status)."""
+    import glob
+    n = 0
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    for f in nodes:
+        try:
+            props = dict(l.split()[:2] for l in open(f).read().splitlines() if len(l.split()) >= 2)
+        except OSError:
+            return None
+        n += int(props.get("simd_count", "0")) > 0
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch_ranks(args, argv) -> int:
     """``python bench.py --gpus N`` (N > 1) outside a torchrun environment: start the N ranks as a CHILD process (never an exec:
-    nothing in this process has touched the GPU, and nothing will), forward the child's output (rank 0 prints the JSON line) and
+    nothing in this process has touched the GPU, and nothing will -- the device count comes from sysfs), forward the child's output (rank 0 prints the JSON line) and
     return its exit status -- a plain `--gpus 8` can never end as a silent single-GPU number."""
     import subprocess
     cmd = launcher_command(args.gpus, argv)
     if os.environ.get("SPV_BENCH_LAUNCH_DRYRUN") == "1":   # (tests: show the command, start nothing)
         print(json.dumps({"launch": cmd}), flush=True)
         return 0
-    n_dev = torch.cuda.device_count()   # (does not initialise the GPU)
-    if n_dev < args.gpus:
+    n_dev = visible_gpu_count()
+    if n_dev is not None and n_dev < args.gpus:
         print(f"bench.py: --gpus {args.gpus} but this node exposes {n_dev} GPU(s)", file=sys.stderr, flush=True)
         return 2
     env = dict(os.environ)
@@ -327,7 +385,7 @@ def main(argv=None):
     _abi.load()
     torch.manual_seed(0)
     NG = args.groups
-    groups = [make_synthetic_group(g, args.cells, args.genes, dev, dtype=args.count_dtype) for g in range(NG)]
+    groups = [make_synthetic_group(g, args.cells, args.genes, dev, dtype=args.count_dtype, shard=rank) for g in range(NG)]   # every rank its own cells
     plan = None
     mkw = {}
     if args.poe == "label":
@@ -426,26 +484,29 @@ def main(argv=None):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         exposed = float(tt)
 
-    # Weak-scaling reference measured in the same job: rank 0 alone repeats the timed loop on its own shard with the collectives
-    # switched off (same two-graph step, same workload), the other ranks wait at the barrier.  value / this = the speed-up over ONE GPU
-    # on the SAME per-GPU workload (the default N = 1 run of this script is preset c2, a different shape).
-    n1_ref = None
+    # Weak-scaling reference measured in the same job, in the form a ONE-GPU job runs: rank 0 builds a fresh trainer
+    # with world = 1 -- one graph per step, no split backward pass, Adam as the graph's last node -- on its own shard and repeats the
+    # warm-up + timed loop; the other ranks wait at the barrier.  value / this = the speed-up over ONE GPU on the SAME per-GPU
+    # workload (the default N = 1 run of this script is preset c2, a different shape).
+    n1_ref = n1_form = None
     if world > 1:
         torch.cuda.synchronize()
         dist.barrier()
         if rank == 0:
-            w_saved, trainer.world = trainer.world, 1
-            try:
-                for _ in range(3):
-                    trainer.step(next(it), kl_weight=1.0)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(args.steps):
-                    trainer.step(next(it), kl_weight=1.0)
-                torch.cuda.synchronize()
-                n1_ref = NG * args.batch_size * args.steps / (time.perf_counter() - t1)
-            finally:
-                trainer.world = w_saved
+            t1gpu = Trainer(module, [g.counts for g in groups], labels=[g.labels for g in groups] if args.poe == "label" else None,
+                            components=[g.labels for g in groups] if args.poe == "cluster" else None, overlap_allreduce=False, world=1)
+            if use_graph:
+                t1gpu.capture(next(it))
+            for _ in range(args.warmup):
+                t1gpu.step(next(it), kl_weight=1.0)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                t1gpu.step(next(it), kl_weight=1.0)
+            torch.cuda.synchronize()
+            n1_ref = NG * args.batch_size * args.steps / (time.perf_counter() - t1)
+            n1_form = ("one hipGraph per step with Adam as its last node" if getattr(t1gpu, "_adam_in_graph", False) else
+                       "one hipGraph per step, Adam launched after it" if use_graph else "eager launches") + ", no collective, no split backward pass"
         dist.barrier()
 
     if rank == 0 and delta_state is not None:
@@ -493,7 +554,9 @@ def main(argv=None):
             "value": value, "unit": "cells/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_median": median_ms,
             "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32(split-bf16)",   # (bf16 mode: bf16 decoder operands, f16 encoder fc1 operands, fp32 accumulation) "data": "synthetic",
+            # dtype, bf16 mode: bf16 decoder operands, f16 encoder fc1 operands, fp32 accumulation
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32(split-bf16)",
+            "data": "synthetic",
             "config": {"workload": f"{NG} groups x {args.cells} cells x {G} genes per GPU, {poe_txt}, n_shared={n_s} n_private={n_p} "
                                    f"n_hidden={H}, batch {B} cells/group/step/GPU, counts resident as {args.count_dtype} ({CONFIGS[args.config]['what']})",
                        "preset": args.config,
@@ -501,7 +564,7 @@ def main(argv=None):
                        "allreduce": ("none (1 rank)" if world == 1 else "2 buckets, decoder bucket overlapped with the encoder backward"
                                      if trainer.overlap else "1 bucket after the backward pass (north_star form)"),
                        "allreduce_exposed_ms_per_step": exposed,
-                       "one_gpu_same_workload_cells_per_s": n1_ref},   # rank 0 alone, collectives off, same step form (N > 1 runs only)
+                       "one_gpu_same_workload_cells_per_s": n1_ref},   # rank 0 alone as a one-GPU job would run it (N > 1 runs only)
             "final_loss": loss,
             "elbo_delta": delta,
             "roofline": roof,
@@ -511,12 +574,13 @@ def main(argv=None):
             # preset c2: a ratio of the two `value`s mixes workloads.  The one-GPU number of THIS line's per-GPU workload, measured in this
             # job (rank 0 alone, collectives off), is repeated here at top level so that it cannot be missed.
             out["n1_same_workload"] = {"value": n1_ref, "unit": "cells/s", "preset": args.config,
-                                       "what": "rank 0 alone on the same per-GPU workload and step form, collectives off, measured in this job after the timed region"}
+                                       "what": "rank 0 alone on the same per-GPU workload with a fresh world-1 trainer (" + str(n1_form) + "), "
+                                               "measured in this job after the timed region; the data-parallel ranks run the two-graph split-backward step"}
         if world == 1 and not args.no_cpu_baseline and NG == 2:
             try:
-                out["cpu_baseline"] = cpu_baseline(groups, args, min(os.cpu_count() or 1, 16), plan)
+                out["cpu_baseline"] = cpu_baseline(groups, args, plan)
             except Exception as e:  # the baseline is a reported extra; never lose the GPU number over it
-                out["cpu_baseline"] = {"value": None, "unit": "cells/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
+                out["cpu_baseline"] = {"value": None, "unit": "cells/s", "cores": host_cpus()[0], "kind": "port", "sample": f"failed: {e!r}"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

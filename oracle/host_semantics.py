@@ -2,9 +2,13 @@
 which cells meet in which minibatch, and how per-batch latents are assembled into the arrays the user gets.
 
 TEST INFRASTRUCTURE: imported by tests/ only (the product's counterparts are spvipes_amd/data.py and
-spvipes_amd/model.py).  Parity status: the reference has no tests or fixtures for these functions and its loaders
-need scvi-tools / anndata (absent here), so this file is "parity unpinned" against running reference code; it follows
-the cited lines statement by statement.  Citations are into /root/reference/src/spVIPES.
+spvipes_amd/model.py).  Parity status: PINNED by reference-run fixtures -- tests/golden/make_host_goldens.py loads the
+reference's own dataloaders/_ann_dataloader.py, dataloaders/_concat_dataloader.py, data/_multi_datasplitter.py,
+model/base/training_mixin.py and model/spvipes.py by path (third-party imports stubbed, a fake AnnDataManager behind the
+loaders, a recording module behind get_latent_representation) and records the split, two epochs of the train loader, the
+steps and the assembled arrays of get_latent_representation for 83 cases, and what train() hands to TrainingPlan /
+TrainRunner (tests/golden/host_*.npz); tests/test_host_semantics.py holds every function below to them.  Still a stand-in:
+scvi-tools' ``validate_data_split`` (oracle/scvi_standins.py).  Citations are into /root/reference/src/spVIPES.
 """
 from __future__ import annotations
 
@@ -15,23 +19,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 
-def validate_data_split(n_samples: int, train_size: float, validation_size: Optional[float] = None) -> Tuple[int, int]:
-    """scvi-tools 0.20.0 ``scvi.dataloaders._data_splitting.validate_data_split`` (called at
-    data/_multi_datasplitter.py:55-60): n_train = ceil(train_size * n); n_val = n - n_train, or floor(n * validation_size)."""
-    if train_size > 1.0 or train_size <= 0.0:
-        raise ValueError("Invalid train_size. Must be: 0 < train_size <= 1")
-    n_train = math.ceil(train_size * n_samples)
-    if validation_size is None:
-        n_val = n_samples - n_train
-    elif validation_size >= 1.0 or validation_size < 0.0:
-        raise ValueError("Invalid validation_size. Must be 0 <= validation_size < 1")
-    elif (train_size + validation_size) > 1:
-        raise ValueError("train_size + validation_size must be between 0 and 1")
-    else:
-        n_val = math.floor(n_samples * validation_size)
-    if n_train == 0:
-        raise ValueError(f"With n_samples={n_samples}, train_size={train_size} and validation_size={validation_size}, the resulting train set will be empty.")
-    return n_train, n_val
+from .scvi_standins import validate_data_split  # noqa: E402,F401  (third-party scvi-tools 0.20.0: stand-in, see there)
 
 
 def split_groups(group_indices_list: Sequence[Sequence[int]], train_size: float, validation_size: Optional[float], seed: int) -> Dict[str, List[np.ndarray]]:
@@ -72,6 +60,22 @@ def concat_loader_steps(indices_list: Sequence[Sequence[int]], batch_size: int, 
     largest = int(np.argmax(lens))
     iters = [iter(l) if i == largest else cycle(l) for i, l in enumerate(loaders)]
     return list(zip(*iters))   # (a group without a single batch makes cycle() empty and with it the whole epoch, as in the reference)
+
+
+def loader_mode(use_labels: bool, labels_registered: bool, use_transport_plan: bool, pair_data: bool,
+                drop_last: Optional[bool]) -> Tuple[bool, bool]:
+    """get_latent_representation's choice of (drop_last, use_cycling) (model/spvipes.py:468-503): every branch of the
+    ``drop_last is None`` ladder sets False (:470-480); cycling = a transport plan, pair_data, no dropped batch, and not the
+    label-based PoE (:497-503)."""
+    if drop_last is None:
+        drop_last = False
+    label_poe = bool(use_labels and labels_registered)
+    return bool(drop_last), bool(use_transport_plan and pair_data and not drop_last and not label_poe)
+
+
+def default_max_epochs(n_obs: int) -> int:
+    """MultiGroupTrainingMixin.train (model/base/training_mixin.py:89-91)."""
+    return np.min([round((20000 / n_obs) * 400), 400]).item()
 
 
 def cycling_chunks(group_indices_list: Sequence[Sequence[int]]) -> List[Tuple[List[int], List[int]]]:

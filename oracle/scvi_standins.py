@@ -11,6 +11,10 @@ NOT installed in this image and is not under /root/reference:
     scvi.module.base.LossOutput                 (spVIPESmodule.py:9)
     scvi.module.base.auto_move_data             (spVIPESmodule.py:9)
 
+plus one symbol of the reference's HOST-side callers (tests/golden/make_host_goldens.py):
+
+    scvi.dataloaders._data_splitting.validate_data_split   (data/_multi_datasplitter.py:9,55-60)
+
 They restate the *published* scvi-tools 0.20.0 algorithm (scvi/nn/_base_components.py
 ``FCLayers``; scvi/distributions/_negative_binomial.py ``log_mixture_nb``;
 scvi/module/base/_base_module.py ``BaseModuleClass.forward``).  The reference
@@ -214,6 +218,28 @@ class BaseModuleClass(nn.Module):
             losses = self.loss(tensors, inference_outputs, generative_outputs, **loss_kwargs)
             return inference_outputs, generative_outputs, losses
         return inference_outputs, generative_outputs
+
+# ----------------------------------------------------------------------------
+# scvi.dataloaders._data_splitting.validate_data_split (0.20.0).  Call site: data/_multi_datasplitter.py:55-60.
+#   n_train = ceil(train_size * n); n_val = n - n_train, or floor(n * validation_size) when a validation size is given.
+# ----------------------------------------------------------------------------
+def validate_data_split(n_samples: int, train_size: float, validation_size: Optional[float] = None):
+    import math
+
+    if train_size > 1.0 or train_size <= 0.0:
+        raise ValueError("Invalid train_size. Must be: 0 < train_size <= 1")
+    n_train = math.ceil(train_size * n_samples)
+    if validation_size is None:
+        n_val = n_samples - n_train
+    elif validation_size >= 1.0 or validation_size < 0.0:
+        raise ValueError("Invalid validation_size. Must be 0 <= validation_size < 1")
+    elif (train_size + validation_size) > 1:
+        raise ValueError("train_size + validation_size must be between 0 and 1")
+    else:
+        n_val = math.floor(n_samples * validation_size)
+    if n_train == 0:
+        raise ValueError(f"With n_samples={n_samples}, train_size={train_size} and validation_size={validation_size}, the resulting train set will be empty.")
+    return n_train, n_val
 
 
 def install() -> None:

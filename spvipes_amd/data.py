@@ -42,18 +42,19 @@ class SyntheticGroup:
 
 
 def make_synthetic_group(g: int, n_cells: int, n_genes: int, device, n_labels: int = 10, dtype: str = "u16",
-                         chunk: int = 4096) -> SyntheticGroup:
+                         chunk: int = 4096, shard: int = 0) -> SyntheticGroup:
     """SURVEY.md 8d synthetic counts: X[c,j] ~ NB(mean = s_c * exp(a[label(c), j]), dispersion 2) * Bernoulli(0.2),
     s_c ~ LogNormal(0, 0.25), a ~ N(0, 1), 10 labels (group 0 never has label 0, group 1 never has
     label n_labels-1 so the non-common-label branch of the PoE runs).  Small tables come from
     numpy.random.default_rng(1000 + g); the [cells, genes] draws are generated on the device with a
-    torch generator seeded 1000 + g (a 5e8-entry numpy NB draw per group would dominate start-up)."""
-    rng = np.random.default_rng(1000 + g)
+    torch generator seeded 1000 + g (a 5e8-entry numpy NB draw per group would dominate start-up).  ``shard`` (a rank of a
+    data-parallel job) offsets both seeds by 10 per shard: ranks hold DIFFERENT cells, as a sharded data set does."""
+    rng = np.random.default_rng(1000 + g + 10 * shard)
     allowed = [l for l in range(n_labels) if l != (0 if g == 0 else n_labels - 1)]
     labels = rng.choice(allowed, size=n_cells)
     a = rng.normal(size=(n_labels, n_genes)).astype(np.float32)
     s = rng.lognormal(0.0, 0.25, size=n_cells).astype(np.float32)
-    gen = torch.Generator(device=device).manual_seed(1000 + g)
+    gen = torch.Generator(device=device).manual_seed(1000 + g + 10 * shard)
     a_d, s_d = torch.tensor(a, device=device), torch.tensor(s, device=device)
     lab_d = torch.tensor(labels, device=device)
     out = torch.empty((n_cells, n_genes), dtype=torch.int16 if dtype == "u16" else torch.float32, device=device)
@@ -133,6 +134,14 @@ class MinibatchSampler:
         idx = torch.as_tensor(np.asarray(indices), dtype=torch.int32, device=device)
         for lo in range(0, len(idx), batch_size):
             yield idx[lo:lo + batch_size].contiguous()
+
+
+def latent_loader_mode(use_labels: bool, use_transport_plan: bool, pair_data: bool, drop_last: Optional[bool]):
+    """(drop_last, use_cycling) as get_latent_representation decides them (model/spvipes.py:468-503): ``drop_last=None``
+    means False for every PoE flavour; the cycling path is taken by the paired PoE only (a transport plan, ``pair_data``, no
+    labels) and only when no batch is dropped."""
+    drop_last = bool(drop_last) if drop_last is not None else False
+    return drop_last, bool(use_transport_plan and pair_data and not drop_last and not use_labels)
 
 
 def latent_steps(local: Sequence[Sequence[int]], batch_size: int, drop_last: bool, use_cycling: bool):

@@ -1,5 +1,5 @@
 """scvi-tools-style user surface of the MI355X hot path: ``setup_anndata`` / ``train`` /
-``get_latent_representation`` / ``get_loadings`` / ``save`` / ``load``.
+``get_latent_representation`` / ``get_loadings`` / ``save(dir)`` / ``load(dir, adata=...)``.
 
 Mirrors /root/reference/src/spVIPES/model/spvipes.py (class ``spVIPES``: ctor :216-283,
 ``setup_anndata`` :285-422, ``get_latent_representation`` :424-650, ``get_loadings`` :652-677) and
@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import _abi
-from .data import MinibatchSampler, format_latent_results, latent_steps, to_group_counts
+from .data import MinibatchSampler, format_latent_results, latent_loader_mode, latent_steps, to_group_counts
 from .module import spVIPESmodule
 from .train import Trainer, default_max_epochs
 
@@ -85,6 +85,9 @@ class spVIPES:
                        if n_batch > 1 else None)
         self.is_trained_ = False
         self.history: Dict[str, List[float]] = {}
+        # what load() re-creates the model from (scvi's BaseModelClass keeps the same record: _get_init_params(locals()), :281)
+        self.init_params_ = dict(n_hidden=n_hidden, n_dimensions_shared=n_dimensions_shared, n_dimensions_private=n_dimensions_private,
+                                 dropout_rate=dropout_rate, precision=precision, device=str(self.device), **model_kwargs)
 
     # ------------------------------------------------------------------------------------------
     @classmethod
@@ -183,10 +186,9 @@ class spVIPES:
         if normalized:
             raise NotImplementedError("normalized=True is broken in the reference (nothing is collected for the shared latents, :542-544)")
         batch_size = batch_size or 128
-        drop_last = bool(drop_last) if drop_last is not None else False
         n1, n2 = (len(g) for g in group_indices_list)
         local = [self._local_rows(g, group_indices_list[g]) for g in range(2)]
-        use_cycling = self.module.use_transport_plan and self.module.pair_data and not drop_last and not self.module.use_labels   # :497-503
+        drop_last, use_cycling = latent_loader_mode(self.module.use_labels, self.module.use_transport_plan, self.module.pair_data, drop_last)   # :468-503
         res = {k: [] for k in ("s0", "s1", "p0", "p1", "i1")}
         was_training = self.module.training
         self.module.eval()
@@ -225,9 +227,55 @@ class spVIPES:
         return out
 
     # ------------------------------------------------------------------------------------------
-    def save(self, path: str) -> None:
-        """state_dict with the reference's parameter names (loads into the reference module and back)."""
-        torch.save({k: v.detach().cpu() for k, v in self.module.state_dict().items()}, path)
+    def save(self, dir_path: str, prefix: Optional[str] = None, overwrite: bool = False, save_anndata: bool = False, **anndata_write_kwargs) -> None:
+        """``spvipes.save("spvipes_model")`` (docs/notebooks/Tutorial.ipynb:487; inherited scvi-tools 0.20.0 ``BaseModelClass.save``):
+        creates ``dir_path`` (an existing one is an error unless ``overwrite``) and writes ``{prefix}model.pt`` =
+        ``{"model_state_dict", "var_names", "attr_dict"}``.  The state_dict carries the reference's parameter names (BatchNorm
+        buffers included), so the file's weights load into the reference module and back; ``attr_dict`` holds the constructor
+        arguments (``init_params_``), the ``setup_anndata`` arguments, ``is_trained_`` and the training history."""
+        import os
 
-    def load_state(self, path: str) -> None:
-        self.module.load_state_dict(torch.load(path, map_location=self.device))
+        if os.path.exists(dir_path) and not overwrite:
+            raise ValueError(f"{dir_path} already exists. Please provide an unexisting directory for saving.")
+        if save_anndata:
+            raise NotImplementedError("save_anndata=True needs anndata's writer, which is outside this build: keep the AnnData yourself and pass it to load()")
+        os.makedirs(dir_path, exist_ok=True)
+        var_names = getattr(self.adata, "var_names", None)
+        attr = {"init_params_": dict(self.init_params_), "setup_args_": dict(self._setup), "is_trained_": bool(self.is_trained_),
+                "history_": {k: list(v) for k, v in self.history.items()}}
+        torch.save({"model_state_dict": {k: v.detach().cpu() for k, v in self.module.state_dict().items()},
+                    "var_names": None if var_names is None else np.asarray(var_names).astype(str), "attr_dict": attr},
+                   os.path.join(dir_path, f"{prefix or ''}model.pt"))
+
+    @classmethod
+    def load(cls, dir_path: str, adata=None, use_gpu=None, prefix: Optional[str] = None, backup_url: Optional[str] = None,
+             device: Optional[str] = None) -> "spVIPES":
+        """``spVIPES.load("spvipes_model", adata=adata)`` (Tutorial.ipynb:538; scvi-tools ``BaseModelClass.load``): rebuilds the
+        model from the saved constructor arguments on ``adata`` (registering it with the saved ``setup_anndata`` arguments when
+        it has not been set up), loads the state_dict, leaves the module in eval mode.  ``adata`` is required (the AnnData is
+        never written by this build); ``use_gpu`` is accepted and ignored, ``backup_url`` is not supported (no network)."""
+        import os
+        import warnings
+
+        path = os.path.join(dir_path, f"{prefix or ''}model.pt")
+        if not os.path.exists(path):
+            raise ValueError(f"Failed to load model file at {path}. If attempting to load a saved model from <v0.15.0, please use the util function `convert_legacy_save` to convert to an updated format.")
+        if adata is None:
+            raise ValueError("Save path contains no saved anndata and no adata was passed.")
+        blob = torch.load(path, map_location="cpu", weights_only=False)
+        attr = blob["attr_dict"]
+        if _SETUP_KEY not in adata.uns:
+            cls.setup_anndata(adata, **attr["setup_args_"])
+        saved_names, names = blob.get("var_names"), getattr(adata, "var_names", None)
+        if saved_names is not None and names is not None and not np.array_equal(np.asarray(names).astype(str), saved_names):
+            warnings.warn("var_names for adata passed in does not match var_names of adata used to train the model. "
+                          "For valid results, the vars need to be the same and in the same order as the adata used to train the model.")
+        init = dict(attr["init_params_"])
+        if device is not None:
+            init["device"] = device
+        model = cls(adata, **init)
+        model.module.load_state_dict(blob["model_state_dict"])
+        model.module.eval()
+        model.is_trained_ = bool(attr["is_trained_"])
+        model.history = {k: list(v) for k, v in attr.get("history_", {}).items()}
+        return model

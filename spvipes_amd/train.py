@@ -162,7 +162,9 @@ class Trainer:
     def __init__(self, module: spVIPESmodule, counts: Sequence[GroupCounts], labels: Optional[Sequence[torch.Tensor]] = None,
                  components: Optional[Sequence[torch.Tensor]] = None, lr: float = 1e-3, eps: float = 0.01,
                  weight_decay: float = 1e-6, n_epochs_kl_warmup: Optional[int] = 400, n_steps_kl_warmup: Optional[int] = None,
-                 overlap_allreduce: Optional[bool] = None, batch_codes: Optional[Sequence[torch.Tensor]] = None):
+                 overlap_allreduce: Optional[bool] = None, batch_codes: Optional[Sequence[torch.Tensor]] = None, world: Optional[int] = None):
+        """``world``: number of ranks whose gradients are summed (default: the size of the initialised process group; ``world=1``
+        inside a data-parallel job gives the trainer a single-GPU job would build -- bench.py's one-GPU reference on rank 0)."""
         self.module, self.counts, self.labels, self.components = module, list(counts), labels, components
         # batch covariates (module built with n_batch > 1): one integer code per cell of every group, gathered per minibatch
         self.batch_codes = None
@@ -187,7 +189,8 @@ class Trainer:
         self.fp = FlatParams(module, late=lambda name: name.startswith("encoder_"))
         self.opt = HipAdam(self.fp, lr=lr, eps=eps, weight_decay=weight_decay)
         self.n_epochs_kl_warmup, self.n_steps_kl_warmup = n_epochs_kl_warmup, n_steps_kl_warmup
-        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self._pg_world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.world = self._pg_world if world is None else int(world)
         # two gradient buckets with the backward pass split between them (default: whenever there is more than one rank)
         self.overlap = (self.world > 1) if overlap_allreduce is None else bool(overlap_allreduce)
         self.global_step, self.epoch = 0, 0
@@ -404,7 +407,7 @@ class Trainer:
         # capture in the default "global" error mode makes such a call from ANOTHER thread an error (HIP refuses event
         # queries while any global-mode capture is open).  Drain the device first and capture in thread-local mode.
         mode = {}
-        if self.world > 1:
+        if self._pg_world > 1:
             torch.cuda.synchronize(self.device)
             mode = {"capture_error_mode": "thread_local"}
         # SPV_GRAPH_KEEP=1 (tools/graph_dump.py): keep the captured hipGraph_t alive beside its executable, so that its nodes and

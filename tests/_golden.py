@@ -7,7 +7,8 @@ import numpy as np
 import torch
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-ALL_CASES = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+ALL_CASES = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
+                   if not os.path.basename(p).startswith("host_"))   # host_*.npz: host-side semantics (tests/golden/make_host_goldens.py)
 LOSS_CASES = [c for c in ALL_CASES if "infer" not in c]
 INFER_CASES = [c for c in ALL_CASES if "infer" in c]
 
@@ -71,3 +72,15 @@ class Golden:
 
     def grads(self):
         return {k[5:]: torch.tensor(v) for k, v in self.raw.items() if k.startswith("grad/")}
+
+
+def host_golden(name):
+    """tests/golden/host_<name>.npz: arrays recorded from the reference's own loaders / splitter / model methods
+    (tests/golden/make_host_goldens.py)."""
+    z = np.load(os.path.join(GOLDEN_DIR, f"host_{name}.npz"), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def unragged(raw, key):
+    v, o = raw[key + "/values"], raw[key + "/offsets"]
+    return [v[o[i]:o[i + 1]] for i in range(len(o) - 1)]

@@ -16,7 +16,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _setup(dev, precision, B, Gs, H, n_s, n_p, nb, cells=1024, seed=0):
+def _setup(dev, precision, B, Gs, H, n_s, n_p, nb, cells=1024, seed=0, overlap=None):
     from spvipes_amd.data import make_synthetic_group
     from spvipes_amd.module import spVIPESmodule
     from spvipes_amd.train import Trainer
@@ -31,7 +31,7 @@ def _setup(dev, precision, B, Gs, H, n_s, n_p, nb, cells=1024, seed=0):
             for kind in ("private", "shared"):
                 module.encoders[g][kind].fc1.weight[:, Gs[g]:].normal_(0.0, 0.3)
     module.train()
-    trainer = Trainer(module, [g.counts for g in groups], labels=[g.labels for g in groups], batch_codes=codes, lr=1e-3)
+    trainer = Trainer(module, [g.counts for g in groups], labels=[g.labels for g in groups], batch_codes=codes, lr=1e-3, overlap_allreduce=overlap)
     rows = [torch.tensor(rng.permutation(cells)[:B], dtype=torch.int32, device=dev) for _ in range(2)]
     gen = torch.Generator().manual_seed(seed + 1)
     noise = {f"enc_{g}_{k}": torch.randn(B, n, generator=gen) for g in range(2) for k, n in (("private", n_p), ("shared", n_s))}
@@ -121,6 +121,42 @@ def test_graph_replay_equals_eager_steps_with_batch_covariates(dev):
     assert la == lb
     assert bool((fa == fb).all())
     assert la[-1] < la[0]
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_split_backward_with_batch_covariates_overwrites_and_equals_the_single_pass(dev, graph):
+    """the split backward pass of a data-parallel job takes gradients w.r.t. the cut tensors only (autograd.grad) and
+    relies on every PARAMETER gradient being written by a gradient-sink kernel.  Covariates add torch-side pieces between the cut and
+    the fused decoder op (the concatenations of module._decoder_operands, CovariateColumns): a gradient that came back through
+    autograd instead of the sink would be dropped silently.  NaN-filled buffer, split pass (eager and as two captured graphs), every
+    element overwritten and equal to the one-pass step's gradient."""
+    from spvipes_amd.data import MinibatchSampler
+    n_s, n_p, nb = 25, 10, 3
+    B, Gs, H = 256, (640, 600), 128
+
+    def run(overlap, use_graph):
+        module, trainer, groups, codes, rows, noise = _setup(dev, "bf16", B, Gs, H, n_s, n_p, nb, cells=1024, seed=7, overlap=overlap)
+        assert trainer.overlap == overlap
+        sampler = MinibatchSampler([1024, 1024], B, dev, seed=2)
+        rows = next(iter(sampler.epoch()))
+        if use_graph:
+            trainer.capture(rows, warmup=1)
+            assert (trainer.graph2 is not None) == overlap
+        trainer.fp.grad.fill_(float("nan"))
+        trainer.step(rows, kl_weight=0.7, optimizer_step=False)
+        torch.cuda.synchronize()
+        bad = [(n_, int(torch.isnan(p.grad).sum())) for n_, p in module.named_parameters() if p.grad is not None and bool(torch.isnan(p.grad).any())]
+        assert not bad, bad
+        for g in range(2):   # the covariate columns themselves carry a gradient
+            assert float(module.encoders[g]["private"].fc1.weight.grad[:, Gs[g]:].abs().max()) > 0
+            assert float(module.decoders[g].mixture.linear.weight.grad.abs().max()) > 0
+        return trainer.fp.grad.clone(), {n_: p.grad.clone() for n_, p in module.named_parameters()}
+
+    flat_one, by_name_one = run(False, False)
+    flat_split, by_name_split = run(True, graph)
+    for n_ in by_name_one:
+        assert torch.equal(by_name_one[n_], by_name_split[n_]), n_
+    assert torch.equal(flat_one, flat_split)
 
 
 def test_covariate_errors(dev):

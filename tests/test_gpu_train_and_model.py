@@ -410,3 +410,84 @@ def test_every_gradient_element_is_overwritten_by_a_step(dev, mode, precision, H
     torch.cuda.synchronize()
     bad = [(n_, int(torch.isnan(p.grad).sum())) for n_, p in module.named_parameters() if p.grad is not None and bool(torch.isnan(p.grad).any())]
     assert not bad, bad
+
+
+# ---- the DEVICE sampler against the oracle that the reference-run loader fixtures pin (tests/golden/host_*.npz) ----
+@pytest.mark.parametrize("sizes,B,train_size,val_size,seed", [((40, 33), 4, 0.9, None, 0), ((250, 31), 16, 0.5, 0.25, 11), ((5000, 1800), 128, 0.9, None, 3)])
+def test_device_sampler_split_and_epoch_order_follow_the_oracle(dev, sizes, B, train_size, val_size, seed):
+    from oracle import host_semantics as HS
+    from spvipes_amd.data import MinibatchSampler
+    gi = [np.arange(100, 100 + sizes[0]), np.arange(10_000, 10_000 + sizes[1])]
+    s = MinibatchSampler(list(sizes), B, dev, seed=seed, train_size=train_size, validation_size=val_size, group_indices_list=gi)
+    want = HS.split_groups(gi, train_size, val_size, seed)          # data/_multi_datasplitter.py:65-79
+    for g in range(2):
+        assert s.train_idx[g].tolist() == want["train"][g].tolist() and s.val_idx[g].tolist() == want["val"][g].tolist()
+        assert s._train_dev[g].device.type == "cuda" and s._train_dev[g].cpu().tolist() == want["train"][g].tolist()
+    firsts = []
+    for ep in range(2):
+        perms = s.draw_permutations()                                # one device randperm per group and epoch
+        assert all(p.device.type == "cuda" and p.dtype == torch.int32 for p in perms)
+        orders = []
+        for g in range(2):
+            pos = {int(c): i for i, c in enumerate(want["train"][g])}
+            orders.append(np.asarray([pos[int(c)] for c in perms[g].cpu().tolist()]))
+            assert sorted(orders[g].tolist()) == list(range(len(want["train"][g])))      # a permutation of the training rows
+        ref_steps = HS.concat_loader_steps(want["train"], B, drop_last=True, orders=orders)   # dataloaders/_concat_dataloader.py:101-110
+        got = list(s.epoch_from_permutations(perms))
+        assert len(got) == len(ref_steps) == s.steps_per_epoch == max(len(t) // B for t in want["train"])
+        for a, b in zip(got, ref_steps):
+            for g in range(2):
+                assert a[g].device.type == "cuda" and a[g].is_contiguous() and a[g].cpu().tolist() == b[g].tolist()
+        firsts.append(got[0][0].cpu().tolist())
+    assert firsts[0] != firsts[1]                                    # reshuffled every epoch
+    ep = list(s.epoch())                                             # the generator the trainer consumes: same shape of epoch
+    assert len(ep) == s.steps_per_epoch and all(r.numel() == B for st in ep for r in st)
+
+
+# ---- save(dir) / load(dir, adata=...) as the tutorial calls them (Tutorial.ipynb:487,538) ---------------------------
+@pytest.mark.parametrize("mode", ["label", "paired"])
+def test_save_and_load_round_trip(dev, tmp_path, mode):
+    from spvipes_amd.model import spVIPES
+    ad = _duck(with_plan=(mode == "paired"), n=(300, 300) if mode == "paired" else (300, 260))
+    kw = {"label_key": "cell_type"} if mode == "label" else {"transport_plan_key": "plan"}
+    spVIPES.setup_anndata(ad, groups_key="groups", **kw)
+    torch.manual_seed(0)
+    model = spVIPES(ad, n_hidden=32, n_dimensions_shared=10, n_dimensions_private=5, dropout_rate=0.05, precision="fp32")
+    gi = [list(ad.uns["groups_obs_indices"][0]), list(ad.uns["groups_obs_indices"][1])]
+    model.train(gi, batch_size=64, max_epochs=3, train_size=1.0)     # moves parameters AND BatchNorm running statistics
+    d = str(tmp_path / "spvipes_model")
+    model.save(d)
+    with pytest.raises(ValueError, match="already exists"):
+        model.save(d)
+    model.save(d, overwrite=True)
+    blob = torch.load(d + "/model.pt", map_location="cpu", weights_only=False)
+    assert set(blob) == {"model_state_dict", "var_names", "attr_dict"}
+    assert any(k.endswith("running_var") for k in blob["model_state_dict"]) and "px_r.0" in blob["model_state_dict"]
+    # a fresh AnnData object that was never set up: load() registers it with the saved setup arguments
+    ad2 = _duck(with_plan=(mode == "paired"), n=(300, 300) if mode == "paired" else (300, 260))
+    back = spVIPES.load(d, adata=ad2)
+    assert back.is_trained_ and not back.module.training and back.history["train_loss"] == model.history["train_loss"]
+    assert back.init_params_ == model.init_params_ and back.module.dropout_rate == 0.05
+    sd_a, sd_b = model.module.state_dict(), back.module.state_dict()
+    assert list(sd_a) == list(sd_b)
+    for k in sd_a:
+        assert torch.equal(sd_a[k], sd_b[k]), k                       # parameters, BN running statistics, num_batches_tracked
+    la, lb = model.get_loadings(), back.get_loadings()
+    for k in la:
+        np.testing.assert_array_equal(la[k].to_numpy(), lb[k].to_numpy())
+    # the same latents from both models given the same injected draws
+    def noise(step, b0, b1):
+        g = torch.Generator(device="cpu").manual_seed(step)
+        mk = lambda b, n: torch.randn(b, n, generator=g).to(dev)
+        return {"enc_0_private": mk(b0, 5), "enc_0_shared": mk(b0, 10), "enc_1_private": mk(b1, 5), "enc_1_shared": mk(b1, 10), "poe_0": mk(b0, 10), "poe_1": mk(b1, 10)}
+    za = model.get_latent_representation(gi, batch_size=128, _noise=noise)
+    zb = back.get_latent_representation(gi, batch_size=128, _noise=noise)
+    for k in za:
+        for g in (0, 1):
+            np.testing.assert_array_equal(za[k][g], zb[k][g])
+    with pytest.raises(ValueError, match="no adata was passed"):
+        spVIPES.load(d)
+    with pytest.raises(ValueError, match="Failed to load model file"):
+        spVIPES.load(str(tmp_path / "nowhere"), adata=ad2)
+    with pytest.raises(NotImplementedError):
+        model.save(str(tmp_path / "with_adata"), save_anndata=True)

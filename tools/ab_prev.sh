@@ -8,7 +8,7 @@ ROUNDS=2; ARGS=""
 while getopts "n:a:" o; do case $o in n) ROUNDS=$OPTARG;; a) ARGS=$OPTARG;; esac; done
 for i in $(seq 1 "$ROUNDS"); do
   for d in . _prev; do
-    (cd $d && timeout -k 10 300 python bench.py --no-cpu-baseline --no-elbo-delta $ARGS 2>/dev/null | \
+    (cd $d && timeout -k 10 300 python bench.py --no-cpu-baseline --no-elbo-delta $ARGS 2>>"$GRAFT_REPO_ROOT/gpurun_out/ab_stderr.log" | \
       python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('[$d]', round(d['ms_per_step'],4), round(d['ms_per_step_median'],4), flush=True)") || echo "[$d] FAILED"
   done
 done
