@@ -177,74 +177,79 @@ def cpu_baseline(groups, args, plan=None):
 
 
 
-def _pmc_fields(args):
-    """HBM bytes per launch of the dominant kernel = FETCH_SIZE + WRITE_SIZE (KiB) and its VALU-busy fraction, from the newest
-    committed rocprofv3 --pmc passes under profiles/ (separate passes of this same command; bench.py itself cannot run
-    under the profiler).  Only reported when THIS run has the workload the passes were taken on (the profile file names
-    it in a `# workload:` line; files without one were taken on the default c2 / bf16 / u16 workload): any other
-    invocation gets nulls rather than another shape's counters.  The kernel's reads are 8 B / lane, outside the access
-    widths the gfx950 FETCH_SIZE correction is calibrated for, so the raw counter is reported."""
-    import glob, re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_dec_nb_kernel.txt")))
+def _workload_tag(args) -> str:
+    return f"{args.config} {args.precision} {args.count_dtype} B{args.batch_size} G{args.genes}"
+
+
+def _pmc_table(args):
+    """The committed per-kernel counter table of THIS run's workload (profiles/<LATEST>_<preset>_pmc_table.json, written by
+    tools/pmc_workload.sh from five separate rocprofv3 --pmc passes of this command; bench.py itself cannot run under the profiler),
+    or (None, None): a table is only used when its `workload` tag names this run's preset / precision / count dtype / batch / genes."""
     latest = os.path.join(ROOT, "profiles", "LATEST")   # tag of the newest evidence set (file names do not sort by time)
-    if os.path.exists(latest):
-        want = os.path.join(ROOT, "profiles", open(latest).read().strip() + "_pmc_dec_nb_kernel.txt")
-        if os.path.exists(want):
-            files = [want]
-    if not files:
-        return None, None, None
-    txt = open(files[-1]).read()
-    m = re.search(r"^# workload: (.*)$", txt, re.M)
-    tag = m.group(1).strip() if m else "c2 bf16 u16 B4096 G10000"
-    mine = f"{args.config} {args.precision} {args.count_dtype} B{args.batch_size} G{args.genes}"
-    if tag != mine:
-        return None, None, None
-    f = re.search(r"FETCH_SIZE\s+n=\s*\d+\s+avg=\s*([0-9.]+)", txt)
-    w = re.search(r"WRITE_SIZE\s+n=\s*\d+\s+avg=\s*([0-9.]+)", txt)
-    a = re.search(r"SQ_ACTIVE_INST_VALU\s+n=\s*\d+\s+avg=\s*([0-9.]+)", txt)
-    g = re.search(r"GRBM_GUI_ACTIVE\s+n=\s*\d+\s+avg=\s*([0-9.]+)", txt)
-    traffic = (float(f.group(1)) + float(w.group(1))) * 1024.0 if (f and w) else None
-    # SQ_ACTIVE_INST_VALU: quad-cycles summed over the 1024 SIMDs; GRBM_GUI_ACTIVE: cycles summed over the 8 XCDs
-    busy = (float(a.group(1)) * 4.0 / 1024.0) / (float(g.group(1)) / 8.0) if (a and g) else None
-    return traffic, "profiles/" + os.path.basename(files[-1]) + " (raw FETCH_SIZE + WRITE_SIZE, KiB -> bytes)", busy
-
-
-def _pmc_decoder_chain(args):
-    """[B, G] traffic of the whole decoder + likelihood chain of ONE group-step (likelihood, one-pass decoder backward, d A_m and d W_m GEMMs,
-    logits GEMM, softmax statistics) from the newest committed --pmc passes, against SURVEY 8d's algorithmic bytes for that chain:
-    2 B G s_x (x read by the likelihood forward and backward) + 40 bytes per decoder parameter.  FETCH_SIZE is doubled for the kernels
-    whose reads are 16 B / lane (LDS-DMA GEMMs, the one-pass backward): MI355X_MICROARCH.md, HBM section; the likelihood kernel's
-    8 B / lane reads are outside the calibrated widths and stay raw.  None unless the passes were taken on this run's workload."""
-    import re
-    latest = os.path.join(ROOT, "profiles", "LATEST")
     if not os.path.exists(latest):
+        return None, None
+    name = f"{open(latest).read().strip()}_{args.config}_pmc_table.json"
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, None
+    try:
+        d = json.load(open(path))
+    except (OSError, ValueError):
+        return None, None
+    return (d, "profiles/" + name) if d.get("workload") == _workload_tag(args) else (None, None)
+
+
+def _pmc_fields(args):
+    """HBM bytes per launch of the dominant kernel = FETCH_SIZE + WRITE_SIZE (KiB) and its VALU-busy fraction from the counter table of
+    this run's workload; any other invocation gets nulls rather than another shape's counters.  The kernel's reads are 8 B / lane,
+    outside the access widths the gfx950 FETCH_SIZE correction is calibrated for, so the raw counter is reported."""
+    tab, src = _pmc_table(args)
+    if tab is None:
+        return None, None, None
+    hit = [e for k, e in tab["kernels"].items() if "dec_nb_kernel" in k and e.get("launches_per_step", 0) >= 1]
+    if not hit or "FETCH_SIZE" not in hit[0] or "WRITE_SIZE" not in hit[0]:
+        return None, None, None
+    e = max(hit, key=lambda e: e["launches_per_step"])
+    return (e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024.0, src + " (raw FETCH_SIZE + WRITE_SIZE, KiB -> bytes)", e.get("valu_busy_frac")
+
+
+# kernels of the decoder + likelihood chain (forward and backward) by name, and the FETCH_SIZE factor of each: x2 where the reads are
+# 16 B / lane (LDS-DMA GEMMs, the one-pass backward: MI355X_MICROARCH.md, HBM section), raw elsewhere
+_CHAIN = (("dec_nb_kernel", 1.0), ("dec_heads_bwd_kernel", 2.0), ("dec_softmax_bwd_kernel", 1.0), ("dec_gemm320_dma4", 2.0), ("dec_logits_dma_kernel", 2.0),
+          ("dec_lse_kernel", 1.0), ("dec_lse_combine_kernel", 1.0), ("dec_heads_wgrad", 2.0), ("gemm_kernel<", 1.0))
+_CHAIN_ENTRY_POINTS = ("spv_dec_nb_fwd", "spv_dec_logits", "spv_dec_lse", "spv_dec_softmax_bwd", "spv_dec_heads_bwd", "spv_gemm_bf16", "spv_dec_heads_wgrad")
+
+
+def _pmc_decoder_chain(args, n_groups=2, chain_ms_per_group_step=None):
+    """[B, G] traffic of the whole decoder + likelihood chain of ONE group-step (likelihood, decoder backward, d A_m and d W_m GEMMs, logits GEMM,
+    softmax statistics; in fp32 mode also the register-staged logits and regressor weight-gradient GEMMs) from the counter table of this
+    run's workload, against SURVEY 8d's algorithmic bytes for that chain: 2 B G s_x (x read by the likelihood forward and backward) + 40
+    bytes per decoder parameter.  With the chain's time (HIP events of this run, single stream) also the rate the counters imply against
+    the HBM peak -- what BASELINE configs[4] asks for.  None unless a table of this workload is committed."""
+    tab, src = _pmc_table(args)
+    if tab is None:
         return None
-    tag = open(latest).read().strip()
-    mine = f"{args.config} {args.precision} {args.count_dtype} B{args.batch_size} G{args.genes}"
-    kernels = [("dec_nb_kernel", 1, 1.0), ("dec_heads_bwd_kernel", 1, 2.0), ("dec_gemm320_dma4_kernel", 2, 2.0), ("dec_logits_dma_kernel", 1, 2.0),
-               ("dec_lse_kernel", 1, 1.0)]   # (name, launches per group-step, FETCH_SIZE factor)
     per, total = {}, 0.0
-    for name, n, ff in kernels:
-        f = os.path.join(ROOT, "profiles", f"{tag}_pmc_{name}.txt")
-        if not os.path.exists(f):
-            return None
-        txt = open(f).read()
-        m = re.search(r"^# workload: (.*)$", txt, re.M)
-        if not m or m.group(1).strip() != mine:
-            return None
-        fe = re.search(r"FETCH_SIZE\s+n=\s*\d+\s+avg=\s*([0-9.]+)", txt)
-        wr = re.search(r"WRITE_SIZE\s+n=\s*\d+\s+avg=\s*([0-9.]+)", txt)
-        if not (fe and wr):
-            return None
-        b = (float(fe.group(1)) * ff + float(wr.group(1))) * 1024.0 * n
-        per[name] = b
+    for k, e in tab["kernels"].items():
+        f = next((ff for pat, ff in _CHAIN if pat in k), None)
+        if f is None or "FETCH_SIZE" not in e or "WRITE_SIZE" not in e:
+            continue
+        b = (e["FETCH_SIZE"] * f + e["WRITE_SIZE"]) * 1024.0 * e["launches_per_step"] / n_groups
+        per[k[:60]] = b
         total += b
+    if not per:
+        return None
     B, G, n_s, n_p = args.batch_size, args.genes, args.n_shared, args.n_private
     sx = 2 if args.count_dtype == "u16" else 4
     p_dec = G * (n_p + 2) + G * (n_s + 2) + ((n_s + n_p) * 256 + 3 * 256) + G * (256 + n_s + n_p + 1) + G
     alg = 2.0 * B * G * sx + 40.0 * p_dec
-    return {"traffic_bytes_per_group_step": total, "algorithmic_bytes_per_group_step": alg, "ratio": total / alg, "per_kernel_bytes": per,
-            "source": f"profiles/{tag}_pmc_<kernel>.txt (FETCH_SIZE x2 where reads are 16 B / lane, + WRITE_SIZE)"}
+    out = {"traffic_bytes_per_group_step": total, "algorithmic_bytes_per_group_step": alg, "ratio": total / alg, "per_kernel_bytes": per,
+           "source": src + " (FETCH_SIZE x2 where reads are 16 B / lane, + WRITE_SIZE)"}
+    if chain_ms_per_group_step:
+        gbs = total / (chain_ms_per_group_step * 1e-3) / 1e9
+        out.update({"chain_ms_per_group_step": chain_ms_per_group_step, "counter_GBs": gbs, "counter_frac_of_hbm_peak": gbs / HBM_PEAK_GBS,
+                    "algorithmic_GBs": alg / (chain_ms_per_group_step * 1e-3) / 1e9})
+    return out
 
 
 def synthetic_plan(n0, n1, k=8, seed=2000):
@@ -538,7 +543,8 @@ def main(argv=None):
                 "avg_launch_ms": nb_avg, "algorithmic_bytes_per_launch": nb_bytes,
                 "mfma_view": {"achieved_TFLOPs": nb_flops / (nb_avg * 1e-3) / 1e12, "peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS,
                               "frac": nb_flops / (nb_avg * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS},
-                "decoder_chain": _pmc_decoder_chain(args),
+                "traffic_GBs": (traffic / (nb_avg * 1e-3) / 1e9) if (traffic and nb_avg == nb_avg) else None,
+                "decoder_chain": _pmc_decoder_chain(args, NG, (sum(sum(prof.get(k, [])) for k in _CHAIN_ENTRY_POINTS) / prof_steps / NG) or None),
                 "per_entry_point": per_kernel}
         fc1_ms = prof.get("spv_enc_fc1_fwd", [])
         if not fc1_ms and prof.get("spv_enc_fc1_fwd_grouped"):   # one launch per kernel for all groups: per-group share of the entry point

@@ -429,9 +429,12 @@ typedef struct spv_poe_args {
   const float* expert[2]; int64_t ld_expert[2];  /* cluster PoE: plan-weighted experts [B][ld] (loc | logvar) fused in
                                                     place of the encoder statistics; NULL = label / paired PoE      */
   float* d_expert[2];                      /* backward output for expert (zeroed by the call itself)                */
-  /* label PoE, forward only: when lab[0] != NULL spv_poe_fuse_fwd derives every cell's partner / mode itself from the ranking left
+  /* label PoE: when lab[0] != NULL spv_poe_fuse_fwd derives every cell's partner / mode itself from the ranking left
    * by spv_poe_rank (labels, rank within label, cells of each label in batch order, per-label count / start tables) and STORES them
-   * through partner / mode (which are then outputs) for the backward pass -- the separate lookup launch of spv_poe_partner is gone */
+   * through partner / mode (which are then outputs) for the backward pass -- the separate lookup launch of spv_poe_partner is gone.
+   * spv_poe_fuse_bwd reads lab[0] only as a flag: non-NULL = partners are one to one (label pairing: one atomic per cell and column);
+   * NULL = partners are arg maxima / component ranks that may coincide (paired, cluster PoE): contributions to one partner are first
+   * summed inside a 32-cell workgroup */
   const float* lab[2]; const int32_t* order[2]; const int32_t* rank[2]; const int32_t* tables;
 } spv_poe_args;
 int spv_poe_fuse_fwd(const spv_poe_args* a, void* stream);

@@ -1070,7 +1070,10 @@ extern "C" int spv_poe_fuse_bwd(const spv_poe_args* a, void* stream) {
         return fail(SPV_ERR_LAUNCH, "spv_poe_fuse_bwd: fill failed%s");
     }
   }
-  hipLaunchKernelGGL(poe_fuse_bwd_kernel, dim3((Bm + 7) / 8, 2), dim3(256), 0, (hipStream_t)stream, *a);
+  if (a->lab[0] != nullptr)   // label PoE: one-to-one pairs
+    hipLaunchKernelGGL(poe_fuse_bwd_kernel<false>, dim3((Bm + 7) / 8, 2), dim3(256), 0, (hipStream_t)stream, *a);
+  else                        // arg-max partners may coincide: per-workgroup sums per partner, one atomic per column and partner
+    hipLaunchKernelGGL(poe_fuse_bwd_kernel<true>, dim3((Bm + 31) / 32, 2), dim3(1024), 0, (hipStream_t)stream, *a);
   return launch_status("spv_poe_fuse_bwd");
 }
 

@@ -62,6 +62,10 @@ __device__ __forceinline__ void load8_strided(const float* p, long ld, int c0, i
   for (int j = 0; j < 8; ++j) { const bool ok = c0 + j < lim; const float t = p[ok ? (long)(c0 + j) * ld : 0]; v[j] = ok ? t : 0.f; }
 }
 __device__ __forceinline__ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+// (Round 4, measured and taken back: FOUR 16-deep steps of operands in flight instead of one -- tools/probes/graph_chain_probe.py prices a
+// launch of these kernels at 2.5 us + 0.55 us per step, 2.6 x the eight MFMAs' time, i.e. one L2 round trip per step -- made every shape
+// SLOWER (4 x [4096 x 128] x [128 x 128]: 12.1 -> 16.1 us per dependent launch, [128 x 64] x [64 x 64]: 5.8 -> 8.0): hipcc hoists the
+// zero-selects of load8 behind the loads, so the first MFMA waits for the whole prologue, and steps beyond K still issue their loads.)
 
 // Y = act(X W^T + b): workgroup = 2 x 2 waves = 64 rows x 64 columns
 template <bool VX, bool VW>
@@ -884,44 +888,67 @@ __global__ __launch_bounds__(256) void poe_fuse_fwd_kernel(PoeArgs a) {
 // gradient of a cell's self expert and, through its partner, of the other group's expert.  Label PoE: at most two adds
 // per element (order-independent); paired PoE: a cell can be the arg max of several rows, so its adds commute only up
 // to fp32 rounding (the same holds for the index_add of the reference's autograd).
-__global__ __launch_bounds__(256) void poe_fuse_bwd_kernel(PoeArgs a) {
+// AGG (paired / cluster PoE: partners are arg maxima and may coincide -- with a sparse plan most rows of a minibatch block are empty
+// and their arg max is cell 0, so thousands of cells add into ONE row; 136 us at C5's shard shape with one atomic per cell and
+// column): a workgroup takes 32 cells, the contributions of cells that share a partner are summed in the workgroup (cell order) and the
+// first of them issues one atomic per column.  Label PoE pairs cells one to one: no aggregation, 8 cells per workgroup.
+template <bool AGG>
+__global__ __launch_bounds__(AGG ? 1024 : 256) void poe_fuse_bwd_kernel(PoeArgs a) {
+  constexpr int CPB = AGG ? 32 : 8;
+  __shared__ float s_c[AGG ? 32 : 1][64];
+  __shared__ int s_pr[AGG ? 32 : 1];
   const int g = blockIdx.y, o = 1 - g;
-  const int b = blockIdx.x * 8 + (threadIdx.x >> 5), d = threadIdx.x & 31;
+  const int cell = threadIdx.x >> 5, d = threadIdx.x & 31;
+  const int b = blockIdx.x * CPB + cell;
   const int n = a.n;
-  if (b >= a.B[g] || d >= n) return;
-  const int m = a.mode[g][b], pr = a.partner[g][b];
-  const long prc = pr < 0 ? 0 : pr;
-  const float* own = a.stats[g] + (long)b * a.ld[g];
-  const float* self = a.expert[g] ? a.expert[g] + (long)b * a.ld_expert[g] : own;
-  const float* oth = a.expert[o] ? a.expert[o] + prc * a.ld_expert[o] : a.stats[o] + prc * a.ld[o];
-  float* d_own = a.d_stats[g] + (long)b * a.ld[g];
-  float* d_self = a.expert[g] ? a.d_expert[g] + (long)b * a.ld_expert[g] : d_own;
-  float* d_oth = a.expert[o] ? a.d_expert[o] + prc * a.ld_expert[o] : a.d_stats[o] + prc * a.ld[o];
-  const float gk = ld_or_zero(a.g_kl[g], b);
-  const long i = (long)b * n + d;
-  const float jl = a.loc[g][i], sc = a.scale[g][i];
-  const bool live = !a.clamp_scale || sc >= 1e-6f;   // below the clamp the draw and the KL do not depend on the scale
-  const float sq = a.clamp_scale ? fmaxf(sc, 1e-6f) : sc;
-  const float gz = ld_or_zero(a.g_logz[g], i);
-  const float Gl = ld_or_zero(a.g_loc[g], i) + gz + gk * jl;
-  const float Gs = ld_or_zero(a.g_scale[g], i) + (live ? gz * a.eps[g][i] + gk * (sq - 1.0f / sq) : 0.f);
-  const float Gv = ld_or_zero(a.g_logvar[g], i) + 0.5f * sc * Gs;
-  if (m == 2 && a.lone_passthrough) {  // loc* = loc, logvar* = logvar, scale* = exp(logvar / 2)
-    atomicAdd(&d_own[d], Gl);
-    atomicAdd(&d_own[n + d], Gv);
-    return;
+  const bool ok = b < a.B[g] && d < n;
+  float c0 = 0.f, c1 = 0.f;
+  int prt = -1;
+  if (ok) {
+    const int m = a.mode[g][b], pr = a.partner[g][b];
+    const long prc = pr < 0 ? 0 : pr;
+    const float* own = a.stats[g] + (long)b * a.ld[g];
+    const float* self = a.expert[g] ? a.expert[g] + (long)b * a.ld_expert[g] : own;
+    const float* oth = a.expert[o] ? a.expert[o] + prc * a.ld_expert[o] : a.stats[o] + prc * a.ld[o];
+    float* d_own = a.d_stats[g] + (long)b * a.ld[g];
+    float* d_self = a.expert[g] ? a.d_expert[g] + (long)b * a.ld_expert[g] : d_own;
+    const float gk = ld_or_zero(a.g_kl[g], b);
+    const long i = (long)b * n + d;
+    const float jl = a.loc[g][i], sc = a.scale[g][i];
+    const bool live = !a.clamp_scale || sc >= 1e-6f;   // below the clamp the draw and the KL do not depend on the scale
+    const float sq = a.clamp_scale ? fmaxf(sc, 1e-6f) : sc;
+    const float gz = ld_or_zero(a.g_logz[g], i);
+    const float Gl = ld_or_zero(a.g_loc[g], i) + gz + gk * jl;
+    const float Gs = ld_or_zero(a.g_scale[g], i) + (live ? gz * a.eps[g][i] + gk * (sq - 1.0f / sq) : 0.f);
+    const float Gv = ld_or_zero(a.g_logvar[g], i) + 0.5f * sc * Gs;
+    if (m == 2 && a.lone_passthrough) {  // loc* = loc, logvar* = logvar, scale* = exp(logvar / 2)
+      atomicAdd(&d_own[d], Gl);
+      atomicAdd(&d_own[n + d], Gv);
+    } else {
+      const float loc = self[d], inv = expf(-self[n + d]);
+      float t = (m == 1) ? 1.0f : 0.36787944117144233f, lo = 0.f;
+      if (m == 0) { lo = oth[d]; t = expf(-oth[n + d]); }
+      const float J = 1.0f / (1.0f + (inv + t));
+      const float dN = Gl * J, dP = -J * (Gl * jl + Gv);
+      atomicAdd(&d_self[d], dN * inv);
+      atomicAdd(&d_self[n + d], -inv * (dN * loc + dP));
+      if (m == 0) { c0 = dN * t; c1 = -t * (dP + dN * lo); prt = pr; }
+    }
   }
-  const float loc = self[d], inv = expf(-self[n + d]);
-  float t = (m == 1) ? 1.0f : 0.36787944117144233f, lo = 0.f;
-  if (m == 0) { lo = oth[d]; t = expf(-oth[n + d]); }
-  const float J = 1.0f / (1.0f + (inv + t));
-  const float dN = Gl * J, dP = -J * (Gl * jl + Gv);
-  atomicAdd(&d_self[d], dN * inv);
-  atomicAdd(&d_self[n + d], -inv * (dN * loc + dP));
-  if (m == 0) {
-    atomicAdd(&d_oth[d], dN * t);
-    atomicAdd(&d_oth[n + d], -t * (dP + dN * lo));
+  if constexpr (AGG) {
+    s_c[cell][d] = c0; s_c[cell][32 + d] = c1;
+    if (d == 0) s_pr[cell] = prt;   // (lane 0 of a cell is in range whenever the cell is: n >= 1)
+    __syncthreads();
+    if (prt < 0) return;
+    for (int c = 0; c < cell; ++c) if (s_pr[c] == prt) return;   // an earlier cell of the workgroup carries this partner's sum
+    for (int c = cell + 1; c < CPB; ++c)
+      if (s_pr[c] == prt) { c0 += s_c[c][d]; c1 += s_c[c][32 + d]; }
+  } else {
+    if (prt < 0) return;
   }
+  float* d_oth = a.expert[o] ? a.d_expert[o] + (long)prt * a.ld_expert[o] : a.d_stats[o] + (long)prt * a.ld[o];
+  atomicAdd(&d_oth[d], c0);
+  atomicAdd(&d_oth[n + d], c1);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -448,15 +448,23 @@ class spVIPESmodule(nn.Module):
             if self.training and self.dropout_rate > 0:
                 self._seed_dev.add_(1)
         from . import ops as _ops_mod
-        # the label pairing (rank within label + partner lookup, ~28 us of two tiny launches) depends on the labels alone: with
-        # LABEL_PRE it runs on a side stream beside the fc1 GEMMs instead of on the chain between the encoder tails and the fusion
+        # the label pairing (rank within label, one workgroup per group, 13-14 us at B 4096) depends on the labels alone.  LABEL_PRE 1: on a
+        # side stream beside the fc1 GEMMs (measured: no gain -- its two workgroups hold two CUs' LDS, two of the one-per-CU fc1 workgroups
+        # wait for them and run as a second round); LABEL_PRE 2: forked BEHIND the fc1 launches, beside the encoder tails, whose kernels leave
+        # most of the chip idle, and joined in front of the fusion kernel
         label_pre, pre_stream = None, None
-        if (_ops_mod.LABEL_PRE and self.n_groups == 2 and self.use_labels and kwargs.get("labels") is not None and not _ops_mod.SERIAL_STREAMS):
+        label_pre_ok = bool(self.n_groups == 2 and self.use_labels and kwargs.get("labels") is not None and not _ops_mod.SERIAL_STREAMS)
+
+        def fork_label_pairing():
             from .nn_ops import label_partners
-            pre_stream = group_streams(dev0, 3)[2]
-            pre_stream.wait_stream(torch.cuda.current_stream(dev0))
-            with torch.cuda.stream(pre_stream):
-                label_pre = label_partners([kwargs["labels"][0], kwargs["labels"][1]], self._workspace(0, dev0))
+            st = group_streams(dev0, 3)[2]
+            st.wait_stream(torch.cuda.current_stream(dev0))
+            with torch.cuda.stream(st):
+                res = label_partners([kwargs["labels"][0], kwargs["labels"][1]], self._workspace(0, dev0))
+            return res, st
+
+        if _ops_mod.LABEL_PRE == 1 and label_pre_ok:
+            label_pre, pre_stream = fork_label_pairing()
         streams = None
         grouped = bool(_ops_mod.FC1_GROUPED and len(groups_) >= 2)
         if grouped:   # one autograd node, one launch per kernel for every pair of groups (ops.EncoderFC1Grouped)
@@ -484,6 +492,8 @@ class spVIPESmodule(nn.Module):
             library[g] = lib.unsqueeze(1)
         if streams is not None:
             join(streams)
+        if _ops_mod.LABEL_PRE == 2 and label_pre_ok:
+            label_pre, pre_stream = fork_label_pairing()
         # all encoder tails (fc2, dropout, heads, BatchNorm, draw, KL) as a few batched HIP launches: one batch over the
         # four encoders when the groups' minibatches have the same size (training), one batch per group otherwise (ragged
         # inference batches: the last step of get_latent_representation).  Injected dropout keep-masks (parity tests)

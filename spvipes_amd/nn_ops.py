@@ -228,7 +228,9 @@ class EncoderTails(torch.autograd.Function):
         for i, s in enumerate(specs):
             _add_lin(b, N=s.n, K=H, W=ptr(par[i][2]), X=ptr(h2[i]), ldx=H, dY=_fptr(d_pre[i], 0), lddy=2 * s.n, dW=ptr(dWmu[i]), db=ptr(dbmu[i]))
             _add_lin(b, N=s.n, K=H, W=ptr(par[i][4]), X=ptr(h2[i]), ldx=H, dY=_fptr(d_pre[i], s.n), lddy=2 * s.n, dW=ptr(dWlv[i]), db=ptr(dblv[i]))
-        _wgrad(b, ws if not isinstance(ws, (list, tuple)) else ws[0])
+        from . import ops as _ops
+        wsw = ws if not isinstance(ws, (list, tuple)) else ws[0]
+        _ops.run_param_grads(dev, lambda b=b: _wgrad(b, wsw), keep=[*h2, *d_pre])   # (feeds only the optimiser: off the critical chain)
         # 4. d h2 = d_pre_mu Wmu + d_pre_lv Wlv
         #    one launch: the contraction runs over the 2n columns of d_pre, rows 0..n-1 of the weight from Wmu, rows n.. from Wlv
         dh2 = [new(B, H) for _ in specs]
@@ -249,7 +251,7 @@ class EncoderTails(torch.autograd.Function):
             x, ldx = _fptr(h1[s.h1_group], s.h1_col), h1[s.h1_group].shape[1]
             _add_lin(bw, N=H, K=H, W=ptr(par[i][0]), X=x, ldx=ldx, Y=ptr(h2[i]), ldy=H, dY=ptr(dh2[i]), lddy=H, dW=ptr(dW2[i]), db=ptr(db2[i]))
             _add_lin(bd, N=H, K=H, W=ptr(par[i][0]), Y=ptr(h2[i]), ldy=H, dY=ptr(dh2[i]), lddy=H, dX=_fptr(dh1[s.h1_group], s.h1_col), lddx=ldx)
-        _wgrad(bw, ws if not isinstance(ws, (list, tuple)) else ws[0])
+        _ops.run_param_grads(dev, lambda: _wgrad(bw, wsw), keep=[*h1, *h2, *dh2])
         _abi.call("spv_linear_dgrad", C.byref(bd), stream_ptr())
         grads: List[Optional[torch.Tensor]] = list(dh1)
         for i in range(E):
@@ -319,6 +321,7 @@ class PoELabel(torch.autograd.Function):
         a.tables = ptr(tables)
         _abi.call("spv_poe_fuse_fwd", C.byref(a), stream_ptr())
         ctx.blocks, ctx.eps, ctx.partner, ctx.mode, ctx.n, ctx.Bs = blocks, eps, partner, mode, n, Bs
+        ctx.lab = lab
         ctx.save_for_backward(out["loc"][0], out["loc"][1], out["scale"][0], out["scale"][1])
         res = []
         for g in range(2):
@@ -347,6 +350,7 @@ class PoELabel(torch.autograd.Function):
             a.stats[k], a.ld[k], a.partner[k], a.mode[k], a.eps[k], a.B[k] = ctx.blocks[k][1], ctx.blocks[k][2], ptr(ctx.partner[k]), ptr(ctx.mode[k]), ptr(ctx.eps[k]), Bs[k]
             a.loc[k], a.scale[k] = ptr(loc[k]), ptr(scale[k])
             a.g_loc[k], a.g_logvar[k], a.g_scale[k], a.g_logz[k], a.g_kl[k] = ptr(gl), ptr(gv), ptr(gs), ptr(gz), ptr(gk)
+            a.lab[k] = ptr(ctx.lab[k])   # (a flag for the backward kernel: label pairs are one to one)
         for k in range(2):  # (d_stats uses the same pitch as stats, which may be views of a wider buffer)
             a.d_stats[k] = ptr(d[k])
         _abi.call("spv_poe_fuse_bwd", C.byref(a), stream_ptr())

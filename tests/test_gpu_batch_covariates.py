@@ -156,7 +156,8 @@ def test_split_backward_with_batch_covariates_overwrites_and_equals_the_single_p
     flat_split, by_name_split = run(True, graph)
     for n_ in by_name_one:
         assert torch.equal(by_name_one[n_], by_name_split[n_]), n_
-    assert torch.equal(flat_one, flat_split)
+    # (the flat buffer's alignment padding keeps the NaN fill: compare it with the padding mapped to zero)
+    assert torch.equal(torch.nan_to_num(flat_one), torch.nan_to_num(flat_split))
 
 
 def test_covariate_errors(dev):
