@@ -254,7 +254,7 @@ int spv_dec_dz(const spv_dec_params* p, const float* Tp, const float* Ts, float*
  * through the two rate heads, columns 0..15 = sum_g tP[b][g] * W'_p[g][.], columns 16..47 = sum_g tS[b][g] * W'_s[g][.]
  * (sum the slabs with spv_reduce_slabs): replaces the two [B,G] x [G,K] GEMMs over tP and tS. */
 int spv_dec_softmax_bwd(const spv_dec_params* p, const float* Tp, const float* Ts, float* dz_part, void* stream);
-/* bf16 mode: ONE read-only pass over t_P / t_S for everything the backward pass needs from them (nn/networks.py:314-320 through
+/* ONE read-only pass over t_P / t_S (bf16 words, or the hi / lo planes of split-bf16 words when p->grads_f32) for everything the backward pass needs from them (nn/networks.py:314-320 through
  * autograd): the latent gradient of the two rate heads (dz_part, as above) and the two regressor weight gradients
  * d [W'_p | c_p] = t'_P^T [z_p | 1], d [W'_s | c_s] = t'_S^T [z_s | 1] as one partial slab per 128-cell workgroup row:
  * dw_part [Bp / 128][Gp][48], a row = [d W'_p | d c_p | 0.. (16 columns) | d W'_s | d c_s | 0.. (32 columns)] like the regressor operand

@@ -607,9 +607,15 @@ extern "C" int spv_dec_heads_bwd(const spv_dec_params* q, const float* Tp, const
   if (rc != SPV_OK) return rc;
   if (!Tp || !Ts || !p.tP || !p.tS || !p.lse_p || !p.lse_s || !dz_part || !dw_part) return fail(SPV_ERR_ARG, "spv_dec_heads_bwd: null pointer%s");
   if (p.n_gene_tiles != p.Gp / 32) return fail(SPV_ERR_ARG, "spv_dec_heads_bwd: n_gene_tiles must be Gp / 32%s");
-  if (p.grads_f32) return fail(SPV_ERR_UNSUPPORTED, "spv_dec_heads_bwd: bf16 gradient arrays only%s");
   if (p.Bp % DEC_CELLS_PER_WG) return fail(SPV_ERR_ARG, "spv_dec_heads_bwd: Bp must be a multiple of 128%s");
   dim3 grid(p.Bp / DEC_CELLS_PER_WG, p.gene_splits);
+  if (p.grads_f32) {   // hi / lo planes of split-bf16 gradient words ("fp32" mode)
+    if (!p.Wps_lo || !p.Aps_lo) return fail(SPV_ERR_ARG, "spv_dec_heads_bwd: split gradient words need the lo planes of the operand images%s");
+    static bool raised = false;
+    if (!raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_heads_bwd_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, HBS_LDS_BYTES); raised = true; }
+    hipLaunchKernelGGL(dec_heads_bwd_split_kernel, grid, dim3(256), HBS_LDS_BYTES, (hipStream_t)stream, p, Tp, Ts, dz_part, dw_part);
+    return launch_status("spv_dec_heads_bwd");
+  }
   // (the partial slabs cover gene rows the splits do not reach only when genes_per_split * gene_splits < round_up(G, 32): the host sizes
   // the splits to cover; rows in [round_up(G, 32), Gp) are never written and never read)
   hipLaunchKernelGGL(dec_heads_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, p, Tp, Ts, dz_part, dw_part);

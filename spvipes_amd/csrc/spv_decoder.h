@@ -1185,4 +1185,220 @@ __global__ __launch_bounds__(256, 2) void dec_heads_bwd_kernel(DecParams p, cons
   }
 }
 
+
+// ---- one-pass decoder backward for split-bf16 gradient words ("fp32" precision mode, round 4) -----------------------------------------
+// dec_heads_bwd_kernel's structure (every wave in every tile's contraction, one barrier per tile, an instruction stream that is the same for
+// every wave and tile) on the hi / lo planes the likelihood kernel writes in this mode: t = hi + lo (~2^-17), the corrected value is split
+// again, and every product runs as hi * lo + lo * hi + hi * hi (the arithmetic of dec_softmax_bwd_kernel<split_t, true> for the latent
+// gradient and of the split-bf16 GEMMs for the two regressor weight gradients).  It replaces, per group, the in-place softmax fix (reads AND
+// writes both planes of t_P / t_S: 4 x [B, G] x 2 B each way) and the two register-staged weight-gradient GEMMs that re-read them: one
+// read of the four planes instead of two reads and one write.
+// LDS (dynamic, 112 128 B: one workgroup per CU): W'^T tiles [parity][hi | lo][48][36], parked tiles [parity][head][hi | lo][128 cells][32 genes]
+// (chunk-swizzled as in the bf16 kernel), latent images [head][hi | lo][128][32].  Per tile and wave the vector-memory stream is
+// 6 fragment loads, 2 staging loads, 8 tile loads (two tiles ahead), 8 stores -- in that order, always.
+constexpr int HBS_WT_ELEMS = DEC_KPS * HB_WT_PITCH;             // one plane of one staged W'^T tile
+constexpr int HBS_LDS_BYTES = (2 * 2 * HBS_WT_ELEMS + 2 * 2 * 2 * SMB_TILE_ELEMS + 2 * 2 * DEC_CELLS_PER_WG * 32) * 2;
+__global__ __launch_bounds__(256, 1) void dec_heads_bwd_split_kernel(DecParams p, const float* Tp, const float* Ts, float* dz_part, float* dw_part) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char hbs_smem[];
+  bf16_t* const s_wT = reinterpret_cast<bf16_t*>(hbs_smem);                   // [parity][hl][k][gene of the tile]
+  bf16_t* const s_tile = s_wT + 2 * 2 * HBS_WT_ELEMS;                          // [parity][head][hl][cell][gene], chunk-swizzled
+  bf16_t* const s_zh = s_tile + 2 * 2 * 2 * SMB_TILE_ELEMS;                    // [head][hl][cell][32 columns] of the latent image
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
+  const int cell_tile = blockIdx.x * (DEC_CELLS_PER_WG / 32) + wave;
+  const int cell0 = cell_tile * 32;
+  const int cell = cell0 + r;
+  const int split = blockIdx.y;
+  const long plane = (long)p.Bp * p.Gp;
+  PsFrags cf;
+  load_ps_cell_frags(p, cell0, lane, cf);
+  const float lp = p.lse_p[cell], ls = p.lse_s[cell];
+  const float tpb = Tp[cell], tsb = Ts[cell];
+  const int gbeg = split * p.genes_per_split;
+  int gend = gbeg + p.genes_per_split;
+  if (gend > p.Gp) gend = p.Gp;
+  if (gend > ((p.G + 31) & ~31)) gend = (p.G + 31) & ~31;
+  const int ntile = (gend - gbeg) >> 5;
+  f16v accP, accS;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { accP[q] = 0.f; accS[q] = 0.f; }
+  if (ntile > 0) {   // (block-uniform)
+    {   // the workgroup's 128 rows of the latent image: one 32-column image per head and plane
+      const int cb0 = blockIdx.x * DEC_CELLS_PER_WG;
+      for (int i = threadIdx.x; i < 2 * 2 * DEC_CELLS_PER_WG * 4; i += 256) {   // 8-element chunks: 4 per row, head and plane
+        const int hd = i / (2 * DEC_CELLS_PER_WG * 4), hl = (i / (DEC_CELLS_PER_WG * 4)) & 1, row = (i / 4) % DEC_CELLS_PER_WG, c8 = (i % 4) * 8;
+        const bf16_t* src = hl ? p.Aps_lo : p.Aps_hi;
+        u4v v = u4v{0u, 0u, 0u, 0u};
+        if (hd == 1 || c8 < DEC_KP) v = *reinterpret_cast<const u4v*>(src + (long)(cb0 + row) * DEC_KPS + (hd ? DEC_KP : 0) + c8);
+        *reinterpret_cast<u4v*>(s_zh + ((hd * 2 + hl) * DEC_CELLS_PER_WG + row) * 32 + c8) = v;
+      }
+    }
+    // W'^T staging (both planes): thread i < 192 owns gene i / 6 of a tile and the 8 columns 8 (i % 6) ..; threads 192.. repeat pieces 0..63
+    const int st_i = (threadIdx.x < 192) ? (int)threadIdx.x : (int)threadIdx.x - 192;
+    const int st_g = st_i / (DEC_KPS / 8), st_c = (st_i % (DEC_KPS / 8)) * 8;
+    auto wt_store = [&](int t, int hl, const u4v& w) {
+      bf16_t* dst = s_wT + ((t & 1) * 2 + hl) * HBS_WT_ELEMS + st_c * HB_WT_PITCH + st_g;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { dst[(2 * j) * HB_WT_PITCH] = (bf16_t)(w[j] & 0xFFFFu); dst[(2 * j + 1) * HB_WT_PITCH] = (bf16_t)(w[j] >> 16); }
+    };
+    auto wt_off = [&](int t) { return (long)(gbeg + 32 * min(t, ntile - 1) + st_g) * DEC_KPS + st_c; };
+    const long trow = (long)cell_tile * p.n_gene_tiles;
+    PsW wA;
+    u2v rp0[4], rs0[4], rp1[4], rs1[4];       // hi planes, two register stages
+    u2v rpl0[4], rsl0[4], rpl1[4], rsl1[4];   // lo planes
+    load_ps_w(p, gbeg, lane, wA);
+    auto request = [&](int t, u2v (&rp)[4], u2v (&rs)[4], u2v (&rpl)[4], u2v (&rsl)[4]) {   // 16-byte loads of the lane pair's words (see dec_heads_bwd_kernel)
+      const long tb = (trow + ((gbeg + 32 * min(t, ntile - 1)) >> 5)) * 1024 + lane * 4;
+      const long tb2 = tb - (lane & 1) * 4 + (lane & 1) * 256;
+      const bf16_t* tP = reinterpret_cast<const bf16_t*>(p.tP);
+      const bf16_t* tS = reinterpret_cast<const bf16_t*>(p.tS);
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const u4v a = *reinterpret_cast<const u4v*>(tP + tb2 + 512 * pr);
+        const u4v b = *reinterpret_cast<const u4v*>(tS + tb2 + 512 * pr);
+        const u4v al = *reinterpret_cast<const u4v*>(tP + plane + tb2 + 512 * pr);
+        const u4v bl = *reinterpret_cast<const u4v*>(tS + plane + tb2 + 512 * pr);
+        rp[2 * pr] = u2v{a[0], a[1]}; rp[2 * pr + 1] = u2v{a[2], a[3]};
+        rs[2 * pr] = u2v{b[0], b[1]}; rs[2 * pr + 1] = u2v{b[2], b[3]};
+        rpl[2 * pr] = u2v{al[0], al[1]}; rpl[2 * pr + 1] = u2v{al[2], al[3]};
+        rsl[2 * pr] = u2v{bl[0], bl[1]}; rsl[2 * pr + 1] = u2v{bl[2], bl[3]};
+      }
+    };
+    auto unswap = [&](u2v (&r4)[4]) {
+      const bool odd = lane & 1;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const u2v lo = r4[2 * pr], hi = r4[2 * pr + 1];
+        const u2v send = odd ? lo : hi;
+        const u2v recv = u2v{(unsigned)__shfl_xor((int)send[0], 1, 64), (unsigned)__shfl_xor((int)send[1], 1, 64)};
+        r4[2 * pr] = odd ? recv : lo;
+        r4[2 * pr + 1] = odd ? hi : recv;
+      }
+    };
+    wt_store(0, 0, *reinterpret_cast<const u4v*>(p.Wps_hi + wt_off(0)));
+    wt_store(0, 1, *reinterpret_cast<const u4v*>(p.Wps_lo + wt_off(0)));
+    request(0, rp0, rs0, rpl0, rsl0);
+    request(1, rp1, rs1, rpl1, rsl1);
+    lds_barrier();   // latent images and the first W'^T tile are in LDS
+    const int role0 = wave, role1 = (wave + 4) % 6;   // this wave's two [16 genes x 16 columns] blocks of every tile (dec_heads_bwd_kernel)
+    float* const wslab = dw_part + (long)blockIdx.x * p.Gp * DEC_KPS;
+    auto lo2 = [](unsigned hi2, float a, float b) { return pack2bf(a - __uint_as_float(hi2 << 16), b - __uint_as_float(hi2 & 0xffff0000u)); };
+    auto tile = [&](const int t, u2v (&rpA)[4], u2v (&rsA)[4], u2v (&rplA)[4], u2v (&rslA)[4]) {
+      const int g0 = gbeg + 32 * t, gn = gbeg + 32 * min(t + 1, ntile - 1);
+      f16v yp, ys;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { yp[q] = 0.f; ys[q] = 0.f; }
+      yp = mfma32_split<3>(wA.hi[0], wA.lo[0], cf.hi[0], cf.lo[0], yp);
+      ys = mfma32_split<3>(wA.hi[1], wA.lo[1], cf.hi[1], cf.lo[1], ys);
+      ys = mfma32_split<3>(wA.hi[2], wA.lo[2], cf.hi[2], cf.lo[2], ys);
+      PsW wB;
+      load_ps_w(p, gn, lane, wB);                                                        // 6 loads: next tile's W' fragments
+      const u4v wsth = *reinterpret_cast<const u4v*>(p.Wps_hi + wt_off(t + 1));          // 2 loads: next tile's W'^T pieces
+      const u4v wstl = *reinterpret_cast<const u4v*>(p.Wps_lo + wt_off(t + 1));
+      unsigned cpk[8], csk[8], cpl[8], csl[8];   // corrected values: hi words and the bf16 of what the first rounding left
+      unswap(rpA); unswap(rsA); unswap(rplA); unswap(rslA);
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        float vp[4], vs[4], wp[4], wsv[4];
+        decode4(rpA[qq], vp); decode4(rplA[qq], wp);
+        decode4(rsA[qq], vs); decode4(rslA[qq], wsv);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int q = 4 * qq + j;
+          vp[j] = (vp[j] + wp[j]) - fast_exp(yp[q] - lp) * tpb;
+          vs[j] = (vs[j] + wsv[j]) - fast_exp(ys[q] - ls) * tsb;
+        }
+        cpk[2 * qq] = pack2bf(vp[0], vp[1]); cpk[2 * qq + 1] = pack2bf(vp[2], vp[3]);
+        csk[2 * qq] = pack2bf(vs[0], vs[1]); csk[2 * qq + 1] = pack2bf(vs[2], vs[3]);
+        cpl[2 * qq] = lo2(cpk[2 * qq], vp[0], vp[1]); cpl[2 * qq + 1] = lo2(cpk[2 * qq + 1], vp[2], vp[3]);
+        csl[2 * qq] = lo2(csk[2 * qq], vs[0], vs[1]); csl[2 * qq + 1] = lo2(csk[2 * qq + 1], vs[2], vs[3]);
+      }
+      request(t + 2, rpA, rsA, rplA, rslA);       // 8 loads: the tile after next, into the registers just decoded
+      const bf16_t* wTh = s_wT + ((t & 1) * 2 + 0) * HBS_WT_ELEMS;
+      const bf16_t* wTl = wTh + HBS_WT_ELEMS;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const u4v bPw = u4v{cpk[4 * m], cpk[4 * m + 1], cpk[4 * m + 2], cpk[4 * m + 3]}, bSw = u4v{csk[4 * m], csk[4 * m + 1], csk[4 * m + 2], csk[4 * m + 3]};
+        const u4v bPlw = u4v{cpl[4 * m], cpl[4 * m + 1], cpl[4 * m + 2], cpl[4 * m + 3]}, bSlw = u4v{csl[4 * m], csl[4 * m + 1], csl[4 * m + 2], csl[4 * m + 3]};
+        const s8v bP = *reinterpret_cast<const s8v*>(&bPw), bS = *reinterpret_cast<const s8v*>(&bSw);
+        const s8v bPl = *reinterpret_cast<const s8v*>(&bPlw), bSl = *reinterpret_cast<const s8v*>(&bSlw);
+        auto afrag = [&](const bf16_t* wT, int row, bool zero) {
+          const bf16_t* wr = wT + 16 * m + 4 * h + row * HB_WT_PITCH;
+          const u2v x0 = *reinterpret_cast<const u2v*>(wr), x1 = *reinterpret_cast<const u2v*>(wr + 8);
+          u4v a4 = u4v{x0[0], x0[1], x1[0], x1[1]};
+          if (zero) a4 = u4v{0u, 0u, 0u, 0u};
+          return *reinterpret_cast<const s8v*>(&a4);
+        };
+        const s8v ap = afrag(wTh, r & 15, r >= DEC_KP), apl = afrag(wTl, r & 15, r >= DEC_KP);   // the private head has 16 rows
+        const s8v as8 = afrag(wTh, DEC_KP + r, false), asl = afrag(wTl, DEC_KP + r, false);
+        accP = mfma32(ap, bPl, accP);   // small terms first, as mfma32_split
+        accP = mfma32(apl, bP, accP);
+        accP = mfma32(ap, bP, accP);
+        accS = mfma32(as8, bSl, accS);
+        accS = mfma32(asl, bS, accS);
+        accS = mfma32(as8, bS, accS);
+        // park the tile's two planes (64-byte rows, chunks XOR-swizzled with (row >> 1) & 7: conflict-free stores and transposed reads)
+        const int row = wave * 32 + r, sw = (row >> 1) & 7;
+        bf16_t* tph = s_tile + (((t & 1) * 2 + 0) * 2 + 0) * SMB_TILE_ELEMS + row * 32;
+        bf16_t* tpl = tph + SMB_TILE_ELEMS;
+        bf16_t* tsh = tph + 2 * SMB_TILE_ELEMS;
+        bf16_t* tsl = tph + 3 * SMB_TILE_ELEMS;
+        const int ca = 4 * ((4 * m + h) ^ sw), cb = 4 * ((4 * m + 2 + h) ^ sw);
+        *reinterpret_cast<u2v*>(tph + ca) = u2v{bPw[0], bPw[1]};   *reinterpret_cast<u2v*>(tph + cb) = u2v{bPw[2], bPw[3]};
+        *reinterpret_cast<u2v*>(tpl + ca) = u2v{bPlw[0], bPlw[1]}; *reinterpret_cast<u2v*>(tpl + cb) = u2v{bPlw[2], bPlw[3]};
+        *reinterpret_cast<u2v*>(tsh + ca) = u2v{bSw[0], bSw[1]};   *reinterpret_cast<u2v*>(tsh + cb) = u2v{bSw[2], bSw[3]};
+        *reinterpret_cast<u2v*>(tsl + ca) = u2v{bSlw[0], bSlw[1]}; *reinterpret_cast<u2v*>(tsl + cb) = u2v{bSlw[2], bSlw[3]};
+      }
+      wt_store(t + 1, 0, wsth);   // buffer (t + 1) & 1 was last read during tile t - 1, i.e. before the previous barrier
+      wt_store(t + 1, 1, wstl);
+      lds_barrier();              // the parked planes of gene tile t and the next W'^T tile are visible
+      {   // this wave's two weight-gradient blocks: D[16 genes][16 columns] = sum over 128 cells, three v_mfma_f32_16x16x32_bf16 per 32 cells
+        const int kq = 8 * (lane >> 4) + ((lane & 15) >> 2), p4 = lane & 3;
+        const int b0 = role0 % 3, g0h = role0 / 3, b1 = role1 % 3, g1h = role1 / 3;
+        const bf16_t* img0 = s_tile + (((t & 1) * 2 + (b0 ? 1 : 0)) * 2) * SMB_TILE_ELEMS;   // hi plane; lo plane SMB_TILE_ELEMS further
+        const bf16_t* img1 = s_tile + (((t & 1) * 2 + (b1 ? 1 : 0)) * 2) * SMB_TILE_ELEMS;
+        const bf16_t* z0 = s_zh + ((b0 ? 1 : 0) * 2) * DEC_CELLS_PER_WG * 32 + (b0 ? 16 * (b0 - 1) : 0) + 4 * p4;   // hi plane of the block's head, its 16 columns
+        const bf16_t* z1 = s_zh + ((b1 ? 1 : 0) * 2) * DEC_CELLS_PER_WG * 32 + (b1 ? 16 * (b1 - 1) : 0) + 4 * p4;
+        constexpr int ZL = DEC_CELLS_PER_WG * 32;   // lo plane of a latent image
+        f4acc d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+        auto tr2 = [&](const bf16_t* a, const bf16_t* b) {
+          const s4v x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)a), y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v*)b);
+          return s8v{x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+        };
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int row0 = 32 * ks + kq, row1 = row0 + 4, s0 = (row0 >> 1) & 7, s1 = (row1 >> 1) & 7;
+          const int o00 = row0 * 32 + 4 * ((4 * g0h + p4) ^ s0), o01 = row1 * 32 + 4 * ((4 * g0h + p4) ^ s1);
+          const int o10 = row0 * 32 + 4 * ((4 * g1h + p4) ^ s0), o11 = row1 * 32 + 4 * ((4 * g1h + p4) ^ s1);
+          const s8v a0h = tr2(img0 + o00, img0 + o01), a0l = tr2(img0 + SMB_TILE_ELEMS + o00, img0 + SMB_TILE_ELEMS + o01);
+          const s8v a1h = tr2(img1 + o10, img1 + o11), a1l = tr2(img1 + SMB_TILE_ELEMS + o10, img1 + SMB_TILE_ELEMS + o11);
+          const s8v b0h = tr2(z0 + row0 * 32, z0 + row1 * 32), b0l = tr2(z0 + ZL + row0 * 32, z0 + ZL + row1 * 32);
+          const s8v b1h = tr2(z1 + row0 * 32, z1 + row1 * 32), b1l = tr2(z1 + ZL + row0 * 32, z1 + ZL + row1 * 32);
+          d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0h, b0l, d0, 0, 0, 0);
+          d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0l, b0h, d0, 0, 0, 0);
+          d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0h, b0h, d0, 0, 0, 0);
+          d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1h, b1l, d1, 0, 0, 0);
+          d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1l, b1h, d1, 0, 0, 0);
+          d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1h, b1h, d1, 0, 0, 0);
+        }
+        float* o0 = wslab + (long)(g0 + 16 * g0h + 4 * (lane >> 4)) * DEC_KPS + 16 * b0 + (lane & 15);
+        float* o1 = wslab + (long)(g0 + 16 * g1h + 4 * (lane >> 4)) * DEC_KPS + 16 * b1 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o0[j * DEC_KPS] = d0[j]; o1[j * DEC_KPS] = d1[j]; }
+      }
+      wA = wB;
+    };
+    for (int t = 0; t < ntile; t += 2) {   // (block-uniform trip structure: every wave reaches every barrier)
+      tile(t, rp0, rs0, rpl0, rsl0);
+      if (t + 1 < ntile) tile(t + 1, rp1, rs1, rpl1, rsl1);
+    }
+  }
+  float* out = dz_part + ((long)split * p.Bp + cell) * DEC_KPS;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int k = crow(q, h);
+    if (k < DEC_KP) out[k] = accP[q];
+    out[DEC_KP + k] = accS[q];
+  }
+}
+
 }  // namespace spv

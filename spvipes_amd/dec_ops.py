@@ -79,6 +79,10 @@ class _DecoderBwd:
         # bf16 mode: the regressor weight gradients come out of the softmax-fix pass itself (spv_dec_heads_bwd), one partial slab per
         # 128-cell workgroup row
         self.fused_heads = bool(_ops.FUSED_HEADS and not _ops.DZ_ONLY and self.fused_dz and self.heads_dma and Bp % DEC_CELLS_PER_WG == 0)
+        # "fp32" mode (split-bf16 gradient words, round 4): the same one-pass kernel on the hi / lo planes -- no in-place fix of the four
+        # planes and no register-staged weight-gradient GEMMs re-reading them
+        if _ops.FUSED_HEADS_F32 and grads_f32 and nsplit == 3 and not _ops.DZ_ONLY and self.fused_dz and Bp % DEC_CELLS_PER_WG == 0:
+            self.fused_heads = True
         if self.fused_heads:
             self.csp_n = Bp // DEC_CELLS_PER_WG
             self.dw_part = wsg.get("dec_dW48", (self.csp_n, Gp, DEC_KPS), torch.float32)   # [d W'_p | d W'_s] rows over the padded genes

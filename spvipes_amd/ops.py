@@ -175,6 +175,7 @@ FUSED_HEADS = os.environ.get("SPV_FUSED_HEADS", "1") != "0"
 # per-split partials (statistics, latent gradient) to write and re-read.  Same-box A/B 1024 / 768 / 512 / 384 / 256 at C2: 1.440 / 1.438 / 1.412 / 1.417 / 1.426 ms;
 # C3 2.39 -> 2.36, C4 3.90 -> 3.88, C5 8.29 -> 8.18, C1 unchanged
 GSPLIT_WANT = int(os.environ.get("SPV_GSPLIT_WANT", "512"))
+FUSED_HEADS_F32 = os.environ.get("SPV_FUSED_HEADS_F32", "1") != "0"   # ... and in "fp32" mode on the hi / lo planes of the split gradient words (spv_dec_heads_bwd, grads_f32)
 FUSED_DZ = os.environ.get("SPV_FUSED_DZ", "1") != "0"  # softmax fix also produces the latent gradient of the rate heads
 FUSED_DZ_F32 = os.environ.get("SPV_FUSED_DZ_F32", "1") != "0"   # "fp32" mode: the latent gradient of the rate heads comes out of the softmax-fix pass too (split-bf16 contraction)
 FUSED_PACK = os.environ.get("SPV_FUSED_PACK", "1") != "0"  # latent / trunk kernels also write the decoder's bf16 operand images
