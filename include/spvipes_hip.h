@@ -334,6 +334,9 @@ typedef struct spv_linear_prob {
   const float* W2; int32_t n_w2;   /* dgrad only, optional: rows n >= n_w2 of the [N][K] weight are W2[n - n_w2] (two layers that read the
                                       same input -- the mu / logvar heads, nn/networks.py:123-124 -- back-propagate into it in ONE launch:
                                       dY = their gradients side by side [B][N], N = the two widths together); W2 == NULL: one matrix */
+  /* forward only, optional: Y also as bf16 hi (and lo: split-bf16) words into columns 0..N-1 of a packed operand image [img_rows][ld_img]
+   * (the decoder's mixing-logits operand); rows B..img_rows-1 of those columns are zero filled.  img_hi == NULL: no image */
+  uint16_t* img_hi; uint16_t* img_lo; int64_t ld_img; int32_t img_rows;
 } spv_linear_prob;
 typedef struct spv_linear_batch {
   spv_linear_prob p[SPV_MAXP];
@@ -536,6 +539,31 @@ typedef struct spv_fold_prob {
 typedef struct spv_fold_batch { spv_fold_prob p[SPV_MAXP]; int32_t nprob, B, training; float eps, momentum; } spv_fold_batch;
 int spv_bn_fold_fwd(const spv_fold_batch* a, void* stream);
 int spv_bn_fold_bwd(const spv_fold_batch* a, void* stream);   /* fold backward + the z-statistics backward */
+
+/* The decoder's mixing trunk m = relu(BN_256(cat(z) W_a^T + b_a)) (nn/networks.py:322-323; scvi FCLayers: BatchNorm1d eps 1e-3, momentum
+ * 0.01) with its training-mode BatchNorm folded the same way: batch mean and variance of a LINEAR map of z follow from zbar and cov(z)
+ * (mean_j = w_j . zbar + b_j, var_j = w_j^T C w_j), so the layer is one affine map W'_j = (gamma_j / sqrt(var_j + eps)) w_j,
+ * c'_j = beta_j - W'_j . zbar (the Linear's own bias cancels in the batch mean: its gradient is exactly zero, as in the reference) followed
+ * by the rectifier: spv_trunk_fold_fwd writes (W', c') for spv_linear_fwd(relu); three launches (statistics, finalise, normalise) and the
+ * pre-activation round trip are gone from the forward pass, three (partial sums, finalise, apply) from the backward pass.
+ * Backward: from d W' [N][K] and d c' [N] (spv_linear_wgrad of the folded layer, masked by the rectifier) spv_trunk_fold_bwd forms d W_a,
+ * d gamma, d beta (d b_a = 0) and (d zbar | d C) [K + K*K], then adds d z[b] += d zbar / B + (d C + d C^T)(z[b] - zbar) / B into dz.
+ * Eval mode (training == 0): running statistics instead of batch statistics, no z-statistics term.  N <= 256, K <= 48. */
+#define SPV_TRUNK_KMAX 48
+typedef struct spv_trunk_prob {
+  const float* W; const float* bias; const float* gamma; const float* beta;   /* Linear [N][K], [N]; BatchNorm affine [N], [N]          */
+  float* running_mean; float* running_var;                                    /* [N] (updated by the forward call in training mode)    */
+  const float* zsum; const float* zz;                                         /* [K] column sums of z, [K][K] z^T z over the batch     */
+  float* Wf; float* cf; float* stat;                                          /* forward out: W' [N][K], c' [N], (mean, var) [N][2]    */
+  const float* dWf; const float* dcf;                                         /* backward in: d W' [N][K], d c' [N]                    */
+  float* dW; float* dbias; float* dgamma; float* dbeta;                       /* backward out: [N][K], [N] (zeros), [N], [N]           */
+  float* dred;                                                                /* backward scratch: [ceil(N / 64)][K + K*K] partials of (d zbar | d C) */
+  const float* z; int64_t ldz; float* dz; int64_t lddz;                       /* z [B][K] (read), d z [B][K] (accumulated into)        */
+  int32_t N, K;
+} spv_trunk_prob;
+typedef struct spv_trunk_batch { spv_trunk_prob p[2]; int32_t nprob, B, training; float eps, momentum; } spv_trunk_batch;
+int spv_trunk_fold_fwd(const spv_trunk_batch* a, void* stream);
+int spv_trunk_fold_bwd(const spv_trunk_batch* a, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Deterministic slab reduction (the tail of every split-K GEMM and of the per-wave partials):

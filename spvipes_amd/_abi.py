@@ -60,7 +60,8 @@ BN_ROWS = 32  # rows per workgroup of the BatchNorm kernels (sizes their partial
 class SpvLinearProb(C.Structure):
     _fields_ = [("X", C.c_void_p), ("ldx", C.c_int64), ("W", C.c_void_p), ("bias", C.c_void_p), ("Y", C.c_void_p), ("ldy", C.c_int64),
                 ("dY", C.c_void_p), ("lddy", C.c_int64), ("dX", C.c_void_p), ("lddx", C.c_int64), ("dW", C.c_void_p), ("db", C.c_void_p),
-                ("N", C.c_int32), ("K", C.c_int32), ("keep", C.c_void_p), ("W2", C.c_void_p), ("n_w2", C.c_int32)]
+                ("N", C.c_int32), ("K", C.c_int32), ("keep", C.c_void_p), ("W2", C.c_void_p), ("n_w2", C.c_int32),
+                ("img_hi", C.c_void_p), ("img_lo", C.c_void_p), ("ld_img", C.c_int64), ("img_rows", C.c_int32)]
 
 
 class SpvLinearBatch(C.Structure):
@@ -177,6 +178,20 @@ class SpvFoldBatch(C.Structure):
                 ("momentum", C.c_float)]
 
 
+TRUNK_KMAX = 48
+
+
+class SpvTrunkProb(C.Structure):
+    _fields_ = [("W", C.c_void_p), ("bias", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p),
+                ("running_var", C.c_void_p), ("zsum", C.c_void_p), ("zz", C.c_void_p), ("Wf", C.c_void_p), ("cf", C.c_void_p), ("stat", C.c_void_p),
+                ("dWf", C.c_void_p), ("dcf", C.c_void_p), ("dW", C.c_void_p), ("dbias", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
+                ("dred", C.c_void_p), ("z", C.c_void_p), ("ldz", C.c_int64), ("dz", C.c_void_p), ("lddz", C.c_int64), ("N", C.c_int32), ("K", C.c_int32)]
+
+
+class SpvTrunkBatch(C.Structure):
+    _fields_ = [("p", SpvTrunkProb * 2), ("nprob", C.c_int32), ("B", C.c_int32), ("training", C.c_int32), ("eps", C.c_float), ("momentum", C.c_float)]
+
+
 _SIGNATURES = {
     "spv_version": (C.c_int, []),
     "spv_last_error": (C.c_char_p, []),
@@ -236,6 +251,8 @@ _SIGNATURES = {
     "spv_zsplit_bwd": (C.c_int, [C.POINTER(SpvZsplitArgs), C.c_void_p]),
     "spv_bn_fold_fwd": (C.c_int, [C.POINTER(SpvFoldBatch), C.c_void_p]),
     "spv_bn_fold_bwd": (C.c_int, [C.POINTER(SpvFoldBatch), C.c_void_p]),
+    "spv_trunk_fold_fwd": (C.c_int, [C.POINTER(SpvTrunkBatch), C.c_void_p]),
+    "spv_trunk_fold_bwd": (C.c_int, [C.POINTER(SpvTrunkBatch), C.c_void_p]),
     "spv_reduce_slabs": (C.c_int, [C.POINTER(SpvReduceBatch), C.c_void_p]),
     "spv_loss_assemble": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]),

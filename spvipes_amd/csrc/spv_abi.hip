@@ -851,7 +851,13 @@ extern "C" int spv_linear_fwd(const spv_linear_batch* a, void* stream) {
   if (rc) return rc;
   for (int i = 0; i < a->nprob; ++i) if (!a->p[i].X || !a->p[i].Y) return fail(SPV_ERR_ARG, "spv_linear_fwd: null pointer%s");
   int nmax, kmax; linear_extents(a, nmax, kmax);
-  hipLaunchKernelGGL(linear_fwd_kernel, dim3((a->B + 63) / 64, (nmax + 63) / 64, a->nprob), dim3(256), 0, (hipStream_t)stream, *a);
+  int rows = a->B;
+  for (int i = 0; i < a->nprob; ++i) {
+    const spv_linear_prob& q = a->p[i];
+    if (q.img_hi && (q.ld_img < q.N || q.img_rows < 0)) return fail(SPV_ERR_ARG, "spv_linear_fwd: bad operand image%s");
+    if (q.img_hi && q.img_rows > rows) rows = q.img_rows;   // the image's padding rows are zero filled by the same launch
+  }
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3((rows + 63) / 64, (nmax + 63) / 64, a->nprob), dim3(256), 0, (hipStream_t)stream, *a);
   return launch_status("spv_linear_fwd");
 }
 extern "C" int spv_linear_dgrad(const spv_linear_batch* a, void* stream) {
@@ -1191,6 +1197,44 @@ extern "C" int spv_bn_fold_bwd(const spv_fold_batch* a, void* stream) {
     hipLaunchKernelGGL(zstats_bwd_kernel, dim3((a->B + 63) / 64, a->nprob), dim3(256), 0, s, *a);
   }
   return launch_status("spv_bn_fold_bwd");
+}
+
+static int check_trunk(const spv_trunk_batch* a, const char* who) {
+  if (!a || a->nprob <= 0 || a->nprob > 2 || a->B <= 0) return fail(SPV_ERR_ARG, "%s: bad batch", who);
+  for (int i = 0; i < a->nprob; ++i) {
+    const spv_trunk_prob& q = a->p[i];
+    if (q.N <= 0 || q.N > 256 || q.K <= 0 || q.K > SPV_TRUNK_KMAX) return fail(SPV_ERR_UNSUPPORTED, "%s: N <= 256 and K <= 48", who);
+    if (!q.W || !q.gamma || !q.beta || !q.running_mean || !q.running_var || !q.stat) return fail(SPV_ERR_ARG, "%s: null pointer", who);
+    if (a->training && (!q.zsum || !q.zz)) return fail(SPV_ERR_ARG, "%s: training mode needs the z statistics", who);
+  }
+  return SPV_OK;
+}
+extern "C" int spv_trunk_fold_fwd(const spv_trunk_batch* a, void* stream) {
+  int rc = check_trunk(a, "spv_trunk_fold_fwd");
+  if (rc) return rc;
+  int nmax = 0;
+  for (int i = 0; i < a->nprob; ++i) {
+    if (!a->p[i].Wf || !a->p[i].cf) return fail(SPV_ERR_ARG, "spv_trunk_fold_fwd: null output%s");
+    nmax = a->p[i].N > nmax ? a->p[i].N : nmax;
+  }
+  hipLaunchKernelGGL(trunk_fold_fwd_kernel, dim3((nmax + TRUNK_FWD_ROWS - 1) / TRUNK_FWD_ROWS, a->nprob), dim3(1024), 0, (hipStream_t)stream, *a);
+  return launch_status("spv_trunk_fold_fwd");
+}
+extern "C" int spv_trunk_fold_bwd(const spv_trunk_batch* a, void* stream) {
+  int rc = check_trunk(a, "spv_trunk_fold_bwd");
+  if (rc) return rc;
+  for (int i = 0; i < a->nprob; ++i) {
+    const spv_trunk_prob& q = a->p[i];
+    if (!q.dWf || !q.dcf || !q.dW || !q.dgamma || !q.dbeta) return fail(SPV_ERR_ARG, "spv_trunk_fold_bwd: null pointer%s");
+    if (a->training && (!q.dred || !q.z || !q.dz || q.ldz < q.K || q.lddz < q.K)) return fail(SPV_ERR_ARG, "spv_trunk_fold_bwd: z-statistics buffers missing%s");
+  }
+  hipStream_t s = (hipStream_t)stream;
+  int nmax = 0;
+  for (int i = 0; i < a->nprob; ++i) nmax = a->p[i].N > nmax ? a->p[i].N : nmax;
+  const int nblk = (nmax + TRUNK_BWD_ROWS - 1) / TRUNK_BWD_ROWS;
+  hipLaunchKernelGGL(trunk_fold_bwd_kernel, dim3(nblk, a->nprob), dim3(1024), 0, s, *a);
+  if (a->training) hipLaunchKernelGGL(trunk_zstats_kernel, dim3((a->B + 63) / 64, a->nprob), dim3(256), 0, s, *a, nblk);
+  return launch_status("spv_trunk_fold_bwd");
 }
 
 extern "C" int spv_reduce_slabs(const spv_reduce_batch* b, void* stream) {

@@ -170,6 +170,12 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
   return v;
 }
+// sum over all 64 lanes, result in every lane
+__device__ __forceinline__ float wave_sum_all(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
 // sum over the 32 lanes of each wave half (result valid in every lane of the half)
 __device__ __forceinline__ float half_sum(float v) {
 #pragma unroll

@@ -73,7 +73,8 @@ __device__ __forceinline__ void linear_fwd_body(const LinearBatch& a) {
   const LinearProb& q = a.p[blockIdx.z];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
   const int b0 = blockIdx.x * 64 + 32 * (wave >> 1), n0 = blockIdx.y * 64 + 32 * (wave & 1);
-  if (n0 >= q.N || b0 >= a.B) return;  // wave-uniform
+  const int rows_out = (q.img_hi != nullptr && q.img_rows > a.B) ? q.img_rows : a.B;   // image rows beyond the batch are zero filled
+  if (n0 >= q.N || b0 >= rows_out) return;  // wave-uniform
   const int row = b0 + r, col = n0 + r;
   const float* xr = q.X + (long)min(row, a.B - 1) * q.ldx;   // rows / columns beyond the problem only feed outputs never stored
   const float* wr = q.W + (long)min(col, q.N - 1) * q.K;
@@ -98,7 +99,12 @@ __device__ __forceinline__ void linear_fwd_body(const LinearBatch& a) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int b = b0 + crow(i, h);
-    if (b >= a.B) continue;
+    if (b >= rows_out) continue;
+    if (b >= a.B) {   // (only with an image: its padding rows)
+      q.img_hi[(long)b * q.ld_img + col] = 0;
+      if (q.img_lo != nullptr) q.img_lo[(long)b * q.ld_img + col] = 0;
+      continue;
+    }
     float v = acc[i] + bias;
     if (a.relu) v = fmaxf(v, 0.f);
     if (a.drop_p > 0.f) {
@@ -107,6 +113,12 @@ __device__ __forceinline__ void linear_fwd_body(const LinearBatch& a) {
       v = keep ? v * (1.0f / (1.0f - a.drop_p)) : 0.f;
     }
     q.Y[(long)b * q.ldy + col] = v;
+    if (q.img_hi != nullptr) {   // the same value as split-bf16 words into a packed operand image (spv_linear_prob.img_hi)
+      bf16_t hi, lo;
+      split_bf16(v, hi, lo);
+      q.img_hi[(long)b * q.ld_img + col] = hi;
+      if (q.img_lo != nullptr) q.img_lo[(long)b * q.ld_img + col] = lo;
+    }
   }
 }
 __global__ __launch_bounds__(256) void linear_fwd_kernel(LinearBatch a) {
@@ -1317,7 +1329,7 @@ __global__ __launch_bounds__(256) void fold_red_finalize_kernel(FoldBatch a) {
 // (the latent-slicing backward, zsplit_bwd_kernel) instead of back into q.dz.
 __global__ __launch_bounds__(256) void zstats_bwd_kernel(FoldBatch a) {
   const FoldProb& q = a.p[blockIdx.y];
-  __shared__ float s_zbar[FOLD_KMAX], s_dz[FOLD_KMAX], s_S[FOLD_KMAX * FOLD_KMAX], s_red[FOLD_KMAX + FOLD_KMAX * FOLD_KMAX];
+  __shared__ float s_zbar[FOLD_KMAX], s_dz[FOLD_KMAX], s_S[FOLD_KMAX * FOLD_KMAX], s_red[FOLD_KMAX + FOLD_KMAX * FOLD_KMAX], s_z[64 * (FOLD_KMAX + 1)];
   const int K = q.K, nred = K + K * K;
   const int nblk = (q.G + 255) / 256;
   const float invB = 1.0f / (float)a.B;
@@ -1335,23 +1347,229 @@ __global__ __launch_bounds__(256) void zstats_bwd_kernel(FoldBatch a) {
   __syncthreads();
   for (int i = threadIdx.x; i < K; i += 256) s_dz[i] = s_red[i] * invB;
   for (int i = threadIdx.x; i < K * K; i += 256) s_S[i] = (s_red[K + i] + s_red[K + (i % K) * K + i / K]) * invB;
+  // Workgroup = 64 cells: their z rows are staged (centred) in LDS; thread (kg = tid / 64, cell = tid % 64) forms the outputs k = kg, kg + 4, ...
+  // -- the 64 lanes of a wave share their k set, so every S[k][l] read is a broadcast and the eight sums are independent chains -- and the
+  // finished values go back through LDS for coalesced accesses to d z and the outputs.  (Round 4; before: four threads per cell, each a
+  // K x K chain of LDS reads against L1 reads of z: 19 us at C2 on the critical chain of the backward pass.  Same summation order per output.)
+  const int b0 = blockIdx.x * 64;
+  for (int i = threadIdx.x; i < 64 * K; i += 256) {
+    const int c = i / K, l = i - c * K, b = min(b0 + c, a.B - 1);
+    s_z[c * (FOLD_KMAX + 1) + l] = q.z[(long)b * q.ldz + l] - s_zbar[l];
+  }
   __syncthreads();
-  // 4 threads per cell, each a quarter of the K outputs
-  const int b = blockIdx.x * 64 + (threadIdx.x >> 2), part = threadIdx.x & 3;
-  if (b >= a.B) return;
-  const float* zrow = q.z + (long)b * q.ldz;
-  for (int k = part; k < K; k += 4) {
-    float v = s_dz[k];
-    for (int l = 0; l < K; ++l) v += s_S[k * K + l] * (zrow[l] - s_zbar[l]);
-    const float out = q.dz[(long)b * q.lddz + k] + v;
+  const int c = threadIdx.x & 63, kg = threadIdx.x >> 6;
+  constexpr int KK = FOLD_KMAX / 4;
+  float acc[KK];
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) acc[kk] = s_dz[min(kg + 4 * kk, K - 1)];
+  for (int l = 0; l < K; ++l) {
+    const float zl = s_z[c * (FOLD_KMAX + 1) + l];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) acc[kk] += s_S[min(kg + 4 * kk, K - 1) * K + l] * zl;
+  }
+  __syncthreads();   // every thread has read its z row: the tile is reused for the results
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) {
+    const int k = kg + 4 * kk;
+    if (k < K) s_z[c * (FOLD_KMAX + 1) + k] = acc[kk];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * K; i += 256) {
+    const int cc = i / K, k = i - cc * K, b = b0 + cc;
+    if (b >= a.B) continue;
+    const float out = q.dz[(long)b * q.lddz + k] + s_z[cc * (FOLD_KMAX + 1) + k];
     if (q.out_priv != nullptr) {
-      const int c = q.zcol + k;                                   // column of zcat = [z_private | z_shared]
-      const int zc = (c >= q.n_p) ? c - q.n_p : c + q.n_s;        // the column of Z = cat(private_log_z, poe_log_z) it came from
+      const int col = q.zcol + k;                                     // column of zcat = [z_private | z_shared]
+      const int zc = (col >= q.n_p) ? col - q.n_p : col + q.n_s;      // the column of Z = cat(private_log_z, poe_log_z) it came from
       if (zc < q.n_p) q.out_priv[(long)b * q.n_p + zc] = out;
       else q.out_poe[(long)b * q.n_s + zc - q.n_p] = out;
     } else {
       q.dz[(long)b * q.lddz + k] = out;
     }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Decoder mixing trunk m = relu(BN(cat(z) W_a^T + b_a)) with the training-mode BatchNorm folded (spv_trunk_prob in the header;
+// nn/networks.py:322-323).  mean0_j = w_j . zbar (the Linear's bias cancels in the batch mean), var_j = w_j^T C w_j,
+// inv_j = gamma_j / sqrt(var_j + eps):  W'_j = inv_j w_j,  c'_j = beta_j - inv_j mean0_j.   stat = (mean0, var).
+// Eval mode: mean0_j = running_mean_j - b_j, var_j = running_var_j.
+// ---------------------------------------------------------------------------------------------
+typedef spv_trunk_prob TrunkProb;
+typedef spv_trunk_batch TrunkBatch;
+constexpr int TRUNK_KMAX = SPV_TRUNK_KMAX;
+
+__device__ __forceinline__ void trunk_stats_to_lds(const TrunkProb& q, int B, float* s_zbar, float* s_C, int nthreads) {
+  const int K = q.K;
+  const float invB = 1.0f / (float)B;
+  for (int i = threadIdx.x; i < K; i += nthreads) s_zbar[i] = q.zsum[i] * invB;
+  for (int i = threadIdx.x; i < K * K; i += nthreads) s_C[i] = q.zz[i] * invB - (q.zsum[i / K] * invB) * (q.zsum[i % K] * invB);
+}
+
+// One WAVE per row of the layer (lane l = column l of the row, K <= 48 < 64), 16 rows per workgroup: (C w)_l = sum_k w_k C[k][l] is a K-step
+// loop with w_k broadcast from lane k and C[k][.] read coalesced from LDS -- the first version gave a row to 4 lanes, each walking its share
+// of the K x K products as one dependent chain (14 us for 2 x 256 rows on 8 CUs).
+constexpr int TRUNK_FWD_ROWS = 16;
+// (C w)_l for the row whose weights sit in LDS at wrow[0..K): w_k is a broadcast read, C[k][.] a coalesced one; independent of lane l's own
+// chain only through the accumulate (a __shfl of w_k from lane k costs a ds_bpermute per step: 35 of them in a row made this loop the
+// kernels' longest stretch)
+__device__ __forceinline__ float trunk_Cw(const float* s_C, const float* wrow, int K, int l) {
+  float t = 0.f;
+  const int lc = min(l, K - 1);
+#pragma unroll 4
+  for (int k = 0; k < K; ++k) t += wrow[k] * s_C[k * K + lc];
+  return (l < K) ? t : 0.f;
+}
+__global__ __launch_bounds__(1024) void trunk_fold_fwd_kernel(TrunkBatch a) {
+  const TrunkProb& q = a.p[blockIdx.y];
+  __shared__ float s_zbar[TRUNK_KMAX], s_C[TRUNK_KMAX * TRUNK_KMAX], s_wr[TRUNK_FWD_ROWS][64];
+  const int K = q.K;
+  if (blockIdx.x * TRUNK_FWD_ROWS >= q.N) return;   // (the grid is sized for the largest problem)
+  const int l = threadIdx.x & 63, wv = threadIdx.x >> 6, j = blockIdx.x * TRUNK_FWD_ROWS + wv;
+  const int ji = min(j, q.N - 1);
+  const float wl = (l < K) ? q.W[(long)ji * K + l] : 0.f;   // (requested before the statistics: one round trip for both)
+  const float bj = q.bias ? q.bias[ji] : 0.f;
+  s_wr[wv][l] = wl;
+  if (a.training) trunk_stats_to_lds(q, a.B, s_zbar, s_C, 1024);
+  __syncthreads();
+  if (j >= q.N) return;   // (wave-uniform)
+  float mean0, var;
+  if (a.training) {
+    const float t = trunk_Cw(s_C, s_wr[wv], K, l);
+    mean0 = wave_sum_all(wl * ((l < K) ? s_zbar[l] : 0.f));
+    var = fmaxf(wave_sum_all(wl * t), 0.f);
+    if (l == 0) {   // torch: running statistics take the batch mean (bias included) and the UNBIASED variance
+      q.running_mean[j] = (1.f - a.momentum) * q.running_mean[j] + a.momentum * (mean0 + bj);
+      q.running_var[j] = (1.f - a.momentum) * q.running_var[j] + a.momentum * var * ((float)a.B / fmaxf((float)a.B - 1.f, 1.f));
+    }
+  } else {
+    mean0 = q.running_mean[j] - bj;
+    var = q.running_var[j];
+  }
+  const float inv = q.gamma[j] * rsqrtf(var + a.eps);
+  if (l < K) q.Wf[(long)j * K + l] = wl * inv;
+  if (l == 0) { q.cf[j] = q.beta[j] - inv * mean0; q.stat[2 * j] = mean0; q.stat[2 * j + 1] = var; }
+}
+
+// backward of the fold: 64 rows per workgroup (one wave per row, four passes of 16), then the block's partial of
+// (d zbar | d C) = (sum_j dmean0_j w_j | sum_j dvar_j w_j w_j^T) on the exact-fp32 matrix pipe: wave t < 4 owns the 32 x 32 tile (t >> 1, t & 1)
+// of d C (K <= 48: 2 x 2 tiles) and, in the first tile row, d zbar as row 0 of a second accumulator.  One partial [K + K*K] per workgroup in
+// q.dred (summed in block order by trunk_zstats_kernel): a fixed summation order, no atomics.
+constexpr int TRUNK_BWD_ROWS = 64;
+__global__ __launch_bounds__(1024) void trunk_fold_bwd_kernel(TrunkBatch a) {
+  const TrunkProb& q = a.p[blockIdx.y];
+  __shared__ float s_zbar[TRUNK_KMAX], s_C[TRUNK_KMAX * TRUNK_KMAX], s_w[TRUNK_BWD_ROWS * TRUNK_KMAX], s_dm[TRUNK_BWD_ROWS], s_dv[TRUNK_BWD_ROWS];
+  const int K = q.K;
+  const int j0 = blockIdx.x * TRUNK_BWD_ROWS;
+  if (j0 >= q.N) return;
+  if (a.training) trunk_stats_to_lds(q, a.B, s_zbar, s_C, 1024);
+  __syncthreads();
+  const int l = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int pass = 0; pass < TRUNK_BWD_ROWS / 16; ++pass) {
+    const int jl = 16 * pass + wv, j = j0 + jl;
+    const bool real = j < q.N;   // (wave-uniform)
+    const int ji = min(j, q.N - 1);
+    const float wl = (real && l < K) ? q.W[(long)ji * K + l] : 0.f;
+    const float gWl = (real && l < K) ? q.dWf[(long)ji * K + l] : 0.f;
+    const float mean0 = q.stat[2 * ji], var = q.stat[2 * ji + 1];
+    const float rs = rsqrtf(var + a.eps), gam = q.gamma[ji], inv = gam * rs;
+    const float gc = real ? q.dcf[ji] : 0.f;
+    const float dinv = wave_sum_all(gWl * wl) - gc * mean0;
+    float dmean = 0.f, dvar = 0.f;
+    if (real && l == 0) {
+      q.dbeta[j] = gc;
+      q.dgamma[j] = dinv * rs;
+      if (q.dbias) q.dbias[j] = a.training ? 0.f : gc * inv;   // training: the bias cancels in the batch mean
+    }
+    if (a.training) {
+      if (l < TRUNK_KMAX) s_w[jl * TRUNK_KMAX + l] = wl;   // (zero beyond K and for rows past N; row jl belongs to this wave alone)
+      const float v = trunk_Cw(s_C, s_w + jl * TRUNK_KMAX, K, l);
+      if (real) { dmean = -gc * inv; dvar = dinv * gam * (-0.5f) * rs * rs * rs; }
+      if (real && l < K) q.dW[(long)j * K + l] = gWl * inv + dmean * s_zbar[l] + 2.0f * dvar * v;
+      if (l == 0) { s_dm[jl] = dmean; s_dv[jl] = dvar; }
+    } else if (real && l < K) {
+      q.dW[(long)j * K + l] = gWl * inv;
+    }
+  }
+  if (!a.training) return;
+  __syncthreads();
+  const int lane = l, h = lane >> 5, r = lane & 31;
+  if (wv >= 4) return;
+  const int tr = wv >> 1, tc = wv & 1;
+  if (32 * tr >= K || 32 * tc >= K) return;   // (wave-uniform: a tile outside the K x K block)
+  f16v accC, accM;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { accC[i] = 0.f; accM[i] = 0.f; }
+  const int ca = 32 * tr + r, cb = 32 * tc + r;
+  for (int t = 0; t < TRUNK_BWD_ROWS; t += 2) {
+    const float wa = (ca < TRUNK_KMAX) ? s_w[(t + h) * TRUNK_KMAX + min(ca, TRUNK_KMAX - 1)] : 0.f;
+    const float wb = (cb < TRUNK_KMAX) ? s_w[(t + h) * TRUNK_KMAX + min(cb, TRUNK_KMAX - 1)] : 0.f;
+    accC = mfma_f32(s_dv[t + h] * wa, wb, accC);
+    if (tr == 0) accM = mfma_f32((r == 0) ? s_dm[t + h] : 0.f, wb, accM);
+  }
+  float* out = q.dred + (long)blockIdx.x * (K + K * K);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = 32 * tr + crow(i, h), col = cb;
+    if (row < K && col < K) out[K + row * K + col] = accC[i];
+  }
+  if (tr == 0 && h == 0 && cb < K) out[cb] = accM[0];   // register 0 of lane half 0 = row 0 of the tile
+}
+
+// d z[b][k] += d zbar[k] / B + (1 / B) sum_l (d C + d C^T)[k][l] (z[b][l] - zbar[l]),  (d zbar | d C) = the sum of trunk_fold_bwd_kernel's block
+// partials in block order.  Workgroup = 64 cells: their z rows are staged (centred) in LDS, thread (kg = tid / 64, cell = tid % 64) forms the
+// outputs k = kg, kg + 4, ... -- the 64 lanes of a wave share their k set, so every S[k][l] read is a broadcast and the twelve sums are
+// independent chains; the results go back through LDS for coalesced read-modify-writes of d z.
+constexpr int TRUNK_ZS_KK = (TRUNK_KMAX + 3) / 4;
+__global__ __launch_bounds__(256) void trunk_zstats_kernel(TrunkBatch a, int nblk) {
+  const TrunkProb& q = a.p[blockIdx.y];
+  __shared__ float s_zbar[TRUNK_KMAX], s_dz[TRUNK_KMAX], s_S[TRUNK_KMAX * TRUNK_KMAX], s_z[64 * (TRUNK_KMAX + 1)];
+  const int K = q.K, nred = K + K * K;
+  const float invB = 1.0f / (float)a.B;
+  const int nb = (q.N + TRUNK_BWD_ROWS - 1) / TRUNK_BWD_ROWS;   // (<= 4: N <= 256)
+  // the block partials are requested all at once (clamped index + select: a loop over a run-time count is one dependent round trip per partial)
+  auto part4 = [&](int i) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = q.dred[(long)min(u, nb - 1) * nred + i];
+    float d = v[0];
+#pragma unroll
+    for (int u = 1; u < 4; ++u) d += (u < nb) ? v[u] : 0.f;
+    return d;
+  };
+  for (int i = threadIdx.x; i < K; i += 256) { s_zbar[i] = q.zsum[i] * invB; s_dz[i] = part4(i) * invB; }
+  for (int i = threadIdx.x; i < K * K; i += 256) {
+    const int k = i / K, l = i - k * K;
+    s_S[i] = (part4(K + i) + part4(K + l * K + k)) * invB;
+  }
+  const int b0 = blockIdx.x * 64;
+  __syncthreads();   // (s_zbar is read by the staging below)
+  for (int i = threadIdx.x; i < 64 * K; i += 256) {
+    const int c = i / K, l = i % K, b = min(b0 + c, a.B - 1);
+    s_z[c * (TRUNK_KMAX + 1) + l] = q.z[(long)b * q.ldz + l] - s_zbar[l];
+  }
+  __syncthreads();
+  const int c = threadIdx.x & 63, kg = threadIdx.x >> 6;
+  float acc[TRUNK_ZS_KK];
+#pragma unroll
+  for (int kk = 0; kk < TRUNK_ZS_KK; ++kk) acc[kk] = s_dz[min(kg + 4 * kk, K - 1)];
+  for (int l = 0; l < K; ++l) {
+    const float zl = s_z[c * (TRUNK_KMAX + 1) + l];
+#pragma unroll
+    for (int kk = 0; kk < TRUNK_ZS_KK; ++kk) acc[kk] += s_S[min(kg + 4 * kk, K - 1) * K + l] * zl;
+  }
+  __syncthreads();   // every thread has read its z row: the tile is reused for the outputs
+#pragma unroll
+  for (int kk = 0; kk < TRUNK_ZS_KK; ++kk) {
+    const int k = kg + 4 * kk;
+    if (k < K) s_z[c * (TRUNK_KMAX + 1) + k] = acc[kk];
+  }
+  __syncthreads();
+  (void)nblk;
+  for (int i = threadIdx.x; i < 64 * K; i += 256) {
+    const int cc = i / K, k = i % K, b = b0 + cc;
+    if (b < a.B) q.dz[(long)b * q.lddz + k] += s_z[cc * (TRUNK_KMAX + 1) + k];
   }
 }
 

@@ -17,7 +17,7 @@ from typing import List, Sequence
 import torch
 
 from . import _abi
-from ._abi import (DEC_CELLS_PER_WG, DEC_KP, DEC_KPS, DEC_KS, NB_CMAX, SpvBnBatch, SpvDecParams, SpvFoldBatch, SpvReduceBatch, SpvZsplitArgs,
+from ._abi import (DEC_CELLS_PER_WG, DEC_KP, DEC_KPS, DEC_KS, NB_CMAX, TRUNK_KMAX, SpvBnBatch, SpvDecParams, SpvFoldBatch, SpvReduceBatch, SpvTrunkBatch, SpvZsplitArgs,
                    ptr, round_up, stream_ptr)
 from .nn_ops import _add_lin, _fptr, _lin_batch, _wgrad, grad_out
 from . import ops as _ops
@@ -219,11 +219,17 @@ class DecoderFused(torch.autograd.Function):
         # ---- 2. batch statistics of z (column sums and z^T z) for the BatchNorm fold ---------------
         zsum = [[new(n_p), new(n_s)] for _ in range(NG)]
         zz = [[new(n_p, n_p), new(n_s, n_s)] for _ in range(NG)]
+        # the mixing trunk's BatchNorm is folded too (spv_trunk_fold_fwd): it needs the statistics of ALL of zcat's columns, cross terms included
+        trunk_fold = bool(_ops.TRUNK_FOLD and nt <= TRUNK_KMAX and n_m <= 256)
+        zsum_t = [new(nt) for _ in range(NG)] if trunk_fold else None
+        zz_t = [new(nt, nt) for _ in range(NG)] if trunk_fold else None
         if training:
             b = _lin_batch(B)
             for g in range(NG):
                 for k, (off, n) in enumerate(((0, n_p), (n_p, n_s))):
                     _add_lin(b, N=n, K=n, W=ptr(zz[g][k]), X=_fptr(zcat[g], off), ldx=nt, dY=_fptr(zcat[g], off), lddy=nt, dW=ptr(zz[g][k]), db=ptr(zsum[g][k]))
+                if trunk_fold:
+                    _add_lin(b, N=nt, K=nt, W=ptr(zz_t[g]), X=ptr(zcat[g]), ldx=nt, dY=ptr(zcat[g]), lddy=nt, dW=ptr(zz_t[g]), db=ptr(zsum_t[g]))
             _wgrad(b, ws if not isinstance(ws, (list, tuple)) else ws[0])
         # ---- 3. fold the regressors' BatchNorm into the packed [Gp][48] operand image ---------------
         Wps = [_bf16_image(ws[g], "dec_Wps", Gps[g], DEC_KPS, True) for g in range(NG)]
@@ -258,25 +264,47 @@ class DecoderFused(torch.autograd.Function):
                 Wm_img.append((Wm_hi, Wm_lo))
                 tabs.append((gene_tab, cnt_tab))
         # ---- 4. mixing trunk: m = relu(BN(zcat Wa^T + ba)) -------------------------------------------
-        pre_a = [new(B, n_m) for _ in range(NG)]
         m = [new(B, n_m) for _ in range(NG)]
         tstat = [new(n_m, 2) for _ in range(NG)]
-        b = _lin_batch(B)
-        for g in range(NG):
-            _add_lin(b, N=n_m, K=nt, W=ptr(par[g][6]), bias=ptr(par[g][7]), X=ptr(zcat[g]), ldx=nt, Y=ptr(pre_a[g]), ldy=n_m)
-        _abi.call("spv_linear_fwd", C.byref(b), stream_ptr())
-        nblk = -(-B // _abi.BN_ROWS)
-        bn = SpvBnBatch()
-        bn.nprob, bn.B, bn.training, bn.relu, bn.eps, bn.momentum = NG, B, int(training), 1, 1e-3, 0.01
-        for g in range(NG):
-            tb = decoders[g].sigmoid_decoder.bn
-            q = bn.p[g]
-            q.X, q.ldx, q.Y, q.ldy, q.gamma, q.beta = ptr(pre_a[g]), n_m, ptr(m[g]), n_m, ptr(par[g][8]), ptr(par[g][9])
-            q.running_mean, q.running_var, q.stats, q.N = ptr(tb.running_mean), ptr(tb.running_var), ptr(tstat[g]), n_m
-            q.part = ptr(ws[g].get("trunk_bn_part", (nblk, n_m, 2), torch.float32))
-            if fused_pack:  # m straight into the logits operand image
-                q.img_hi, q.img_lo, q.ld_img, q.img_rows = ptr(Am_img[g][0]), ptr(Am_img[g][1]), KMP, Bp
-        _abi.call("spv_bn_fwd", C.byref(bn), stream_ptr())
+        Wf = cf = pre_a = None
+        if trunk_fold:
+            # the BatchNorm folded into the layer (batch mean / variance of a linear map of z from zbar and cov(z)): one affine map + rectifier,
+            # written by spv_linear_fwd straight into m AND into the logits operand image -- no statistics / finalise / normalise launches
+            Wf, cf = [new(n_m, nt) for _ in range(NG)], [new(n_m) for _ in range(NG)]
+            tb_ = SpvTrunkBatch()
+            tb_.nprob, tb_.B, tb_.training, tb_.eps, tb_.momentum = NG, B, int(training), 1e-3, 0.01
+            for g in range(NG):
+                bnm = decoders[g].sigmoid_decoder.bn
+                q = tb_.p[g]
+                q.W, q.bias, q.gamma, q.beta = ptr(cont(par[g][6])), ptr(par[g][7]), ptr(par[g][8]), ptr(par[g][9])
+                q.running_mean, q.running_var = ptr(bnm.running_mean), ptr(bnm.running_var)
+                q.zsum, q.zz, q.Wf, q.cf, q.stat, q.N, q.K = ptr(zsum_t[g]), ptr(zz_t[g]), ptr(Wf[g]), ptr(cf[g]), ptr(tstat[g]), n_m, nt
+            _abi.call("spv_trunk_fold_fwd", C.byref(tb_), stream_ptr())
+            b = _lin_batch(B, relu=True)
+            for g in range(NG):
+                _add_lin(b, N=n_m, K=nt, W=ptr(Wf[g]), bias=ptr(cf[g]), X=ptr(zcat[g]), ldx=nt, Y=ptr(m[g]), ldy=n_m)
+                if fused_pack:  # m straight into the logits operand image
+                    q = b.p[g]
+                    q.img_hi, q.img_lo, q.ld_img, q.img_rows = ptr(Am_img[g][0]), ptr(Am_img[g][1]), KMP, Bp
+            _abi.call("spv_linear_fwd", C.byref(b), stream_ptr())
+        else:
+            pre_a = [new(B, n_m) for _ in range(NG)]
+            b = _lin_batch(B)
+            for g in range(NG):
+                _add_lin(b, N=n_m, K=nt, W=ptr(par[g][6]), bias=ptr(par[g][7]), X=ptr(zcat[g]), ldx=nt, Y=ptr(pre_a[g]), ldy=n_m)
+            _abi.call("spv_linear_fwd", C.byref(b), stream_ptr())
+            nblk = -(-B // _abi.BN_ROWS)
+            bn = SpvBnBatch()
+            bn.nprob, bn.B, bn.training, bn.relu, bn.eps, bn.momentum = NG, B, int(training), 1, 1e-3, 0.01
+            for g in range(NG):
+                tb = decoders[g].sigmoid_decoder.bn
+                q = bn.p[g]
+                q.X, q.ldx, q.Y, q.ldy, q.gamma, q.beta = ptr(pre_a[g]), n_m, ptr(m[g]), n_m, ptr(par[g][8]), ptr(par[g][9])
+                q.running_mean, q.running_var, q.stats, q.N = ptr(tb.running_mean), ptr(tb.running_var), ptr(tstat[g]), n_m
+                q.part = ptr(ws[g].get("trunk_bn_part", (nblk, n_m, 2), torch.float32))
+                if fused_pack:  # m straight into the logits operand image
+                    q.img_hi, q.img_lo, q.ld_img, q.img_rows = ptr(Am_img[g][0]), ptr(Am_img[g][1]), KMP, Bp
+            _abi.call("spv_bn_fwd", C.byref(bn), stream_ptr())
         # ---- 5. per group: operand images, tables, logits GEMM, softmax statistics, likelihood ------
         if w_pad.numel() < Bp or w_pad.dtype != torch.float32 or not w_pad.is_contiguous():
             raise _abi.SpvError("DecoderFused: w_pad must be contiguous fp32 of length >= round_up(B, 128)")
@@ -356,6 +384,7 @@ class DecoderFused(torch.autograd.Function):
             ctx.grads_f32, ctx.done, ctx.keep = grads_f32, False, keep
             ctx.Wps, ctx.fb = Wps, fb
             ctx.small = (zcat, zsum, zz, fstat, pre_a, m, tstat)
+            ctx.trunk = (Wf, cf, zsum_t, zz_t) if trunk_fold else None
             ctx.gkl, ctx.n_kl = gkl, n_kl
             ctx.save_for_backward(*tensors[:2 * NG + NG * N_DEC_PARAMS])
         ctx.mark_non_differentiable(rec_sum, *rec)
@@ -530,26 +559,52 @@ class DecoderFused(torch.autograd.Function):
         if not wm_late:
             issue_wm()
         # ---- trunk backward (BatchNorm + relu, Linear) ----------------------------------------------
-        nblk = -(-B // _abi.BN_ROWS)
-        d_pre = [new(B, n_m) for _ in range(NG)]
-        d_gam_a, d_bet_a = [pg[g][8][0] for g in range(NG)], [pg[g][9][0] for g in range(NG)]
-        bn = SpvBnBatch()
-        bn.nprob, bn.B, bn.training, bn.relu, bn.eps, bn.momentum = NG, B, int(training), 1, 1e-3, 0.01
-        for g in range(NG):
-            tb = ctx.decoders[g].sigmoid_decoder.bn
-            q = bn.p[g]
-            q.X, q.ldx, q.Y, q.ldy, q.gamma, q.beta = ptr(pre_a[g]), n_m, ptr(m[g]), n_m, ptr(par[g][8]), ptr(par[g][9])
-            q.running_mean, q.running_var, q.stats, q.N = ptr(tb.running_mean), ptr(tb.running_var), ptr(tstat[g]), n_m
-            q.part = ptr(ws[g].get("trunk_bn_part", (nblk, n_m, 2), torch.float32))
-            q.dY, q.lddy, q.dX, q.lddx, q.dgamma, q.dbeta = ptr(dAm[g]), n_m, ptr(d_pre[g]), n_m, ptr(d_gam_a[g]), ptr(d_bet_a[g])
-        _abi.call("spv_bn_bwd", C.byref(bn), stream_ptr())
         dWa, dba = [pg[g][6][0] for g in range(NG)], [pg[g][7][0] for g in range(NG)]
-        bw, bd = _lin_batch(B), _lin_batch(B, accumulate=True)
-        for g in range(NG):
-            _add_lin(bw, N=n_m, K=nt, W=ptr(par[g][6]), X=ptr(zcat[g]), ldx=nt, dY=ptr(d_pre[g]), lddy=n_m, dW=ptr(dWa[g]), db=ptr(dba[g]))
-            _add_lin(bd, N=n_m, K=nt, W=ptr(par[g][6]), dY=ptr(d_pre[g]), lddy=n_m, dX=ptr(d_zcat[g]), lddx=nt)
-        _ops.run_param_grads(dev, lambda: _wgrad(bw, ws if not isinstance(ws, (list, tuple)) else ws[0]), keep=[*zcat, *d_pre])   # (optimiser only)
-        _abi.call("spv_linear_dgrad", C.byref(bd), stream_ptr())
+        d_gam_a, d_bet_a = [pg[g][8][0] for g in range(NG)], [pg[g][9][0] for g in range(NG)]
+        if ctx.trunk is not None:
+            # folded trunk (spv_trunk_fold_fwd): the layer is relu(zcat W'^T + c'); its input gradient and the gradients of (W', c') come from the
+            # rectifier-masked linear kernels, spv_trunk_fold_bwd takes (d W', d c') back to W_a / gamma / beta and adds the part of d zcat that
+            # flows through the batch statistics -- the three BatchNorm-backward launches are gone from this chain
+            Wf, cf, zsum_t, zz_t = ctx.trunk
+            dWf, dcf = [new(n_m, nt) for _ in range(NG)], [new(n_m) for _ in range(NG)]
+            dred = [new(-(-n_m // 64), nt + nt * nt) for _ in range(NG)]
+            bw, bd = _lin_batch(B, relu=True), _lin_batch(B, relu=True, accumulate=True)
+            for g in range(NG):
+                _add_lin(bw, N=n_m, K=nt, W=ptr(Wf[g]), X=ptr(zcat[g]), ldx=nt, Y=ptr(m[g]), ldy=n_m, dY=ptr(dAm[g]), lddy=n_m, dW=ptr(dWf[g]), db=ptr(dcf[g]))
+                _add_lin(bd, N=n_m, K=nt, W=ptr(Wf[g]), Y=ptr(m[g]), ldy=n_m, dY=ptr(dAm[g]), lddy=n_m, dX=ptr(d_zcat[g]), lddx=nt)
+            _abi.call("spv_linear_dgrad", C.byref(bd), stream_ptr())
+            _wgrad(bw, ws if not isinstance(ws, (list, tuple)) else ws[0])
+            tb_ = SpvTrunkBatch()
+            tb_.nprob, tb_.B, tb_.training, tb_.eps, tb_.momentum = NG, B, int(training), 1e-3, 0.01
+            wa_c = [par[g][6] if par[g][6].is_contiguous() else par[g][6].contiguous() for g in range(NG)]
+            for g in range(NG):
+                bnm = ctx.decoders[g].sigmoid_decoder.bn
+                q = tb_.p[g]
+                q.W, q.bias, q.gamma, q.beta = ptr(wa_c[g]), ptr(par[g][7]), ptr(par[g][8]), ptr(par[g][9])
+                q.running_mean, q.running_var = ptr(bnm.running_mean), ptr(bnm.running_var)
+                q.zsum, q.zz, q.Wf, q.cf, q.stat, q.N, q.K = ptr(zsum_t[g]), ptr(zz_t[g]), ptr(Wf[g]), ptr(cf[g]), ptr(tstat[g]), n_m, nt
+                q.dWf, q.dcf, q.dW, q.dbias, q.dgamma, q.dbeta = ptr(dWf[g]), ptr(dcf[g]), ptr(dWa[g]), ptr(dba[g]), ptr(d_gam_a[g]), ptr(d_bet_a[g])
+                q.dred, q.z, q.ldz, q.dz, q.lddz = ptr(dred[g]), ptr(zcat[g]), nt, ptr(d_zcat[g]), nt
+            _abi.call("spv_trunk_fold_bwd", C.byref(tb_), stream_ptr())
+        else:
+            nblk = -(-B // _abi.BN_ROWS)
+            d_pre = [new(B, n_m) for _ in range(NG)]
+            bn = SpvBnBatch()
+            bn.nprob, bn.B, bn.training, bn.relu, bn.eps, bn.momentum = NG, B, int(training), 1, 1e-3, 0.01
+            for g in range(NG):
+                tb = ctx.decoders[g].sigmoid_decoder.bn
+                q = bn.p[g]
+                q.X, q.ldx, q.Y, q.ldy, q.gamma, q.beta = ptr(pre_a[g]), n_m, ptr(m[g]), n_m, ptr(par[g][8]), ptr(par[g][9])
+                q.running_mean, q.running_var, q.stats, q.N = ptr(tb.running_mean), ptr(tb.running_var), ptr(tstat[g]), n_m
+                q.part = ptr(ws[g].get("trunk_bn_part", (nblk, n_m, 2), torch.float32))
+                q.dY, q.lddy, q.dX, q.lddx, q.dgamma, q.dbeta = ptr(dAm[g]), n_m, ptr(d_pre[g]), n_m, ptr(d_gam_a[g]), ptr(d_bet_a[g])
+            _abi.call("spv_bn_bwd", C.byref(bn), stream_ptr())
+            bw, bd = _lin_batch(B), _lin_batch(B, accumulate=True)
+            for g in range(NG):
+                _add_lin(bw, N=n_m, K=nt, W=ptr(par[g][6]), X=ptr(zcat[g]), ldx=nt, dY=ptr(d_pre[g]), lddy=n_m, dW=ptr(dWa[g]), db=ptr(dba[g]))
+                _add_lin(bd, N=n_m, K=nt, W=ptr(par[g][6]), dY=ptr(d_pre[g]), lddy=n_m, dX=ptr(d_zcat[g]), lddx=nt)
+            _ops.run_param_grads(dev, lambda: _wgrad(bw, ws if not isinstance(ws, (list, tuple)) else ws[0]), keep=[*zcat, *d_pre])   # (optimiser only)
+            _abi.call("spv_linear_dgrad", C.byref(bd), stream_ptr())
         # ---- BatchNorm-fold backward (+ the z statistics it used) ------------------------------------
         fb = ctx.fb
         d_priv, d_poe = [new(B, n_p) for _ in range(NG)], [new(B, n_s) for _ in range(NG)]

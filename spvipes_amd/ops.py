@@ -178,6 +178,7 @@ GSPLIT_WANT = int(os.environ.get("SPV_GSPLIT_WANT", "512"))
 FUSED_HEADS_F32 = os.environ.get("SPV_FUSED_HEADS_F32", "1") != "0"   # ... and in "fp32" mode on the hi / lo planes of the split gradient words (spv_dec_heads_bwd, grads_f32)
 FUSED_DZ = os.environ.get("SPV_FUSED_DZ", "1") != "0"  # softmax fix also produces the latent gradient of the rate heads
 FUSED_DZ_F32 = os.environ.get("SPV_FUSED_DZ_F32", "1") != "0"   # "fp32" mode: the latent gradient of the rate heads comes out of the softmax-fix pass too (split-bf16 contraction)
+TRUNK_FOLD = os.environ.get("SPV_TRUNK_FOLD", "1") != "0"  # the mixing trunk's BatchNorm folded into its Linear (spv_trunk_fold_fwd / _bwd)
 FUSED_PACK = os.environ.get("SPV_FUSED_PACK", "1") != "0"  # latent / trunk kernels also write the decoder's bf16 operand images
 DEFER_WM = os.environ.get("SPV_DEFER_WM", "1") != "0"  # mixture-weight gradient GEMMs on the late side stream
 # bf16 mode, two groups: group 0's fold backward (slab sums, spv_bn_fold_bwd) issued under group 1's one-pass decoder backward instead of after both.

@@ -4,7 +4,7 @@ fused-dz softmax backward, gradient sink into the flat buffer), resident uint16 
 oracle on the same parameters, minibatch rows and noise (reference path: module/spVIPESmodule.py:425-899).
 
 Shapes: C2 (B 4096, G 10 000, H 128, 25/10; bf16 and fp32), C3's per-GPU shard (G 20 000, B 4096), C5's
-(G 30 000, paired PoE on a sparse transport plan, fp32; B 1024).  C4 (3 groups) has no reference to compare with
+(G 30 000, paired PoE on a sparse transport plan, fp32; B 4096, as bench.py --config c5 runs it).  C4 (3 groups) has no reference to compare with
 (data/prepare_adatas.py:94-95) and is covered by tests/test_gpu_three_groups.py as a consistency check only.
 
 Tolerances (bound  <-  worst value measured over the four cases on the MI355X, round 3: the encoder's first layer now runs on
@@ -179,6 +179,7 @@ def test_c3_shard_whole_step_vs_oracle(dev):
 
 
 def test_c5_paired_fp32_whole_step_vs_oracle(dev):
-    """BASELINE configs[4]'s shape: G 30 000, paired-cells PoE on a sparse plan, fp32 mode, B 1024"""
-    got, want = run_step(dev, G=30_000, B=1024, n_cells=3000, H=128, n_s=25, n_p=10, precision="fp32", mode="paired")
-    check(got, want, "fp32", "C5 1024x30000 paired")
+    """BASELINE configs[4]'s shard shape as the bench runs it: G 30 000, B 4096, paired-cells PoE on a sparse plan, fp32 mode (split-bf16
+    operands; the one-pass decoder backward on hi / lo planes)"""
+    got, want = run_step(dev, G=30_000, B=4096, n_cells=5000, H=128, n_s=25, n_p=10, precision="fp32", mode="paired")
+    check(got, want, "fp32", "C5 4096x30000 paired")
