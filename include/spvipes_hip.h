@@ -188,6 +188,23 @@ int spv_gemm_bf16(int32_t a_kmajor, const uint16_t* A_hi, const uint16_t* A_lo, 
                   float* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
                   int32_t nsplit, int32_t splits, int64_t slab_stride, int32_t a_tiles, void* stream);
 
+/* The same GEMM with its split-K slabs summed INSIDE the launch (only where spv_gemm_bf16_uses_dma() says 1; else SPV_ERR_UNSUPPORTED):
+ * every workgroup stores its slab tile, releases it (agent scope) and takes a ticket on its row tile's counter; the workgroup that draws
+ * the last ticket acquires, adds the `splits` slabs of the tile IN SLAB ORDER (for splits <= 8 what spv_reduce_slabs produces, bit for bit), scales
+ * by *alpha and writes columns [0, n0) to dst0 and columns [c1, c1 + n1) to dst1 -- the separate reduction launch and its re-read of the
+ * slabs from HBM are gone (the decoder backward's d A_m: 2 x 21 MB per step at B 4096, on the critical chain).
+ * counters: uint32 [ceil(M / 128)], ZERO when the call is made; the call leaves them zero (the last arriver resets its counter). */
+typedef struct spv_gemm_fixup {
+  uint32_t* counters;
+  const float* alpha;                          /* device scalar, or NULL = 1                        */
+  float* dst0; int64_t ld0; int32_t n0;        /* columns [0, n0) of the summed C                    */
+  float* dst1; int64_t ld1; int32_t c1, n1;    /* columns [c1, c1 + n1) (dst1 == NULL: none)         */
+} spv_gemm_fixup;
+int spv_gemm_bf16_fix(int32_t a_kmajor, const uint16_t* A_hi, const uint16_t* A_lo, int64_t lda,
+                      const uint16_t* B_hi, const uint16_t* B_lo, int64_t ldb,
+                      float* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
+                      int32_t nsplit, int32_t splits, int64_t slab_stride, int32_t a_tiles, const spv_gemm_fixup* fix, void* stream);
+
 /* Weight gradients of both rate heads' regressors (BatchNorm folded) in one streaming pass, bf16 mode:
  *   slabP[split][g][0..15] = sum_{cells of the split} tP(cell, g) * Aps[cell][0..15]
  *   slabS[split][g][0..31] = sum_{cells of the split} tS(cell, g) * Aps[cell][16..47]        (backward of nn/networks.py:314-320)

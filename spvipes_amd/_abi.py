@@ -178,6 +178,11 @@ class SpvFoldBatch(C.Structure):
                 ("momentum", C.c_float)]
 
 
+class SpvGemmFixup(C.Structure):
+    _fields_ = [("counters", C.c_void_p), ("alpha", C.c_void_p), ("dst0", C.c_void_p), ("ld0", C.c_int64), ("n0", C.c_int32),
+                ("dst1", C.c_void_p), ("ld1", C.c_int64), ("c1", C.c_int32), ("n1", C.c_int32)]
+
+
 TRUNK_KMAX = 48
 
 
@@ -217,6 +222,8 @@ _SIGNATURES = {
     "spv_gemm_bf16_uses_dma": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64]),
     "spv_gemm_bf16": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                 C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p]),
+    "spv_gemm_bf16_fix": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                    C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.POINTER(SpvGemmFixup), C.c_void_p]),
     "spv_dec_tables": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "spv_dec_lse": (C.c_int, [C.POINTER(SpvDecParams), C.c_void_p, C.c_void_p]),
     "spv_dec_nb_fwd": (C.c_int, [C.POINTER(SpvDecParams), C.c_int32, C.c_void_p]),

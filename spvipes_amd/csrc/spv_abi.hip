@@ -369,7 +369,22 @@ extern "C" int spv_gemm_bf16_uses_dma(int32_t a_kmajor, int32_t M, int32_t N, in
 extern "C" int spv_gemm_bf16(int32_t a_kmajor, const uint16_t* A_hi, const uint16_t* A_lo, int64_t lda, const uint16_t* B_hi,
                              const uint16_t* B_lo, int64_t ldb, float* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
                              int32_t nsplit, int32_t splits, int64_t slab_stride, int32_t a_tiles, void* stream) {
+  return spv_gemm_bf16_fix(a_kmajor, A_hi, A_lo, lda, B_hi, B_lo, ldb, C, ldc, M, N, K, nsplit, splits, slab_stride, a_tiles, nullptr, stream);
+}
+
+extern "C" int spv_gemm_bf16_fix(int32_t a_kmajor, const uint16_t* A_hi, const uint16_t* A_lo, int64_t lda, const uint16_t* B_hi,
+                                 const uint16_t* B_lo, int64_t ldb, float* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
+                                 int32_t nsplit, int32_t splits, int64_t slab_stride, int32_t a_tiles, const spv_gemm_fixup* fix, void* stream) {
   if (!A_hi || !B_hi || !C) return fail(SPV_ERR_ARG, "spv_gemm_bf16: null pointer%s");
+  if (fix) {
+    if (!spv_gemm_bf16_uses_dma(a_kmajor, M, N, K, nsplit, a_tiles, ldb)) return fail(SPV_ERR_UNSUPPORTED, "spv_gemm_bf16_fix: only the LDS-DMA 320-column kernels sum their slabs in the launch%s");
+    if (!fix->counters || !fix->dst0 || fix->n0 <= 0 || fix->n0 > N || fix->ld0 < fix->n0 || (ldc & 3) || (slab_stride & 3) || (reinterpret_cast<uintptr_t>(C) & 15) ||
+        (fix->dst1 && (fix->c1 < fix->n0 || fix->n1 <= 0 || fix->c1 + fix->n1 > N || fix->ld1 < fix->n1)) || ldc < N)
+      return fail(SPV_ERR_ARG, "spv_gemm_bf16_fix: bad fix-up description%s");
+    // (the LDS-DMA kernels want 16-byte aligned planes; the register-staged kernels they would fall back to know nothing of the fix-up)
+    if (((reinterpret_cast<uintptr_t>(A_hi) | reinterpret_cast<uintptr_t>(B_hi) | (nsplit == 3 ? (reinterpret_cast<uintptr_t>(A_lo) | reinterpret_cast<uintptr_t>(B_lo)) : 0)) & 15) != 0)
+      return fail(SPV_ERR_ARG, "spv_gemm_bf16_fix: operand planes must be 16-byte aligned%s");
+  }
   if (M <= 0 || N <= 0 || K <= 0 || splits <= 0 || (!a_tiles && (lda % 8)) || (ldb % 8) || a_tiles < 0) return fail(SPV_ERR_ARG, "spv_gemm_bf16: bad shape%s");
   if (nsplit != 1 && nsplit != 3) return fail(SPV_ERR_ARG, "spv_gemm_bf16: nsplit must be 1 or 3%s");
   if (nsplit == 3 && (!A_lo || !B_lo)) return fail(SPV_ERR_ARG, "spv_gemm_bf16: nsplit=3 needs lo images%s");
@@ -384,6 +399,10 @@ extern "C" int spv_gemm_bf16(int32_t a_kmajor, const uint16_t* A_hi, const uint1
   p.k_per_split = ((ktiles + splits - 1) / splits) * 64;
   p.epi = EPI_STORE;
   p.tiles_inner = a_tiles;
+  if (fix) {
+    p.fix_cnt = fix->counters; p.fix_alpha = fix->alpha; p.fix_d0 = fix->dst0; p.fix_ld0 = fix->ld0; p.fix_n0 = fix->n0;
+    p.fix_d1 = fix->dst1; p.fix_ld1 = fix->ld1; p.fix_c1 = fix->c1; p.fix_n1 = fix->n1;
+  }
   hipStream_t s = (hipStream_t)stream;
   if (nsplit == 3 && spv_gemm_bf16_uses_dma(a_kmajor, M, N, K, nsplit, a_tiles, ldb) &&
       ((reinterpret_cast<uintptr_t>(A_hi) | reinterpret_cast<uintptr_t>(B_hi) | reinterpret_cast<uintptr_t>(A_lo) | reinterpret_cast<uintptr_t>(B_lo)) & 15) == 0) {

@@ -163,6 +163,57 @@ __global__ __launch_bounds__(512) void dec_gemm320_dma_kernel(GemmParams p) {
   }
 }
 
+// ---- split-K fix-up inside the launch (spv_gemm_fixup) ------------------------------------------------------------------------------
+// After its slab tile is stored, a workgroup publishes it and takes a ticket; the last of the row tile's `c_split_row` workgroups sums the
+// slabs.  The hand-off is the release / acquire form of cdna_hip_programming.md ("In-launch split-K reduction"): every storing wave drains its
+// stores, workgroup barrier, ONE lane releases at agent scope and waits for the release before the relaxed agent-scope ticket add; the last
+// arriver's lane 0 acquires at agent scope, waits, workgroup barrier, then every wave reads the slabs with plain 16-byte loads.  Correct for
+// any placement of the tile's workgroups on CUs / XCDs.  The sum runs in slab order 0, 1, ..: the bits spv_reduce_slabs gives.
+__device__ __forceinline__ void splitk_fixup_tile(const GemmParams& p, int mtile, int m0, volatile unsigned* s_ticket) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's slab stores have left
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the compiler may drop the fence's own wait: keep this one)
+    *s_ticket = __hip_atomic_fetch_add(p.fix_cnt + mtile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (*s_ticket != (unsigned)(p.c_split_row - 1)) return;   // (workgroup-uniform)
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    p.fix_cnt[mtile] = 0u;   // the next launch finds its counter at zero (a kernel boundary lies between)
+  }
+  __syncthreads();
+  const int S = p.c_split_row;
+  const int ncol = max(p.fix_n0, p.fix_d1 ? p.fix_c1 + p.fix_n1 : 0);
+  const int nc4 = (ncol + 3) >> 2;                       // (ldc is a multiple of 4 and the rows are 16-byte aligned: checked by the host)
+  const int rows = min(DG_BM, p.M - m0);
+  const float alpha = p.fix_alpha ? *p.fix_alpha : 1.f;
+  const int nthreads = (int)blockDim.x;
+#pragma unroll 2
+  for (int e = threadIdx.x; e < rows * nc4; e += nthreads) {
+    const int row = e / nc4, c4 = e - row * nc4;
+    const float* src = p.C + (long)(m0 + row) * p.ldc + 4 * c4;
+    f4v acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < S; s0 += 4) {   // four slabs requested at once (clamped index + select: no load behind a run-time test)
+      f4v v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f4v*>(src + (long)min(s0 + u, S - 1) * p.slab_stride);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (s0 + u < S) { acc[0] += v[u][0]; acc[1] += v[u][1]; acc[2] += v[u][2]; acc[3] += v[u][3]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = 4 * c4 + j;
+      const float val = acc[j] * alpha;
+      if (col < p.fix_n0) p.fix_d0[(long)(m0 + row) * p.fix_ld0 + col] = val;
+      else if (p.fix_d1 && col >= p.fix_c1 && col < p.fix_c1 + p.fix_n1) p.fix_d1[(long)(m0 + row) * p.fix_ld1 + col - p.fix_c1] = val;
+    }
+  }
+}
+
 // ---- the same two GEMMs with K tiles of 32 and FOUR LDS stages (three tiles = 84 KiB in flight per CU instead of one of 56 KiB) ------
 // The two-stage kernel above waits for a whole tile's fill between two multiplies: it runs at the LATENCY of one 56 KiB fill per tile
 // (~1.4 us) rather than at the CU's fill rate.  Here a tile is 8 KiB of dL (4 tiles' halves: one 32 x 32 tile per wave pair) + 20 KiB
@@ -288,6 +339,7 @@ __global__ __launch_bounds__(512) void dec_gemm320_dma4_kernel(GemmParams p) {
       if (row < p.M) slab[(long)row * p.ldc + col] = acc[j][q];
     }
   }
+  if (p.fix_cnt != nullptr) splitk_fixup_tile(p, mtile, m0, reinterpret_cast<volatile unsigned*>(d4_smem));   // (kernel-uniform; the stages are dead)
 }
 
 // ---- the same two GEMMs on split-bf16 operands ("fp32" mode: x = hi + lo, x*y ~ hi*hi + hi*lo + lo*hi, three MFMAs) -----------------------
@@ -428,6 +480,7 @@ __global__ __launch_bounds__(512) void dec_gemm320_dma4s_kernel(GemmParams p) {
       if (row < p.M) slab[(long)row * p.ldc + col] = acc[j][q];
     }
   }
+  if (p.fix_cnt != nullptr) splitk_fixup_tile(p, mtile, m0, reinterpret_cast<volatile unsigned*>(d4s_smem));   // (kernel-uniform; the stages are dead)
 }
 
 // ---- regressor weight gradients of both rate heads in one pass --------------------------------------------------------------------

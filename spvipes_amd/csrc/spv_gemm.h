@@ -50,6 +50,8 @@ struct GemmParams {
   int tiles_inner;   // gene tiles per cell tile of a SRC_TILED operand / EPI_TILED_* output (= Gp / 32)
   bf16_t* xb_out; long ld_xb;  // optional (natural-A counts, NSPLIT 1): bf16 log1p(x) image [cells][ld_xb] written as a by-product
   int counts_aligned;  // count matrix base, row pitch and col_off all multiples of 16 bytes: every 8-gene chunk is one 16-B load
+  // optional in-launch split-K fix-up (spv_gemm_fixup; LDS-DMA 320-column kernels only): fix_cnt != nullptr turns it on
+  unsigned* fix_cnt; const float* fix_alpha; float* fix_d0; long fix_ld0; int fix_n0; float* fix_d1; long fix_ld1; int fix_c1, fix_n1;
 };
 
 __host__ __device__ constexpr int kmajor_pitch(int cols) {

@@ -89,6 +89,8 @@ class _DecoderBwd:
         # bf16 mode: the two 320-column GEMMs run the LDS-DMA 128 x 320 kernels, which want their own split counts
         # (d A_m of the two groups run side by side on the group streams; d W_m one after the other on the side stream)
         self.ksp_m = self._splits(False, B, G, self.ksp_m, 128 if (pair and _ops.DEC_PAIR_SPLITS) else 256)
+        # the d A_m GEMM may sum its split-K slabs inside the launch (LDS-DMA kernels only)
+        self.can_fix_d = bool((_ops.DA_FIXUP == "1" or (_ops.DA_FIXUP == "auto" and nsplit == 3)) and _abi.load().spv_gemm_bf16_uses_dma(0, B, KMP, G, nsplit, self.T, KMP))
         self.csp_m = self._splits(True, G, Bp, self.csp_m)
 
     def _operand(self, key: str):
@@ -132,8 +134,21 @@ class _DecoderBwd:
             return self._dma_splits(M, K, cus)
         return default
 
-    def gemm_d(self):
+    def gemm_d(self, fix=None):
+        """``fix``: (alpha, dAm [B][n_m], d_zcat [B][nt], n_m, nt) -- the slabs are summed inside the launch (spv_gemm_bf16_fix) straight into the
+        two consumers of d A_m; returns None then (nothing is left for spv_reduce_slabs)"""
         (Wm_hi, Wm_lo), (dL_hi, dL_lo) = self.S["Wm"], self._operand("dL")
+        if fix is not None and self.can_fix_d:
+            alpha, dAm, d_zcat, n_m, nt = fix
+            M, N, K = self.B, KMP, self.G
+            out = self.wsg.get("dec_dAm", (self.ksp_m, M, N), torch.float32)
+            fx = _abi.SpvGemmFixup()
+            fx.counters = ptr(self.wsg.get("dec_dAm_cnt", (-(-M // 128),), torch.int32, zero=True))
+            fx.alpha, fx.dst0, fx.ld0, fx.n0 = ptr(alpha), ptr(dAm), n_m, n_m
+            fx.dst1, fx.ld1, fx.c1, fx.n1 = ptr(d_zcat), nt, n_m, nt
+            _abi.call("spv_gemm_bf16_fix", 0, ptr(dL_hi), ptr(dL_lo), self.Gp, ptr(Wm_hi), ptr(Wm_lo) if Wm_lo is not None else None, KMP, ptr(out), N, M, N, K,
+                      self.nsplit, self.ksp_m, M * N, self.T, C.byref(fx), stream_ptr())
+            return None
         return _gemm_slabs(False, dL_hi, dL_lo, self.Gp, Wm_hi, Wm_lo, KMP, self.B, KMP, self.G, self.nsplit,
                            self.ksp_m, self.wsg, "dec_dAm", a_tiles=self.T)
 
@@ -443,7 +458,7 @@ class DecoderFused(torch.autograd.Function):
         for g in range(NG):
             if da_first:
                 with torch.cuda.stream(streams[g]):
-                    d_slabs[g] = stages[g].gemm_d()
+                    d_slabs[g] = stages[g].gemm_d(fix=(g_loss, dAm[g], d_zcat[g], n_m, nt))
                 continue
             with torch.cuda.stream(streams[g]):
                 # group 1 issues its (MFMA / LDS-bound) d A_m GEMM BEFORE its (HBM-bound) softmax fix, group 0 the other way round: the two
@@ -489,9 +504,10 @@ class DecoderFused(torch.autograd.Function):
                 else:
                     _add_red(red, bc_slabs[g][0], st.csp_n, G * DEC_KP, DEC_KP, G, DEC_KP, dWp[g], DEC_KP, alpha=al)      # d [W'_p | c_p]
                     _add_red(red, bc_slabs[g][1], st.csp_n, G * DEC_KS, DEC_KS, G, DEC_KS, dWs[g], DEC_KS, alpha=al)      # d [W'_s | c_s]
-            _add_red(red, d_slabs[g], st.ksp_m, B * KMP, KMP, B, n_m, dAm[g], n_m, alpha=al)                          # d m (trunk output)
-            # gradient reaching zcat directly: through the logits GEMM (columns n_m..) and the two regressors
-            _add_red(red, d_slabs[g], st.ksp_m, B * KMP, KMP, B, nt, d_zcat[g], nt, col_off=n_m, alpha=al)
+            if d_slabs[g] is not None:   # (else: the GEMM summed its slabs itself, straight into dAm / d_zcat -- spv_gemm_bf16_fix)
+                _add_red(red, d_slabs[g], st.ksp_m, B * KMP, KMP, B, n_m, dAm[g], n_m, alpha=al)                          # d m (trunk output)
+                # gradient reaching zcat directly: through the logits GEMM (columns n_m..) and the two regressors
+                _add_red(red, d_slabs[g], st.ksp_m, B * KMP, KMP, B, nt, d_zcat[g], nt, col_off=n_m, alpha=al)
             if st.fused_dz:
                 r2 = redg[g] if pipe else red2
                 _add_red(r2, st.dz_part, st.P.gene_splits, Bp * DEC_KPS, DEC_KPS, B, n_p, d_zcat[g], nt, accumulate=True, alpha=al)
