@@ -90,7 +90,7 @@ class _DecoderBwd:
         # (d A_m of the two groups run side by side on the group streams; d W_m one after the other on the side stream)
         self.ksp_m = self._splits(False, B, G, self.ksp_m, 128 if (pair and _ops.DEC_PAIR_SPLITS) else 256)
         # the d A_m GEMM may sum its split-K slabs inside the launch (LDS-DMA kernels only)
-        self.can_fix_d = bool((_ops.DA_FIXUP == "1" or (_ops.DA_FIXUP == "auto" and nsplit == 3)) and _abi.load().spv_gemm_bf16_uses_dma(0, B, KMP, G, nsplit, self.T, KMP))
+        self.can_fix_d = bool((_ops.DA_FIXUP == "1" or (_ops.DA_FIXUP == "fp32" and nsplit == 3)) and _abi.load().spv_gemm_bf16_uses_dma(0, B, KMP, G, nsplit, self.T, KMP))
         self.csp_m = self._splits(True, G, Bp, self.csp_m)
 
     def _operand(self, key: str):

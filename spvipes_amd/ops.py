@@ -178,12 +178,14 @@ GSPLIT_WANT = int(os.environ.get("SPV_GSPLIT_WANT", "512"))
 FUSED_HEADS_F32 = os.environ.get("SPV_FUSED_HEADS_F32", "1") != "0"   # ... and in "fp32" mode on the hi / lo planes of the split gradient words (spv_dec_heads_bwd, grads_f32)
 FUSED_DZ = os.environ.get("SPV_FUSED_DZ", "1") != "0"  # softmax fix also produces the latent gradient of the rate heads
 FUSED_DZ_F32 = os.environ.get("SPV_FUSED_DZ_F32", "1") != "0"   # "fp32" mode: the latent gradient of the rate heads comes out of the softmax-fix pass too (split-bf16 contraction)
-# d A_m GEMM sums its split-K slabs inside the launch (spv_gemm_bf16_fix: the last-arriving tile of a row block adds the slabs): no
-# reduction launch on the critical chain.  "auto" = only where it measured faster -- the split-word ("fp32") mode, whose three products
-# per tile make the launch long against the 600 KB of slabs a tile's finisher re-reads; in bf16 mode the finisher's read is the tail of
-# a short launch and the separate reduction wins.  Same box, ms/step: c2 bf16 1.3268 / 1.3029 / 1.3165 with, 1.2873 / 1.2840 / 1.2979
-# without; c5 (fp32 words, B 4096) 5.032 with, 5.100 without; c3 within noise.
-DA_FIXUP = os.environ.get("SPV_DA_FIXUP", "auto")
+# d A_m GEMM sums its split-K slabs inside the launch (spv_gemm_bf16_fix: the last-arriving tile of a row block adds the slabs) instead of
+# a reduction launch on the critical chain.  Measured and NOT the default: the finisher of a 128 x 320 tile re-reads splits x 160 KB
+# (600 KB at c2) at the tail of a short launch while the other CUs are already idle, and that costs more than the 1.5 us boundary plus the
+# chip-wide reduction it replaces.  Same box, ms/step, with / without: c2 bf16 1.3268 1.3029 1.3165 / 1.2873 1.2840 1.2979;
+# c2 split words 2.214 2.203 2.208 / 2.193 2.184 2.172; c5 5.018 5.016 / 5.031 5.019 (first box: 5.032 / 5.100); c4 3.761 3.789 /
+# 3.797 3.793.  "1" = on wherever the LDS-DMA kernels run, "fp32" = split-word mode only.  (tests/test_gpu_gemm_fixup.py keeps the
+# entry point bit-exact against the slab sum.)
+DA_FIXUP = os.environ.get("SPV_DA_FIXUP", "0")
 TRUNK_FOLD = os.environ.get("SPV_TRUNK_FOLD", "1") != "0"  # the mixing trunk's BatchNorm folded into its Linear (spv_trunk_fold_fwd / _bwd)
 FUSED_PACK = os.environ.get("SPV_FUSED_PACK", "1") != "0"  # latent / trunk kernels also write the decoder's bf16 operand images
 DEFER_WM = os.environ.get("SPV_DEFER_WM", "1") != "0"  # mixture-weight gradient GEMMs on the late side stream
