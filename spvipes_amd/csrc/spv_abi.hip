@@ -1493,10 +1493,31 @@ extern "C" int spv_enc_fc1_bwd_grouped(const spv_fc1_bwd_args* g, int32_t n_grou
     const int mth = a.N1 / FW_BM;   // 256-unit halves of the dh image (H = 256: one per encoder)
     const bool use96 = (n96 * mth + 255) / 256 < (n64 * mth + 255) / 256;
     const int Kp0 = (a.B + FW_BK - 1) / FW_BK * FW_BK, Kp1 = (b.B + FW_BK - 1) / FW_BK * FW_BK;
-    const int lds = fw_lds_bytes(use96 ? 96 : 64, Kp0 > Kp1 ? Kp0 : Kp1);
-    void (*kfn)(GemmParams, GemmParams, int) = use96 ? fc1_wgrad_dma_pair_kernel<96> : fc1_wgrad_dma_pair_kernel<64>;
+    const int Kp = Kp0 > Kp1 ? Kp0 : Kp1;
+    // ... unless a WIDE tile (192 / 256 genes, fc1_wgrad_dma_wide_body) needs fewer ROUNDS of workgroups: a workgroup re-reads the dh image
+    // (512 B per cell) beside its 2 t bytes per cell of image rows, so a wide tile is the slower one per workgroup and the faster one only
+    // where the narrow tiles need a second round (rocprofv3, us per pair launch: C2 96: 77, 128: 83, 192: 112, 256: 114; G 20 000 96: 154,
+    // 192: 123, 256: 125)
+    const char* const force_env = getenv("SPV_FC1_WGRAD_TILE");   // (tuning / test switch, read per call: 64 / 96 / 128 / 192 / 256)
+    const int force_tile = force_env ? atoi(force_env) : 0;
+    int t = use96 ? 96 : 64;
+    auto model_us = [&](int tile) {   // every workgroup pulls its bytes at the ONE CU's fill rate, ~32 GB/s measured on every LDS-DMA kernel here, round after round
+      const long nwg = (long)((a.G + tile - 1) / tile + (b.G + tile - 1) / tile) * mth;
+      return (double)((nwg + 255) / 256) * (double)Kp * (512 + 2 * tile) / 32e3;
+    };
+    if (Kp >= 512) {
+      if (fww_lds_bytes(192, Kp) <= 160 * 1024 && model_us(192) < model_us(t)) t = 192;
+      if (fww_lds_bytes(256, Kp) <= 160 * 1024 && model_us(256) < model_us(t)) t = 256;
+    }
+    if (force_tile == 64 || force_tile == 96 || force_tile == 128 || force_tile == 192 || force_tile == 256) {
+      const int need = force_tile >= 192 ? fww_lds_bytes(force_tile, Kp) : fw_lds_bytes(force_tile, Kp);
+      if (need <= 160 * 1024) t = force_tile;
+    }
+    const int lds = t >= 192 ? fww_lds_bytes(t, Kp) : fw_lds_bytes(t, Kp);
+    void (*kfn)(GemmParams, GemmParams, int) = t == 256 ? fc1_wgrad_dma_wide_pair_kernel<256> : t == 192 ? fc1_wgrad_dma_wide_pair_kernel<192> :
+                                               t == 96 ? fc1_wgrad_dma_pair_kernel<96> : (t == 128 ? fc1_wgrad_dma_pair_kernel<128> : fc1_wgrad_dma_pair_kernel<64>);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    const int t = use96 ? 96 : 64, nA = (a.G + t - 1) / t, nB = (b.G + t - 1) / t;
+    const int nA = (a.G + t - 1) / t, nB = (b.G + t - 1) / t;
     hipLaunchKernelGGL(kfn, dim3(nA + nB, mth), dim3(512), lds, s, p[0], p[1], nA);
     if (hipGetLastError() != hipSuccess) return launch_status("spv_enc_fc1_bwd_grouped wgrad");
   }

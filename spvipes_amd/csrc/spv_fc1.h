@@ -479,6 +479,190 @@ __device__ __forceinline__ void fc1_wgrad_dma_body(const GemmParams& p, const in
     }
 }
 
+// ---- the same weight gradient on WIDE gene tiles (192 / 256 genes), K tiles of 32 cells, four stages -------------------------------
+// What bounds fc1_wgrad_dma_body is the bytes its workgroups pull through the L2 -> LDS path: every workgroup re-reads the whole dh image
+// (2 MB at B 4096) for its 96 genes -- 420 MB per step at C2 beside the 164 MB of the gathered image, at the 6 - 7 TB/s all CUs together
+// get through that path.  A 192- / 256-gene tile halves / thirds the dh re-reads per gene (C2: 106 workgroups x 3.6 MB), and with fewer
+// workgroups than CUs the limit becomes the single CU's fill rate (~28 B/clk).  A stage is 32 cells deep so that FOUR fit (16 KB of dh +
+// 12 / 16 KB of image rows each, three tiles in flight behind counted waits); LDS rows are the global rows (512-byte dh rows, 384- /
+// 512-byte gene rows) with the 64-byte granule index XOR-ed by (row & 3) (512-byte rows) / its low bit by (row >> 1) & 1 (384-byte rows: four
+// consecutive rows then start 0 / 2 / 1 / 3 granules into the 256-byte bank period).  8 waves as 4 (M) x 2 (N): wave tile 64 x 96 / 128.
+constexpr int FWW_BK = 32, FWW_NBUF = 4;
+template <int WG_BN>
+struct FwwCfg {
+  static constexpr int A_BYTES = FWW_BK * FW_BM * 2, B_ROW = WG_BN * 2, B_BYTES = FWW_BK * B_ROW, STAGE = A_BYTES + B_BYTES;
+  static constexpr int A_PIECES = A_BYTES / 1024 / 8;                 // 2 per wave
+  static constexpr int B_PIECES_ALL = B_BYTES / 1024;                 // 12 (192 genes), 16 (256)
+  static constexpr int B_PIECES = (B_PIECES_ALL + 7) / 8;             // per wave; 192 genes: waves 0..3 issue two, waves 4..7 one
+  static constexpr int WAVES_N = 2, WAVES_M = 4, TM = FW_BM / WAVES_M / 32, TN = WG_BN / WAVES_N / 32;
+  static_assert(WG_BN == 192 || WG_BN == 256, "wide gene tile");
+};
+__host__ __device__ constexpr int fww_lds_bytes(int wg_bn, int kpad) { return (FWW_BK * FW_BM * 2 + FWW_BK * wg_bn * 2) * FWW_NBUF + kpad * 4; }
+
+template <int WG_BN>
+__device__ __forceinline__ void fc1_wgrad_dma_wide_body(const GemmParams& p, const int blk, const int mtile, unsigned char* fw_smem) {
+  typedef FwwCfg<WG_BN> Cfg;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uniform_wave_id();
+  const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
+  const int n0 = blk * WG_BN;
+  const int Kpad = (p.n_cells + FW_BK - 1) / FW_BK * FW_BK, ntiles = Kpad / FWW_BK;   // (the dh image is padded to 64 cells: an even tile count)
+  int* rowtab = reinterpret_cast<int*>(fw_smem + Cfg::STAGE * FWW_NBUF);
+  for (int k = tid; k < Kpad; k += 512) {
+    const int c = k < p.n_cells ? k : p.n_cells - 1;   // padding cells re-read the last row: their dh rows are zero
+    rowtab[k] = p.rows ? p.rows[c] : c;
+  }
+  __syncthreads();
+
+  lds_byte* const lds = (lds_byte*)(fw_smem);
+  // A pieces (2 dh rows of 512 B each): wave w owns pieces 2w, 2w + 1 = rows 4w .. 4w + 3 of the K tile
+  const glb_byte* srcA[Cfg::A_PIECES];
+#pragma unroll
+  for (int i = 0; i < Cfg::A_PIECES; ++i) {
+    const int piece = Cfg::A_PIECES * wave + i, row = 2 * piece + (lane >> 5), ch = lane & 31;
+    const int chs = (((ch >> 2) ^ (row & 3)) << 2) | (ch & 3);
+    srcA[i] = (glb_byte*)(p.A) + ((long)row * p.lda + mtile * FW_BM) * 2 + chs * 16;
+  }
+  int browB[Cfg::B_PIECES], bcolB[Cfg::B_PIECES];
+#pragma unroll
+  for (int i = 0; i < Cfg::B_PIECES; ++i) {
+    int row, cb;
+    if constexpr (WG_BN == 256) {   // as the dh rows
+      const int piece = Cfg::B_PIECES * wave + i, ch = lane & 31;
+      row = 2 * piece + (lane >> 5);
+      cb = ((((ch >> 2) ^ (row & 3)) << 2) | (ch & 3)) * 16;
+    } else {                        // piece = wave + 8 i (the second one only exists for waves 0..3); pieces cross the 384-byte rows
+      const int o = (wave + 8 * i) * 1024 + lane * 16;
+      row = (o / Cfg::B_ROW) & (FWW_BK - 1);
+      const int ch = (o % Cfg::B_ROW) >> 4;
+      cb = ((((ch >> 2) ^ ((row >> 1) & 1)) << 2) | (ch & 3)) * 16;
+    }
+    if ((long)n0 + cb / 2 + 8 > p.ldb) cb = 0;   // the last workgroup's columns beyond the image row: any in-bounds bytes do (never stored)
+    browB[i] = row; bcolB[i] = cb;
+  }
+  const glb_byte* const Bbase = (glb_byte*)(p.B) + (long)n0 * 2;
+  auto issueA = [&](int t, int i) {
+    dma16(srcA[i] + (long)t * (FWW_BK * p.lda * 2), lds + (t % FWW_NBUF) * Cfg::STAGE + (Cfg::A_PIECES * wave + i) * 1024);
+  };
+  auto issueB = [&](int t) {          // all B pieces of tile t (their row indices come out of the LDS table)
+#pragma unroll
+    for (int i = 0; i < Cfg::B_PIECES; ++i) {
+      if (WG_BN == 192 && i == 1 && wave >= 4) break;   // (wave-uniform)
+      const long ridx = rowtab[t * FWW_BK + browB[i]];
+      const int piece = (WG_BN == 192) ? wave + 8 * i : Cfg::B_PIECES * wave + i;
+      dma16(Bbase + ridx * p.ldb * 2 + bcolB[i], lds + (t % FWW_NBUF) * Cfg::STAGE + Cfg::A_BYTES + piece * 1024);
+    }
+  };
+  auto issue = [&](int t) {
+    issueB(t);
+#pragma unroll
+    for (int i = 0; i < Cfg::A_PIECES; ++i) issueA(t, i);
+  };
+
+  f16v acc[Cfg::TM][Cfg::TN];
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  if (ntiles > 0) issue(0);
+  if (ntiles > 1) issue(1);
+  if (ntiles > 2) issue(2);
+  const int gi = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3, h = lane >> 5;
+  const int in_gran = 32 * (gi & 1) + 8 * p4;   // byte offset inside the 64-byte granule (32 columns of one k row)
+  const unsigned lds0 = lds_addr_of(fw_smem);
+  for (int t = 0; t < ntiles; ++t) {
+    // tile t has landed once all but this wave's pieces of the (up to two) younger tiles are done: 4 per tile (192 genes, waves 4..7: 3)
+    const int younger = ntiles - 1 - t;
+    if (WG_BN == 256 || wave < 4) {
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    raw_barrier();
+    const bool more = t + 3 < ntiles;
+    if (more) issueB(t + 3);   // (first: its LDS-table reads are compiler-visible and must not sit between the asm reads below and their waits)
+    const unsigned stA = lds0 + (t % FWW_NBUF) * Cfg::STAGE, stB = stA + Cfg::A_BYTES;
+    s4v ra[2][Cfg::TM][2], rb[2][Cfg::TN][2];
+    auto reads_a = [&](int ks, int set) {
+      const int row = 16 * ks + 8 * h + q4;   // (row & 3) == q4
+#pragma unroll
+      for (int i = 0; i < Cfg::TM; ++i) {
+        const unsigned ad = stA + row * 512 + (((wm * Cfg::TM + i) ^ q4) * 64) + in_gran;
+        tr_issue(ra[set][i][0], ad);
+        tr_issue(ra[set][i][1], ad + 4 * 512);
+      }
+    };
+    auto reads_b = [&](int ks, int set) {
+      const int row = 16 * ks + 8 * h + q4;
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j) {
+        const int f = (WG_BN == 256) ? q4 : ((q4 >> 1) & 1);
+        const unsigned ad = stB + row * Cfg::B_ROW + (((wn * Cfg::TN + j) ^ f) * 64) + in_gran;
+        tr_issue(rb[set][j][0], ad);
+        tr_issue(rb[set][j][1], ad + 4 * Cfg::B_ROW);
+      }
+    };
+    // (at most 16 LDS reads outstanding: the first k-step's 2 TM + 2 TN and the second one's 2 TM; its 2 TN follow the first wait)
+    reads_a(0, 0); reads_b(0, 0); reads_a(1, 1);
+    if constexpr (Cfg::TN == 4)
+      asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ra[0][0][0]), "+v"(ra[0][0][1]), "+v"(ra[0][1][0]), "+v"(ra[0][1][1]), "+v"(rb[0][0][0]), "+v"(rb[0][0][1]), "+v"(rb[0][1][0]), "+v"(rb[0][1][1]),
+                                            "+v"(rb[0][2][0]), "+v"(rb[0][2][1]), "+v"(rb[0][3][0]), "+v"(rb[0][3][1]));
+    else
+      asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ra[0][0][0]), "+v"(ra[0][0][1]), "+v"(ra[0][1][0]), "+v"(ra[0][1][1]), "+v"(rb[0][0][0]), "+v"(rb[0][0][1]), "+v"(rb[0][1][0]), "+v"(rb[0][1][1]),
+                                            "+v"(rb[0][2][0]), "+v"(rb[0][2][1]));
+    reads_b(1, 1);
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j) acc[i][j] = mfma32h(join8(ra[0][i][0], ra[0][i][1]), join8(rb[0][j][0], rb[0][j][1]), acc[i][j]);
+    if (more) issueA(t + 3, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (Cfg::TN == 4)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[1][0][0]), "+v"(ra[1][0][1]), "+v"(ra[1][1][0]), "+v"(ra[1][1][1]), "+v"(rb[1][0][0]), "+v"(rb[1][0][1]), "+v"(rb[1][1][0]), "+v"(rb[1][1][1]),
+                                            "+v"(rb[1][2][0]), "+v"(rb[1][2][1]), "+v"(rb[1][3][0]), "+v"(rb[1][3][1]));
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[1][0][0]), "+v"(ra[1][0][1]), "+v"(ra[1][1][0]), "+v"(ra[1][1][1]), "+v"(rb[1][0][0]), "+v"(rb[1][0][1]), "+v"(rb[1][1][0]), "+v"(rb[1][1][1]),
+                                            "+v"(rb[1][2][0]), "+v"(rb[1][2][1]));
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j) acc[i][j] = mfma32h(join8(ra[1][i][0], ra[1][i][1]), join8(rb[1][j][0], rb[1][j][1]), acc[i][j]);
+    if (more) issueA(t + 3, 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // ---- dW rows 0 .. 127 -> p.C, rows 128 .. 255 -> p.C2 (the two encoders' weight gradients), fp32 [128][ldc] ----------------------
+  const int r = lane & 31;
+  const float oscale = *(p.out_scale ? p.out_scale : &g_spv_one);   // 1 / (power-of-two scale of the f16 dh image)
+#pragma unroll
+  for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j) {
+      const int col = n0 + wn * (WG_BN / Cfg::WAVES_N) + 32 * j + r;
+      if (col >= p.N) continue;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = mtile * FW_BM + wm * (FW_BM / Cfg::WAVES_M) + 32 * i + crow(q, h);
+        float* dst = (row >= p.c_split_row) ? p.C2 + (long)(row - p.c_split_row) * p.ldc + col : p.C + (long)row * p.ldc + col;
+        *dst = acc[i][j][q] * oscale;
+      }
+    }
+}
+// both groups in one grid (workgroups 0 .. n0 - 1: the first group's gene tiles); dynamic LDS = fww_lds_bytes of the larger group
+template <int WG_BN>
+__global__ __launch_bounds__(512) void fc1_wgrad_dma_wide_pair_kernel(GemmParams p0, GemmParams p1, int n0) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fw_smem_[];
+  const bool first = (int)blockIdx.x < n0;
+  const GemmParams p = first ? p0 : p1;
+  fc1_wgrad_dma_wide_body<WG_BN>(p, first ? (int)blockIdx.x : (int)blockIdx.x - n0, blockIdx.y, fw_smem_);
+}
+
 // ---- the weight gradient on split-bf16 operands ("fp32" mode), 96- or 128-gene tiles -----------------------------------------------
 // p.A / p.A_lo = the hi / lo dh images [Kpad][lda], p.B = the resident image of spv_prepare_log1p_split (hi / lo interleaved per 32-gene
 // block).  A stage is 32 cells deep: LDS rows 0..31 hold the hi rows of its cells, rows 32..63 the lo rows, for both operands -- the

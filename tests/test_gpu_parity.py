@@ -182,6 +182,45 @@ def test_encoder_fc1_resident_image_dma_path(dev, B, G, gather, H, grouped):
     torch.testing.assert_close(torch.cat([params[1].grad, params[3].grad]).cpu().double(), dpre.sum(0), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("B,G,H", [(100, 333, 128), (1000, 3001, 128), (4096, 2050, 128), (1030, 2050, 256), (576, 10000, 128)])
+def test_fc1_weight_gradient_gene_tiles_agree(dev, B, G, H, monkeypatch):
+    """the pair launch of the fc1 weight gradient picks its gene tile (64 / 96 / 128, or the wide 192 / 256 of fc1_wgrad_dma_wide_body) by
+    a cost model; every tile accumulates a gradient element over the cells in the same order, so all of them must give the SAME bits, and
+    the first is checked against fp64 on the f16-rounded operands (backward of nn/networks.py:119)"""
+    from spvipes_amd import ops
+    rng = np.random.default_rng(B + G)
+    g = torch.Generator().manual_seed(2)
+    mk = lambda *s: (torch.randn(*s, generator=g) * 0.05)
+    shapes = [(B, G), (max(B // 2, 70), max(G // 3, 200))]
+    data = []
+    for (b_, g_) in shapes:
+        Xh = (rng.poisson(2.0, size=(b_ + 11, g_)) * (rng.random((b_ + 11, g_)) < 0.3)).astype(np.float32)
+        Xh[:, 0] += 1
+        rows_h = rng.permutation(b_ + 11)[:b_]
+        data.append((Xh, rows_h, ops.GroupCounts(torch.tensor(Xh.astype(np.uint16).view(np.int16)).to(dev), g_, 0, resident=True),
+                     [mk(H, g_), mk(H), mk(H, g_), mk(H)], torch.randn(b_, 2 * H, generator=g)))
+    got = {}
+    for tile in ("", "64", "96", "128", "192", "256"):
+        if tile:
+            monkeypatch.setenv("SPV_FC1_WGRAD_TILE", tile)
+        else:
+            monkeypatch.delenv("SPV_FC1_WGRAD_TILE", raising=False)
+        params = [[t.clone().to(dev).requires_grad_(True) for t in d[3]] for d in data]
+        outs = ops.EncoderFC1Grouped.apply([d[2] for d in data], [torch.tensor(d[1], dtype=torch.int32, device=dev) for d in data], [s_[0] for s_ in shapes], 1,
+                                           [ops.Workspace(dev), ops.Workspace(dev)], None, *params[0], *params[1])
+        ((outs[0] * data[0][4].to(dev)).sum() + (outs[2] * data[1][4].to(dev)).sum()).backward()
+        torch.cuda.synchronize()
+        got[tile] = [torch.cat([p_[0].grad, p_[2].grad]).cpu() for p_ in params], [outs[0].detach().cpu(), outs[2].detach().cpu()]
+    for k in range(2):
+        Xh, rows_h, _, _, dh = data[k]
+        xr = _f16_round(torch.log1p(torch.tensor(Xh[rows_h])).float()).double()
+        dpre = dh.double() * (got[""][1][k].double() > 0)
+        want = _f16_round(dpre.float(), _dh_scale(dpre)).double().t() @ xr
+        torch.testing.assert_close(got[""][0][k].double(), want, rtol=1e-4, atol=1e-4 * float(want.abs().max()))
+        for tile in ("64", "96", "128", "192", "256"):
+            assert torch.equal(got[tile][0][k], got[""][0][k]), (tile, k, float((got[tile][0][k] - got[""][0][k]).abs().max()))
+
+
 def _decoder_case(dev, B, G, n_p, n_s, seed, dtype="f32"):
     from spvipes_amd import ops
     rng = np.random.default_rng(seed)

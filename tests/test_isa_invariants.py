@@ -60,7 +60,7 @@ def test_dma_kernels_keep_their_queue_in_flight(disassembly):
     """The multi-stage LDS-DMA GEMMs (csrc/spv_fc1.h, the four-stage kernel of csrc/spv_dec_gemm.h) rely on a COUNTED s_waitcnt vmcnt(N) at the top of every K tile: a compiler-inserted
     vmcnt(0) in front of the fragment reads (what hipcc emits for the transposed-read builtin) would drain the two tiles in
     flight once per tile."""
-    for key in ("fc1_fwd_dma_kernel", "fc1_fwd_dma_pair_kernel", "fc1_wgrad_dma_kernel", "fc1_wgrad_dma_pair_kernel", "dec_gemm320_dma4_kernel"):
+    for key in ("fc1_fwd_dma_kernel", "fc1_fwd_dma_pair_kernel", "fc1_wgrad_dma_kernel", "fc1_wgrad_dma_pair_kernel", "fc1_wgrad_dma_wide_pair_kernel", "dec_gemm320_dma4_kernel"):
         ks = {k: v for k, v in disassembly.items() if key in k}
         assert ks, key
         for name, ins in ks.items():
