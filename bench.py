@@ -215,7 +215,7 @@ def _pmc_fields(args):
 
 # kernels of the decoder + likelihood chain (forward and backward) by name, and the FETCH_SIZE factor of each: x2 where the reads are
 # 16 B / lane (LDS-DMA GEMMs, the one-pass backward: MI355X_MICROARCH.md, HBM section), raw elsewhere
-_CHAIN = (("dec_nb_kernel", 1.0), ("dec_heads_bwd_kernel", 2.0), ("dec_softmax_bwd_kernel", 1.0), ("dec_gemm320_dma4", 2.0), ("dec_logits_dma_kernel", 2.0),
+_CHAIN = (("dec_nb_kernel", 1.0), ("dec_heads_bwd", 2.0), ("dec_softmax_bwd_kernel", 1.0), ("dec_gemm320_dma4", 2.0), ("dec_logits_dma_kernel", 2.0),
           ("dec_lse_kernel", 1.0), ("dec_lse_combine_kernel", 1.0), ("dec_heads_wgrad", 2.0), ("gemm_kernel<", 1.0))
 _CHAIN_ENTRY_POINTS = ("spv_dec_nb_fwd", "spv_dec_logits", "spv_dec_lse", "spv_dec_softmax_bwd", "spv_dec_heads_bwd", "spv_gemm_bf16", "spv_dec_heads_wgrad")
 
