@@ -450,7 +450,8 @@ class DecoderFused(torch.autograd.Function):
         sm_done = None
         # BWD_PIPE: the fold backward of group 0 (its slab sums, spv_bn_fold_bwd, the z statistics) does not wait for group 1's one-pass
         # decoder backward: the side stream records an event per group and the main stream finishes group 0 while group 1 still streams
-        pipe = bool(_ops.BWD_PIPE and da_first == 1 and NG == 2 and not (_ops.WM_LATE and side is not cur) and all(st.fused_heads for st in stages))
+        wm_late = bool(_ops.wm_late_for(max(Gs), bool(ctx.grads_f32)) and side is not cur)
+        pipe = bool(_ops.BWD_PIPE and da_first == 1 and NG == 2 and not wm_late and all(st.fused_heads for st in stages))
         hb_done = []
         if da_first == 2:
             side.wait_stream(cur)
@@ -571,7 +572,6 @@ class DecoderFused(torch.autograd.Function):
         # WM_LATE: the mixture-weight GEMMs are held back until the main stream reaches the BatchNorm-fold backward: they then run beside
         # the ~25 tiny launches of the fold / PoE / encoder-tail backward, where the GPU is otherwise almost idle, instead of beside the
         # trunk backward, which they slow down
-        wm_late = bool(_ops.WM_LATE and side is not cur)
         if not wm_late:
             issue_wm()
         # ---- trunk backward (BatchNorm + relu, Linear) ----------------------------------------------

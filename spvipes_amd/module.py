@@ -463,7 +463,8 @@ class spVIPESmodule(nn.Module):
                 res = label_partners([kwargs["labels"][0], kwargs["labels"][1]], self._workspace(0, dev0))
             return res, st
 
-        if _ops_mod.LABEL_PRE == 1 and label_pre_ok:
+        label_pre_mode = _ops_mod.label_pre_for(max(self._step_inputs[g][2] for g in groups_))
+        if label_pre_mode == 1 and label_pre_ok:
             label_pre, pre_stream = fork_label_pairing()
         streams = None
         grouped = bool(_ops_mod.FC1_GROUPED and len(groups_) >= 2)
@@ -492,7 +493,7 @@ class spVIPESmodule(nn.Module):
             library[g] = lib.unsqueeze(1)
         if streams is not None:
             join(streams)
-        if _ops_mod.LABEL_PRE == 2 and label_pre_ok:
+        if label_pre_mode == 2 and label_pre_ok:
             label_pre, pre_stream = fork_label_pairing()
         # all encoder tails (fc2, dropout, heads, BatchNorm, draw, KL) as a few batched HIP launches: one batch over the
         # four encoders when the groups' minibatches have the same size (training), one batch per group otherwise (ragged

@@ -160,11 +160,35 @@ OVERLAP_SMALL = os.environ.get("SPV_OVERLAP_SMALL", "1") != "0"  # side-stream o
 STAGGER = os.environ.get("SPV_STAGGER", "1") != "0"  # group 1 orders its independent kernels differently from group 0
 STAGGER_BWD = os.environ.get("SPV_STAGGER_BWD", "0") != "0"  # backward: group 1 runs its d A_m GEMM ahead of its softmax fix (A/B on MI355X: 1.703 vs 1.693 ms, noise -> off)
 DA_FIRST = int(os.environ.get("SPV_DA_FIRST", "1"))  # backward: d A_m GEMMs first, softmax fixes on the side stream (1: side starts after them, 2: with them); A/B with the half-chip d A_m launches: -9 / -3 us on two boxes
-WM_LATE = os.environ.get("SPV_WM_LATE", "0") != "0"  # mixture-weight GEMMs held back until the BatchNorm-fold backward (beside the tiny-kernel tail)
+# mixture-weight GEMMs held back until the BatchNorm-fold backward (beside the tiny-kernel tail) instead of beside the trunk backward, which they
+# slow down.  Same box, ms/step, held back / not: C3 (G 20 000) 2.118 2.122 / 2.157 2.152; C2 1.307 1.316 1.318 1.343 1.313 1.320 / 1.323 1.314
+# 1.312 1.317 1.313 1.316; C5 4.941 4.965 4.946 5.022 5.003 / 4.981 4.904 4.921 5.005 5.001; C2 split words 2.125 2.133 / 2.122 2.115; C4 3.618
+# 3.570 / 3.604 3.595.  "auto": only where it paid -- 16-bit gradient words and G >= WM_LATE_MIN_G (the GEMMs grow with G, the tail does not).
+WM_LATE = os.environ.get("SPV_WM_LATE", "auto")
+WM_LATE_MIN_G = 16384
+
+
+def wm_late_for(G_max: int, grads_f32: bool) -> bool:
+    if WM_LATE == "auto":
+        return (not grads_f32) and G_max >= WM_LATE_MIN_G
+    return WM_LATE != "0"
+
+
+
 FC1_GROUPED = os.environ.get("SPV_FC1_GROUPED", "1") != "0"  # both groups' fc1 GEMMs as one launch per kernel (EncoderFC1Grouped) instead of two streams
 # label pairing on a side stream: 1 beside the fc1 GEMMs, 2 beside the encoder tails (module.inference).  Same-box A/B at C2, three rounds:
-# 2: 1.3218 / 1.3205 / 1.3154 ms, 0: 1.3229 / 1.3236 / 1.3375
-LABEL_PRE = int(os.environ.get("SPV_LABEL_PRE", "2"))
+# 2: 1.3218 / 1.3205 / 1.3154 ms, 0: 1.3229 / 1.3236 / 1.3375.  At C1 (B 128, where the pairing is a 3 us kernel and the fork + join costs more
+# than it hides): 0: 0.4578 / 0.4574 / 0.4567, 2: 0.4614 / 0.4654 / 0.4645, 1: 0.4658 / 0.4652 / 0.4654.  "auto" (-1) = 2 from LABEL_PRE_MIN_B
+# cells per minibatch, else 0.
+LABEL_PRE = int(os.environ.get("SPV_LABEL_PRE", "-1"))
+LABEL_PRE_MIN_B = 1024
+
+
+def label_pre_for(B: int) -> int:
+    return LABEL_PRE if LABEL_PRE >= 0 else (2 if B >= LABEL_PRE_MIN_B else 0)
+
+
+
 FC1_PAIR_SPLITS = os.environ.get("SPV_FC1_PAIR_SPLITS", "1") != "0"  # grouped fc1 forward: K splits sized for the pair's shared grid
 DEC_PAIR_SPLITS = os.environ.get("SPV_DEC_PAIR_SPLITS", "1") != "0"  # d A_m GEMMs of the two groups: K splits sized so that the pair shares one round
 HEADS_DMA = os.environ.get("SPV_HEADS_DMA", "1") != "0"  # both regressor weight gradients in one LDS-DMA pass (spv_dec_heads_wgrad)
