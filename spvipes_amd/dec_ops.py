@@ -448,11 +448,7 @@ class DecoderFused(torch.autograd.Function):
         # side stream, ahead of the regressor and mixture weight-gradient GEMMs they feed
         da_first = int(_ops.DA_FIRST) if (_ops.DEFER_BC and _ops.DEFER_WM and side is not cur and not split_fix and all(st.fused_dz for st in stages)) else 0
         sm_done = None
-        # BWD_PIPE: the fold backward of group 0 (its slab sums, spv_bn_fold_bwd, the z statistics) does not wait for group 1's one-pass
-        # decoder backward: the side stream records an event per group and the main stream finishes group 0 while group 1 still streams
         wm_late = bool(_ops.wm_late_for(max(Gs), bool(ctx.grads_f32)) and side is not cur)
-        pipe = bool(_ops.BWD_PIPE and da_first == 1 and NG == 2 and not wm_late and all(st.fused_heads for st in stages))
-        hb_done = []
         if da_first == 2:
             side.wait_stream(cur)
         fork(streams)
@@ -484,20 +480,12 @@ class DecoderFused(torch.autograd.Function):
             with torch.cuda.stream(side):
                 for g in range(NG):
                     stages[g].softmax()
-                    if pipe:
-                        hb_done.append(torch.cuda.Event())
-                        hb_done[-1].record(side)
                 sm_done = torch.cuda.Event()
                 sm_done.record(side)
         # slab sums, scaled by the upstream gradient, straight into their consumers' buffers
         al = g_loss
-        redg = [SpvReduceBatch() for _ in range(NG)] if pipe else None   # per group: what its fold backward waits for
         for g in range(NG):
             st, G, Gp = stages[g], Gs[g], Gps[g]
-            if pipe:
-                redg[g].nprob = 0
-                _add_red(redg[g], st.dw_part, st.csp_n, st.Gp * DEC_KPS, DEC_KPS, G, DEC_KP, dWp[g], DEC_KP, alpha=al)                  # d [W'_p | c_p]
-                _add_red(redg[g], st.dw_part, st.csp_n, st.Gp * DEC_KPS, DEC_KPS, G, DEC_KS, dWs[g], DEC_KS, col_off=DEC_KP, alpha=al)  # d [W'_s | c_s]
             if bc_slabs[g] is not None:
                 if st.fused_heads:
                     _add_red(red, bc_slabs[g][0], st.csp_n, st.Gp * DEC_KPS, DEC_KPS, G, DEC_KP, dWp[g], DEC_KP, alpha=al)                  # d [W'_p | c_p]
@@ -510,9 +498,8 @@ class DecoderFused(torch.autograd.Function):
                 # gradient reaching zcat directly: through the logits GEMM (columns n_m..) and the two regressors
                 _add_red(red, d_slabs[g], st.ksp_m, B * KMP, KMP, B, nt, d_zcat[g], nt, col_off=n_m, alpha=al)
             if st.fused_dz:
-                r2 = redg[g] if pipe else red2
-                _add_red(r2, st.dz_part, st.P.gene_splits, Bp * DEC_KPS, DEC_KPS, B, n_p, d_zcat[g], nt, accumulate=True, alpha=al)
-                _add_red(r2, st.dz_part, st.P.gene_splits, Bp * DEC_KPS, DEC_KPS, B, n_s, d_zcat[g], nt, col_off=DEC_KP, dst_col=n_p, accumulate=True, alpha=al)
+                _add_red(red2, st.dz_part, st.P.gene_splits, Bp * DEC_KPS, DEC_KPS, B, n_p, d_zcat[g], nt, accumulate=True, alpha=al)
+                _add_red(red2, st.dz_part, st.P.gene_splits, Bp * DEC_KPS, DEC_KPS, B, n_s, d_zcat[g], nt, col_off=DEC_KP, dst_col=n_p, accumulate=True, alpha=al)
             else:
                 _add_red(red2, ef_slabs[g][0], st.ksp_n, B * DEC_KP, DEC_KP, B, n_p, d_zcat[g], nt, accumulate=True, alpha=al)
                 _add_red(red2, ef_slabs[g][1], st.ksp_n, B * DEC_KS, DEC_KS, B, n_s, d_zcat[g], nt, dst_col=n_p, accumulate=True, alpha=al)
@@ -521,7 +508,7 @@ class DecoderFused(torch.autograd.Function):
         gk = None
         if ctx.n_kl:  # d loss / d kl_i[b] = g * kl_weight / B for every KL vector: rides in the second reduction launch
             gk = new(B)
-            _add_red(red if pipe else red2, ctx.gkl, 1, B, B, 1, B, gk, B, alpha=g_loss)
+            _add_red(red2, ctx.gkl, 1, B, B, 1, B, gk, B, alpha=g_loss)
         _run_red(red)
         if not da_first:
             _run_red(red2)
@@ -530,7 +517,7 @@ class DecoderFused(torch.autograd.Function):
         # pass, which feed nothing but the optimiser)
         bc_done = None
         with torch.cuda.stream(side):
-            if _ops.DEFER_BC and not pipe:
+            if _ops.DEFER_BC:
                 red_bc = SpvReduceBatch()
                 red_bc.nprob = 0
                 for g in range(NG):
@@ -619,7 +606,7 @@ class DecoderFused(torch.autograd.Function):
             for g in range(NG):
                 _add_lin(bw, N=n_m, K=nt, W=ptr(par[g][6]), X=ptr(zcat[g]), ldx=nt, dY=ptr(d_pre[g]), lddy=n_m, dW=ptr(dWa[g]), db=ptr(dba[g]))
                 _add_lin(bd, N=n_m, K=nt, W=ptr(par[g][6]), dY=ptr(d_pre[g]), lddy=n_m, dX=ptr(d_zcat[g]), lddx=nt)
-            _ops.run_param_grads(dev, lambda: _wgrad(bw, ws if not isinstance(ws, (list, tuple)) else ws[0]), keep=[*zcat, *d_pre])   # (optimiser only)
+            _wgrad(bw, ws if not isinstance(ws, (list, tuple)) else ws[0])
             _abi.call("spv_linear_dgrad", C.byref(bd), stream_ptr())
         # ---- BatchNorm-fold backward (+ the z statistics it used) ------------------------------------
         fb = ctx.fb
@@ -637,25 +624,16 @@ class DecoderFused(torch.autograd.Function):
                 if training:   # the latent-slicing backward rides in the same kernel (spv_fold_prob.out_priv)
                     q.zcol, q.out_priv, q.out_poe, q.n_p, q.n_s = zoff, ptr(d_priv[g]), ptr(d_poe[g]), n_p, n_s
                 i += 1
-        if pipe:
-            for g in range(NG):   # group g: its decoder-backward pass -> slab sums (regressor weight gradients, latent gradient) -> fold backward
-                cur.wait_event(hb_done[g])
-                _run_red(redg[g])
-                fbg = SpvFoldBatch()
-                fbg.nprob, fbg.B, fbg.training, fbg.eps, fbg.momentum = 2, fb.B, fb.training, fb.eps, fb.momentum
-                fbg.p[0], fbg.p[1] = fb.p[2 * g], fb.p[2 * g + 1]
-                _abi.call("spv_bn_fold_bwd", C.byref(fbg), stream_ptr())
-        else:
-            if da_first:   # the rate heads' latent gradient (softmax fix on the side stream) joins d_zcat here
-                cur.wait_event(sm_done)
-                _run_red(red2)
-            if bc_done is not None:
-                cur.wait_event(bc_done)
-            if wm_late:
-                ev = torch.cuda.Event()
-                ev.record(cur)
-                issue_wm(ev)
-            _abi.call("spv_bn_fold_bwd", C.byref(fb), stream_ptr())
+        if da_first:   # the rate heads' latent gradient (softmax fix on the side stream) joins d_zcat here
+            cur.wait_event(sm_done)
+            _run_red(red2)
+        if bc_done is not None:
+            cur.wait_event(bc_done)
+        if wm_late:
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            issue_wm(ev)
+        _abi.call("spv_bn_fold_bwd", C.byref(fb), stream_ptr())
         # ---- latent slicing backward (training: already done by the z-statistics kernel of spv_bn_fold_bwd) ---------------------
         if not training:
             za = SpvZsplitArgs()
@@ -663,8 +641,6 @@ class DecoderFused(torch.autograd.Function):
             for g in range(NG):
                 za.d_zcat[g], za.d_priv[g], za.d_poe[g] = ptr(d_zcat[g]), ptr(d_priv[g]), ptr(d_poe[g])
             _abi.call("spv_zsplit_bwd", C.byref(za), stream_ptr())
-        if _ops.DEC_GRADS_DONE is not None:   # every decoder-side parameter gradient of this chunk of groups has been issued
-            _ops.DEC_GRADS_DONE(dev, side if side is not cur else None)
         grads = []
         for g in range(NG):
             grads += [d_priv[g], d_poe[g]]

@@ -230,7 +230,7 @@ class EncoderTails(torch.autograd.Function):
             _add_lin(b, N=s.n, K=H, W=ptr(par[i][4]), X=ptr(h2[i]), ldx=H, dY=_fptr(d_pre[i], s.n), lddy=2 * s.n, dW=ptr(dWlv[i]), db=ptr(dblv[i]))
         from . import ops as _ops
         wsw = ws if not isinstance(ws, (list, tuple)) else ws[0]
-        _ops.run_param_grads(dev, lambda b=b: _wgrad(b, wsw), keep=[*h2, *d_pre])   # (feeds only the optimiser: off the critical chain)
+        _wgrad(b, wsw)
         # 4. d h2 = d_pre_mu Wmu + d_pre_lv Wlv
         #    one launch: the contraction runs over the 2n columns of d_pre, rows 0..n-1 of the weight from Wmu, rows n.. from Wlv
         dh2 = [new(B, H) for _ in specs]
@@ -251,7 +251,7 @@ class EncoderTails(torch.autograd.Function):
             x, ldx = _fptr(h1[s.h1_group], s.h1_col), h1[s.h1_group].shape[1]
             _add_lin(bw, N=H, K=H, W=ptr(par[i][0]), X=x, ldx=ldx, Y=ptr(h2[i]), ldy=H, dY=ptr(dh2[i]), lddy=H, dW=ptr(dW2[i]), db=ptr(db2[i]))
             _add_lin(bd, N=H, K=H, W=ptr(par[i][0]), Y=ptr(h2[i]), ldy=H, dY=ptr(dh2[i]), lddy=H, dX=_fptr(dh1[s.h1_group], s.h1_col), lddx=ldx)
-        _ops.run_param_grads(dev, lambda: _wgrad(bw, wsw), keep=[*h1, *h2, *dh2])
+        _wgrad(bw, wsw)
         _abi.call("spv_linear_dgrad", C.byref(bd), stream_ptr())
         grads: List[Optional[torch.Tensor]] = list(dh1)
         for i in range(E):

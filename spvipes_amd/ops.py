@@ -213,10 +213,6 @@ DA_FIXUP = os.environ.get("SPV_DA_FIXUP", "0")
 TRUNK_FOLD = os.environ.get("SPV_TRUNK_FOLD", "1") != "0"  # the mixing trunk's BatchNorm folded into its Linear (spv_trunk_fold_fwd / _bwd)
 FUSED_PACK = os.environ.get("SPV_FUSED_PACK", "1") != "0"  # latent / trunk kernels also write the decoder's bf16 operand images
 DEFER_WM = os.environ.get("SPV_DEFER_WM", "1") != "0"  # mixture-weight gradient GEMMs on the late side stream
-# bf16 mode, two groups: group 0's fold backward (slab sums, spv_bn_fold_bwd) issued under group 1's one-pass decoder backward instead of after both.
-# Same-box A/B at C2, three rounds: on 1.3825 / 1.3800 / 1.3817 ms, off 1.3218 / 1.3205 / 1.3154 -- the critical chain of that stretch is the
-# MAIN stream's trunk backward (slowed 2.5x by the full-chip pass beside it), and the per-group launches lengthen exactly that chain: OFF
-BWD_PIPE = os.environ.get("SPV_BWD_PIPE", "0") != "0"
 DEFER_BC = os.environ.get("SPV_DEFER_BC", "1") != "0"  # regressor weight-gradient GEMMs beside the trunk backward (side stream)
 # critical chain runs the read-only latent-gradient pass (spv_dec_dz), the in-place softmax fix moves beside it on the side stream.
 # Measured at C2, same box, alternating (round 2): OFF 1.690 / 1.690 ms per step, ON 1.745 / 1.737 ms -- the second pass over the two
@@ -226,18 +222,8 @@ DZ_ONLY = os.environ.get("SPV_DZ_ONLY", "0") != "0"
 # branches) or one after the other on the caller's stream (every fork / join of graph branches leaves the GPU idle for >= 10 us)
 FWD_GROUP_STREAMS = os.environ.get("SPV_FWD_GROUP_STREAMS", "1") != "0"
 BWD_GROUP_STREAMS = os.environ.get("SPV_BWD_GROUP_STREAMS", "1") != "0"
-# the small parameter-gradient launches of the backward pass (spv_linear_wgrad + its slice sum: trunk, encoder heads, fc2) feed nothing but
-# the optimiser: inside train.Trainer's step (DEFER_JOIN) they go to a side stream of their own and are joined with the other deferred
-# work after the backward pass, instead of sitting on the critical chain of the trunk / encoder-tail backward
-# (same-box A/B at C2, two rounds: on 1.3665 / 1.3466 ms, off 1.345 / 1.3442 -- the launches are too short to gain from the fork: OFF)
-PG_SIDE = os.environ.get("SPV_PG_SIDE", "0") != "0"
-# set by train.Trainer around a captured single-rank step: called by DecoderFused.backward when every decoder-side parameter gradient
-# has been issued (main stream: fold / trunk backward; side stream: the mixture-weight GEMMs), so that the optimiser can update
-# the decoder's slice of the flat buffer under the PoE / encoder-tail backward instead of after the whole pass
-DEC_GRADS_DONE = None
 _PENDING: list = []
 _PENDING_KEEP: list = []
-_PG_USED: list = []   # the parameter-gradient stream, while it carries un-joined work of the current backward pass
 
 
 def defer(stream, keep=()) -> None:
@@ -245,23 +231,6 @@ def defer(stream, keep=()) -> None:
     if stream not in _PENDING:
         _PENDING.append(stream)
     _PENDING_KEEP.extend(keep)
-
-
-def run_param_grads(device, fn, keep=()) -> None:
-    """``fn()`` launches kernels whose only outputs are parameter gradients: on the parameter-gradient side stream when the caller
-    joins deferred work itself (train.Trainer: DEFER_JOIN), else in line."""
-    dev = torch.device(device)
-    if not (PG_SIDE and DEFER_JOIN) or SERIAL_STREAMS:
-        fn()
-        return
-    cur = torch.cuda.current_stream(dev)
-    side = group_streams(dev, 4)[3]
-    side.wait_stream(cur)
-    with torch.cuda.stream(side):
-        fn()
-    defer(side, keep)
-    if side not in _PG_USED:
-        _PG_USED.append(side)
 
 
 def join_all_side_streams(device) -> None:
@@ -289,7 +258,6 @@ def join_pending(device=None) -> None:
         st = _PENDING.pop()
         torch.cuda.current_stream(st.device if device is None else device).wait_stream(st)
     _PENDING_KEEP.clear()
-    _PG_USED.clear()
 
 
 def _pack(src: torch.Tensor, dst_hi: torch.Tensor, dst_lo: Optional[torch.Tensor], *, extra_col: Optional[torch.Tensor] = None,

@@ -155,19 +155,6 @@ class HipAdam:
                   grad_scale, images if n_img else None, n_img, _abi.ptr(counter), _abi.ptr(self.t_dev), float(b1), float(b2), _abi.stream_ptr())
         _abi.call("spv_counter_bump", _abi.ptr(self.t_dev), _abi.stream_ptr())
 
-    def launch_range(self, lo: int, hi: int, grad_scale: float = 1.0, images=None, counter=None, bump: bool = False):
-        """Adam on elements [lo, hi) of the flat buffers only (``lo`` a multiple of 4; ``images``: descriptors whose ``begin`` counts from
-        ``lo``).  Element for element the arithmetic of ``launch``: the bias corrections come from the same device-resident step count,
-        which only the LAST slice's launch may advance (``bump``)."""
-        b1, b2 = self.betas
-        n_img = len(images) if images is not None else 0
-        off = 4 * lo
-        _abi.call("spv_adam_step_images", _abi.ptr(self.fp.flat) + off, _abi.ptr(self.fp.grad) + off, _abi.ptr(self.m) + off, _abi.ptr(self.v) + off,
-                  hi - lo, self.lr, b1, b2, self.eps, self.wd, 1.0, 1.0,
-                  grad_scale, images if n_img else None, n_img, _abi.ptr(counter), _abi.ptr(self.t_dev), float(b1), float(b2), _abi.stream_ptr())
-        if bump:
-            _abi.call("spv_counter_bump", _abi.ptr(self.t_dev), _abi.stream_ptr())
-
 
 class Trainer:
     """Runs optimisation steps of a spVIPESmodule on device-resident count matrices."""
@@ -232,12 +219,6 @@ class Trainer:
     DEVICE_RNG = os.environ.get("SPV_DEVICE_RNG", "1") != "0"
     MULTI_GATHER = os.environ.get("SPV_MULTI_GATHER", "1") != "0"   # the groups' label gathers / row-index copies as one launch each (spv_gather_u32)
     ADAM_IN_GRAPH = os.environ.get("SPV_ADAM_IN_GRAPH", "1") != "0"  # single rank: the Adam launch is the captured graph's last node
-    # ... and the decoder's slice of the flat buffer (fp.flat[:fp.split], more than half of the parameters) is updated as soon as the
-    # decoder half of the backward pass has produced its gradients: an HBM-bound launch under the latency-bound PoE / encoder-tail
-    # backward, on the side stream of the mixture-weight GEMMs; only the encoder slice is left for the end of the step
-    # (same-box A/B at C2, two rounds, PG_SIDE off: early 1.345 / 1.3442 ms, one launch at the end 1.3425 / 1.3373 -- the HBM-bound slice
-    # slows the latency-bound tail it runs beside by as much as it saves: OFF)
-    ADAM_EARLY = os.environ.get("SPV_ADAM_EARLY", "0") != "0"
 
     def _image_specs(self):
         """[(workspace, key, image tensor, [(parameter, rows_off, col_off)], token parameters)] for every packed weight image"""
@@ -286,21 +267,6 @@ class Trainer:
             self._img_specs, self._img_plan = [], None
             return
         self._img_specs, self._img_plan = specs, (_abi.SpvAdamImage * len(descs))(*descs)
-        # the same descriptors per gradient bucket (decoder slice [0, split), encoder slice [split, numel)), offsets from the slice's start
-        split = self.fp.split
-        lo, hi = [d for d in descs if d.begin + d.count <= split], [d for d in descs if d.begin >= split]
-        self._img_plan_halves = None
-        if len(lo) + len(hi) == len(descs):
-            def shifted(ds, off):
-                out = []
-                for d in ds:
-                    e = _abi.SpvAdamImage()
-                    for f, _t in _abi.SpvAdamImage._fields_:
-                        setattr(e, f, getattr(d, f))
-                    e.begin = d.begin - off
-                    out.append(e)
-                return (_abi.SpvAdamImage * len(out))(*out) if out else None
-            self._img_plan_halves = (shifted(lo, 0), shifted(hi, split))
 
     def _images_are_fresh(self) -> bool:
         from .ops import image_token
@@ -465,26 +431,10 @@ class Trainer:
         # parameters updated instead of leaving a host launch (and its ~15-20 us of idle GPU) behind it.  Data-parallel jobs keep
         # Adam outside: the all-reduce comes between.
         self._adam_in_graph = bool(self.ADAM_IN_GRAPH and self.world == 1 and not self.overlap)
-        # (batch covariates: two decoder weights get their gradient from a torch-side node that runs AFTER the fused decoder's backward)
-        early = bool(self._adam_in_graph and self.ADAM_EARLY and not getattr(self.module, "n_cov", 0) and 0 < self.fp.split < self.fp.numel
-                     and (self._img_plan is None or getattr(self, "_img_plan_halves", None) is not None))
         with torch.cuda.graph(g, **mode):
-            self._dec_chunks_left = -(-self.module.n_groups // 2) if early else 0   # DecoderFused runs once per chunk of <= 2 groups
-            self._adam_dec_done = False
-            if early:
-                ops.DEC_GRADS_DONE = self._decoder_grads_done
-            try:
-                self._static_lo = self._forward_backward(self._static_rows, self._klw)
-            finally:
-                ops.DEC_GRADS_DONE = None
+            self._static_lo = self._forward_backward(self._static_rows, self._klw)
             if self._adam_in_graph:
-                cnt = getattr(self.module, "_rng_counter", None)
-                if self._adam_dec_done:
-                    halves = self._img_plan_halves if self._img_plan is not None else (None, None)
-                    self.opt.launch_range(self.fp.split, self.fp.numel, grad_scale=1.0, images=halves[1], counter=cnt, bump=True)
-                else:
-                    self.opt.launch(grad_scale=1.0, images=self._img_plan, counter=cnt)
-        self._adam_early = bool(self._adam_dec_done)
+                self.opt.launch(grad_scale=1.0, images=self._img_plan, counter=getattr(self.module, "_rng_counter", None))
         if keep:
             g.instantiate()
         self.graph = g
@@ -495,30 +445,6 @@ class Trainer:
             if keep:
                 g2.instantiate()
             self.graph2 = g2
-
-    def _decoder_grads_done(self, dev, side) -> None:
-        """ops.DEC_GRADS_DONE during the capture of a single-rank step: after the LAST decoder chunk's backward, the decoder bucket
-        fp.flat[:fp.split] takes its Adam step on the side stream, behind everything that writes decoder gradients (main stream up
-        to here, the mixture-weight GEMMs' side stream, the small parameter-gradient stream); joined with the other deferred work."""
-        from . import ops
-        self._dec_chunks_left -= 1
-        if self._dec_chunks_left != 0:
-            return
-        cur = torch.cuda.current_stream(dev)
-        st = side if side is not None else ops.group_streams(dev, 3)[2]
-        if st is cur:   # (single-stream runs: the slice is simply launched in line)
-            st = cur
-        else:
-            st.wait_stream(cur)
-            for pg in ops._PG_USED:
-                if pg is not st:
-                    st.wait_stream(pg)
-        halves = self._img_plan_halves if self._img_plan is not None else (None, None)
-        with torch.cuda.stream(st):
-            self.opt.launch_range(0, self.fp.split, grad_scale=1.0, images=halves[0], counter=None, bump=False)
-        if st is not cur:
-            ops.defer(st, [])
-        self._adam_dec_done = True
 
     def step(self, rows: Sequence[torch.Tensor], kl_weight: Optional[float] = None, noise=None, optimizer_step: bool = True):
         """forward + loss + backward + (all-reduce) + Adam for one minibatch; returns the LossOutput.  ``noise`` (eager steps
