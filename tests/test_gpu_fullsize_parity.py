@@ -134,6 +134,15 @@ def check(got, want, precision, label):
     loc_err = lambda a, b: float(((a - b).abs().max(0).values / b.abs().max(0).values.clamp_min(1e-6)).max())  # per latent column, relative to its scale
     m["private_loc"] = max(loc_err(a, b) for a, b in zip(got["private_loc"], want["private_loc"]))
     m["poe_loc"] = max(loc_err(a, b) for a, b in zip(got["poe_loc"], want["poe_loc"]))
+    # the same latent means element by element (reported): the share of elements within a pure rtol of 1e-3, and the 99.9th
+    # percentile of |a - b| / max(|b|, 1e-2 column max) -- an element close to zero cannot meet a relative bound on its own value
+    def elementwise(a, b):
+        den = torch.maximum(b.abs(), 1e-2 * b.abs().max(0).values.clamp_min(1e-6))
+        rel = ((a - b).abs() / den).flatten().double()
+        pure = ((a - b).abs() <= 1e-3 * b.abs()).double().mean()
+        return float(pure), float(torch.quantile(rel[:: max(1, rel.numel() // 1_000_000)], 0.999))
+    ew = [elementwise(a, b) for a, b in zip(got["private_loc"] + got["poe_loc"], want["private_loc"] + want["poe_loc"])]
+    m["loc_share_within_rtol_1e-3"], m["loc_rel_p999"] = min(e[0] for e in ew), max(e[1] for e in ew)
     # gradients per parameter KIND (e.g. all fc1 weights): max |g - g_ref| over the kind / max |g_ref| over the kind, and the
     # relative L2 error of the kind.  (Per kind, not per tensor: a bias in front of a training-mode BatchNorm has an
     # analytically zero gradient and holds only rounding noise on both sides.)

@@ -2,7 +2,7 @@
 # usage (GPU box): bash tools/checkpoint.sh <tag> [a|b|ab]   -- one evidence set (copy what is to be judged from gpurun_out/ into profiles/)
 #   part a: GPU tests, bench lines of every BASELINE config (+ the headline workload in split-word mode), rocprofv3 kernel statistics (default
 #           and single-stream), step timeline, full-size parity report, captured graph's node / edge dump
-#   part b: tools/pmc_workload.sh on c2, c3 and c5 (five --pmc passes + serial statistics each; the tables bench.py's roofline block reads)
+#   part b: tools/pmc_workload.sh on c2, c3, c5 and c4 (five --pmc passes + serial statistics each; the tables bench.py's roofline block reads)
 set -e -o pipefail
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; T=$1; PART=${2:-ab}
@@ -35,4 +35,5 @@ if [[ $PART == *b* ]]; then
   bash tools/pmc_workload.sh $T c2
   bash tools/pmc_workload.sh $T c3
   bash tools/pmc_workload.sh $T c5
+  bash tools/pmc_workload.sh $T c4
 fi
