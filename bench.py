@@ -463,6 +463,7 @@ def main(argv=None):
     for i in range(args.steps):
         last = trainer.step(next(it), kl_weight=1.0)
         ev[i + 1].record()
+    host_enqueue_ms = (time.perf_counter() - t0) * 1e3 / args.steps   # what the host spends issuing one step (close to ms_per_step = host bound)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -558,7 +559,7 @@ def main(argv=None):
         out = {
             "metric": "cells/sec/training-step (2-group PoE VAE)" if NG == 2 else f"cells/sec/training-step ({NG}-group PoE VAE)",
             "value": value, "unit": "cells/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_median": median_ms,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_median": median_ms, "host_enqueue_ms_per_step": host_enqueue_ms,
             "higher_is_better": True,
             # dtype, bf16 mode: bf16 decoder operands, f16 encoder fc1 operands, fp32 accumulation
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32(split-bf16)",
