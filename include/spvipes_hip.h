@@ -205,6 +205,16 @@ int spv_gemm_bf16_fix(int32_t a_kmajor, const uint16_t* A_hi, const uint16_t* A_
                       float* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
                       int32_t nsplit, int32_t splits, int64_t slab_stride, int32_t a_tiles, const spv_gemm_fixup* fix, void* stream);
 
+/* spv_gemm_bf16 for the two groups of a step in ONE grid (group = blockIdx.y) where both calls take the bf16 LDS-DMA kernel in the same
+ * direction; otherwise, and for an odd group left over, the per-group entry point in order.  Same arguments, same slabs. */
+typedef struct spv_gemm_args {
+  int32_t a_kmajor; int32_t pad0_;
+  const uint16_t* A_hi; const uint16_t* A_lo; int64_t lda;
+  const uint16_t* B_hi; const uint16_t* B_lo; int64_t ldb;
+  float* C; int64_t ldc; int32_t M, N, K, nsplit, splits, a_tiles; int64_t slab_stride;
+} spv_gemm_args;
+int spv_gemm_bf16_grouped(const spv_gemm_args* groups, int32_t n_groups, void* stream);
+
 /* Weight gradients of both rate heads' regressors (BatchNorm folded) in one streaming pass, bf16 mode:
  *   slabP[split][g][0..15] = sum_{cells of the split} tP(cell, g) * Aps[cell][0..15]
  *   slabS[split][g][0..31] = sum_{cells of the split} tS(cell, g) * Aps[cell][16..47]        (backward of nn/networks.py:314-320)
@@ -253,6 +263,28 @@ int spv_dec_lse(const spv_dec_params* p, const float* library, void* stream);
 /* rec_part/tp_part/ts_part [nb_splits][Bp], dtheta_part [Bp/64][Gp]; when train != 0 also the
  * per-element gradients dL, tP, tS (accumulator-tile order; bf16, or bf16 hi + lo planes when grads_f32). */
 int spv_dec_nb_fwd(const spv_dec_params* p, int32_t train, void* stream);
+
+/* The decoder's per-group launches for the two groups of a step in ONE grid each (group = blockIdx.z; csrc/spv_decoder.h *_pair_kernel):
+ * workgroups outside a group's own grid extent leave at once, the others run the single-group kernel body unchanged -- the results are
+ * bit-identical to the per-group calls.  A pair goes out as one grid where both groups take the same kernel variant (count storage,
+ * logits and gradient word types; bf16 LDS-DMA logits GEMM; bf16 words for the one-pass backward); otherwise, and for an odd group left
+ * over, the per-group entry points run in order.  Each entry point reads the fields of spv_dec_group its per-group twin takes as arguments:
+ *   spv_dec_tables_grouped   px_r  (writes p.gene_tab / p.cnt_tab)              spv_dec_logits_grouped   Am_*, Wm_*, K, nsplit (writes p.logits)
+ *   spv_dec_lse_grouped      library                                            spv_dec_nb_fwd_grouped   --
+ *   spv_dec_heads_bwd_grouped  Tp, Ts, dz_part, dw_part
+ * At 128 cells per minibatch a likelihood launch is ~15 us of fixed cost: one grid instead of two per kernel is what shortens the step. */
+typedef struct spv_dec_group {
+  spv_dec_params p;
+  const float* library;
+  const float* px_r;
+  const uint16_t* Am_hi; const uint16_t* Am_lo; const uint16_t* Wm_hi; const uint16_t* Wm_lo; int32_t K, nsplit;
+  const float* Tp; const float* Ts; float* dz_part; float* dw_part;
+} spv_dec_group;
+int spv_dec_tables_grouped(const spv_dec_group* groups, int32_t n_groups, void* stream);
+int spv_dec_logits_grouped(const spv_dec_group* groups, int32_t n_groups, void* stream);
+int spv_dec_lse_grouped(const spv_dec_group* groups, int32_t n_groups, void* stream);
+int spv_dec_nb_fwd_grouped(const spv_dec_group* groups, int32_t n_groups, int32_t train, void* stream);
+int spv_dec_heads_bwd_grouped(const spv_dec_group* groups, int32_t n_groups, void* stream);
 
 /* Materialises the decoder outputs the reference's generative() returns (module/spVIPESmodule.py:751-768,
  * nn/networks.py:314-325) for one group: px_scale_k = softmax_G(BN(z_k W_k^T)), px_rate_k = exp(library) * px_scale_k

@@ -183,6 +183,21 @@ class SpvGemmFixup(C.Structure):
                 ("dst1", C.c_void_p), ("ld1", C.c_int64), ("c1", C.c_int32), ("n1", C.c_int32)]
 
 
+class SpvGemmArgs(C.Structure):
+    """one group's arguments of spv_gemm_bf16, for spv_gemm_bf16_grouped"""
+    _fields_ = [("a_kmajor", C.c_int32), ("pad0_", C.c_int32), ("A_hi", C.c_void_p), ("A_lo", C.c_void_p), ("lda", C.c_int64),
+                ("B_hi", C.c_void_p), ("B_lo", C.c_void_p), ("ldb", C.c_int64), ("C", C.c_void_p), ("ldc", C.c_int64),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("nsplit", C.c_int32), ("splits", C.c_int32), ("a_tiles", C.c_int32),
+                ("slab_stride", C.c_int64)]
+
+
+class SpvDecGroup(C.Structure):
+    """one group's decoder launch arguments, for the spv_dec_*_grouped entry points (include/spvipes_hip.h: spv_dec_group)"""
+    _fields_ = [("p", SpvDecParams), ("library", C.c_void_p), ("px_r", C.c_void_p),
+                ("Am_hi", C.c_void_p), ("Am_lo", C.c_void_p), ("Wm_hi", C.c_void_p), ("Wm_lo", C.c_void_p), ("K", C.c_int32), ("nsplit", C.c_int32),
+                ("Tp", C.c_void_p), ("Ts", C.c_void_p), ("dz_part", C.c_void_p), ("dw_part", C.c_void_p)]
+
+
 TRUNK_KMAX = 48
 
 
@@ -233,6 +248,12 @@ _SIGNATURES = {
     "spv_dec_dz": (C.c_int, [C.POINTER(SpvDecParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "spv_dec_softmax_bwd": (C.c_int, [C.POINTER(SpvDecParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "spv_dec_heads_bwd": (C.c_int, [C.POINTER(SpvDecParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "spv_dec_tables_grouped": (C.c_int, [C.POINTER(SpvDecGroup), C.c_int32, C.c_void_p]),
+    "spv_dec_logits_grouped": (C.c_int, [C.POINTER(SpvDecGroup), C.c_int32, C.c_void_p]),
+    "spv_dec_lse_grouped": (C.c_int, [C.POINTER(SpvDecGroup), C.c_int32, C.c_void_p]),
+    "spv_dec_nb_fwd_grouped": (C.c_int, [C.POINTER(SpvDecGroup), C.c_int32, C.c_int32, C.c_void_p]),
+    "spv_dec_heads_bwd_grouped": (C.c_int, [C.POINTER(SpvDecGroup), C.c_int32, C.c_void_p]),
+    "spv_gemm_bf16_grouped": (C.c_int, [C.POINTER(SpvGemmArgs), C.c_int32, C.c_void_p]),
     "spv_linear_fwd": (C.c_int, [C.POINTER(SpvLinearBatch), C.c_void_p]),
     "spv_linear_dgrad": (C.c_int, [C.POINTER(SpvLinearBatch), C.c_void_p]),
     "spv_linear_wgrad": (C.c_int, [C.POINTER(SpvLinearBatch), C.c_void_p, C.c_int64, C.c_void_p]),

@@ -445,6 +445,48 @@ extern "C" int spv_gemm_bf16_fix(int32_t a_kmajor, const uint16_t* A_hi, const u
   return launch_status("spv_gemm_bf16");
 }
 
+// both groups' 320-column GEMMs of the decoder backward (same direction, bf16 words, LDS-DMA shapes) as one grid; anything else: per group
+static bool gemm_pair_ok(const spv_gemm_args& a) {
+  return a.A_hi && a.B_hi && a.C && a.nsplit == 1 && a.M > 0 && a.N > 0 && a.K > 0 && a.splits > 0 &&
+         spv_gemm_bf16_uses_dma(a.a_kmajor, a.M, a.N, a.K, a.nsplit, a.a_tiles, a.ldb) &&
+         ((reinterpret_cast<uintptr_t>(a.A_hi) | reinterpret_cast<uintptr_t>(a.B_hi)) & 15) == 0;
+}
+static GemmParams gemm_pair_params(const spv_gemm_args& a) {
+  GemmParams p{};
+  p.A = a.A_hi; p.lda = a.lda; p.B = a.B_hi; p.ldb = a.ldb; p.C = a.C; p.ldc = a.ldc; p.slab_stride = a.slab_stride;
+  p.M = a.M; p.N = a.N; p.K = a.K;
+  const int ktiles = (a.K + 63) / 64;
+  p.k_per_split = ((ktiles + a.splits - 1) / a.splits) * 64;
+  p.epi = EPI_STORE; p.tiles_inner = a.a_tiles; p.c_split_row = a.splits;
+  return p;
+}
+extern "C" int spv_gemm_bf16_grouped(const spv_gemm_args* g, int32_t n, void* stream) {
+  if (!g || n <= 0) return fail(SPV_ERR_ARG, "spv_gemm_bf16_grouped: bad arguments%s");
+  hipStream_t s = (hipStream_t)stream;
+  int i = 0;
+  for (; i + 1 < n; i += 2) {
+    const spv_gemm_args &a = g[i], &b = g[i + 1];
+    if (!(gemm_pair_ok(a) && gemm_pair_ok(b) && a.a_kmajor == b.a_kmajor)) break;
+    const GemmParams p0 = gemm_pair_params(a), p1 = gemm_pair_params(b);
+    const int n0 = (a.M + DG_BM - 1) / DG_BM * a.splits, n1 = (b.M + DG_BM - 1) / DG_BM * b.splits;
+    static bool raised = false;
+    if (!raised) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm320_dma4_pair_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, D4_LDS_BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_gemm320_dma4_pair_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, D4_LDS_BYTES);
+      raised = true;
+    }
+    if (a.a_kmajor) hipLaunchKernelGGL(dec_gemm320_dma4_pair_kernel<true>, dim3(n0 > n1 ? n0 : n1, 2), dim3(512), D4_LDS_BYTES, s, p0, p1);
+    else hipLaunchKernelGGL(dec_gemm320_dma4_pair_kernel<false>, dim3(n0 > n1 ? n0 : n1, 2), dim3(512), D4_LDS_BYTES, s, p0, p1);
+    if (hipGetLastError() != hipSuccess) return launch_status("spv_gemm_bf16_grouped");
+  }
+  for (; i < n; ++i) {
+    const spv_gemm_args& a = g[i];
+    const int rc = spv_gemm_bf16(a.a_kmajor, a.A_hi, a.A_lo, a.lda, a.B_hi, a.B_lo, a.ldb, a.C, a.ldc, a.M, a.N, a.K, a.nsplit, a.splits, a.slab_stride, a.a_tiles, stream);
+    if (rc != SPV_OK) return rc;
+  }
+  return SPV_OK;
+}
+
 extern "C" int spv_dec_heads_wgrad(const uint16_t* tP, const uint16_t* tS, int32_t a_tiles, const uint16_t* Aps, int32_t G, int32_t Bp,
                                    int32_t splits, float* slabP, float* slabS, void* stream) {
   if (!tP || !tS || !Aps || !slabP || !slabS) return fail(SPV_ERR_ARG, "spv_dec_heads_wgrad: null pointer%s");
@@ -494,18 +536,68 @@ extern "C" int spv_dec_tables(const float* px_r, int32_t G, int32_t Gp, void* ge
   return launch_status("spv_dec_tables");
 }
 
-extern "C" int spv_dec_lse(const spv_dec_params* q, const float* library, void* stream) {
-  DecParams p;
+// ---- the decoder's per-group launches for BOTH groups of a step in one grid each (spv_dec_group; csrc/spv_decoder.h: *_pair_kernel) ------
+// Two groups whose launches take the same kernel variant go out as one grid (group = blockIdx.z); anything else falls back to the
+// per-group entry points in order.
+extern "C" int spv_dec_tables_grouped(const spv_dec_group* g, int32_t n, void* stream) {
+  if (!g || n <= 0) return fail(SPV_ERR_ARG, "spv_dec_tables_grouped: bad arguments%s");
+  int i = 0;
+  for (; i + 1 < n; i += 2) {
+    const spv_dec_group &a = g[i], &b = g[i + 1];
+    if (!a.px_r || !b.px_r || !a.p.gene_tab || !b.p.gene_tab || !a.p.cnt_tab || !b.p.cnt_tab || a.p.G <= 0 || b.p.G <= 0 || a.p.Gp < a.p.G || b.p.Gp < b.p.G)
+      return fail(SPV_ERR_ARG, "spv_dec_tables_grouped: bad arguments%s");
+    const NbTabArgs a0{a.px_r, a.p.G, a.p.Gp, (float4*)a.p.gene_tab, (float2*)a.p.cnt_tab}, a1{b.px_r, b.p.G, b.p.Gp, (float4*)b.p.gene_tab, (float2*)b.p.cnt_tab};
+    const int gp = a.p.Gp > b.p.Gp ? a.p.Gp : b.p.Gp;
+    hipLaunchKernelGGL(nb_tables_pair_kernel, dim3((gp + 255) / 256, NB_CMAX, 2), dim3(256), 0, (hipStream_t)stream, a0, a1);
+    if (hipGetLastError() != hipSuccess) return launch_status("spv_dec_tables_grouped");
+  }
+  for (; i < n; ++i) {
+    const int rc = spv_dec_tables(g[i].px_r, g[i].p.G, g[i].p.Gp, const_cast<void*>(g[i].p.gene_tab), const_cast<void*>(g[i].p.cnt_tab), stream);
+    if (rc != SPV_OK) return rc;
+  }
+  return SPV_OK;
+}
+
+static int lse_prepare(const spv_dec_params* q, const float* library, DecParams& p) {
   int rc = to_dec(q, p);
   if (rc != SPV_OK) return rc;
   if (!library || !p.part_max_p || !p.part_sum_p || !p.part_max_s || !p.part_sum_s || !p.lse_p || !p.lse_s || !p.a_p || !p.a_s)
     return fail(SPV_ERR_ARG, "spv_dec_lse: null pointer%s");
+  return SPV_OK;
+}
+extern "C" int spv_dec_lse(const spv_dec_params* q, const float* library, void* stream) {
+  DecParams p;
+  int rc = lse_prepare(q, library, p);
+  if (rc != SPV_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(dec_lse_kernel, dim3(p.Bp / DEC_CELLS_PER_WG, p.gene_splits), dim3(256), 0, s, p);
   hipLaunchKernelGGL(dec_lse_combine_kernel, dim3((p.Bp + 63) / 64), dim3(256), 0, s, p.part_max_p, p.part_sum_p,
                      p.part_max_s, p.part_sum_s, p.gene_splits, p.Bp, p.B, library, (float*)p.lse_p, (float*)p.lse_s,
                      (float*)p.a_p, (float*)p.a_s);
   return launch_status("spv_dec_lse");
+}
+extern "C" int spv_dec_lse_grouped(const spv_dec_group* g, int32_t n, void* stream) {
+  if (!g || n <= 0) return fail(SPV_ERR_ARG, "spv_dec_lse_grouped: bad arguments%s");
+  hipStream_t s = (hipStream_t)stream;
+  int i = 0;
+  for (; i + 1 < n; i += 2) {
+    DecParams p0, p1;
+    int rc = lse_prepare(&g[i].p, g[i].library, p0);
+    if (rc != SPV_OK) return rc;
+    rc = lse_prepare(&g[i + 1].p, g[i + 1].library, p1);
+    if (rc != SPV_OK) return rc;
+    const int bp = p0.Bp > p1.Bp ? p0.Bp : p1.Bp, gs = p0.gene_splits > p1.gene_splits ? p0.gene_splits : p1.gene_splits;
+    hipLaunchKernelGGL(dec_lse_pair_kernel, dim3(bp / DEC_CELLS_PER_WG, gs, 2), dim3(256), 0, s, p0, p1);
+    const LseCombArgs c0{p0.part_max_p, p0.part_sum_p, p0.part_max_s, p0.part_sum_s, p0.gene_splits, p0.Bp, p0.B, g[i].library, (float*)p0.lse_p, (float*)p0.lse_s, (float*)p0.a_p, (float*)p0.a_s};
+    const LseCombArgs c1{p1.part_max_p, p1.part_sum_p, p1.part_max_s, p1.part_sum_s, p1.gene_splits, p1.Bp, p1.B, g[i + 1].library, (float*)p1.lse_p, (float*)p1.lse_s, (float*)p1.a_p, (float*)p1.a_s};
+    hipLaunchKernelGGL(dec_lse_combine_pair_kernel, dim3((bp + 63) / 64, 1, 2), dim3(256), 0, s, c0, c1);
+    if (hipGetLastError() != hipSuccess) return launch_status("spv_dec_lse_grouped");
+  }
+  for (; i < n; ++i) {
+    const int rc = spv_dec_lse(&g[i].p, g[i].library, stream);
+    if (rc != SPV_OK) return rc;
+  }
+  return SPV_OK;
 }
 
 template <bool TRAIN, typename GT, int CM>
@@ -523,8 +615,7 @@ static void nb_launch(const DecParams& p, hipStream_t s) {
   else nb_launch_mode<TRAIN, GT, CNT_U16_ANY>(p, s);
 }
 
-extern "C" int spv_dec_nb_fwd(const spv_dec_params* q, int32_t train, void* stream) {
-  DecParams p;
+static int nb_prepare(const spv_dec_params* q, int32_t train, DecParams& p) {
   int rc = to_dec(q, p);
   if (rc != SPV_OK) return rc;
   if (!p.X || !p.logits || !p.gene_tab || !p.cnt_tab || !p.a_p || !p.a_s || !p.w_row || !p.rec_part)
@@ -535,6 +626,12 @@ extern "C" int spv_dec_nb_fwd(const spv_dec_params* q, int32_t train, void* stre
     return fail(SPV_ERR_ARG, "spv_dec_nb_fwd: nb_genes_per_split must be a multiple of 32, at most 160, and the splits must cover G%s");
   if (train && (!p.dL || !p.tP || !p.tS || !p.tp_part || !p.ts_part || !p.dtheta_part))
     return fail(SPV_ERR_ARG, "spv_dec_nb_fwd: training outputs missing%s");
+  return SPV_OK;
+}
+extern "C" int spv_dec_nb_fwd(const spv_dec_params* q, int32_t train, void* stream) {
+  DecParams p;
+  int rc = nb_prepare(q, train, p);
+  if (rc != SPV_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (train) {
     if (p.grads_f32) nb_launch<true, split_t>(p, s);
@@ -543,6 +640,51 @@ extern "C" int spv_dec_nb_fwd(const spv_dec_params* q, int32_t train, void* stre
     nb_launch<false, bf16_t>(p, s);
   }
   return launch_status("spv_dec_nb_fwd");
+}
+static int nb_count_mode(const DecParams& p) {
+  if (!p.count_is_u16) return CNT_F32;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(p.X) & 7) == 0) && (p.ldx % 4 == 0) && (p.col_off % 4 == 0);
+  return aligned ? CNT_U16_ALIGNED : CNT_U16_ANY;
+}
+template <bool TRAIN, typename GT, int CM>
+static void nb_launch_pair_mode(const DecParams& p0, const DecParams& p1, hipStream_t s) {
+  auto gx = [](const DecParams& p) { return ((p.Bp + NB_CELLS_PER_WG - 1) / NB_CELLS_PER_WG + p.nb_cell_tiles - 1) / p.nb_cell_tiles; };
+  dim3 grid(gx(p0) > gx(p1) ? gx(p0) : gx(p1), p0.nb_splits > p1.nb_splits ? p0.nb_splits : p1.nb_splits, 2);
+  if (p0.logits_f32) hipLaunchKernelGGL((dec_nb_pair_kernel<TRAIN, GT, float, CM>), grid, dim3(256), 0, s, p0, p1);
+  else hipLaunchKernelGGL((dec_nb_pair_kernel<TRAIN, GT, _Float16, CM>), grid, dim3(256), 0, s, p0, p1);
+}
+template <bool TRAIN, typename GT>
+static void nb_launch_pair(const DecParams& p0, const DecParams& p1, int cm, hipStream_t s) {
+  if (cm == CNT_F32) nb_launch_pair_mode<TRAIN, GT, CNT_F32>(p0, p1, s);
+  else if (cm == CNT_U16_ALIGNED) nb_launch_pair_mode<TRAIN, GT, CNT_U16_ALIGNED>(p0, p1, s);
+  else nb_launch_pair_mode<TRAIN, GT, CNT_U16_ANY>(p0, p1, s);
+}
+extern "C" int spv_dec_nb_fwd_grouped(const spv_dec_group* g, int32_t n, int32_t train, void* stream) {
+  if (!g || n <= 0) return fail(SPV_ERR_ARG, "spv_dec_nb_fwd_grouped: bad arguments%s");
+  hipStream_t s = (hipStream_t)stream;
+  int i = 0;
+  for (; i + 1 < n; i += 2) {
+    DecParams p0, p1;
+    int rc = nb_prepare(&g[i].p, train, p0);
+    if (rc != SPV_OK) return rc;
+    rc = nb_prepare(&g[i + 1].p, train, p1);
+    if (rc != SPV_OK) return rc;
+    // one grid needs one kernel variant: count storage, logits type and gradient word type of both groups must agree
+    if (nb_count_mode(p0) != nb_count_mode(p1) || p0.logits_f32 != p1.logits_f32 || p0.grads_f32 != p1.grads_f32) break;
+    const int cm = nb_count_mode(p0);
+    if (train) {
+      if (p0.grads_f32) nb_launch_pair<true, split_t>(p0, p1, cm, s);
+      else nb_launch_pair<true, bf16_t>(p0, p1, cm, s);
+    } else {
+      nb_launch_pair<false, bf16_t>(p0, p1, cm, s);
+    }
+    if (hipGetLastError() != hipSuccess) return launch_status("spv_dec_nb_fwd_grouped");
+  }
+  for (; i < n; ++i) {
+    const int rc = spv_dec_nb_fwd(&g[i].p, train, stream);
+    if (rc != SPV_OK) return rc;
+  }
+  return SPV_OK;
 }
 
 extern "C" int spv_dec_logits(const uint16_t* Am_hi, const uint16_t* Am_lo, const uint16_t* Wm_hi, const uint16_t* Wm_lo,
@@ -572,6 +714,33 @@ extern "C" int spv_dec_logits(const uint16_t* Am_hi, const uint16_t* Am_lo, cons
   else if (Gp % 256 == 0) launch_gemm<GemmCfg<256, 128, 2, 2, false, false, SRC_PLAIN, SRC_PLAIN, unsigned short, 1, 32, 2, 2>>(p, 1, s);  // 128 x 64 wave tiles: 25 % less LDS traffic per MFMA
   else launch_gemm<GemmCfg<128, 128, 2, 2, false, false, SRC_PLAIN, SRC_PLAIN, unsigned short, 1, 32, 4>>(p, 1, s);
   return launch_status("spv_dec_logits");
+}
+
+static bool logits_dma_ok(const spv_dec_group& a) {
+  static const int logits_dma = getenv("SPV_LOGITS_DMA") ? atoi(getenv("SPV_LOGITS_DMA")) : 1;
+  return logits_dma && a.Am_hi && a.Wm_hi && a.p.logits && a.nsplit == 1 && !a.p.logits_f32 && a.K > 0 && (a.K % 32) == 0 && a.p.Bp > 0 && a.p.Gp > 0 &&
+         a.p.Gp % DL_BM == 0 && a.p.Bp % DL_BN == 0 && ((reinterpret_cast<uintptr_t>(a.Am_hi) | reinterpret_cast<uintptr_t>(a.Wm_hi)) & 15) == 0;
+}
+extern "C" int spv_dec_logits_grouped(const spv_dec_group* g, int32_t n, void* stream) {
+  if (!g || n <= 0) return fail(SPV_ERR_ARG, "spv_dec_logits_grouped: bad arguments%s");
+  int i = 0;
+  for (; i + 1 < n; i += 2) {
+    const spv_dec_group &a = g[i], &b = g[i + 1];
+    if (!(logits_dma_ok(a) && logits_dma_ok(b))) break;
+    static bool raised = false;
+    if (!raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_logits_dma_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DL_LDS_BYTES); raised = true; }
+    const LogitsArgs a0{(const bf16_t*)a.Wm_hi, (const bf16_t*)a.Am_hi, a.K, a.p.Gp / 32, a.p.Bp, (_Float16*)const_cast<void*>(a.p.logits)};
+    const LogitsArgs a1{(const bf16_t*)b.Wm_hi, (const bf16_t*)b.Am_hi, b.K, b.p.Gp / 32, b.p.Bp, (_Float16*)const_cast<void*>(b.p.logits)};
+    const int gp = a.p.Gp > b.p.Gp ? a.p.Gp : b.p.Gp, bp = a.p.Bp > b.p.Bp ? a.p.Bp : b.p.Bp;
+    hipLaunchKernelGGL(dec_logits_dma_pair_kernel, dim3(gp / DL_BM, bp / DL_BN, 2), dim3(512), DL_LDS_BYTES, (hipStream_t)stream, a0, a1);
+    if (hipGetLastError() != hipSuccess) return launch_status("spv_dec_logits_grouped");
+  }
+  for (; i < n; ++i) {
+    const spv_dec_group& a = g[i];
+    const int rc = spv_dec_logits(a.Am_hi, a.Am_lo, a.Wm_hi, a.Wm_lo, a.K, a.p.Bp, a.p.Gp, a.nsplit, const_cast<void*>(a.p.logits), a.p.logits_f32, stream);
+    if (rc != SPV_OK) return rc;
+  }
+  return SPV_OK;
 }
 
 extern "C" int spv_dec_materialize(const spv_dec_params* q, float* scale_p, float* scale_s, float* rate_p, float* rate_s,
@@ -620,16 +789,21 @@ extern "C" int spv_dec_softmax_bwd(const spv_dec_params* q, const float* Tp, con
 // two rate heads (dz_part, as spv_dec_softmax_bwd) AND the two regressor weight gradients as per-workgroup-row partial slabs
 // dw_part [Bp / 128][Gp][48] = [d W'_p (16 columns) | d W'_s (32 columns)] (sum the first G rows with spv_reduce_slabs).  t_P / t_S are left uncorrected: nothing reads
 // them afterwards.  Replaces spv_dec_softmax_bwd + spv_dec_heads_wgrad in bf16 mode.
-extern "C" int spv_dec_heads_bwd(const spv_dec_params* q, const float* Tp, const float* Ts, float* dz_part, float* dw_part, void* stream) {
-  DecParams p;
+static int heads_bwd_prepare(const spv_dec_params* q, const float* Tp, const float* Ts, const float* dz_part, const float* dw_part, DecParams& p) {
   int rc = to_dec(q, p);
   if (rc != SPV_OK) return rc;
   if (!Tp || !Ts || !p.tP || !p.tS || !p.lse_p || !p.lse_s || !dz_part || !dw_part) return fail(SPV_ERR_ARG, "spv_dec_heads_bwd: null pointer%s");
   if (p.n_gene_tiles != p.Gp / 32) return fail(SPV_ERR_ARG, "spv_dec_heads_bwd: n_gene_tiles must be Gp / 32%s");
   if (p.Bp % DEC_CELLS_PER_WG) return fail(SPV_ERR_ARG, "spv_dec_heads_bwd: Bp must be a multiple of 128%s");
+  if (p.grads_f32 && (!p.Wps_lo || !p.Aps_lo)) return fail(SPV_ERR_ARG, "spv_dec_heads_bwd: split gradient words need the lo planes of the operand images%s");
+  return SPV_OK;
+}
+extern "C" int spv_dec_heads_bwd(const spv_dec_params* q, const float* Tp, const float* Ts, float* dz_part, float* dw_part, void* stream) {
+  DecParams p;
+  int rc = heads_bwd_prepare(q, Tp, Ts, dz_part, dw_part, p);
+  if (rc != SPV_OK) return rc;
   dim3 grid(p.Bp / DEC_CELLS_PER_WG, p.gene_splits);
   if (p.grads_f32) {   // hi / lo planes of split-bf16 gradient words ("fp32" mode)
-    if (!p.Wps_lo || !p.Aps_lo) return fail(SPV_ERR_ARG, "spv_dec_heads_bwd: split gradient words need the lo planes of the operand images%s");
     static bool raised = false;
     if (!raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_heads_bwd_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, HBS_LDS_BYTES); raised = true; }
     hipLaunchKernelGGL(dec_heads_bwd_split_kernel, grid, dim3(256), HBS_LDS_BYTES, (hipStream_t)stream, p, Tp, Ts, dz_part, dw_part);
@@ -639,6 +813,28 @@ extern "C" int spv_dec_heads_bwd(const spv_dec_params* q, const float* Tp, const
   // the splits to cover; rows in [round_up(G, 32), Gp) are never written and never read)
   hipLaunchKernelGGL(dec_heads_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, p, Tp, Ts, dz_part, dw_part);
   return launch_status("spv_dec_heads_bwd");
+}
+extern "C" int spv_dec_heads_bwd_grouped(const spv_dec_group* g, int32_t n, void* stream) {
+  if (!g || n <= 0) return fail(SPV_ERR_ARG, "spv_dec_heads_bwd_grouped: bad arguments%s");
+  int i = 0;
+  for (; i + 1 < n; i += 2) {
+    HeadsBwdArgs a0, a1;
+    int rc = heads_bwd_prepare(&g[i].p, g[i].Tp, g[i].Ts, g[i].dz_part, g[i].dw_part, a0.p);
+    if (rc != SPV_OK) return rc;
+    rc = heads_bwd_prepare(&g[i + 1].p, g[i + 1].Tp, g[i + 1].Ts, g[i + 1].dz_part, g[i + 1].dw_part, a1.p);
+    if (rc != SPV_OK) return rc;
+    if (a0.p.grads_f32 || a1.p.grads_f32) break;   // (the split-word kernel takes a whole CU's LDS: no pair form)
+    a0.Tp = g[i].Tp; a0.Ts = g[i].Ts; a0.dz_part = g[i].dz_part; a0.dw_part = g[i].dw_part;
+    a1.Tp = g[i + 1].Tp; a1.Ts = g[i + 1].Ts; a1.dz_part = g[i + 1].dz_part; a1.dw_part = g[i + 1].dw_part;
+    const int bp = a0.p.Bp > a1.p.Bp ? a0.p.Bp : a1.p.Bp, gs = a0.p.gene_splits > a1.p.gene_splits ? a0.p.gene_splits : a1.p.gene_splits;
+    hipLaunchKernelGGL(dec_heads_bwd_pair_kernel, dim3(bp / DEC_CELLS_PER_WG, gs, 2), dim3(256), 0, (hipStream_t)stream, a0, a1);
+    if (hipGetLastError() != hipSuccess) return launch_status("spv_dec_heads_bwd_grouped");
+  }
+  for (; i < n; ++i) {
+    const int rc = spv_dec_heads_bwd(&g[i].p, g[i].Tp, g[i].Ts, g[i].dz_part, g[i].dw_part, stream);
+    if (rc != SPV_OK) return rc;
+  }
+  return SPV_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -224,8 +224,7 @@ constexpr int D4_A_BYTES = DG_BM * D4_BK * 2, D4_B_BYTES = D4_BK * DG_B_ROW, D4_
 constexpr int D4_LDS_BYTES = D4_NBUF * D4_STAGE;   // 114 688 B
 
 template <bool A_CELLS_ON_K>
-__global__ __launch_bounds__(512) void dec_gemm320_dma4_kernel(GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char d4_smem[];
+__device__ __forceinline__ void dec_gemm320_dma4_body(const GemmParams& p, unsigned char* d4_smem) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = uniform_wave_id();
   const int wm = wave >> 1, wn = wave & 1;
@@ -340,6 +339,19 @@ __global__ __launch_bounds__(512) void dec_gemm320_dma4_kernel(GemmParams p) {
     }
   }
   if (p.fix_cnt != nullptr) splitk_fixup_tile(p, mtile, m0, reinterpret_cast<volatile unsigned*>(d4_smem));   // (kernel-uniform; the stages are dead)
+}
+template <bool A_CELLS_ON_K>
+__global__ __launch_bounds__(512) void dec_gemm320_dma4_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char d4_smem_[];
+  dec_gemm320_dma4_body<A_CELLS_ON_K>(p, d4_smem_);
+}
+// both groups' GEMMs in one grid: group = blockIdx.y (the grid is 1-D per group: row tile x split)
+template <bool A_CELLS_ON_K>
+__global__ __launch_bounds__(512) void dec_gemm320_dma4_pair_kernel(GemmParams p0, GemmParams p1) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char d4_smem_[];
+  const GemmParams p = blockIdx.y ? p1 : p0;
+  if ((int)blockIdx.x >= (p.M + DG_BM - 1) / DG_BM * p.c_split_row) return;   // (workgroup-uniform)
+  dec_gemm320_dma4_body<A_CELLS_ON_K>(p, d4_smem_);
 }
 
 // ---- the same two GEMMs on split-bf16 operands ("fp32" mode: x = hi + lo, x*y ~ hi*hi + hi*lo + lo*hi, three MFMAs) -----------------------
@@ -589,8 +601,7 @@ constexpr int DL_A_BYTES = DL_BM * DL_BK * 2, DL_B_BYTES = DL_BN * DL_BK * 2, DL
 constexpr int DL_LDS_BYTES = 2 * DL_STAGE;
 
 // Wm bf16 [Gp][K], Am bf16 [Bp][K] (K % 32 == 0, rows zero padded), T = Gp / 32, out f16 tiles.  grid = (Gp / 256, Bp / 128), 512 threads.
-__global__ __launch_bounds__(512, 2) void dec_logits_dma_kernel(const bf16_t* Wm, const bf16_t* Am, int K, int T, _Float16* out) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char dl_smem[];
+__device__ __forceinline__ void dec_logits_dma_body(const bf16_t* Wm, const bf16_t* Am, int K, int T, _Float16* out, unsigned char* dl_smem) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = uniform_wave_id();
   const int wm = wave >> 1, wn = wave & 1;
@@ -655,6 +666,17 @@ __global__ __launch_bounds__(512, 2) void dec_logits_dma_kernel(const bf16_t* Wm
         *reinterpret_cast<h4v*>(o + qq * 256) = h4v{(_Float16)acc[i][j][q], (_Float16)acc[i][j][q + 1], (_Float16)acc[i][j][q + 2], (_Float16)acc[i][j][q + 3]};
       }
     }
+}
+__global__ __launch_bounds__(512, 2) void dec_logits_dma_kernel(const bf16_t* Wm, const bf16_t* Am, int K, int T, _Float16* out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dl_smem_[];
+  dec_logits_dma_body(Wm, Am, K, T, out, dl_smem_);
+}
+struct LogitsArgs { const bf16_t* Wm; const bf16_t* Am; int K, T, Bp; _Float16* out; };
+__global__ __launch_bounds__(512, 2) void dec_logits_dma_pair_kernel(LogitsArgs a0, LogitsArgs a1) {   // group = blockIdx.z
+  extern __shared__ __attribute__((aligned(16))) unsigned char dl_smem_[];
+  const LogitsArgs a = blockIdx.z ? a1 : a0;
+  if ((int)blockIdx.x * DL_BM >= a.T * 32 || (int)blockIdx.y * DL_BN >= a.Bp) return;   // (workgroup-uniform)
+  dec_logits_dma_body(a.Wm, a.Am, a.K, a.T, a.out, dl_smem_);
 }
 
 }  // namespace spv

@@ -61,7 +61,7 @@ struct DecParams {
 };
 
 // ---- per-gene tables ----------------------------------------------------------
-__global__ void nb_tables_kernel(const float* px_r, int G, int Gp, float4* gene_tab, float2* cnt_tab) {
+__device__ __forceinline__ void nb_tables_body(const float* px_r, int G, int Gp, float4* gene_tab, float2* cnt_tab) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   const int c = blockIdx.y;
   if (g >= Gp) return;
@@ -80,6 +80,14 @@ __global__ void nb_tables_kernel(const float* px_r, int G, int Gp, float4* gene_
   const float x = log1p_count((float)c);
   const LgammaDigamma t = lgamma_digamma(theta), xt = lgamma_digamma(x + theta), x1 = lgamma_digamma(x + 1.0f);
   cnt_tab[(long)c * Gp + g] = make_float2(xt.lg - t.lg - x1.lg, xt.dg - t.dg);
+}
+__global__ void nb_tables_kernel(const float* px_r, int G, int Gp, float4* gene_tab, float2* cnt_tab) { nb_tables_body(px_r, G, Gp, gene_tab, cnt_tab); }
+// "pair" launches (here and below): both groups of a step in ONE grid, group = blockIdx.z -- workgroups outside a group's own grid extent
+// leave at once, the others run the single-group body unchanged (same blockIdx.x / .y, same bits)
+struct NbTabArgs { const float* px_r; int G, Gp; float4* gene_tab; float2* cnt_tab; };
+__global__ void nb_tables_pair_kernel(NbTabArgs a0, NbTabArgs a1) {
+  const NbTabArgs a = blockIdx.z ? a1 : a0;
+  nb_tables_body(a.px_r, a.G, a.Gp, a.gene_tab, a.cnt_tab);   // (its own g >= Gp test covers the x extent)
 }
 
 // Count words of 4 consecutive genes g..g+3 (g % 4 == 0) of one cell, kept undecoded so that the load
@@ -150,7 +158,7 @@ __device__ __forceinline__ void load_ps_w(const DecParams& p, int g0, int lane, 
 
 constexpr float NB_LOG2E_C = 1.4426950408889634f;
 // ---- pass 1: per-cell log-sum-exp over genes of y_p and y_s (softmax denominators) ------------
-__global__ __launch_bounds__(256) void dec_lse_kernel(DecParams p) {
+__device__ __forceinline__ void dec_lse_body(const DecParams& p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
   const int cell0 = blockIdx.x * DEC_CELLS_PER_WG + 32 * wave;
   const int split = blockIdx.y;
@@ -219,6 +227,12 @@ __global__ __launch_bounds__(256) void dec_lse_kernel(DecParams p) {
     p.part_max_s[o] = ms; p.part_sum_s[o] = ss;
   }
 }
+__global__ __launch_bounds__(256) void dec_lse_kernel(DecParams p) { dec_lse_body(p); }
+__global__ __launch_bounds__(256) void dec_lse_pair_kernel(DecParams p0, DecParams p1) {
+  const DecParams p = blockIdx.z ? p1 : p0;
+  if ((int)blockIdx.x * DEC_CELLS_PER_WG >= p.Bp || (int)blockIdx.y >= p.gene_splits) return;   // (workgroup-uniform)
+  dec_lse_body(p);
+}
 
 // lse_k[b] = log sum_splits ...;  a_k[b] = library[b] - lse_k[b]   (log of exp(library) * softmax)
 // block = 64 cells x 4 split groups: group y merges splits y, y+4, ... in order (online log-sum-exp), the four group
@@ -230,9 +244,8 @@ __device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2
   s = s * __expf(m - base) + s2 * __expf(m2 - base);
   m = mn;
 }
-__global__ __launch_bounds__(256) void dec_lse_combine_kernel(const float* pmp, const float* psp, const float* pms, const float* pss, int splits,
-                                                              int Bp, int B, const float* library, float* lse_p, float* lse_s, float* a_p,
-                                                              float* a_s) {
+__device__ __forceinline__ void dec_lse_combine_body(const float* pmp, const float* psp, const float* pms, const float* pss, int splits,
+                                                     int Bp, int B, const float* library, float* lse_p, float* lse_s, float* a_p, float* a_s) {
   __shared__ float s_m[2][4][64], s_s[2][4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int b = blockIdx.x * 64 + tx;
@@ -257,6 +270,17 @@ __global__ __launch_bounds__(256) void dec_lse_combine_kernel(const float* pmp, 
     lse_p[b] = lp; lse_s[b] = ls;
     a_p[b] = lib - lp; a_s[b] = lib - ls;
   }
+}
+__global__ __launch_bounds__(256) void dec_lse_combine_kernel(const float* pmp, const float* psp, const float* pms, const float* pss, int splits,
+                                                              int Bp, int B, const float* library, float* lse_p, float* lse_s, float* a_p,
+                                                              float* a_s) {
+  dec_lse_combine_body(pmp, psp, pms, pss, splits, Bp, B, library, lse_p, lse_s, a_p, a_s);
+}
+struct LseCombArgs { const float *pmp, *psp, *pms, *pss; int splits, Bp, B; const float* library; float *lse_p, *lse_s, *a_p, *a_s; };
+__global__ __launch_bounds__(256) void dec_lse_combine_pair_kernel(LseCombArgs a0, LseCombArgs a1) {
+  const LseCombArgs a = blockIdx.z ? a1 : a0;
+  if ((int)blockIdx.x * 64 >= a.Bp) return;
+  dec_lse_combine_body(a.pmp, a.psp, a.pms, a.pss, a.splits, a.Bp, a.B, a.library, a.lse_p, a.lse_s, a.a_p, a.a_s);
 }
 
 // Counts >= NB_CMAX fall outside the (count, gene) table: the hot loop looks them up clamped to the
@@ -394,7 +418,7 @@ __device__ unsigned long long* g_nb_stamps;
 #define SPV_NB_OCC 3   // waves per SIMD the likelihood kernel's register budget is sized for (tools/probes/nb_bench.hip sweeps it)
 #endif
 template <bool TRAIN, typename GT, typename LT, int CM>
-__global__ __launch_bounds__(256, SPV_NB_OCC) void dec_nb_kernel(DecParams p) {
+__device__ __forceinline__ void dec_nb_body(const DecParams& p) {
   __shared__ __attribute__((aligned(16))) bf16_t s_whi[NB_GSPL_MAX * NB_WPITCH], s_wlo[NB_GSPL_MAX * NB_WPITCH];
   __shared__ float4 s_gt[NB_GSPL_MAX];
   __shared__ float s_dth[TRAIN ? 4 : 1][NB_GSPL_MAX];
@@ -628,6 +652,15 @@ __global__ __launch_bounds__(256, SPV_NB_OCC) void dec_nb_kernel(DecParams p) {
       p.dtheta_part[(long)blockIdx.x * p.Gp + gbeg + i] = ((s_dth[0][i] + s_dth[1][i]) + s_dth[2][i]) + s_dth[3][i];
   }
   NB_STAMP(5);
+}
+template <bool TRAIN, typename GT, typename LT, int CM>
+__global__ __launch_bounds__(256, SPV_NB_OCC) void dec_nb_kernel(DecParams p) { dec_nb_body<TRAIN, GT, LT, CM>(p); }
+template <bool TRAIN, typename GT, typename LT, int CM>
+__global__ __launch_bounds__(256, SPV_NB_OCC) void dec_nb_pair_kernel(DecParams p0, DecParams p1) {
+  const DecParams p = blockIdx.z ? p1 : p0;
+  const int ctiles = (p.Bp + NB_CELLS_PER_WG - 1) / NB_CELLS_PER_WG;
+  if ((int)blockIdx.x >= (ctiles + p.nb_cell_tiles - 1) / p.nb_cell_tiles || (int)blockIdx.y >= p.nb_splits) return;   // (workgroup-uniform)
+  dec_nb_body<TRAIN, GT, LT, CM>(p);
 }
 
 // ---- materialising path: the decoder outputs the reference's generative() returns ---------------------------------
@@ -997,7 +1030,7 @@ __global__ __launch_bounds__(256, 2) void dec_softmax_bwd_kernel(DecParams p, co
 // 192 threads: one load per tile, no drain.  Per tile and wave the vector-memory stream is: 6 fragment loads, 1 staging load, 4 tile
 // loads (two tiles ahead), 8 stores -- in that order, always.
 constexpr int HB_WT_PITCH = 36;   // bf16 per row of a staged W'^T tile [48][32 | 4 pad]: 18 dwords, 32 rows on 32 distinct even banks
-__global__ __launch_bounds__(256, 2) void dec_heads_bwd_kernel(DecParams p, const float* Tp, const float* Ts, float* dz_part, float* dw_part) {
+__device__ __forceinline__ void dec_heads_bwd_body(const DecParams& p, const float* Tp, const float* Ts, float* dz_part, float* dw_part) {
   __shared__ __attribute__((aligned(16))) bf16_t s_wT[2 * DEC_KPS * HB_WT_PITCH];                 // [tile parity][k][gene of the tile]
   __shared__ __attribute__((aligned(16))) bf16_t s_tile[2 * 2 * SMB_TILE_ELEMS];                  // [tile parity][head][cell][gene], chunk-swizzled
   __shared__ __attribute__((aligned(16))) bf16_t s_zh[2 * DEC_CELLS_PER_WG * 32];                 // [head][cell][32 columns] of the latent image (private: 16 + zeros)
@@ -1183,6 +1216,15 @@ __global__ __launch_bounds__(256, 2) void dec_heads_bwd_kernel(DecParams p, cons
     if (k < DEC_KP) out[k] = accP[q];
     out[DEC_KP + k] = accS[q];
   }
+}
+__global__ __launch_bounds__(256, 2) void dec_heads_bwd_kernel(DecParams p, const float* Tp, const float* Ts, float* dz_part, float* dw_part) {
+  dec_heads_bwd_body(p, Tp, Ts, dz_part, dw_part);
+}
+struct HeadsBwdArgs { DecParams p; const float *Tp, *Ts; float *dz_part, *dw_part; };
+__global__ __launch_bounds__(256, 2) void dec_heads_bwd_pair_kernel(HeadsBwdArgs a0, HeadsBwdArgs a1) {
+  const HeadsBwdArgs a = blockIdx.z ? a1 : a0;
+  if ((int)blockIdx.x * DEC_CELLS_PER_WG >= a.p.Bp || (int)blockIdx.y >= a.p.gene_splits) return;   // (workgroup-uniform)
+  dec_heads_bwd_body(a.p, a.Tp, a.Ts, a.dz_part, a.dw_part);
 }
 
 

@@ -17,7 +17,7 @@ from typing import List, Sequence
 import torch
 
 from . import _abi
-from ._abi import (DEC_CELLS_PER_WG, DEC_KP, DEC_KPS, DEC_KS, NB_CMAX, TRUNK_KMAX, SpvBnBatch, SpvDecParams, SpvFoldBatch, SpvReduceBatch, SpvTrunkBatch, SpvZsplitArgs,
+from ._abi import (DEC_CELLS_PER_WG, DEC_KP, DEC_KPS, DEC_KS, NB_CMAX, TRUNK_KMAX, SpvBnBatch, SpvDecGroup, SpvDecParams, SpvFoldBatch, SpvGemmArgs, SpvReduceBatch, SpvTrunkBatch, SpvZsplitArgs,
                    ptr, round_up, stream_ptr)
 from .nn_ops import _add_lin, _fptr, _lin_batch, _wgrad, grad_out
 from . import ops as _ops
@@ -171,6 +171,19 @@ class _DecoderBwd:
         return _gemm_slabs(True, dL_hi, dL_lo, self.Gp, Am_hi, Am_lo, KMP, self.G, KMP, self.Bp, self.nsplit,
                            self.csp_m, self.wsg, "dec_dWm", a_tiles=self.T)
 
+    def gemm_args(self, which: str, a: "SpvGemmArgs") -> torch.Tensor:
+        """fill ``a`` with the spv_gemm_bf16 arguments of gemm_d ("d") / gemm_a ("a") for spv_gemm_bf16_grouped; returns the slab tensor"""
+        (dL_hi, dL_lo) = self._operand("dL")
+        if which == "d":
+            (B_hi, B_lo), kmaj, M, K, splits, name = self.S["Wm"], 0, self.B, self.G, self.ksp_m, "dec_dAm"
+        else:
+            (B_hi, B_lo), kmaj, M, K, splits, name = self.S["Am"], 1, self.G, self.Bp, self.csp_m, "dec_dWm"
+        out = self.wsg.get(name, (splits, M, KMP), torch.float32)
+        a.a_kmajor, a.A_hi, a.A_lo, a.lda = kmaj, ptr(dL_hi), ptr(dL_lo), self.Gp
+        a.B_hi, a.B_lo, a.ldb, a.C, a.ldc = ptr(B_hi), ptr(B_lo) if B_lo is not None else None, KMP, ptr(out), KMP
+        a.M, a.N, a.K, a.nsplit, a.splits, a.a_tiles, a.slab_stride = M, KMP, K, self.nsplit, splits, self.T, M * KMP
+        return out
+
     def gemm_ef(self):
         (tP_hi, tP_lo), (tS_hi, tS_lo) = self._operand("tP"), self._operand("tS")
         e = _gemm_slabs(False, tP_hi, tP_lo, self.Gp, self.Wps_g[0], self.Wps_g[1], DEC_KPS, self.B, DEC_KP, self.G, self.nsplit, self.ksp_n, self.wsg, "dec_dAp", a_tiles=self.T)
@@ -261,6 +274,7 @@ class DecoderFused(torch.autograd.Function):
                 q.img_hi, q.img_lo, q.ld_img, q.col_off, q.slot = ptr(Wps[g][0]), ptr(Wps[g][1]), DEC_KPS, off, slot
                 q.G, q.Gp, q.K = Gs[g], Gps[g], n
                 fb.nprob += 1
+        pair = _ops.dec_pair_for(B, NG)   # both groups' per-group launches as one grid per kernel (ops.DEC_PAIR)
         # The fold, the mixture-weight images and the (count, gene) tables depend on nothing the trunk (step 4) computes:
         # they run beside it on a side stream and are joined before the per-group section.
         side = group_streams(dev, 3)[2] if _ops.OVERLAP_SMALL else torch.cuda.current_stream(dev)
@@ -275,9 +289,16 @@ class DecoderFused(torch.autograd.Function):
                     _pack(cont(par[g][10]), Wm_hi, Wm_lo, extra_col=cont(par[g][11]))
                 gene_tab = ws[g].get("dec_gene_tab", (Gps[g], 4), torch.float32)
                 cnt_tab = ws[g].get("dec_cnt_tab", (NB_CMAX, Gps[g], 2), torch.float32)
-                _abi.call("spv_dec_tables", ptr(cont(par[g][12])), Gs[g], Gps[g], ptr(gene_tab), ptr(cnt_tab), stream_ptr())
+                if not pair:
+                    _abi.call("spv_dec_tables", ptr(cont(par[g][12])), Gs[g], Gps[g], ptr(gene_tab), ptr(cnt_tab), stream_ptr())
                 Wm_img.append((Wm_hi, Wm_lo))
                 tabs.append((gene_tab, cnt_tab))
+            if pair:   # one grid for both groups' tables
+                tg = (SpvDecGroup * NG)()
+                px_keep = [cont(par[g][12]) for g in range(NG)]
+                for g in range(NG):
+                    tg[g].px_r, tg[g].p.G, tg[g].p.Gp, tg[g].p.gene_tab, tg[g].p.cnt_tab = ptr(px_keep[g]), Gs[g], Gps[g], ptr(tabs[g][0]), ptr(tabs[g][1])
+                _abi.call("spv_dec_tables_grouped", tg, NG, stream_ptr())
         # ---- 4. mixing trunk: m = relu(BN(zcat Wa^T + ba)) -------------------------------------------
         m = [new(B, n_m) for _ in range(NG)]
         tstat = [new(n_m, 2) for _ in range(NG)]
@@ -333,8 +354,10 @@ class DecoderFused(torch.autograd.Function):
         red.nprob = 0
         if _ops.OVERLAP_SMALL:
             torch.cuda.current_stream(dev).wait_stream(side)
-        streams = group_streams(dev, NG) if _ops.FWD_GROUP_STREAMS else [torch.cuda.current_stream(dev)] * NG
+        streams = group_streams(dev, NG) if (_ops.FWD_GROUP_STREAMS and not pair) else [torch.cuda.current_stream(dev)] * NG
         fork(streams)
+        dgrp = (SpvDecGroup * NG)() if pair else None
+        lib_keep = []
         for g in range(NG):
           with torch.cuda.stream(streams[g]):
               G, Gp, wsg = Gs[g], Gps[g], ws[g]
@@ -347,7 +370,7 @@ class DecoderFused(torch.autograd.Function):
                   _pack(zcat[g][:, n_p:], Aps_hi, Aps_lo, extra_one=True, dst_col_off=DEC_KP, cslot=DEC_KS)
               logits = wsg.get("dec_logits_" + ("f32" if mlo else "f16"), (Bp, Gp), torch.float32 if mlo else torch.float16)
               lse_first = bool(_ops.STAGGER and g % 2 == 1)  # group 1 runs its (VALU-bound) softmax statistics beside group 0's logits GEMM
-              if not lse_first:
+              if not lse_first and not pair:
                   _abi.call("spv_dec_logits", ptr(Am_hi), ptr(Am_lo), ptr(Wm_hi), ptr(Wm_lo), KMP, Bp, Gp, nsplit, ptr(logits), int(mlo), stream_ptr())
               splits, per = _gene_splits(Bp, Gp)
               nbs, nbper = _nb_splits(Gp)
@@ -375,10 +398,16 @@ class DecoderFused(torch.autograd.Function):
                   dtheta_part=ptr(dth), dL=ptr(dL), tP=ptr(tP), tS=ptr(tS), grads_f32=int(grads_f32), nb_splits=nbs, nb_genes_per_split=nbper,
                   nb_cell_tiles=_nb_cell_tiles(Bp, Gp),
               )
-              _abi.call("spv_dec_lse", C.byref(p), ptr(cont(library[g].flatten())), stream_ptr())
-              if lse_first:
-                  _abi.call("spv_dec_logits", ptr(Am_hi), ptr(Am_lo), ptr(Wm_hi), ptr(Wm_lo), KMP, Bp, Gp, nsplit, ptr(logits), int(mlo), stream_ptr())
-              _abi.call("spv_dec_nb_fwd", C.byref(p), int(need_grad), stream_ptr())
+              if pair:
+                  lib_keep.append(cont(library[g].flatten()))
+                  q = dgrp[g]
+                  q.p, q.library = p, ptr(lib_keep[-1])
+                  q.Am_hi, q.Am_lo, q.Wm_hi, q.Wm_lo, q.K, q.nsplit = ptr(Am_hi), ptr(Am_lo), ptr(Wm_hi), ptr(Wm_lo), KMP, nsplit
+              else:
+                  _abi.call("spv_dec_lse", C.byref(p), ptr(cont(library[g].flatten())), stream_ptr())
+                  if lse_first:
+                      _abi.call("spv_dec_logits", ptr(Am_hi), ptr(Am_lo), ptr(Wm_hi), ptr(Wm_lo), KMP, Bp, Gp, nsplit, ptr(logits), int(mlo), stream_ptr())
+                  _abi.call("spv_dec_nb_fwd", C.byref(p), int(need_grad), stream_ptr())
               r = rec[g]
               _add_red(red, nbpart("dec_rec"), nbs, Bp, Bp, 1, B, r, B)
               if need_grad:
@@ -388,6 +417,10 @@ class DecoderFused(torch.autograd.Function):
               if need_grad:
                   saved_g.append(dict(Wm=(Wm_hi, Wm_lo), Am=(Am_hi, Am_lo), Aps=(Aps_hi, Aps_lo), dL=dL, tP=tP, tS=tS, dth=dth, Tp=Tp, Ts=Ts))
         join(streams)
+        if pair:   # logits GEMM, softmax statistics and likelihood of both groups: one grid each
+            _abi.call("spv_dec_logits_grouped", dgrp, NG, stream_ptr())
+            _abi.call("spv_dec_lse_grouped", dgrp, NG, stream_ptr())
+            _abi.call("spv_dec_nb_fwd_grouped", dgrp, NG, int(need_grad), stream_ptr())
         _run_red(red)
         loss, rec_sum, gkl = new(()), new(()), new(B)
         klp = (C.c_void_p * 4)(*[ptr(k) for k in kls], *([None] * (4 - n_kl)))
@@ -449,10 +482,33 @@ class DecoderFused(torch.autograd.Function):
         da_first = int(_ops.DA_FIRST) if (_ops.DEFER_BC and _ops.DEFER_WM and side is not cur and not split_fix and all(st.fused_dz for st in stages)) else 0
         sm_done = None
         wm_late = bool(_ops.wm_late_for(max(Gs), bool(ctx.grads_f32)) and side is not cur)
+        # ops.DEC_PAIR: the default schedule's per-group launches (d A_m GEMMs, one-pass backward, d W_m GEMMs) as one grid per kernel
+        pair = bool(_ops.dec_pair_for(B, NG) and da_first in (0, 1) and not split_fix and _ops.DEFER_BC and all(st.fused_heads and not st.grads_f32 for st in stages))
+
+        def pair_gemm(which):
+            ga = (SpvGemmArgs * NG)()
+            outs = [stages[g].gemm_args(which, ga[g]) for g in range(NG)]
+            _abi.call("spv_gemm_bf16_grouped", ga, NG, stream_ptr())
+            return outs
+
+        def pair_heads_bwd():
+            hg = (SpvDecGroup * NG)()
+            for g in range(NG):
+                st = stages[g]
+                hg[g].p, hg[g].Tp, hg[g].Ts, hg[g].dz_part, hg[g].dw_part = st.P, ptr(st.S["Tp"]), ptr(st.S["Ts"]), ptr(st.dz_part), ptr(st.dw_part)
+            _abi.call("spv_dec_heads_bwd_grouped", hg, NG, stream_ptr())
+
+        if pair:
+            streams = [cur] * NG
+            if not da_first:   # (single stream: the one-pass backward first, as the per-group schedule orders it)
+                pair_heads_bwd()
+            d_slabs = pair_gemm("d")
         if da_first == 2:
             side.wait_stream(cur)
         fork(streams)
         for g in range(NG):
+            if pair:
+                continue
             if da_first:
                 with torch.cuda.stream(streams[g]):
                     d_slabs[g] = stages[g].gemm_d(fix=(g_loss, dAm[g], d_zcat[g], n_m, nt))
@@ -478,7 +534,11 @@ class DecoderFused(torch.autograd.Function):
             side.wait_stream(cur)   # (before the reductions: the side work needs none of them)
         if da_first:
             with torch.cuda.stream(side):
+                if pair:
+                    pair_heads_bwd()
                 for g in range(NG):
+                    if pair:
+                        break
                     stages[g].softmax()
                 sm_done = torch.cuda.Event()
                 sm_done.record(side)
@@ -543,9 +603,10 @@ class DecoderFused(torch.autograd.Function):
                     side.wait_event(after)
                 red3 = SpvReduceBatch()
                 red3.nprob = 0
+                wm_slabs = pair_gemm("a") if pair else None
                 for g in range(NG):
                     st, G = stages[g], Gs[g]
-                    a = st.gemm_a()
+                    a = wm_slabs[g] if pair else st.gemm_a()
                     _add_red(red3, a, st.csp_m, G * KMP, KMP, G, KM - 1, pg[g][10][0], KM - 1, alpha=g_loss)                 # d W_m
                     _add_red(red3, a, st.csp_m, G * KMP, KMP, G, 1, pg[g][11][0], 1, col_off=KM - 1, alpha=g_loss)           # d b_m
                 _run_red(red3)

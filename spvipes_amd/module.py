@@ -448,12 +448,13 @@ class spVIPESmodule(nn.Module):
             if self.training and self.dropout_rate > 0:
                 self._seed_dev.add_(1)
         from . import ops as _ops_mod
+        _ops_mod.set_step_shape(max(self._step_inputs[g][2] for g in groups_), max(self._step_inputs[g][0].G for g in groups_), len(groups_))
         # the label pairing (rank within label, one workgroup per group, 13-14 us at B 4096) depends on the labels alone.  LABEL_PRE 1: on a
         # side stream beside the fc1 GEMMs (measured: no gain -- its two workgroups hold two CUs' LDS, two of the one-per-CU fc1 workgroups
         # wait for them and run as a second round); LABEL_PRE 2: forked BEHIND the fc1 launches, beside the encoder tails, whose kernels leave
         # most of the chip idle, and joined in front of the fusion kernel
         label_pre, pre_stream = None, None
-        label_pre_ok = bool(self.n_groups == 2 and self.use_labels and kwargs.get("labels") is not None and not _ops_mod.SERIAL_STREAMS)
+        label_pre_ok = bool(self.n_groups == 2 and self.use_labels and kwargs.get("labels") is not None and not _ops_mod.serial_streams())
 
         def fork_label_pairing():
             from .nn_ops import label_partners

@@ -121,7 +121,26 @@ def image_token(*tensors) -> Tuple:
 
 
 _SIDE_STREAMS: Dict[Tuple, "torch.cuda.Stream"] = {}
-SERIAL_STREAMS = os.environ.get("SPV_SERIAL_STREAMS", "0") == "1"
+SERIAL_STREAMS = os.environ.get("SPV_SERIAL_STREAMS", "auto") == "1"   # every launch on the caller's stream
+# "Small" steps -- at most SMALL_STEP_ELEMS cells x genes per group and minibatch, two groups -- are launch-bound: every kernel is mostly
+# fixed cost, a stream fork / join costs more than the overlap it buys, and one grid for both groups per decoder kernel (DEC_PAIR below) saves
+# a launch's worth each.  Unless SPV_SERIAL_STREAMS / SPV_DEC_PAIR say otherwise such steps run on ONE stream with pair grids.  Same box,
+# ms/step, pair grids + one stream / shipped before (two streams, per-group launches): G 2000, H 64 (BASELINE configs[0] shape): B 128 0.390 /
+# 0.452, B 512 0.433 / 0.497, B 1024 0.519 / 0.607; G 10 000, H 128: B 128 0.532 / 0.552, B 512 0.625 / 0.620 (the threshold), B 4096
+# (pair grids, two streams) 1.349 / 1.318.  One stream WITHOUT the pair grids is slower than two streams at G 10 000 (0.606 vs 0.552).
+SERIAL_AUTO = os.environ.get("SPV_SERIAL_STREAMS", "auto") == "auto"
+SMALL_STEP_ELEMS = 4_000_000
+_SMALL_STEP = False
+
+
+def set_step_shape(B: int, G_max: int, n_groups: int) -> None:
+    """called by spVIPESmodule at the top of a step: is this step a "small" one (above)?"""
+    global _SMALL_STEP
+    _SMALL_STEP = bool(n_groups == 2 and B * G_max <= SMALL_STEP_ELEMS)
+
+
+def serial_streams() -> bool:
+    return SERIAL_STREAMS or (SERIAL_AUTO and _SMALL_STEP and DEC_PAIR != "0")
 
 
 def group_streams(device, n: int = 2):
@@ -131,7 +150,7 @@ def group_streams(device, n: int = 2):
     hipGraph capture the fork/join become parallel branches of the graph."""
     dev = torch.device(device)
     out = [torch.cuda.current_stream(dev)]
-    if SERIAL_STREAMS:  # every chain on the caller's stream: kernels run one at a time (per-kernel timing, debugging)
+    if serial_streams():  # every chain on the caller's stream: kernels run one at a time (per-kernel timing, debugging; small steps)
         return out * n
     for i in range(1, n):
         key = (dev.index, i)
@@ -187,6 +206,18 @@ LABEL_PRE_MIN_B = 1024
 def label_pre_for(B: int) -> int:
     return LABEL_PRE if LABEL_PRE >= 0 else (2 if B >= LABEL_PRE_MIN_B else 0)
 
+
+
+# the decoder's per-group launches (tables, logits GEMM, softmax statistics, likelihood; d A_m / d W_m GEMMs, one-pass backward) as ONE grid
+# per kernel for the two groups of a step (spv_dec_*_grouped, spv_gemm_bf16_grouped; bit-identical results) instead of one launch per group
+# on two streams.  "auto": in small steps (set_step_shape above); "1" / "0": always / never.
+DEC_PAIR = os.environ.get("SPV_DEC_PAIR", "auto")
+
+
+def dec_pair_for(B: int, n_groups: int) -> bool:
+    if n_groups != 2 or DEC_PAIR == "0":
+        return False
+    return True if DEC_PAIR == "1" else _SMALL_STEP
 
 
 FC1_PAIR_SPLITS = os.environ.get("SPV_FC1_PAIR_SPLITS", "1") != "0"  # grouped fc1 forward: K splits sized for the pair's shared grid

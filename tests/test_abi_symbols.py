@@ -65,7 +65,7 @@ def test_every_ctypes_struct_has_the_size_the_c_header_gives(tmp_path):
         "spv_zsplit_args": _abi.SpvZsplitArgs, "spv_fold_prob": _abi.SpvFoldProb, "spv_fold_batch": _abi.SpvFoldBatch,
         "spv_reduce_prob": _abi.SpvReduceProb, "spv_reduce_batch": _abi.SpvReduceBatch, "spv_plan": _abi.SpvPlan,
         "spv_plan_expert_args": _abi.SpvPlanExpertArgs, "spv_poe_comp_args": _abi.SpvPoeCompArgs,
-        "spv_trunk_prob": _abi.SpvTrunkProb, "spv_trunk_batch": _abi.SpvTrunkBatch, "spv_gemm_fixup": _abi.SpvGemmFixup,
+        "spv_trunk_prob": _abi.SpvTrunkProb, "spv_trunk_batch": _abi.SpvTrunkBatch, "spv_gemm_fixup": _abi.SpvGemmFixup, "spv_gemm_args": _abi.SpvGemmArgs, "spv_dec_group": _abi.SpvDecGroup,
     }
     src = tmp_path / "sizes.c"
     lines = ['#include <stdio.h>', f'#include "{os.path.join(ROOT, "include", "spvipes_hip.h")}"', "int main(void) {"]
