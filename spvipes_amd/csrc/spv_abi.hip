@@ -159,6 +159,31 @@ __global__ void fc1_epilogue_kernel(const float* slabs, const float* rowsum_ws, 
   }
 }
 
+struct Fc1EpiPlainArgs { const float* slabs; const float* rowsum_ws; int splits, B, N1; const float* bias; const float* bias2; int n_first; float* h1; float* library;
+                         const float* library_all; const int* rows; float acc_scale; const float* cov; const int* cov_idx; };
+__global__ void fc1_epilogue_pair_kernel(Fc1EpiPlainArgs a0, Fc1EpiPlainArgs a1) {   // blockIdx.y = group; the same arithmetic as fc1_epilogue_kernel
+  const Fc1EpiPlainArgs a = blockIdx.y ? a1 : a0;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)a.B * a.N1;
+  if (idx < total) {
+    const int col = (int)(idx % a.N1);
+    const float bv = (a.bias2 != nullptr && col >= a.n_first) ? a.bias2[col - a.n_first] : a.bias[col];
+    const float cv = a.cov ? a.cov[(long)a.cov_idx[idx / a.N1] * a.N1 + col] : 0.f;
+    float v = 0.f;
+    for (int s = 0; s < a.splits; ++s) v += a.slabs[(long)s * total + idx];
+    a.h1[idx] = fmaxf(v * a.acc_scale + bv + cv, 0.f);
+  }
+  if (idx < a.B) {
+    if (a.library_all != nullptr) {
+      a.library[idx] = a.library_all[a.rows ? a.rows[idx] : (int)idx];
+    } else {
+      float v = 0.f;
+      for (int s = 0; s < a.splits; ++s) v += a.rowsum_ws[(long)s * a.B + idx];
+      a.library[idx] = __logf(v);
+    }
+  }
+}
+
 // every 8-gene chunk of a row is one aligned 16-byte load when base, row pitch and column offset are
 static int counts_aligned(const spv_counts* x) {
   const long esz = (x->dtype == SPV_COUNT_U16) ? 2 : 4;
@@ -1644,7 +1669,38 @@ extern "C" int spv_enc_fc1_fwd_grouped(const spv_fc1_fwd_args* g, int32_t n_grou
     hipLaunchKernelGGL(fc1_epilogue_tiled_pair_kernel, dim3((unsigned)((sem / 4 + 255) / 256), 2), dim3(256), 0, s, e0, e1);
     if (hipGetLastError() != hipSuccess) return launch_status("spv_enc_fc1_fwd_grouped epilogue");
   }
-  for (; i < n_groups; ++i) {   // a leftover group, or shapes the LDS-DMA kernel does not take: the per-group entry point
+  // shapes the LDS-DMA kernel does not take, 16-bit mode on resident images, at most 128 output units (n_hidden <= 64): the register-staged
+  // GEMM and its epilogue for both groups in one grid each (gemm_pair_kernel) -- at 128 cells per minibatch a launch is mostly fixed cost
+  typedef GemmCfg<64, 128, 2, 2, false, false, SRC_GATHER, SRC_PLAIN, unsigned short, 1, 32, 4, 1, true> PlainCfg;
+  auto plain_ok = [](const spv_fc1_fwd_args& a) {
+    return a.x && a.x->X && a.W1_hi && a.bias && a.slabs && a.rowsum_ws && a.h1 && a.library && a.xb_all && a.library_all && a.B > 0 && a.G > 0 && a.splits > 0 &&
+           a.nsplit == 1 && a.N1 > 32 && a.N1 <= 128 && (a.ldw % 32) == 0 && a.ldw >= ((a.G + 31) & ~31) && a.ld_xb >= ((a.G + 31) & ~31) && (a.ld_xb % 8) == 0 &&
+           (a.cov == nullptr) == (a.cov_idx == nullptr);
+  };
+  for (; i + 1 < n_groups; i += 2) {
+    const spv_fc1_fwd_args &a = g[i], &b = g[i + 1];
+    if (!(plain_ok(a) && plain_ok(b) && a.N1 == b.N1 && a.splits == b.splits)) break;
+    GemmParams p[2];
+    for (int k = 0; k < 2; ++k) {
+      const spv_fc1_fwd_args& c = k ? b : a;
+      GemmParams& w = p[k];
+      w = GemmParams{};
+      w.A = c.xb_all; w.lda = c.ld_xb; w.B = c.W1_hi; w.ldb = c.ldw;
+      w.rows = c.x->rows; w.counts_aligned = counts_aligned(c.x); w.col_off = c.x->col_off; w.n_cells = c.B; w.n_genes = c.G;
+      w.C = c.slabs; w.ldc = c.N1; w.slab_stride = (long)c.B * c.N1;
+      w.M = c.B; w.N = c.N1; w.K = c.G;
+      w.k_per_split = (((c.G + 31) / 32 + c.splits - 1) / c.splits) * 32;
+      w.epi = EPI_STORE;
+    }
+    if (launch_gemm_pair<PlainCfg>(p[0], p[1], a.splits, s) != SPV_OK) return launch_status("spv_enc_fc1_fwd_grouped gemm pair");
+    const float sc = 1.0f / SPV_FC1_W_SCALE;
+    const Fc1EpiPlainArgs e0{a.slabs, a.rowsum_ws, a.splits, a.B, a.N1, a.bias, a.bias2, a.n_first, a.h1, a.library, a.library_all, a.x->rows, sc, a.cov, a.cov_idx};
+    const Fc1EpiPlainArgs e1{b.slabs, b.rowsum_ws, b.splits, b.B, b.N1, b.bias, b.bias2, b.n_first, b.h1, b.library, b.library_all, b.x->rows, sc, b.cov, b.cov_idx};
+    const long tmax = (long)(a.B > b.B ? a.B : b.B) * a.N1;
+    hipLaunchKernelGGL(fc1_epilogue_pair_kernel, dim3((unsigned)((tmax + 255) / 256), 2), dim3(256), 0, s, e0, e1);
+    if (hipGetLastError() != hipSuccess) return launch_status("spv_enc_fc1_fwd_grouped epilogue pair");
+  }
+  for (; i < n_groups; ++i) {   // a leftover group, or shapes no pair form takes: the per-group entry point
     const spv_fc1_fwd_args& a = g[i];
     const int rc = spv_enc_fc1_fwd(a.x, a.B, a.G, a.W1_hi, a.W1_lo, a.ldw, a.N1, a.bias, a.bias2, a.n_first, a.nsplit, a.splits, a.slabs, a.rowsum_ws, a.h1,
                                    a.library, a.xb_all, a.ld_xb, a.library_all, a.cov, a.cov_idx, stream);
@@ -1716,6 +1772,39 @@ extern "C" int spv_enc_fc1_bwd_grouped(const spv_fc1_bwd_args* g, int32_t n_grou
     const int nA = (a.G + t - 1) / t, nB = (b.G + t - 1) / t;
     hipLaunchKernelGGL(kfn, dim3(nA + nB, mth), dim3(512), lds, s, p[0], p[1], nA);
     if (hipGetLastError() != hipSuccess) return launch_status("spv_enc_fc1_bwd_grouped wgrad");
+  }
+  // shapes the LDS-DMA kernel does not take (n_hidden <= 64), 16-bit mode on resident images: prep / finish and the register-staged weight-gradient
+  // GEMM for both groups in one grid each
+  auto plain_ok = [](const spv_fc1_bwd_args& a) {
+    return a.x && a.x->X && a.dh1 && a.h1 && a.dh_hi && a.part && a.db && a.dW && a.xb && a.scale_ws && a.B > 0 && a.G > 0 && a.nsplit == 1 &&
+           a.N1 > 32 && a.N1 <= 128 && a.Bp >= a.B && (a.Bp % 64) == 0 && a.Bp / 16 <= 65536 && a.ld_dh >= ((a.N1 + 127) & ~127) && (a.ld_dh % 8) == 0 &&
+           a.ldc >= a.G && a.ld_xb >= ((a.G + 63) & ~63) && (a.ld_xb % 8) == 0;
+  };
+  for (; i + 1 < n_groups; i += 2) {
+    const spv_fc1_bwd_args &a = g[i], &b = g[i + 1];
+    const bool t96a = a.ld_xb >= (a.G + 95) / 96 * 96, t96b = b.ld_xb >= (b.G + 95) / 96 * 96;
+    if (!(plain_ok(a) && plain_ok(b) && a.N1 == b.N1 && t96a == t96b)) break;
+    const Fc1PrepArgs q0{a.dh1, a.h1, a.B, a.N1, (bf16_t*)a.dh_hi, nullptr, (long)a.ld_dh, a.part, a.Bp / 16, a.db, a.db2, a.n_first, a.scale_ws};
+    const Fc1PrepArgs q1{b.dh1, b.h1, b.B, b.N1, (bf16_t*)b.dh_hi, nullptr, (long)b.ld_dh, b.part, b.Bp / 16, b.db, b.db2, b.n_first, b.scale_ws};
+    const int nb = q0.nblk > q1.nblk ? q0.nblk : q1.nblk;
+    const int nf0 = fc1_finish_blocks(q0), nf1 = fc1_finish_blocks(q1);
+    hipLaunchKernelGGL(fc1_bwd_prep_pair_kernel, dim3(nb, 2), dim3(256), 0, s, q0, q1);
+    hipLaunchKernelGGL(fc1_bwd_finish_pair_kernel, dim3(nf0 > nf1 ? nf0 : nf1, 2), dim3(256), 0, s, q0, q1);
+    if (hipGetLastError() != hipSuccess) return launch_status("spv_enc_fc1_bwd_grouped prep pair");
+    GemmParams p[2];
+    for (int k = 0; k < 2; ++k) {   // (as spv_enc_fc1_wgrad builds them for a resident f16 image)
+      const spv_fc1_bwd_args& c = k ? b : a;
+      GemmParams& w = p[k];
+      w = GemmParams{};
+      w.A = c.dh_hi; w.lda = c.ld_dh; w.B = c.xb; w.ldb = c.ld_xb;
+      w.rows = c.x->rows; w.counts_aligned = counts_aligned(c.x); w.col_off = c.x->col_off; w.n_cells = c.B; w.n_genes = c.G;
+      w.C = c.dW; w.ldc = c.ldc; w.C2 = c.dW2; w.c_split_row = c.n_first; w.out_scale = c.scale_ws + 1;
+      w.M = c.N1; w.N = c.G; w.K = c.B; w.k_per_split = (c.B + 63) & ~63; w.epi = EPI_STORE;
+    }
+    int rcg;
+    if (t96a) rcg = launch_gemm_pair<GemmCfg<128, 96, 4, 1, true, true, SRC_PLAIN, SRC_GATHER, unsigned short, 1, 64, 4, 1, true>>(p[0], p[1], 1, s);
+    else rcg = launch_gemm_pair<GemmCfg<128, 64, 4, 1, true, true, SRC_PLAIN, SRC_GATHER, unsigned short, 1, 64, 4, 1, true>>(p[0], p[1], 1, s);
+    if (rcg != SPV_OK) return launch_status("spv_enc_fc1_bwd_grouped wgrad pair");
   }
   for (; i < n_groups; ++i) {
     const spv_fc1_bwd_args& a = g[i];

@@ -269,8 +269,7 @@ struct Stager {
 };
 
 template <typename Cfg>
-__global__ __launch_bounds__(256, Cfg::OCC) void gemm_kernel(GemmParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+__device__ __forceinline__ void gemm_body(const GemmParams& p, const int bx, unsigned char* smem_raw) {   // bx: this workgroup's M tile
   bf16_t* sA = reinterpret_cast<bf16_t*>(smem_raw);
   bf16_t* sA_lo = sA + Cfg::A_ELEMS * (Cfg::NIMG - 1);
   bf16_t* sB = sA + Cfg::A_ELEMS * Cfg::NIMG;
@@ -278,7 +277,7 @@ __global__ __launch_bounds__(256, Cfg::OCC) void gemm_kernel(GemmParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
-  const int m0 = blockIdx.x * Cfg::BM, n0 = blockIdx.y * Cfg::BN;
+  const int m0 = bx * Cfg::BM, n0 = blockIdx.y * Cfg::BN;
   const int split = blockIdx.z;
   const int kbeg = split * p.k_per_split;
   int kend = kbeg + p.k_per_split;
@@ -424,6 +423,34 @@ __global__ __launch_bounds__(256, Cfg::OCC) void gemm_kernel(GemmParams p) {
       }
     }
   }
+}
+template <typename Cfg>
+__global__ __launch_bounds__(256, Cfg::OCC) void gemm_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw_[];
+  gemm_body<Cfg>(p, blockIdx.x, smem_raw_);
+}
+// two problems of one configuration in ONE grid (workgroups 0 .. nx0 - 1 along x: the first problem's M tiles); the y extent covers the
+// wider problem's N tiles, both problems have the same split count (z)
+template <typename Cfg>
+__global__ __launch_bounds__(256, Cfg::OCC) void gemm_pair_kernel(GemmParams p0, GemmParams p1, int nx0) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw_[];
+  const bool first = (int)blockIdx.x < nx0;   // (workgroup-uniform)
+  const GemmParams p = first ? p0 : p1;
+  if ((int)blockIdx.y * Cfg::BN >= p.N) return;   // (the grid's y extent is the larger problem's)
+  gemm_body<Cfg>(p, first ? (int)blockIdx.x : (int)blockIdx.x - nx0, smem_raw_);
+}
+
+template <typename Cfg>
+inline int launch_gemm_pair(const GemmParams& p0, const GemmParams& p1, int splits, hipStream_t stream) {
+  const int nx0 = (p0.M + Cfg::BM - 1) / Cfg::BM, nx1 = (p1.M + Cfg::BM - 1) / Cfg::BM;
+  const int nmax = p0.N > p1.N ? p0.N : p1.N;
+  dim3 grid(nx0 + nx1, (nmax + Cfg::BN - 1) / Cfg::BN, splits);
+  if constexpr (Cfg::LDS_BYTES > 65536) {
+    static bool raised = false;
+    if (!raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pair_kernel<Cfg>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES); raised = true; }
+  }
+  hipLaunchKernelGGL(gemm_pair_kernel<Cfg>, grid, dim3(256), Cfg::LDS_BYTES, stream, p0, p1, nx0);
+  return hipGetLastError() == hipSuccess ? SPV_OK : SPV_ERR_LAUNCH;
 }
 
 template <typename Cfg>

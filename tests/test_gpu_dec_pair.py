@@ -70,3 +70,40 @@ def test_auto_mode_pairs_small_steps_only(monkeypatch):
         ops.set_step_shape(B, G, n)
         assert ops.dec_pair_for(B, n) == small and ops.serial_streams() == small, (B, G, n)
     ops.set_step_shape(4096, 10_000, 2)
+
+
+@pytest.mark.parametrize("B,G,G2,H", [(128, 2000, 2000, 64), (100, 333, 500, 32), (300, 1000, 777, 64)])
+def test_fc1_plain_pair_launches_give_the_bits_of_the_per_group_calls(dev, B, G, G2, H):
+    """n_hidden <= 64 on resident images: the LDS-DMA fc1 kernels do not take the shape, and spv_enc_fc1_fwd_grouped / _bwd_grouped run the
+    register-staged GEMM, its epilogue, the dh-image prep and the weight-gradient GEMM for BOTH groups in one grid each (gemm_pair_kernel):
+    same kernel bodies, same bits as the per-group entry points (nn/networks.py:119 and its backward)"""
+    from spvipes_amd import ops
+    rng = np.random.default_rng(B + G)
+    g = torch.Generator().manual_seed(5)
+    mk = lambda *s: (torch.randn(*s, generator=g) * 0.05)
+    counts, rows, params, dhs = [], [], [], []
+    for b_, g_ in ((B, G), (B, G2)):
+        Xh = (rng.poisson(2.0, size=(b_ + 9, g_)) * (rng.random((b_ + 9, g_)) < 0.3)).astype(np.float32)
+        Xh[:, 0] += 1
+        counts.append(ops.GroupCounts(torch.tensor(Xh.astype(np.uint16).view(np.int16)).to(dev), g_, 0, resident=True))
+        rows.append(torch.tensor(rng.permutation(b_ + 9)[:b_], dtype=torch.int32, device=dev))
+        params.append([mk(H, g_), mk(H), mk(H, g_), mk(H)])
+        dhs.append(torch.randn(b_, 2 * H, generator=g).to(dev))
+    pg = [[t.clone().to(dev).requires_grad_(True) for t in ps] for ps in params]
+    outs = ops.EncoderFC1Grouped.apply(counts, rows, [B, B], 1, [ops.Workspace(dev), ops.Workspace(dev)], None, *pg[0], *pg[1])
+    ((outs[0] * dhs[0]).sum() + (outs[2] * dhs[1]).sum()).backward()
+    torch.cuda.synchronize()
+    for k in range(2):
+        ps = [t.clone().to(dev).requires_grad_(True) for t in params[k]]
+        h1, lib = ops.EncoderFC1.apply(counts[k], rows[k], B, *ps, 1, ops.Workspace(dev))
+        (h1 * dhs[k]).sum().backward()
+        torch.cuda.synchronize()
+        assert torch.equal(h1.detach(), outs[2 * k].detach()) and torch.equal(lib, outs[2 * k + 1])
+        for a, b in zip(ps, pg[k]):
+            assert torch.equal(a.grad, b.grad), (k, float((a.grad - b.grad).abs().max()))
+        # and the values themselves against fp64 on the f16-rounded operands
+        Xsel = torch.log1p(torch.tensor(np.asarray(counts[k].X.cpu().view(torch.uint16).numpy(), dtype=np.float32))[rows[k].cpu().long()])
+        xr = Xsel.to(torch.float16).double()
+        W = (torch.cat([params[k][0], params[k][2]]) * 256.0).to(torch.float16).double() / 256.0
+        ref = torch.relu(xr @ W.t() + torch.cat([params[k][1], params[k][3]]).double())
+        torch.testing.assert_close(h1.detach().cpu().double(), ref, rtol=1e-4, atol=1e-4)
