@@ -1119,6 +1119,10 @@ extern "C" int spv_linear_wgrad(const spv_linear_batch* a, float* wpart, int64_t
   const long prob_stride = (long)WG_SLICES * nmax * (kmax + 1);
   if (wpart_elems < prob_stride * a->nprob) return fail(SPV_ERR_ARG, "spv_linear_wgrad: workspace too small%s");
   hipStream_t s = (hipStream_t)stream;
+  if (a->B <= WG_DIRECT_MAX_B) {   // one slice holds the whole minibatch: results straight into dW / db
+    hipLaunchKernelGGL(linear_wgrad_direct_kernel, dim3((nmax + 31) / 32, (kmax + 31) / 32, a->nprob), dim3(256), 0, s, *a);
+    return launch_status("spv_linear_wgrad");
+  }
   hipLaunchKernelGGL(linear_wgrad_kernel, dim3((nmax + 31) / 32, (kmax + 31) / 32, a->nprob * WG_SLICES), dim3(256), 0, s, *a, wpart, prob_stride);
   hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((unsigned)(((long)nmax * (kmax + 1) + 255) / 256), a->nprob), dim3(256), 0, s, *a, wpart, prob_stride);
   return launch_status("spv_linear_wgrad");

@@ -202,16 +202,20 @@ __global__ __launch_bounds__(256) void linear_dgrad_kernel(LinearBatch a) {
 // tiles go to `wpart` and are summed in slice order by linear_wgrad_reduce_kernel.
 constexpr int WG_SLICES = 16;
 
-template <bool MASKED>
+// DIRECT (minibatches of at most WG_DIRECT_MAX_B rows): ONE slice per problem holds every row, and its workgroup writes dW / db itself --
+// no partials, no linear_wgrad_reduce_kernel launch (at 128 cells a launch is mostly fixed cost, and 14 of the 16 slices were empty)
+constexpr int WG_DIRECT_MAX_B = 256;
+template <bool MASKED, bool DIRECT>
 __device__ __forceinline__ void linear_wgrad_body(const LinearBatch& a, float* wpart, long prob_stride) {
-  const int prob = blockIdx.z / WG_SLICES, slice = blockIdx.z % WG_SLICES;
+  constexpr int NSL = DIRECT ? 1 : WG_SLICES;
+  const int prob = blockIdx.z / NSL, slice = blockIdx.z % NSL;
   const LinearProb& q = a.p[prob];
   const int n0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
   if (n0 >= q.N || k0 >= q.K) return;  // block-uniform
   __shared__ float s_acc[3][16][64], s_b[3][32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, r = lane & 31;
   constexpr bool masked = MASKED;
-  const int per = ((a.B + WG_SLICES * 64 - 1) / (WG_SLICES * 64)) * 64;   // rows per slice, a multiple of 64 (16 per wave and step)
+  const int per = ((a.B + NSL * 64 - 1) / (NSL * 64)) * 64;   // rows per slice, a multiple of 64 (16 per wave and step)
   const int bbeg = slice * per + wave * (per / 4), bend = min(bbeg + per / 4, a.B);
   const float* gc = q.dY + min(n0 + r, q.N - 1);
   const float* yc = masked ? q.Y + min(n0 + r, q.N - 1) : gc;
@@ -246,9 +250,18 @@ __device__ __forceinline__ void linear_wgrad_body(const LinearBatch& a, float* w
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = ((acc[i] + s_acc[0][i][lane]) + s_acc[1][i][lane]) + s_acc[2][i][lane];
   bsum = ((bsum + s_b[0][r]) + s_b[1][r]) + s_b[2][r];
+  const int k = k0 + r;
+  if constexpr (DIRECT) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int n = n0 + crow(i, h);
+      if (n < q.N && k < q.K) q.dW[(long)n * q.K + k] = acc[i];
+    }
+    if (blockIdx.y == 0 && h == 0 && n0 + r < q.N && q.db) q.db[n0 + r] = bsum;
+    return;
+  }
   // partial layout per problem: [slice][N][K + 1] (last column = bias partial)
   float* base = wpart + prob * prob_stride + (long)slice * q.N * (q.K + 1);
-  const int k = k0 + r;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int n = n0 + crow(i, h);
@@ -257,8 +270,12 @@ __device__ __forceinline__ void linear_wgrad_body(const LinearBatch& a, float* w
   if (blockIdx.y == 0 && h == 0 && n0 + r < q.N) base[(long)(n0 + r) * (q.K + 1) + q.K] = bsum;
 }
 __global__ __launch_bounds__(256) void linear_wgrad_kernel(LinearBatch a, float* wpart, long prob_stride) {
-  if (a.relu || a.drop_p > 0.f) linear_wgrad_body<true>(a, wpart, prob_stride);
-  else linear_wgrad_body<false>(a, wpart, prob_stride);
+  if (a.relu || a.drop_p > 0.f) linear_wgrad_body<true, false>(a, wpart, prob_stride);
+  else linear_wgrad_body<false, false>(a, wpart, prob_stride);
+}
+__global__ __launch_bounds__(256) void linear_wgrad_direct_kernel(LinearBatch a) {
+  if (a.relu || a.drop_p > 0.f) linear_wgrad_body<true, true>(a, nullptr, 0);
+  else linear_wgrad_body<false, true>(a, nullptr, 0);
 }
 
 __global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(LinearBatch a, const float* wpart, long prob_stride) {
