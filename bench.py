@@ -206,18 +206,22 @@ def _pmc_fields(args):
     tab, src = _pmc_table(args)
     if tab is None:
         return None, None, None
-    hit = [e for k, e in tab["kernels"].items() if "dec_nb_kernel" in k and e.get("launches_per_step", 0) >= 1]
-    if not hit or "FETCH_SIZE" not in hit[0] or "WRITE_SIZE" not in hit[0]:
+    hit = [(e, 1.0) for k, e in tab["kernels"].items() if "dec_nb_kernel" in k and e.get("launches_per_step", 0) >= 1]
+    # small steps: one grid for both groups (dec_nb_pair_kernel): a launch's bytes are two groups' -- the per-group share, like `achieved`
+    hit += [(e, 0.5) for k, e in tab["kernels"].items() if "dec_nb_pair_kernel" in k and e.get("launches_per_step", 0) >= 1]
+    if not hit or "FETCH_SIZE" not in hit[0][0] or "WRITE_SIZE" not in hit[0][0]:
         return None, None, None
-    e = max(hit, key=lambda e: e["launches_per_step"])
-    return (e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024.0, src + " (raw FETCH_SIZE + WRITE_SIZE, KiB -> bytes)", e.get("valu_busy_frac")
+    e, share = max(hit, key=lambda h: h[0]["launches_per_step"])
+    return (e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024.0 * share, src + " (raw FETCH_SIZE + WRITE_SIZE, KiB -> bytes)", e.get("valu_busy_frac")
 
 
 # kernels of the decoder + likelihood chain (forward and backward) by name, and the FETCH_SIZE factor of each: x2 where the reads are
 # 16 B / lane (LDS-DMA GEMMs, the one-pass backward: MI355X_MICROARCH.md, HBM section), raw elsewhere
-_CHAIN = (("dec_nb_kernel", 1.0), ("dec_heads_bwd", 2.0), ("dec_softmax_bwd_kernel", 1.0), ("dec_gemm320_dma4", 2.0), ("dec_logits_dma_kernel", 2.0),
+_CHAIN = (("dec_nb_kernel", 1.0), ("dec_nb_pair_kernel", 1.0), ("dec_logits_dma_pair_kernel", 2.0), ("dec_lse_pair_kernel", 1.0), ("dec_lse_combine_pair_kernel", 1.0),
+          ("dec_heads_bwd", 2.0), ("dec_softmax_bwd_kernel", 1.0), ("dec_gemm320_dma4", 2.0), ("dec_logits_dma_kernel", 2.0),
           ("dec_lse_kernel", 1.0), ("dec_lse_combine_kernel", 1.0), ("dec_heads_wgrad", 2.0), ("gemm_kernel<", 1.0))
-_CHAIN_ENTRY_POINTS = ("spv_dec_nb_fwd", "spv_dec_logits", "spv_dec_lse", "spv_dec_softmax_bwd", "spv_dec_heads_bwd", "spv_gemm_bf16", "spv_dec_heads_wgrad")
+_CHAIN_ENTRY_POINTS = ("spv_dec_nb_fwd", "spv_dec_logits", "spv_dec_lse", "spv_dec_softmax_bwd", "spv_dec_heads_bwd", "spv_gemm_bf16", "spv_dec_heads_wgrad",
+                       "spv_dec_nb_fwd_grouped", "spv_dec_logits_grouped", "spv_dec_lse_grouped", "spv_dec_heads_bwd_grouped", "spv_gemm_bf16_grouped")
 
 
 def _pmc_decoder_chain(args, n_groups=2, chain_ms_per_group_step=None):
@@ -419,7 +423,8 @@ def main(argv=None):
 
     it = batches()
     prof_names = ["spv_dec_nb_fwd", "spv_dec_logits", "spv_enc_fc1_fwd", "spv_enc_fc1_wgrad", "spv_dec_lse", "spv_dec_softmax_bwd", "spv_dec_heads_bwd",
-                  "spv_gemm_bf16", "spv_dec_heads_wgrad", "spv_adam_step", "spv_adam_step_images", "spv_enc_fc1_fwd_grouped", "spv_enc_fc1_bwd_grouped"]
+                  "spv_gemm_bf16", "spv_dec_heads_wgrad", "spv_adam_step", "spv_adam_step_images", "spv_enc_fc1_fwd_grouped", "spv_enc_fc1_bwd_grouped",
+                  "spv_dec_nb_fwd_grouped", "spv_dec_logits_grouped", "spv_dec_lse_grouped", "spv_dec_heads_bwd_grouped", "spv_gemm_bf16_grouped"]
     use_graph = not args.no_graph
     delta = delta_state = None
     if rank == 0 and world == 1 and NG == 2 and not args.no_elbo_delta:
@@ -530,13 +535,17 @@ def main(argv=None):
         #   algorithmic bytes: the B x G counts once + mixture/regressor weights once (bf16 images)
         #   algorithmic flops: logits GEMM 2*B*G*(256+n_s+n_p+1) + the two regressor GEMMs
         nb_ms = prof.get("spv_dec_nb_fwd", [])
+        nb_launch = "dec_nb_kernel (spv_dec_nb_fwd)"
+        if not nb_ms and prof.get("spv_dec_nb_fwd_grouped"):   # small steps: ONE grid for both groups (ops.DEC_PAIR) = NG launches' worth of work
+            nb_ms = [v / NG for v in prof["spv_dec_nb_fwd_grouped"]]
+            nb_launch = f"dec_nb_pair_kernel (spv_dec_nb_fwd_grouped: one grid for {NG} groups; per-group share of its duration)"
         nb_avg = float(np.mean(nb_ms)) if nb_ms else float("nan")
         KM = 256 + n_s + n_p + 1
         nb_bytes = B * G * sx + G * (KM + 2 * (n_s + n_p + 2)) * 2 + B * KM * 2
         nb_flops = 2.0 * B * G * (KM + n_s + n_p + 2)
         per_kernel = {k: {"calls_per_step": len(v) / prof_steps, "avg_ms": float(np.mean(v))} for k, v in prof.items() if v}
         traffic, traffic_src, valu_busy = _pmc_fields(args)
-        roof = {"kernel": "dec_nb_kernel (spv_dec_nb_fwd)", "bound": "hbm", "achieved": nb_bytes / (nb_avg * 1e-3) / 1e9,
+        roof = {"kernel": nb_launch, "bound": "hbm", "achieved": nb_bytes / (nb_avg * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nb_bytes / (nb_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": traffic_src,
                 "limiter": "VALU / transcendental issue and per-wave memory latency, not HBM bandwidth (DESIGN.md section 4)",
