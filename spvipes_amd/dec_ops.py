@@ -373,7 +373,7 @@ class DecoderFused(torch.autograd.Function):
               if not lse_first and not pair:
                   _abi.call("spv_dec_logits", ptr(Am_hi), ptr(Am_lo), ptr(Wm_hi), ptr(Wm_lo), KMP, Bp, Gp, nsplit, ptr(logits), int(mlo), stream_ptr())
               splits, per = _gene_splits(Bp, Gp)
-              nbs, nbper = _nb_splits(Gp)
+              nbs, nbper = _nb_splits(Gp, Bp)
               vec = lambda nme: wsg.get(nme, (Bp,), torch.float32)
               part = lambda nme: wsg.get(nme, (splits, Bp), torch.float32)
               nbpart = lambda nme: wsg.get(nme, (nbs, Bp), torch.float32)

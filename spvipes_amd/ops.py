@@ -558,8 +558,18 @@ def _gene_splits(Bp: int, Gp: int) -> Tuple[int, int]:
 NB_GSPL_MAX = 160  # genes per likelihood split (their regressor weights sit in LDS)
 
 
-def _nb_splits(Gp: int) -> Tuple[int, int]:
+NB_WG_WANT = int(os.environ.get("SPV_NB_WG_WANT", "512"))
+
+
+def _nb_splits(Gp: int, Bp: Optional[int] = None) -> Tuple[int, int]:
+    """(splits, genes per split) of the likelihood kernel: 160 genes per workgroup (what its LDS weight slice holds) -- fewer for small
+    minibatches, where 160-gene splits leave most CUs without a workgroup and every workgroup with a chain of ten 16-gene chunks: about
+    NB_WG_WANT workgroups per group, at least 32 genes each"""
     per = min(NB_GSPL_MAX, Gp)
+    if Bp is not None and NB_WG_WANT > 0:
+        cell_tiles = max(1, Bp // 64)
+        want = -(-NB_WG_WANT // cell_tiles)                      # gene splits wanted
+        per = max(32, min(per, -(-(-(-Gp // want)) // 32) * 32))   # genes per split, a multiple of 32
     return -(-Gp // per), per
 
 
